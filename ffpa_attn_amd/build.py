@@ -1,0 +1,110 @@
+"""In-tree build of the gfx950 C-ABI library (``libffpa_attn_hip.so``).
+
+The reference drives nvcc through setup.py/env.py and generates one TU per
+(dtype, acc, headdim, stage) (``env.py:455-521``, ``setup.py:112-145``).  Here the
+library has no torch / pybind dependency, so the build is plain ``hipcc``: one
+object per head dim (compiled in parallel) + the C-ABI object, linked into a
+shared library that stays next to the sources (it travels to the GPU box with the
+repo snapshot; a JIT cache would not).
+
+Usage:  python -m ffpa_attn_amd.build [--force] [--jobs N] [--save-temps]
+"""
+
+from __future__ import annotations
+
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+REPO = os.path.dirname(HERE)
+INCLUDE = os.path.join(REPO, "include")
+OBJ_DIR = os.path.join(CSRC, "build")
+LIB_NAME = "libffpa_attn_hip.so"
+LIB_PATH = os.path.join(HERE, LIB_NAME)
+
+HEAD_DIMS = [64 * i for i in range(1, 17)]
+# head dims that also get the test-only "safe path" kernel (register staging +
+# scalar V gather) used to bisect LDS-DMA / transpose-read problems on hardware.
+SAFE_HEAD_DIMS = {64, 128, 320, 512, 640, 1024}
+
+ARCH = "gfx950"
+CXXFLAGS = [
+  f"--offload-arch={ARCH}",
+  "-O3",
+  "-std=c++17",
+  "-fPIC",
+  "-mcode-object-version=5",
+  f"-I{INCLUDE}",
+  f"-I{CSRC}",
+]
+
+
+def _hipcc() -> str:
+  for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+    if cand and os.path.exists(cand):
+      return cand
+  raise RuntimeError("hipcc not found: the HIP toolchain is required to build ffpa_attn_amd")
+
+
+def _sources_mtime() -> float:
+  paths = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]
+  paths.append(os.path.join(INCLUDE, "ffpa_attn.h"))
+  paths.append(os.path.abspath(__file__))
+  return max(os.path.getmtime(p) for p in paths)
+
+
+def _run(cmd: list[str], cwd: str | None = None) -> None:
+  proc = subprocess.run(cmd, capture_output=True, text=True, cwd=cwd)
+  if proc.returncode != 0:
+    raise RuntimeError("command failed: " + " ".join(cmd) + "\n" + proc.stdout + proc.stderr)
+
+
+def build(force: bool = False, jobs: int | None = None, save_temps: bool = False, verbose: bool = True) -> str:
+  """Compile every kernel for gfx950 and link ``libffpa_attn_hip.so``; returns its path."""
+  newest = _sources_mtime()
+  if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
+    return LIB_PATH
+  hipcc = _hipcc()
+  os.makedirs(OBJ_DIR, exist_ok=True)
+  jobs = jobs or max(1, (os.cpu_count() or 4))
+  tasks: list[tuple[str, list[str], str | None]] = []
+  objs: list[str] = []
+  extra = ["-save-temps"] if save_temps else []  # temps land in the compile's cwd (one dir per TU)
+  for d in HEAD_DIMS:
+    obj = os.path.join(OBJ_DIR, f"ffpa_fwd_d{d}.o")
+    objs.append(obj)
+    if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
+      defs = [f"-DFFPA_INST_D={d}"] + (["-DFFPA_INST_SAFE=1"] if d in SAFE_HEAD_DIMS else [])
+      tmp = os.path.join(OBJ_DIR, f"temps_d{d}")
+      os.makedirs(tmp, exist_ok=True)
+      tasks.append((obj, [hipcc, *CXXFLAGS, *extra, *defs, "-c", os.path.join(CSRC, "ffpa_fwd_inst.hip"), "-o", obj], tmp))
+  capi = os.path.join(OBJ_DIR, "ffpa_capi.o")
+  objs.append(capi)
+  if force or not os.path.exists(capi) or os.path.getmtime(capi) < newest:
+    tasks.append((capi, [hipcc, *CXXFLAGS, "-c", os.path.join(CSRC, "ffpa_capi.hip"), "-o", capi], None))
+  if verbose:
+    print(f"[ffpa_attn_amd.build] compiling {len(tasks)} objects for {ARCH} with {jobs} jobs", flush=True)
+  with ThreadPoolExecutor(max_workers=jobs) as pool:
+    list(pool.map(lambda t: _run(t[1], cwd=t[2]), tasks))
+  _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH, *objs, "-Wl,-rpath,/opt/rocm/lib"])
+  if verbose:
+    print(f"[ffpa_attn_amd.build] linked {LIB_PATH}", flush=True)
+  return LIB_PATH
+
+
+def main() -> None:
+  ap = argparse.ArgumentParser(description=__doc__)
+  ap.add_argument("--force", action="store_true")
+  ap.add_argument("--jobs", type=int, default=None)
+  ap.add_argument("--save-temps", action="store_true")
+  args = ap.parse_args()
+  print(build(force=args.force, jobs=args.jobs, save_temps=args.save_temps))
+
+
+if __name__ == "__main__":
+  sys.exit(main())

@@ -1,0 +1,185 @@
+// ffpa_capi.hip — the extern "C" boundary declared in include/ffpa_attn.h.
+//
+// Host-side argument validation mirrors what the reference checks in its launcher
+// (csrc/cuffpa/launch.cuh:79-129: shapes, bias layout; ffpa_api.cc:193-197: dtype)
+// but reports through status codes instead of TORCH_CHECK, allocates nothing and
+// keeps no global mutable state (the reference's process-global backend hint,
+// csrc/cuffpa/backend.h:16-27, has no equivalent here: every choice is per call).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "ffpa_attn.h"
+#include "ffpa_fwd_kernel.h"
+#include "ffpa_launch.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+typedef int (*launch_fn)(int, int, const ffpa::FwdArgs&, hipStream_t);
+typedef void (*config_fn)(int*, int*, int*);
+
+struct DimEntry {
+  int d;
+  launch_fn launch;
+  config_fn config;
+};
+
+const DimEntry kDims[] = {
+#define FFPA_ROW(D) {D, &ffpa::launch_fwd_d##D, &ffpa::tile_config_d##D},
+    FFPA_FOR_EACH_HEAD_DIM(FFPA_ROW)
+#undef FFPA_ROW
+};
+
+const DimEntry* find_dim(int d) {
+  for (const DimEntry& e : kDims)
+    if (e.d == d) return &e;
+  return nullptr;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int check_strides(const char* name, const int64_t s[3]) {
+  for (int i = 0; i < 3; ++i) {
+    if (s[i] < 0) return fail(FFPA_ERR_BAD_STRIDE, "%s stride[%d]=%lld is negative", name, i, (long long)s[i]);
+    if (s[i] % 8 != 0)
+      return fail(FFPA_ERR_BAD_STRIDE, "%s stride[%d]=%lld is not a multiple of 8 elements (16 bytes)", name, i,
+                  (long long)s[i]);
+  }
+  return FFPA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
+  if (p == nullptr) return fail(FFPA_ERR_NULL_POINTER, "params is NULL");
+  if (p->struct_size != sizeof(ffpa_fwd_params) || p->abi_version != FFPA_ATTN_ABI_VERSION)
+    return fail(FFPA_ERR_BAD_ABI, "ffpa_fwd_params ABI mismatch: size %u (want %zu), version %u (want %d)",
+                p->struct_size, sizeof(ffpa_fwd_params), p->abi_version, FFPA_ATTN_ABI_VERSION);
+  if (!p->q || !p->k || !p->v || !p->o) return fail(FFPA_ERR_NULL_POINTER, "q/k/v/o must be non-NULL");
+  if (p->dtype != FFPA_DTYPE_BF16 && p->dtype != FFPA_DTYPE_FP16)
+    return fail(FFPA_ERR_BAD_DTYPE, "dtype %d is not bf16(0)/fp16(1)", p->dtype);
+  if (p->batch <= 0 || p->heads_q <= 0 || p->heads_kv <= 0 || p->seqlen_q <= 0 || p->seqlen_kv <= 0)
+    return fail(FFPA_ERR_BAD_SHAPE, "non-positive dimension: B=%d Hq=%d Hkv=%d Nq=%d Nkv=%d", p->batch, p->heads_q,
+                p->heads_kv, p->seqlen_q, p->seqlen_kv);
+  if (p->heads_q % p->heads_kv != 0)
+    return fail(FFPA_ERR_BAD_SHAPE, "num_heads: Hq=%d is not a multiple of Hkv=%d", p->heads_q, p->heads_kv);
+  const DimEntry* de = find_dim(p->head_dim);
+  if (de == nullptr)
+    return fail(FFPA_ERR_BAD_HEADDIM, "headdim not support! D=%d (built: multiples of 64 in [64, 1024])", p->head_dim);
+  if (!aligned16(p->q) || !aligned16(p->k) || !aligned16(p->v) || !aligned16(p->o))
+    return fail(FFPA_ERR_MISALIGNED, "q/k/v/o base pointers must be 16-byte aligned");
+  int rc;
+  if ((rc = check_strides("q", p->q_stride)) || (rc = check_strides("k", p->k_stride)) ||
+      (rc = check_strides("v", p->v_stride)) || (rc = check_strides("o", p->o_stride)))
+    return rc;
+  // K / V tiles are fetched with 32-bit buffer offsets inside one (batch, kv-head) slice
+  for (const int64_t* st : {p->k_stride, p->v_stride}) {
+    const int64_t slice_bytes = ((int64_t)(p->seqlen_kv - 1) * st[2] + p->head_dim) * 2;
+    if (st[2] < p->head_dim || slice_bytes >= (1LL << 32))
+      return fail(FFPA_ERR_BAD_STRIDE, "k/v row stride %lld: one (batch, head) slice must be < 4 GiB and rows must not overlap",
+                  (long long)st[2]);
+  }
+  if ((p->bias == nullptr) != (p->bias_dtype == FFPA_BIAS_NONE))
+    return fail(FFPA_ERR_BAD_DTYPE, "bias pointer and bias_dtype disagree (ptr %s, dtype %d)",
+                p->bias ? "set" : "NULL", p->bias_dtype);
+  if (p->bias_dtype < FFPA_BIAS_NONE || p->bias_dtype > FFPA_BIAS_FP32)
+    return fail(FFPA_ERR_BAD_DTYPE, "unknown bias_dtype %d", p->bias_dtype);
+  for (int i = 0; i < 4; ++i)
+    if (p->bias && p->bias_stride[i] < 0) return fail(FFPA_ERR_BAD_STRIDE, "bias stride[%d] is negative", i);
+  if (p->dropout_p != 0.f)
+    return fail(FFPA_ERR_UNSUPPORTED, "dropout_p=%g: dropout is not built into ABI v%d", (double)p->dropout_p,
+                FFPA_ATTN_ABI_VERSION);
+  if (!isfinite(p->softmax_scale)) return fail(FFPA_ERR_BAD_SHAPE, "softmax_scale is not finite");
+  const int safe = (p->flags & FFPA_FLAG_DEBUG_SAFE_PATH) ? 1 : 0;
+
+  int br = 0, bc = 0, lds = 0;
+  de->config(&br, &bc, &lds);
+  const int64_t nqt = ((int64_t)p->seqlen_q + br - 1) / br;
+  const int64_t grid = (int64_t)p->batch * p->heads_q * nqt;
+  if (grid > 0x7fffffffLL) return fail(FFPA_ERR_BAD_SHAPE, "grid of %lld workgroups is too large", (long long)grid);
+
+  ffpa::FwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.q = p->q;
+  a.k = p->k;
+  a.v = p->v;
+  a.o = p->o;
+  a.lse = p->lse;
+  a.bias = p->bias;
+  for (int i = 0; i < 3; ++i) {
+    a.sq[i] = p->q_stride[i];
+    a.sk[i] = p->k_stride[i];
+    a.sv[i] = p->v_stride[i];
+    a.so[i] = p->o_stride[i];
+  }
+  for (int i = 0; i < 4; ++i) a.sbias[i] = p->bias ? p->bias_stride[i] : 0;
+  a.B = p->batch;
+  a.Hq = p->heads_q;
+  a.Hkv = p->heads_kv;
+  a.Nq = p->seqlen_q;
+  a.Nkv = p->seqlen_kv;
+  a.group = p->heads_q / p->heads_kv;
+  a.nqt = (int)nqt;
+  a.bias_dtype = p->bias_dtype;
+  a.causal = p->causal ? 1 : 0;
+  a.causal_offset = p->causal_offset;
+  a.scale_log2 = p->softmax_scale * 1.4426950408889634f;  // FFPA_M_LOG2E, csrc/cuffpa/common.cuh:9-18
+  a.thr = p->rescale_threshold < 0.f ? 8.0f : p->rescale_threshold;
+  a.flags = p->flags;
+
+  const int st = de->launch(p->dtype, safe, a, static_cast<hipStream_t>(stream));
+  if (st == -3) return fail(FFPA_ERR_UNSUPPORTED, "debug safe-path kernel is not built for D=%d / this dtype", p->head_dim);
+  if (st == -2)
+    return fail(FFPA_ERR_LAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed (is this a gfx950?)", lds);
+  if (st < 0) return fail(FFPA_ERR_LAUNCH, "launch setup failed (%d)", st);
+  if (st != 0)
+    return fail(FFPA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(st)));
+  return FFPA_OK;
+}
+
+size_t ffpa_attn_fwd_workspace_bytes(const ffpa_fwd_params* /*params*/) { return 0; }
+
+int ffpa_attn_query(int what) {
+  switch (what) {
+    case FFPA_QUERY_ABI_VERSION: return FFPA_ATTN_ABI_VERSION;
+    case FFPA_QUERY_FWD_AVAILABLE: return 1;
+    case FFPA_QUERY_MIN_HEAD_DIM: return 64;
+    case FFPA_QUERY_MAX_HEAD_DIM: return 1024;
+    case FFPA_QUERY_HEAD_DIM_MULTIPLE: return 64;
+    case FFPA_QUERY_FP16_AVAILABLE: return 1;
+    case FFPA_QUERY_DROPOUT_AVAILABLE: return 0;
+    case FFPA_QUERY_DEBUG_KERNELS: return 1;
+    default: return -1;
+  }
+}
+
+int ffpa_attn_fwd_tile_config(int head_dim, int* block_rows, int* block_keys, int* lds_bytes) {
+  const DimEntry* de = find_dim(head_dim);
+  if (de == nullptr) return fail(FFPA_ERR_BAD_HEADDIM, "headdim not support! D=%d", head_dim);
+  int br = 0, bc = 0, lds = 0;
+  de->config(&br, &bc, &lds);
+  if (block_rows) *block_rows = br;
+  if (block_keys) *block_keys = bc;
+  if (lds_bytes) *lds_bytes = lds;
+  return FFPA_OK;
+}
+
+const char* ffpa_attn_last_error(void) { return g_err; }
+
+const char* ffpa_attn_version(void) { return "ffpa-attn-amd 0.1.0 gfx950"; }
+
+}  // extern "C"

@@ -1,0 +1,62 @@
+// ffpa_fwd_inst.hip — one translation unit per head dim (compiled with
+// -DFFPA_INST_D=<D>); keeps hipcc invocations small and parallel.  The reference
+// generates one TU per (dtype, acc, headdim, stage) from env.py:455-521; here the
+// only axis is the head dim (bf16 + fp16 in the same TU).
+#include "ffpa_fwd_kernel.h"
+#include "ffpa_launch.h"
+
+#ifndef FFPA_INST_D
+#error "compile with -DFFPA_INST_D=<head dim>"
+#endif
+
+namespace ffpa {
+
+template <typename T, int D, int ND, bool SAFE>
+static int launch_one(const FwdArgs& a, hipStream_t stream) {
+  constexpr int BC = (ND == 1) ? 64 : 32;
+  constexpr int LDS = 2 * BC * D * 2 + (ND == 2 ? 4 * 4096 : 0);
+  auto kern = ffpa_fwd_split_d_kernel<T, D, ND, SAFE>;
+  static bool attr_done[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      (void)hipGetLastError();
+      return -2;
+    }
+    attr_done[dev] = true;
+  }
+  const unsigned grid = (unsigned)a.B * (unsigned)a.Hq * (unsigned)a.nqt;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, stream, a);
+  return (int)hipGetLastError();
+}
+
+#define FFPA_CAT2(a, b) a##b
+#define FFPA_CAT(a, b) FFPA_CAT2(a, b)
+
+int FFPA_CAT(launch_fwd_d, FFPA_INST_D)(int dtype, int safe, const FwdArgs& a, hipStream_t stream) {
+  constexpr int D = FFPA_INST_D;
+  constexpr int ND = (D <= 512) ? 1 : 2;
+#ifdef FFPA_INST_SAFE
+  if (safe) {
+    if (dtype == 0) return launch_one<__bf16, D, ND, true>(a, stream);
+    return -3;
+  }
+#else
+  if (safe) return -3;
+#endif
+  if (dtype == 0) return launch_one<__bf16, D, ND, false>(a, stream);
+  if (dtype == 1) return launch_one<_Float16, D, ND, false>(a, stream);
+  return -4;
+}
+
+void FFPA_CAT(tile_config_d, FFPA_INST_D)(int* br, int* bc, int* lds) {
+  constexpr int D = FFPA_INST_D;
+  constexpr int ND = (D <= 512) ? 1 : 2;
+  constexpr int BC = (ND == 1) ? 64 : 32;
+  *br = 32 * (4 / ND);
+  *bc = BC;
+  *lds = 2 * BC * D * 2 + (ND == 2 ? 4 * 4096 : 0);
+}
+
+}  // namespace ffpa

@@ -1,0 +1,506 @@
+// ffpa_fwd_kernel.h — Split-D fused attention forward for gfx950 (MI355X, CDNA4).
+//
+// Written from scratch for wave64 / MFMA / 160 KiB LDS / 512-register SIMDs.  The
+// algorithm (what is computed, in which order) follows the reference's native kernel
+// split_d_fwd_sm80 (csrc/cuffpa/native/sm_80/split_d.cuh:96-777) and its helpers
+// (csrc/cuffpa/native/prefill.cuh:671-1093); the mapping onto the machine does not.
+//
+// Machine mapping (see DESIGN.md for the derivation):
+//   * one workgroup = 4 waves = one wave per SIMD, each wave owns the SIMD's whole
+//     512-entry register file.  A wave owns 32 query rows and DW = D/ND output columns:
+//       ND = 1 (D <= 512):  4 waves x 32 rows           -> BR = 128 rows / workgroup
+//       ND = 2 (D  > 512):  2 row blocks x 2 D-halves   -> BR =  64 rows / workgroup
+//   * S^T = K.Q^T  (v_mfma_f32_32x32x16, A = K rows from LDS, B = Q rows from VGPRs):
+//     every lane then owns ONE query column, so the softmax row reductions are in-lane
+//     plus a single lane^32 exchange, and the C layout of S^T is already the B-operand
+//     layout of the second contraction (P never leaves registers).
+//   * O^T += V^T.P^T (A = V^T via ds_read_b64_tr_b16 from a row-major V tile in LDS,
+//     B = P^T from registers, accumulator O^T = 16*DW/32 AGPRs per lane).
+//   * Split-D: the Q.K contraction walks D in 16-wide steps against Q fragments that
+//     stay resident in VGPRs (DW/4 registers); for ND = 2 each wave contracts only its
+//     own half of D and the two partial S^T tiles are summed through LDS.  The O^T
+//     accumulator is split over D the same way, so registers + LDS stay bounded in D.
+//   * K and V tiles ([BC keys][D] bf16, BC = 64 / 32) are brought in by LDS-DMA
+//     (global_load_lds_dwordx4: no VGPR round trip); bank-conflict-avoiding XOR swizzles
+//     are applied on the per-lane SOURCE address because the DMA destination is
+//     lane-linear.  K(j+1) streams in under softmax+PV of tile j, V(j+1) under QK of
+//     tile j+1: two workgroup barriers per KV tile.
+//   * blockIdx is remapped so that all row tiles of one (batch, head) run on the same
+//     XCD at the same time and share K/V through that XCD's L2.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ffpa {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define FFPA_LDS __attribute__((address_space(3)))
+#define FFPA_GLB __attribute__((address_space(1)))
+
+constexpr unsigned kFlagNoXcdRemap = 0x2u;
+
+// Kernel argument block (host fills it from ffpa_fwd_params).
+struct FwdArgs {
+  const void* q;
+  const void* k;
+  const void* v;
+  void* o;
+  float* lse;
+  const void* bias;
+  int64_t sq[3], sk[3], sv[3], so[3];  // element strides: batch, head, row
+  int64_t sbias[4];                    // element strides: batch, head, row, key
+  int B, Hq, Hkv, Nq, Nkv;
+  int group;          // Hq / Hkv
+  int nqt;            // row tiles per (batch, head)
+  int bias_dtype;     // 0 none, 1 fp16, 2 bf16, 3 fp32
+  int causal;
+  int causal_offset;  // visible iff key <= row + causal_offset
+  float scale_log2;   // softmax_scale * log2(e)
+  float thr;          // lazy-rescale threshold, log2 units (0 = exact recurrence)
+  unsigned flags;
+};
+
+template <typename T>
+struct Elem;
+
+template <>
+struct Elem<__bf16> {
+  typedef __attribute__((ext_vector_type(8))) __bf16 v8;
+  typedef __attribute__((ext_vector_type(4))) __bf16 v4;
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  // VGPR-form MFMA for the S^T accumulator (hipcc selects the AGPR form for every builtin
+  // MFMA of a kernel, and the 256 AGPRs are exactly the O^T accumulator).  "s_nop 1" covers
+  // the VALU-write -> MFMA-operand wait states the compiler cannot see inside asm.
+  static __device__ __forceinline__ void mfma_v_first(f32x16& d, v8 a, v8 b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+  }
+  static __device__ __forceinline__ void mfma_v_acc(f32x16& d, v8 a, v8 b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+  }
+  static __device__ __forceinline__ v4 tr_read(FFPA_LDS const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((FFPA_LDS v4*)p);
+  }
+};
+
+template <>
+struct Elem<_Float16> {
+  typedef __attribute__((ext_vector_type(8))) _Float16 v8;
+  typedef __attribute__((ext_vector_type(4))) _Float16 v4;
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ void mfma_v_first(f32x16& d, v8 a, v8 b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+  }
+  static __device__ __forceinline__ void mfma_v_acc(f32x16& d, v8 a, v8 b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+  }
+  static __device__ __forceinline__ v4 tr_read(FFPA_LDS const char* p) {
+    typedef __attribute__((ext_vector_type(4))) short s4;
+    const s4 raw = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FFPA_LDS s4*)p);
+    return __builtin_bit_cast(v4, raw);
+  }
+};
+
+// ---------------------------------------------------------------------------------
+// LDS image of a K / V tile: row-major [BC][D] with a per-row XOR swizzle of the
+// 16-byte slot index (K) / the 64-byte quarter (V).  Row stride D*2 bytes.
+//   K is read with ds_read_b128 by 16-lane groups whose rows are distinct mod 16 and
+//   whose column slot is equal -> XOR the slot with a row hash that is a bijection
+//   over row mod 16 onto the slot's bank position.
+//   V is read with ds_read_b64_tr_b16: a 32-lane half reads 4 keys x 64 bytes -> the
+//   4 keys must land in the 4 different 64-byte quarters of the 256-byte bank row.
+// ---------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ int k_slot_swizzle(int key) {
+  return (D % 128 == 0) ? (key & 15) : ((key >> 1) & 7);
+}
+template <int D>
+__device__ __forceinline__ int v_slot_swizzle(int key) {  // in 16-byte slots
+  return (D % 128 == 0) ? ((key & 3) << 2) : (((key >> 1) & 1) << 2);
+}
+
+// Stage one [BC][D] tile (keys key0 .. key0+BC-1, clamped to the last valid key) into
+// LDS.  Each wave moves TILE/4 bytes as 1 KiB LDS-DMA pieces (buffer_load_dwordx4 ... lds):
+// lane i of piece p lands at lds_tile + p*1024 + i*16 (the hardware's lane-linear rule), so
+// the swizzle goes on the per-lane SOURCE offset.  `rsrc` describes the (batch, kv-head)
+// slice; offsets inside it are 32-bit (the host rejects slices of 4 GiB or more).
+template <typename T, int D, int BC, bool IS_V, bool SAFE>
+__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, const T* __restrict__ base,
+                                           uint32_t row_bytes, int key0, int nkv,
+                                           FFPA_LDS char* lds_tile, int wave, int lane) {
+  constexpr int SPR = D / 8;  // 16-byte slots per row
+  constexpr int PIECES = BC * D * 2 / 1024;
+  constexpr int PPW = PIECES / 4;
+  static_assert(PIECES % 4 == 0, "tile must split evenly over 4 waves");
+  // keep the per-lane offset arithmetic inside the tile loop: hoisted, it costs dozens of
+  // long-lived VGPRs that get spilled, and every reload drains the DMA queue (vmcnt(0)).
+  asm volatile("" : "+v"(lane));
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int p = wave * PPW + i;
+    uint32_t voff, soff;
+    if constexpr ((D * 2) % 1024 == 0) {
+      // a row is a whole number of pieces: the row (and its swizzle) is wave-uniform
+      constexpr int RPP = D * 2 / 1024;
+      const int key = p / RPP;
+      int krow = key0 + key;
+      krow = krow < nkv ? krow : nkv - 1;
+      const int sw = IS_V ? v_slot_swizzle<D>(key) : k_slot_swizzle<D>(key);
+      voff = (uint32_t)((lane ^ sw) << 4);
+      soff = (uint32_t)krow * row_bytes + (uint32_t)(p % RPP) * 1024u;
+    } else {
+      const int g = p * 64 + lane;
+      const int key = g / SPR;
+      const int slot = g - key * SPR;
+      const int src_slot = slot ^ (IS_V ? v_slot_swizzle<D>(key) : k_slot_swizzle<D>(key));
+      int krow = key0 + key;
+      krow = krow < nkv ? krow : nkv - 1;
+      voff = (uint32_t)krow * row_bytes + (uint32_t)(src_slot << 4);
+      soff = 0;
+    }
+    if constexpr (!SAFE) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (FFPA_LDS void*)(lds_tile + p * 1024), 16, voff, soff, 0, 0);
+    } else {
+      const u32x4 x = *(const u32x4*)((const char*)base + (size_t)voff + (size_t)soff);
+      *(FFPA_LDS u32x4*)(lds_tile + p * 1024 + lane * 16) = x;
+    }
+  }
+}
+
+// Additive bias for the 16 scores one lane holds of a 32-key block:
+// x[r] += bias[row][k0 + (r&3) + 8 (r>>2) + 4 h] * log2(e)   (prefill.cuh:556-658; here the
+// bias is added after the scale instead of being pre-divided by it — same value).
+template <typename BT>
+__device__ __forceinline__ void add_bias_block(float (&x)[16], const void* bias, int64_t row_off,
+                                               int64_t stride_key, int key_base, int nkv) {
+  const BT* bp = (const BT*)bias + row_off;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int key = key_base + (r & 3) + 8 * (r >> 2);
+    key = key < nkv ? key : nkv - 1;
+    x[r] += (float)bp[key * stride_key] * 1.4426950408889634f;
+  }
+}
+
+template <typename T, int D, int ND, bool SAFE>
+__global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) {
+  using E = Elem<T>;
+  using v8 = typename E::v8;
+  using v4 = typename E::v4;
+  static_assert(ND == 1 || ND == 2, "D is split over at most two waves");
+  static_assert(D % 64 == 0, "head dim must be a multiple of 64");
+  constexpr int DW = D / ND;       // output columns owned by one wave
+  constexpr int NDB = DW / 32;     // 32-column O^T blocks per wave
+  constexpr int KS = DW / 16;      // QK contraction steps per wave
+  constexpr int BC = (ND == 1) ? 64 : 32;
+  constexpr int NKB = BC / 32;     // 32-key S^T blocks per tile
+  constexpr int NKS = BC / 16;     // PV contraction steps per tile
+  constexpr int NQB = 4 / ND;      // 32-row blocks per workgroup
+  constexpr int BR = 32 * NQB;
+  constexpr int RB = D * 2;        // tile row bytes
+  constexpr int TILE = BC * RB;
+  constexpr int PF1 = 6;           // QK: LDS reads run this many MFMAs ahead
+  constexpr int PF2 = 4;           // PV: ditto (two transpose reads per MFMA)
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  FFPA_LDS char* const Kt = (FFPA_LDS char*)smem;
+  FFPA_LDS char* const Vt = Kt + TILE;
+  FFPA_LDS char* const Xb = Kt + 2 * TILE;  // ND == 2: partial-S exchange, 4 KiB per wave
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31;
+  const int h = lane >> 5;
+  const int qb = (ND == 1) ? wave : (wave >> 1);
+  const int dh = (ND == 1) ? 0 : (wave & 1);
+
+  // ---- workgroup -> (batch, head, row tile).  Block b runs on XCD b % 8; give every
+  // XCD a contiguous range of virtual ids so that the row tiles of one head (which
+  // stream the same K/V) are co-resident on one XCD and hit in its L2.
+  int vid = blockIdx.x;
+  if (!(a.flags & kFlagNoXcdRemap)) {
+    const int total = gridDim.x;
+    const int xcd = vid & 7;
+    const int idx = vid >> 3;
+    const int per = total >> 3;
+    const int rem = total & 7;
+    vid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
+  }
+  const int bh = vid / a.nqt;
+  int qt = vid - bh * a.nqt;
+  if (a.causal) qt = a.nqt - 1 - qt;  // longest rows first
+  const int b = bh / a.Hq;
+  const int hq = bh - b * a.Hq;
+  const int hkv = hq / a.group;
+
+  const int q0 = qt * BR;
+  const int wq0 = q0 + qb * 32;
+  const int qrow = wq0 + l31;
+  const int qrow_c = qrow < a.Nq ? qrow : a.Nq - 1;
+
+  const T* __restrict__ Kg = (const T*)a.k + b * a.sk[0] + hkv * a.sk[1];
+  const T* __restrict__ Vg = (const T*)a.v + b * a.sv[0] + hkv * a.sv[1];
+  // buffer descriptors over this (batch, kv-head) slice (0x00020000: raw 32-bit dwords)
+  const uint32_t k_row_bytes = (uint32_t)a.sk[2] * 2u;
+  const uint32_t v_row_bytes = (uint32_t)a.sv[2] * 2u;
+  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)Kg, 0, (uint32_t)(a.Nkv - 1) * k_row_bytes + (uint32_t)RB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)Vg, 0, (uint32_t)(a.Nkv - 1) * v_row_bytes + (uint32_t)RB, 0x00020000);
+
+  // ---- KV tile range (split_d.cuh:222-228: causal tiles past the diagonal are skipped)
+  int nt = (a.Nkv + BC - 1) / BC;
+  if (a.causal) {
+    const int64_t last = (int64_t)q0 + BR - 1 + a.causal_offset;
+    const int ntc = last < 0 ? 0 : (int)(last / BC) + 1;
+    nt = nt < ntc ? nt : ntc;
+  }
+
+  // ---- Q fragments: B operand of S^T = K.Q^T.  lane (row l31, half h) holds
+  // Q[row][dh*DW + 16 s + 8 h .. +8] for every contraction step s.
+  v8 qf[KS];
+  {
+    const T* qp = (const T*)a.q + b * a.sq[0] + hq * a.sq[1] + (int64_t)qrow_c * a.sq[2] + dh * DW + h * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[s] = *(const v8*)(qp + s * 16);
+  }
+
+  f32x16 oacc[NDB];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i) oacc[i] = (f32x16)(0.f);
+  float m_run = -INFINITY;  // running row max, log2 domain (includes softmax_scale)
+  float l_run = 0.f;        // this lane's share of the row sum (other share: lane ^ 32)
+
+  // ---- per-lane LDS addresses, hoisted so that the MFMA loops carry only immediates.
+  // K fragment of step s = 8 q + i, key block kb:  kaddr[i] + 256 q + kb*32*RB
+  //   (slot (c0 + 2 s + h) ^ kx: adding 16 q slots commutes with a 4-bit XOR)
+  FFPA_LDS const char* kaddr[8];
+  {
+    const int kx = k_slot_swizzle<D>(l31);
+    const int c0 = dh * (DW / 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kaddr[i] = Kt + l31 * RB + (((c0 + 2 * i + h) ^ kx) << 4);
+  }
+  // V^T fragment of column block db = 4 q + i, step ks, half hh: vaddr[i] + 256 q + (16 ks + 8 hh)*RB
+  FFPA_LDS const char* vaddr[4];
+  {
+    const int j4 = (lane & 15) >> 2;
+    const int vsw = v_slot_swizzle<D>(j4) * 16;
+    const int vcol = dh * DW * 2 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;  // bytes
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vaddr[i] = Vt + (4 * h + j4) * RB + ((vcol + i * 64) ^ vsw);
+  }
+
+  if (nt > 0) {
+    stage_tile<T, D, BC, false, SAFE>(k_rsrc, Kg, k_row_bytes, 0, a.Nkv, Kt, wave, lane);
+    __syncthreads();  // K(0) landed (the barrier's release waits vmcnt(0)) and visible
+    stage_tile<T, D, BC, true, SAFE>(v_rsrc, Vg, v_row_bytes, 0, a.Nkv, Vt, wave, lane);
+  }
+
+  for (int j = 0; j < nt; ++j) {
+    const int k0 = j * BC;
+
+    // ================= S^T = K.Q^T over this wave's part of D =================
+    // LDS reads run PF1 MFMAs ahead of their consumer; sched_barrier fences pin that
+    // order (left alone, the scheduler hoists every read and spills).
+    f32x16 sacc[NKB];
+    {
+      constexpr int N1 = KS * NKB;
+      v8 kf[N1];
+      auto k_frag = [&](int n) -> v8 {
+        const int s = n / NKB, kb = n % NKB;
+        return *(FFPA_LDS const v8*)(kaddr[s & 7] + (s >> 3) * 256 + kb * 32 * RB);
+      };
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int n = 0; n < PF1 && n < N1; ++n) kf[n] = k_frag(n);
+#pragma unroll
+      for (int n = 0; n < N1; ++n) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (n + PF1 < N1) kf[n + PF1] = k_frag(n + PF1);
+        const int s = n / NKB, kb = n % NKB;
+        if (s == 0) E::mfma_v_first(sacc[kb], kf[n], qf[s]);
+        else E::mfma_v_acc(sacc[kb], kf[n], qf[s]);
+      }
+      // MFMA result -> VALU reader wait states (invisible to the compiler inside asm)
+      if constexpr (NKB == 2) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sacc[0]), "+v"(sacc[1]));
+      else asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sacc[0]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    if constexpr (ND == 2) {  // publish this wave's partial S^T (lane-linear, conflict free)
+      FFPA_LDS char* xw = Xb + wave * 4096 + lane * 16;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        f32x4 t = {sacc[0][4 * r4], sacc[0][4 * r4 + 1], sacc[0][4 * r4 + 2], sacc[0][4 * r4 + 3]};
+        *(FFPA_LDS f32x4*)(xw + r4 * 1024) = t;
+      }
+    }
+
+    // barrier A: every wave is done reading K(j); V(j) has landed; partials visible
+    __syncthreads();
+    if (j + 1 < nt) stage_tile<T, D, BC, false, SAFE>(k_rsrc, Kg, k_row_bytes, k0 + BC, a.Nkv, Kt, wave, lane);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // lane holds x[kb][r] = score(row qrow, key k0 + 32 kb + (r&3) + 8 (r>>2) + 4 h)
+    float x[NKB][16];
+    if constexpr (ND == 2) {
+      FFPA_LDS const char* xr = Xb + (wave ^ 1) * 4096 + lane * 16;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const f32x4 t = *(FFPA_LDS const f32x4*)(xr + r4 * 1024);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[0][4 * r4 + e] = (sacc[0][4 * r4 + e] + t[e]) * a.scale_log2;
+      }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[kb][r] = sacc[kb][r] * a.scale_log2;
+    }
+
+    // ================= score modifiers (split_d.cuh:506-539) =================
+    if (a.bias_dtype != 0) {
+      const int64_t brow = b * a.sbias[0] + hq * a.sbias[1] + (int64_t)qrow_c * a.sbias[2];
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const int kbase = k0 + kb * 32 + 4 * h;
+        if (a.bias_dtype == 3) add_bias_block<float>(x[kb], a.bias, brow, a.sbias[3], kbase, a.Nkv);
+        else if (a.bias_dtype == 2) add_bias_block<__bf16>(x[kb], a.bias, brow, a.sbias[3], kbase, a.Nkv);
+        else add_bias_block<_Float16>(x[kb], a.bias, brow, a.sbias[3], kbase, a.Nkv);
+      }
+    }
+    const bool tail = k0 + BC > a.Nkv;
+    const bool diag = a.causal && ((int64_t)k0 + BC - 1 > (int64_t)wq0 + a.causal_offset);
+    if (tail || diag) {
+      const int64_t lim = a.causal ? (int64_t)qrow + a.causal_offset : (int64_t)a.Nkv;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (key >= a.Nkv || key > lim) x[kb][r] = -INFINITY;
+        }
+    }
+
+    // ================= online softmax (prefill.cuh:671-870, log2 domain) =================
+    float tmax = x[0][0];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, x[kb][r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m_run, tmax);
+    // lazy rescale: keep the stale max while it grew by <= thr (prefill.cuh:684-755);
+    // the first finite max always takes the branch (m_run = -inf).
+    const bool grow = m_new > m_run + a.thr;
+    if (__any(grow)) {
+      const float alpha = grow ? __builtin_amdgcn_exp2f(m_run - m_new) : 1.f;
+      if (j > 0) {
+        // Rare path.  O^T lives in AGPRs, which the VALU cannot address: scale it in place
+        // through one temporary VGPR.  Written as asm on "+a" operands so the accumulator
+        // never acquires a VGPR live range (which makes hipcc spill the whole hot loop).
+#pragma unroll
+        for (int i = 0; i < NDB; ++i) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float e = oacc[i][r];
+            float t;
+            asm volatile(
+                "v_accvgpr_read_b32 %1, %0\n\ts_nop 1\n\tv_mul_f32 %1, %1, %2\n\ts_nop 1\n\t"
+                "v_accvgpr_write_b32 %0, %1"
+                : "+a"(e), "=&v"(t)
+                : "v"(alpha));
+            oacc[i][r] = e;
+          }
+        }
+      }
+      l_run *= alpha;
+      m_run = grow ? m_new : m_run;
+    }
+    const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
+
+    v8 pf[NKS];
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(x[kb][r] - m_use);
+        psum += p;  // row sum from the unrounded P (prefill.cuh:755-756)
+        // contraction slot (h, r & 7) of step 2 kb + (r >> 3) <-> this register: any
+        // permutation of the key index is free as long as V^T uses the same one.
+        pf[kb * 2 + (r >> 3)][r & 7] = (T)p;
+      }
+    l_run += psum;
+
+    // ================= O^T += V^T.P^T =================
+    {
+      constexpr int N2 = NDB * NKS;
+      v8 vf[N2];
+      auto v_frag = [&](int n) -> v8 {
+        const int db = n / NKS, ks = n % NKS;
+        if constexpr (!SAFE) {
+          FFPA_LDS const char* vp = vaddr[db & 3] + (db >> 2) * 256 + (ks * 16) * RB;
+          const v4 lo = E::tr_read(vp);
+          const v4 hi = E::tr_read(vp + 8 * RB);
+          return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        } else {
+          v8 r;
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) {
+            const int key = ks * 16 + 8 * (jj >> 2) + 4 * h + (jj & 3);
+            const int byte = (dh * DW + db * 32 + l31) * 2;
+            const int off = byte ^ (v_slot_swizzle<D>(key) * 16);
+            r[jj] = *(FFPA_LDS const T*)(Vt + key * RB + off);
+          }
+          return r;
+        }
+      };
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int n = 0; n < PF2 && n < N2; ++n) vf[n] = v_frag(n);
+#pragma unroll
+      for (int n = 0; n < N2; ++n) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (n + PF2 < N2) vf[n + PF2] = v_frag(n + PF2);
+        oacc[n / NKS] = E::mfma(vf[n], pf[n % NKS], oacc[n / NKS]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // barrier B: every wave is done reading V(j); K(j+1) has landed and is visible
+    __syncthreads();
+    if (j + 1 < nt) stage_tile<T, D, BC, true, SAFE>(v_rsrc, Vg, v_row_bytes, k0 + BC, a.Nkv, Vt, wave, lane);
+  }
+
+  // ================= epilogue (prefill.cuh:1018-1093) =================
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = __builtin_amdgcn_rcpf(l_tot);  // fully masked row: 0 * inf = NaN, as SDPA
+  if (qrow < a.Nq) {
+    T* op = (T*)a.o + b * a.so[0] + hq * a.so[1] + (int64_t)qrow * a.so[2] + dh * DW + 4 * h;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v4 w;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w[t] = (T)(oacc[db][4 * i + t] * inv);
+        *(v4*)(op + db * 32 + 8 * i) = w;
+      }
+    if (a.lse != nullptr && h == 0 && dh == 0) {
+      // natural-log LSE = ln(l) + m*ln2 (prefill.cuh:1063-1073)
+      a.lse[((int64_t)b * a.Hq + hq) * a.Nq + qrow] = __logf(l_tot) + m_run * 0.6931471805599453f;
+    }
+  }
+}
+
+}  // namespace ffpa

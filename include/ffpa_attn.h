@@ -1,0 +1,158 @@
+/*
+ * ffpa_attn.h — C-ABI of the MI355X (gfx950) fused attention forward.
+ *
+ * This is the drop-in boundary for the ONE hot path this repo accelerates:
+ * the large-headdim Split-D attention forward that the reference reaches via
+ *
+ *   torch.ops.ffpa_attn._fwd_cuda            (src/ffpa_attn/cuda/__init__.py:57-139)
+ *     -> ffpa_attn._C.ffpa_attn_forward      (csrc/cuffpa/ffpa_api.cc:86-239, pybind :265-306)
+ *       -> launch_ffpa_attn_fwd_template     (csrc/cuffpa/launch.cuh:61-606)
+ *         -> split_d_fwd_sm80 & friends      (csrc/cuffpa/native/sm_80/split_d.cuh:96-777)
+ *
+ * Every entry point is extern "C", takes plain pointers / sizes / strides and
+ * a hipStream_t passed as void*.  No torch types, no allocation, no device
+ * synchronisation, no global mutable state: the caller owns every buffer and
+ * picks the stream.  Each function cites the reference interface it replaces.
+ */
+#ifndef FFPA_ATTN_H_
+#define FFPA_ATTN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFPA_ATTN_ABI_VERSION 1
+
+/* status codes (0 == success).  The Python host maps them onto the exception
+ * classes the reference raises (TORCH_CHECK -> RuntimeError,
+ * std::invalid_argument -> ValueError; ffpa_api.cc:193-197, env.py:750-752). */
+enum ffpa_status {
+  FFPA_OK = 0,
+  FFPA_ERR_NULL_POINTER = 1,      /* q/k/v/o missing                                   */
+  FFPA_ERR_BAD_DTYPE = 2,         /* dtype not bf16/fp16, or bias dtype unknown         */
+  FFPA_ERR_BAD_HEADDIM = 3,       /* "headdim not support!" (env.py:750-752)            */
+  FFPA_ERR_BAD_SHAPE = 4,         /* non-positive dims, Hq % Hkv != 0                   */
+  FFPA_ERR_BAD_STRIDE = 5,        /* stride not a multiple of 8 elements / too large    */
+  FFPA_ERR_MISALIGNED = 6,        /* base pointer not 16-byte aligned                   */
+  FFPA_ERR_UNSUPPORTED = 7,       /* feature not built (e.g. dropout)                   */
+  FFPA_ERR_LAUNCH = 8,            /* hipGetLastError() after the launch                 */
+  FFPA_ERR_NO_DEVICE = 9,         /* current device is not gfx950                       */
+  FFPA_ERR_BAD_ABI = 10           /* struct_size / abi_version mismatch                 */
+};
+
+enum ffpa_dtype { FFPA_DTYPE_BF16 = 0, FFPA_DTYPE_FP16 = 1 };
+
+/* attn_bias element type.  Same codes as the reference's native launcher
+ * (csrc/cuffpa/native/launch.cuh:279-281): 0 none, 1 fp16, 2 bf16, 3 fp32. */
+enum ffpa_bias_dtype {
+  FFPA_BIAS_NONE = 0,
+  FFPA_BIAS_FP16 = 1,
+  FFPA_BIAS_BF16 = 2,
+  FFPA_BIAS_FP32 = 3
+};
+
+/* ffpa_fwd_params.flags */
+#define FFPA_FLAG_DEBUG_SAFE_PATH 0x1u /* test-only: register-staged K/V + scalar V gather  */
+#define FFPA_FLAG_NO_XCD_REMAP    0x2u /* bench-only: dispatch-order block mapping          */
+
+/*
+ * One forward call.  Layout contract (replaces the dense-[B,H,N,D] assumption of
+ * split_d.cuh:137-142): element strides for the batch / head / sequence dims,
+ * headdim stride 1, every row 16-byte aligned (D % 8 == 0, strides % 8 == 0).
+ *
+ *   q  [B, Hq,  Nq,  D]     k, v [B, Hkv, Nkv, D]     o [B, Hq, Nq, D]
+ *   lse  [B, Hq, Nq] fp32 contiguous, natural log, may be NULL (cuda/__init__.py:102-112)
+ *   bias [B|1, Hq|1, Nq|1, Nkv|1] additive, stride 0 on broadcast dims
+ *        (native/launch.cuh:277-290); NULL <=> bias_dtype == FFPA_BIAS_NONE.
+ *
+ * Score = scale * q.k + bias ; masked iff (causal && key > row + causal_offset)
+ * or key >= Nkv.  causal_offset = Nkv - Nq reproduces the reference's
+ * tail-aligned causal mask (split_d.cuh:222-228); 0 reproduces PyTorch SDPA's
+ * top-left alignment (SURVEY.md §8 "config-4 semantic trap").
+ */
+typedef struct ffpa_fwd_params {
+  uint32_t struct_size; /* sizeof(ffpa_fwd_params), checked */
+  uint32_t abi_version; /* FFPA_ATTN_ABI_VERSION            */
+
+  const void* q;
+  const void* k;
+  const void* v;
+  void* o;
+  float* lse;       /* optional */
+  const void* bias; /* optional */
+
+  int32_t batch;       /* B   */
+  int32_t heads_q;     /* Hq  */
+  int32_t heads_kv;    /* Hkv */
+  int32_t seqlen_q;    /* Nq  */
+  int32_t seqlen_kv;   /* Nkv */
+  int32_t head_dim;    /* D   */
+
+  int64_t q_stride[3];    /* elements: batch, head, row */
+  int64_t k_stride[3];
+  int64_t v_stride[3];
+  int64_t o_stride[3];
+  int64_t bias_stride[4]; /* elements: batch, head, row, key (0 = broadcast) */
+
+  int32_t dtype;         /* enum ffpa_dtype      */
+  int32_t bias_dtype;    /* enum ffpa_bias_dtype */
+  int32_t causal;        /* 0 / 1                */
+  int32_t causal_offset; /* visible iff key <= row + causal_offset */
+
+  float softmax_scale;     /* applied to q.k before softmax                       */
+  float rescale_threshold; /* lazy-rescale threshold in log2 units; <0 => default
+                              8.0 (FFPA_RESCALE_THRESHOLD, csrc/cuffpa/common.cuh:14);
+                              0 => exact recurrence                                */
+  float dropout_p;         /* must be 0 in ABI v1 (FFPA_ERR_UNSUPPORTED otherwise) */
+  uint32_t flags;
+
+  uint64_t philox_seed;   /* reserved for dropout (prefill.cuh:398-546) */
+  uint64_t philox_offset;
+} ffpa_fwd_params;
+
+/*
+ * Launch the fused forward on `stream` (a hipStream_t; NULL = default stream) of
+ * the CURRENT device.  Asynchronous; returns an ffpa_status.
+ * Replaces: ffpa_attn._C.ffpa_attn_forward (csrc/cuffpa/ffpa_api.cc:86-239).
+ */
+int ffpa_attn_fwd(const ffpa_fwd_params* params, void* stream);
+
+/*
+ * Scratch bytes the call needs (caller allocates; 0 in ABI v1).  Replaces the
+ * in-launcher allocations of native/launch.cuh:314-318,503-509.
+ */
+size_t ffpa_attn_fwd_workspace_bytes(const ffpa_fwd_params* params);
+
+/* Capability / build queries.  Replaces the module attributes
+ * CUDA_FWD_AVAILABLE, F16_ACC_AVAILABLE, ... (csrc/cuffpa/ffpa_api.cc:283-305). */
+enum ffpa_query {
+  FFPA_QUERY_ABI_VERSION = 0,
+  FFPA_QUERY_FWD_AVAILABLE = 1,   /* 1 if the gfx950 kernels are in this build */
+  FFPA_QUERY_MIN_HEAD_DIM = 2,    /* 64   */
+  FFPA_QUERY_MAX_HEAD_DIM = 3,    /* 1024 */
+  FFPA_QUERY_HEAD_DIM_MULTIPLE = 4, /* 64: other D are zero-padded by the host */
+  FFPA_QUERY_FP16_AVAILABLE = 5,
+  FFPA_QUERY_DROPOUT_AVAILABLE = 6,
+  FFPA_QUERY_DEBUG_KERNELS = 7    /* 1 if FFPA_FLAG_DEBUG_SAFE_PATH kernels are built */
+};
+int ffpa_attn_query(int what);
+
+/* Tile geometry the kernel uses for a head dim (for benches / roofline maths).
+ * Returns 0 and fills rows-per-workgroup / keys-per-tile / dynamic LDS bytes,
+ * or FFPA_ERR_BAD_HEADDIM. */
+int ffpa_attn_fwd_tile_config(int head_dim, int* block_rows, int* block_keys,
+                              int* lds_bytes);
+
+/* Human-readable text for the last non-zero status on this thread. */
+const char* ffpa_attn_last_error(void);
+
+/* "ffpa-attn-amd <semver> gfx950" */
+const char* ffpa_attn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFPA_ATTN_H_ */
