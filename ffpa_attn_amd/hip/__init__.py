@@ -1,0 +1,364 @@
+"""``ffpa_attn::_fwd_hip`` — the torch-facing shim over the C-ABI HIP library.
+
+This module is the MI355X replacement for the reference's CUDA op shim
+(``src/ffpa_attn/cuda/__init__.py:57-171`` + ``cuda/_ffpa_fwd.py:6-62``):
+
+* it loads ``libffpa_attn_hip.so`` (built in-tree by :mod:`ffpa_attn_amd.build`) with
+  ``ctypes`` — the library has no torch dependency, the boundary is
+  ``include/ffpa_attn.h``;
+* it registers the torch.library op ``ffpa_attn::_fwd_hip`` whose first eleven
+  arguments are the reference op's (``q, k, v, attn_bias, stages, acc, causal,
+  softmax_scale, dropout_p, philox_seed, philox_offset``) and which returns
+  ``(o, softmax_lse)`` with ``softmax_lse`` an exact-length ``[B, Hq, Nq]`` fp32 tensor
+  (``cuda/__init__.py:100-112``);
+* it registers a fake (meta) implementation so ``torch.compile`` can trace through.
+
+There is NO fallback in here: if the library is missing or was not built for this GPU
+the op raises ``RuntimeError`` (the reference raises the same class when ``_C`` was not
+compiled, ``cuda/__init__.py:94-99``).
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_PKG, "libffpa_attn_hip.so")
+
+ABI_VERSION = 1
+
+# enum ffpa_status (include/ffpa_attn.h)
+_STATUS_EXC = {
+  1: RuntimeError,  # NULL pointer
+  2: TypeError,  # dtype
+  3: RuntimeError,  # "headdim not support!" (env.py:750-752 -> std::runtime_error)
+  4: ValueError,  # shape
+  5: ValueError,  # stride
+  6: ValueError,  # alignment
+  7: NotImplementedError,  # unsupported feature
+  8: RuntimeError,  # launch failure
+  9: RuntimeError,  # no device
+  10: RuntimeError,  # ABI mismatch
+}
+
+FLAG_DEBUG_SAFE_PATH = 0x1
+FLAG_NO_XCD_REMAP = 0x2
+
+_BIAS_DTYPE = {torch.float16: 1, torch.bfloat16: 2, torch.float32: 3}
+_DTYPE = {torch.bfloat16: 0, torch.float16: 1}
+
+
+class FfpaFwdParams(ctypes.Structure):
+  """ctypes mirror of ``struct ffpa_fwd_params`` (include/ffpa_attn.h)."""
+
+  _fields_ = [
+    ("struct_size", ctypes.c_uint32),
+    ("abi_version", ctypes.c_uint32),
+    ("q", ctypes.c_void_p),
+    ("k", ctypes.c_void_p),
+    ("v", ctypes.c_void_p),
+    ("o", ctypes.c_void_p),
+    ("lse", ctypes.c_void_p),
+    ("bias", ctypes.c_void_p),
+    ("batch", ctypes.c_int32),
+    ("heads_q", ctypes.c_int32),
+    ("heads_kv", ctypes.c_int32),
+    ("seqlen_q", ctypes.c_int32),
+    ("seqlen_kv", ctypes.c_int32),
+    ("head_dim", ctypes.c_int32),
+    ("q_stride", ctypes.c_int64 * 3),
+    ("k_stride", ctypes.c_int64 * 3),
+    ("v_stride", ctypes.c_int64 * 3),
+    ("o_stride", ctypes.c_int64 * 3),
+    ("bias_stride", ctypes.c_int64 * 4),
+    ("dtype", ctypes.c_int32),
+    ("bias_dtype", ctypes.c_int32),
+    ("causal", ctypes.c_int32),
+    ("causal_offset", ctypes.c_int32),
+    ("softmax_scale", ctypes.c_float),
+    ("rescale_threshold", ctypes.c_float),
+    ("dropout_p", ctypes.c_float),
+    ("flags", ctypes.c_uint32),
+    ("philox_seed", ctypes.c_uint64),
+    ("philox_offset", ctypes.c_uint64),
+  ]
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+EXPORTS = (
+  "ffpa_attn_fwd",
+  "ffpa_attn_fwd_workspace_bytes",
+  "ffpa_attn_query",
+  "ffpa_attn_fwd_tile_config",
+  "ffpa_attn_last_error",
+  "ffpa_attn_version",
+)
+
+
+def load_library(path: str | None = None) -> ctypes.CDLL:
+  """dlopen the C-ABI library (after torch, so both share one HIP runtime) and bind
+  every symbol ``include/ffpa_attn.h`` declares.  Raises ``RuntimeError`` if it is missing.
+  """
+  global _lib
+  if _lib is not None and path is None:
+    return _lib
+  with _lib_lock:
+    if _lib is not None and path is None:
+      return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+      raise RuntimeError(
+        f"ffpa_attn_amd: {p} not found. The HIP extension is required (there is no fallback "
+        "kernel): build it with `python -m ffpa_attn_amd.build` (needs hipcc, targets gfx950)."
+      )
+    lib = ctypes.CDLL(p)
+    lib.ffpa_attn_fwd.argtypes = [ctypes.POINTER(FfpaFwdParams), ctypes.c_void_p]
+    lib.ffpa_attn_fwd.restype = ctypes.c_int
+    lib.ffpa_attn_fwd_workspace_bytes.argtypes = [ctypes.POINTER(FfpaFwdParams)]
+    lib.ffpa_attn_fwd_workspace_bytes.restype = ctypes.c_size_t
+    lib.ffpa_attn_query.argtypes = [ctypes.c_int]
+    lib.ffpa_attn_query.restype = ctypes.c_int
+    lib.ffpa_attn_fwd_tile_config.argtypes = [
+      ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)
+    ]
+    lib.ffpa_attn_fwd_tile_config.restype = ctypes.c_int
+    lib.ffpa_attn_last_error.argtypes = []
+    lib.ffpa_attn_last_error.restype = ctypes.c_char_p
+    lib.ffpa_attn_version.argtypes = []
+    lib.ffpa_attn_version.restype = ctypes.c_char_p
+    if lib.ffpa_attn_query(0) != ABI_VERSION:
+      raise RuntimeError(f"ffpa_attn_amd: {p} has ABI {lib.ffpa_attn_query(0)}, expected {ABI_VERSION}")
+    if path is None:
+      _lib = lib
+    return lib
+
+
+def library_available() -> bool:
+  return os.path.exists(LIB_PATH)
+
+
+def tile_config(head_dim: int) -> dict:
+  """Rows per workgroup / keys per tile / LDS bytes the kernel uses for ``head_dim``."""
+  lib = load_library()
+  br, bc, lds = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+  rc = lib.ffpa_attn_fwd_tile_config(int(head_dim), ctypes.byref(br), ctypes.byref(bc), ctypes.byref(lds))
+  if rc != 0:
+    raise _STATUS_EXC.get(rc, RuntimeError)(lib.ffpa_attn_last_error().decode())
+  return {"block_rows": br.value, "block_keys": bc.value, "lds_bytes": lds.value}
+
+
+def padded_head_dim(d: int) -> int:
+  """Head dims are built in multiples of 64; others are zero-padded like the reference
+  pads to its compiled multiples (csrc/cuffpa/ffpa_api.cc:123-161)."""
+  return ((d + 63) // 64) * 64
+
+
+def _dense_rows(t: torch.Tensor) -> torch.Tensor:
+  """Make ``t`` satisfy the layout contract: headdim stride 1, all other strides multiples of
+  8 elements, 16-byte aligned base (split_d.cuh:137-142 assumed dense [B,H,N,D]; here arbitrary
+  batch/head/row strides are honoured and only pathological views are copied)."""
+  ok = t.stride(-1) == 1 and all(s % 8 == 0 for s in t.stride()[:-1]) and t.data_ptr() % 16 == 0
+  if ok and t.dim() == 4 and t.size(2) > 1 and t.stride(2) < t.size(3):
+    ok = False  # overlapping rows
+  return t if ok else t.contiguous()
+
+
+def forward(
+  q: torch.Tensor,
+  k: torch.Tensor,
+  v: torch.Tensor,
+  attn_bias: torch.Tensor | None,
+  causal: bool,
+  softmax_scale: float,
+  *,
+  causal_offset: int | None = None,
+  rescale_threshold: float = -1.0,
+  dropout_p: float = 0.0,
+  philox_seed: int = 0,
+  philox_offset: int = 0,
+  flags: int = 0,
+  return_lse: bool = True,
+) -> tuple[torch.Tensor, torch.Tensor | None]:
+  """Run the gfx950 kernel on the current stream of ``q.device``; returns ``(o, lse)``.
+
+  Inputs are ``[B, H, N, D]`` bf16/fp16 device tensors.  ``causal_offset=None`` selects the
+  reference's tail-aligned causal mask (``Nkv - Nq``, split_d.cuh:222-228).
+  """
+  if not q.is_cuda:
+    raise NotImplementedError(
+      f"ffpa_attn::_fwd_hip has no implementation for device '{q.device.type}' (the HIP kernel needs a GPU tensor)"
+    )
+  lib = load_library()
+  if q.dtype not in _DTYPE or k.dtype != q.dtype or v.dtype != q.dtype:
+    raise TypeError(f"ffpa_attn::_fwd_hip only supports fp16/bf16 q/k/v of one dtype, got {q.dtype}, {k.dtype}, {v.dtype}")
+  B, Hq, Nq, D = q.shape
+  _, Hkv, Nkv, _ = k.shape
+  Dp = padded_head_dim(D)
+  if Dp != D:
+    pad = (0, Dp - D)
+    q, k, v = (torch.nn.functional.pad(t, pad) for t in (q, k, v))
+  q, k, v = _dense_rows(q), _dense_rows(k), _dense_rows(v)
+  o = torch.empty((B, Hq, Nq, Dp), dtype=q.dtype, device=q.device)
+  lse = torch.empty((B, Hq, Nq), dtype=torch.float32, device=q.device) if return_lse else None
+
+  p = FfpaFwdParams()
+  p.struct_size = ctypes.sizeof(FfpaFwdParams)
+  p.abi_version = ABI_VERSION
+  p.q, p.k, p.v, p.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
+  p.lse = lse.data_ptr() if lse is not None else None
+  p.batch, p.heads_q, p.heads_kv = B, Hq, Hkv
+  p.seqlen_q, p.seqlen_kv, p.head_dim = Nq, Nkv, Dp
+  for name, t in (("q_stride", q), ("k_stride", k), ("v_stride", v), ("o_stride", o)):
+    getattr(p, name)[:] = list(t.stride()[:3])
+  if attn_bias is not None and attn_bias.numel() > 0:
+    if attn_bias.dim() != 4:
+      raise ValueError("attn_bias must be 4-D [B|1, Hq|1, Nq|1, Nkv|1]")
+    if attn_bias.dtype not in _BIAS_DTYPE:
+      raise TypeError(f"attn_bias dtype must be fp16/bf16/fp32, got {attn_bias.dtype}")
+    full = (B, Hq, Nq, Nkv)
+    strides = []
+    for dim in range(4):
+      if attn_bias.size(dim) == full[dim]:
+        strides.append(attn_bias.stride(dim) if full[dim] > 1 else 0)
+      elif attn_bias.size(dim) == 1:
+        strides.append(0)  # broadcast dims use stride 0 (native/launch.cuh:277-290)
+      else:
+        raise ValueError(f"attn_bias dim {dim} must be 1 or {full[dim]}, got {attn_bias.size(dim)}")
+    p.bias = attn_bias.data_ptr()
+    p.bias_dtype = _BIAS_DTYPE[attn_bias.dtype]
+    p.bias_stride[:] = strides
+  else:
+    p.bias = None
+    p.bias_dtype = 0
+  p.dtype = _DTYPE[q.dtype]
+  p.causal = 1 if causal else 0
+  p.causal_offset = int(Nkv - Nq if causal_offset is None else causal_offset)
+  p.softmax_scale = float(softmax_scale)
+  p.rescale_threshold = float(rescale_threshold)
+  p.dropout_p = float(dropout_p)
+  p.flags = int(flags)
+  p.philox_seed = int(philox_seed) & 0xFFFFFFFFFFFFFFFF
+  p.philox_offset = int(philox_offset) & 0xFFFFFFFFFFFFFFFF
+
+  with torch.cuda.device(q.device):
+    stream = torch.cuda.current_stream(q.device).cuda_stream
+    rc = lib.ffpa_attn_fwd(ctypes.byref(p), ctypes.c_void_p(stream))
+  if rc != 0:
+    raise _STATUS_EXC.get(rc, RuntimeError)(f"ffpa_attn_fwd: {lib.ffpa_attn_last_error().decode()} (status {rc})")
+  if Dp != D:
+    o = o[..., :D]
+  return o, lse
+
+
+# ----------------------------------------------------------------------------------
+# torch.library op.  Same leading schema as ffpa_attn::_fwd_cuda
+# (src/ffpa_attn/cuda/__init__.py:57-66); the fp8/fp4 tail of that schema is dropped
+# (bf16/fp16 only) and two trailing knobs are added with defaults.
+# ----------------------------------------------------------------------------------
+_OP_NAMESPACE = "ffpa_attn"
+
+torch.library.define(
+  f"{_OP_NAMESPACE}::_fwd_hip",
+  "(Tensor q, Tensor k, Tensor v, Tensor attn_bias, int stages, int acc, int causal, "
+  "float softmax_scale, float dropout_p, int philox_seed, int philox_offset, "
+  "int causal_offset=-2147483648, float rescale_threshold=-1.0) -> (Tensor o, Tensor softmax_lse)",
+)
+
+_AUTO_OFFSET = -2147483648
+
+
+@torch.library.impl(f"{_OP_NAMESPACE}::_fwd_hip", "CUDA")  # ROCm tensors dispatch on the CUDA key
+def _fwd_hip_torch_op(
+  q,
+  k,
+  v,
+  attn_bias,
+  stages,
+  acc,
+  causal,
+  softmax_scale,
+  dropout_p,
+  philox_seed,
+  philox_offset,
+  causal_offset=_AUTO_OFFSET,
+  rescale_threshold=-1.0,
+):
+  del stages, acc  # tile/pipeline shape is fixed per head dim; accumulation is always fp32
+  o, lse = forward(
+    q,
+    k,
+    v,
+    attn_bias if attn_bias.numel() > 0 else None,
+    bool(causal),
+    softmax_scale,
+    causal_offset=None if causal_offset == _AUTO_OFFSET else causal_offset,
+    rescale_threshold=rescale_threshold,
+    dropout_p=dropout_p,
+    philox_seed=philox_seed,
+    philox_offset=philox_offset,
+  )
+  return o, lse
+
+
+@torch.library.register_fake(f"{_OP_NAMESPACE}::_fwd_hip")
+def _fwd_hip_fake(
+  q,
+  k,
+  v,
+  attn_bias,
+  stages,
+  acc,
+  causal,
+  softmax_scale,
+  dropout_p,
+  philox_seed,
+  philox_offset,
+  causal_offset=_AUTO_OFFSET,
+  rescale_threshold=-1.0,
+):
+  B, Hq, Nq, D = q.shape
+  o = q.new_empty((B, Hq, Nq, D))
+  lse = q.new_empty((B, Hq, Nq), dtype=torch.float32)
+  return o, lse
+
+
+def ffpa_attn_forward_hip(
+  q: torch.Tensor,
+  k: torch.Tensor,
+  v: torch.Tensor,
+  attn_bias: torch.Tensor | None,
+  *,
+  causal: bool,
+  softmax_scale: float,
+  dropout_p: float = 0.0,
+  philox_seed: int = 0,
+  philox_offset: int = 0,
+  causal_offset: int | None = None,
+  rescale_threshold: float = -1.0,
+) -> tuple[torch.Tensor, torch.Tensor]:
+  """Python-level entry (the analogue of ``_ffpa_attn_forward_cuda``, cuda/_ffpa_fwd.py:6-62):
+  converts ``attn_bias=None`` into the empty tensor the op schema expects and calls the op."""
+  if attn_bias is None:
+    attn_bias = q.new_empty((0,))
+  return torch.ops.ffpa_attn._fwd_hip(
+    q,
+    k,
+    v,
+    attn_bias,
+    0,
+    1,
+    int(causal),
+    float(softmax_scale),
+    float(dropout_p),
+    int(philox_seed),
+    int(philox_offset),
+    _AUTO_OFFSET if causal_offset is None else int(causal_offset),
+    float(rescale_threshold),
+  )

@@ -1,0 +1,132 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/ffpa_attn.h declares;
+argument validation returns the documented status codes BEFORE any device work (no GPU needed)."""
+
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from ffpa_attn_amd import hip
+
+
+@pytest.fixture(scope="module")
+def lib():
+  if not hip.library_available():
+    from ffpa_attn_amd import build
+
+    build.build()
+  return hip.load_library()
+
+
+def _declared_functions():
+  text = open(os.path.join(ROOT, "include", "ffpa_attn.h")).read()
+  text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+  return sorted(set(re.findall(r"\b(ffpa_attn_\w+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+  names = _declared_functions()
+  assert set(names) == set(hip.EXPORTS)
+  for n in names:
+    assert getattr(lib, n) is not None
+
+
+def test_struct_layout_matches_header(lib):
+  # the library checks struct_size itself; a mismatch would surface as FFPA_ERR_BAD_ABI (10)
+  p = hip.FfpaFwdParams()
+  p.struct_size = ctypes.sizeof(hip.FfpaFwdParams) - 8
+  p.abi_version = hip.ABI_VERSION
+  assert lib.ffpa_attn_fwd(ctypes.byref(p), None) == 10
+  assert b"ABI mismatch" in lib.ffpa_attn_last_error()
+  assert ctypes.sizeof(hip.FfpaFwdParams) == 256
+
+
+def test_ctypes_mirror_matches_the_c_header(tmp_path):
+  """Compile the header with gcc (plain C) and compare size / field offsets with the ctypes mirror."""
+  import subprocess
+
+  fields = [f[0] for f in hip.FfpaFwdParams._fields_]
+  src = tmp_path / "layout.c"
+  body = "".join(f'printf("{f} %zu\\n", offsetof(ffpa_fwd_params, {f}));\n' for f in fields)
+  src.write_text(
+    '#include <stdio.h>\n#include <stddef.h>\n#include "ffpa_attn.h"\nint main(void){\n'
+    'printf("sizeof %zu\\n", sizeof(ffpa_fwd_params));\n' + body + "return 0;}\n"
+  )
+  exe = tmp_path / "layout"
+  subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+  out = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+  assert int(out["sizeof"]) == ctypes.sizeof(hip.FfpaFwdParams)
+  for f in fields:
+    assert int(out[f]) == getattr(hip.FfpaFwdParams, f).offset, f
+
+
+def test_queries(lib):
+  assert lib.ffpa_attn_query(0) == hip.ABI_VERSION
+  assert lib.ffpa_attn_query(1) == 1
+  assert (lib.ffpa_attn_query(2), lib.ffpa_attn_query(3), lib.ffpa_attn_query(4)) == (64, 1024, 64)
+  assert lib.ffpa_attn_query(5) == 1 and lib.ffpa_attn_query(6) == 0
+  assert lib.ffpa_attn_query(99) == -1
+  assert lib.ffpa_attn_version().startswith(b"ffpa-attn-amd")
+  assert lib.ffpa_attn_fwd_workspace_bytes(None) == 0
+
+
+def test_tile_configs():
+  for d in range(64, 1025, 64):
+    c = hip.tile_config(d)
+    if d <= 512:
+      assert (c["block_rows"], c["block_keys"]) == (128, 64) and c["lds_bytes"] == 2 * 64 * d * 2
+    else:
+      assert (c["block_rows"], c["block_keys"]) == (64, 32) and c["lds_bytes"] == 2 * 32 * d * 2 + 16384
+    assert c["lds_bytes"] <= 160 * 1024  # one CU's LDS
+  with pytest.raises(RuntimeError, match="headdim not support"):
+    hip.tile_config(100)
+
+
+def _params(**over):
+  buf = (ctypes.c_char * 4096)()
+  base = (ctypes.addressof(buf) + 15) & ~15
+  p = hip.FfpaFwdParams()
+  p.struct_size = ctypes.sizeof(hip.FfpaFwdParams)
+  p.abi_version = hip.ABI_VERSION
+  p.q = p.k = p.v = p.o = base
+  p.batch, p.heads_q, p.heads_kv, p.seqlen_q, p.seqlen_kv, p.head_dim = 1, 4, 2, 128, 128, 512
+  for n in ("q_stride", "k_stride", "v_stride", "o_stride"):
+    getattr(p, n)[:] = [4 * 128 * 512, 128 * 512, 512]
+  p.softmax_scale = 0.04
+  p.rescale_threshold = -1.0
+  for k, v in over.items():
+    if isinstance(v, (list, tuple)):
+      getattr(p, k)[:] = v
+    else:
+      setattr(p, k, v)
+  p._keepalive = buf
+  return p
+
+
+@pytest.mark.parametrize(
+  "over, status, text",
+  [
+    ({"q": None}, 1, b"non-NULL"),
+    ({"dtype": 7}, 2, b"dtype"),
+    ({"head_dim": 100}, 3, b"headdim not support"),
+    ({"heads_q": 5}, 4, b"num_heads"),
+    ({"seqlen_kv": 0}, 4, b"non-positive"),
+    ({"k_stride": [4 * 128 * 512, 128 * 512, 516]}, 5, b"multiple of 8"),
+    ({"v_stride": [4 * 128 * 512, 128 * 512, 256]}, 5, b"rows must not overlap"),
+    ({"bias_dtype": 2}, 2, b"bias pointer and bias_dtype disagree"),
+    ({"dropout_p": 0.1}, 7, b"dropout"),
+    ({"softmax_scale": float("nan")}, 4, b"not finite"),
+  ],
+)
+def test_validation_status_codes(lib, over, status, text):
+  p = _params(**over)
+  assert lib.ffpa_attn_fwd(ctypes.byref(p), None) == status
+  assert text in lib.ffpa_attn_last_error()
+
+
+def test_misaligned_pointer(lib):
+  p = _params()
+  p.k = p.k + 2
+  assert lib.ffpa_attn_fwd(ctypes.byref(p), None) == 6

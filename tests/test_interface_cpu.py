@@ -1,0 +1,78 @@
+"""CPU-side behaviour of the public API: BASELINE config 1 (SDPA plumbing), monkey-patching,
+error contracts, and "large-D CPU tensors raise instead of silently computing somewhere else"."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN
+from ffpa_attn_amd import ffpa_attn_func
+
+
+def _from_bits(a):
+  return torch.from_numpy(a.view(np.int16).copy()).view(torch.bfloat16)
+
+
+def test_config1_bit_equal_to_reference_output():
+  """B1 H4 N1024 D64 bf16 on CPU: the committed output of the REFERENCE's ffpa_attn_func."""
+  z = np.load(os.path.join(GOLDEN, "cfg1_cpu.npz"))
+  q, k, v = (_from_bits(z[n]) for n in "qkv")
+  torch.manual_seed(0)
+  q0 = torch.randn(1, 4, 1024, 64, dtype=torch.bfloat16)
+  assert torch.equal(q, q0)  # fixture inputs are exactly "seed 0, randn, q then k then v"
+  out = ffpa_attn_func(q, k, v)
+  assert torch.equal(out, _from_bits(z["o_reference"]))
+  assert torch.equal(out, F.scaled_dot_product_attention(q, k, v))
+
+
+def test_monkey_patch_does_not_recurse(monkeypatch):
+  """tests/test_monkey_patch.py:65-69 in the reference: fallbacks must call the native op."""
+  monkeypatch.setattr(F, "scaled_dot_product_attention", ffpa_attn_func)
+  q = torch.randn(1, 2, 64, 64, dtype=torch.bfloat16)
+  out = F.scaled_dot_product_attention(q, q, q, is_causal=True)
+  ref = torch._C._nn.scaled_dot_product_attention(q, q, q, is_causal=True)
+  assert torch.equal(out, ref)
+
+
+def test_large_d_cpu_raises_not_implemented():
+  q = torch.randn(1, 2, 512, 320, dtype=torch.bfloat16)
+  with pytest.raises(NotImplementedError, match="_fwd_hip"):
+    ffpa_attn_func(q, q, q)
+
+
+def test_error_contracts():
+  q = torch.randn(1, 8, 512, 320, dtype=torch.bfloat16)
+  k = torch.randn(1, 2, 512, 320, dtype=torch.bfloat16)
+  with pytest.raises(TypeError, match="unexpected keyword"):
+    ffpa_attn_func(q, q, q, nonsense=True)
+  with pytest.raises(ValueError, match="enable_gqa=False"):
+    ffpa_attn_func(q, k, k)
+  with pytest.raises(ValueError, match="seqlen"):
+    ffpa_attn_func(q, q, q[:, :, :500])
+  with pytest.raises(ValueError, match="num_heads"):
+    ffpa_attn_func(q[:, :6], k[:, :2].repeat(1, 2, 1, 1), k[:, :2].repeat(1, 2, 1, 1), enable_gqa=True)
+  with pytest.raises(ValueError, match="is_causal"):
+    ffpa_attn_func(q.repeat(1, 1, 2, 1), q, q, is_causal=True)
+  with pytest.raises(TypeError, match="fp16/bf16"):
+    ffpa_attn_func(q.float(), q.float(), q.float())
+  with pytest.raises(RuntimeError, match="attn_mask should not be set"):
+    ffpa_attn_func(q, q, q, attn_mask=torch.ones(512, 512, dtype=torch.bool), is_causal=True)
+  with pytest.raises((ValueError, TypeError)):
+    ffpa_attn_func(q, q, q, backend="nope")
+
+
+def test_mask_normalisation_shapes():
+  from ffpa_attn_amd.functional import FFPAAttnMeta
+
+  q = torch.empty(2, 4, 600, 320, dtype=torch.bfloat16)
+  k = torch.empty(2, 4, 700, 320, dtype=torch.bfloat16)
+  m = FFPAAttnMeta.from_kwargs()
+  b = m.normalize_attn_mask(q, k, torch.ones(600, 700, dtype=torch.bool))
+  assert b.shape == (1, 1, 600, 700) and b.dtype == torch.bfloat16 and float(b.max()) == 0.0
+  b = m.normalize_attn_mask(q, k, torch.zeros(2, 1, 700, dtype=torch.bool))
+  assert b.shape == (2, 1, 1, 700) and torch.isinf(b).all()
+  b = m.normalize_attn_mask(q, k, torch.zeros(2, 4, 1, 700))
+  assert b.dtype == torch.float32 and b.shape == (2, 4, 1, 700)

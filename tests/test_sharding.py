@@ -1,0 +1,72 @@
+"""(batch, kv-head) sharding across ranks: partition arithmetic + a real world_size=2 gloo run on CPU
+(the N > 1 path of bench.py / sharding.sharded_attention with an injected local attention)."""
+
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ffpa_attn_amd.sharding import partition_units, shard_units, to_units
+
+
+def test_partition_is_a_contiguous_cover():
+  for n in (1, 2, 7, 16, 256):
+    for w in (1, 2, 3, 4, 8):
+      spans = [partition_units(n, w, r) for r in range(w)]
+      assert spans[0][0] == 0 and spans[-1][1] == n
+      for a, b in zip(spans, spans[1:]):
+        assert a[1] == b[0]
+      sizes = [e - s for s, e in spans]
+      assert max(sizes) - min(sizes) <= 1
+
+
+def test_units_keep_kv_heads_with_their_query_group():
+  q = torch.arange(2 * 8 * 3 * 4, dtype=torch.float32).reshape(2, 8, 3, 4)
+  k = torch.arange(2 * 2 * 5 * 4, dtype=torch.float32).reshape(2, 2, 5, 4)
+  qu, ku, vu = to_units(q, k, k)
+  assert qu.shape == (4, 4, 3, 4) and ku.shape == (4, 1, 5, 4)
+  # unit 3 = batch 1, kv head 1 -> query heads 4..7
+  assert torch.equal(qu[3], q[1, 4:8]) and torch.equal(ku[3, 0], k[1, 1])
+  ql, kl, _ = shard_units(q, k, k, world_size=2, rank=1)
+  assert torch.equal(ql, qu[2:]) and torch.equal(kl, ku[2:])
+
+
+def _free_port():
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    return s.getsockname()[1]
+
+
+def _worker(rank, world, port, B, Hq, Hkv, ret):
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  from ffpa_attn_amd.sharding import sharded_attention
+
+  torch.manual_seed(0)
+  q = torch.randn(B, Hq, 40, 64)
+  k = torch.randn(B, Hkv, 56, 64)
+  v = torch.randn(B, Hkv, 56, 64)
+
+  def local(qu, ku, vu):  # stand-in for the HIP kernel: same contract (dim 1 = GQA heads)
+    return torch.nn.functional.scaled_dot_product_attention(qu, ku, vu, enable_gqa=True)
+
+  out = sharded_attention(q, k, v, local, gather=True)
+  ref = torch.nn.functional.scaled_dot_product_attention(q, k, v, enable_gqa=True)
+  ok = torch.allclose(out, ref, atol=1e-5)
+  part = sharded_attention(q, k, v, local, gather=False)
+  ret[rank] = (bool(ok), tuple(part.shape))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharded_attention_matches_unsharded():
+  for (B, Hq, Hkv) in ((2, 8, 2), (1, 6, 3)):  # even and uneven (3 units over 2 ranks) splits
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, B, Hq, Hkv, ret), nprocs=2, join=True)
+    assert ret[0][0] and ret[1][0]
+    n_units = B * Hkv
+    assert ret[0][1][0] + ret[1][1][0] == n_units
