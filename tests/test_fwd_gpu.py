@@ -1,0 +1,373 @@
+"""GPU parity tests proper (`pytest -m gpu`, one MI355X): the HIP kernel, called through the C-ABI,
+against the pinned CPU oracle, the committed SDPA fixtures, and PyTorch SDPA on the same device.
+
+Mirrors the coverage of the reference's tests/test_ffpa_fwd.py (shapes :32-45, boundary seqlens
+:1086-1104, cross-attention tails :1110-1143, GQA/MQA :1158-1196, causal self / tail-aligned cross
+:1226-1304, masks :291-336, decode Nq in {1,7} :929-958) with its tolerance (atol = rtol = 2e-2 bf16 /
+1e-2 fp16, :106-113) plus the tighter max-abs <= 1e-2 the north star states, and adds what a
+from-scratch kernel needs: a bit-exact cross-check of the LDS-DMA / transpose-read path against a
+register-staged twin, forced lazy-rescale inputs, strided views and size-independent properties at
+the BASELINE sizes.
+"""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import case_bias
+from oracle import ffpa_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.bfloat16: 2e-2, torch.float16: 1e-2}  # reference test tolerance (atol = rtol)
+NORTH_STAR_MAX_ABS = 1e-2
+
+
+@pytest.fixture(scope="module")
+def hip():
+  if not torch.cuda.is_available():
+    pytest.fail("these tests need a GPU; run with -m 'not gpu' on CPU boxes")
+  from ffpa_attn_amd import hip as h
+
+  h.load_library()  # fail loudly if the extension is missing: there is no fallback
+  return h
+
+
+def _t(bits, dtype):
+  tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+  return torch.from_numpy(bits.view(np.int16).copy()).view(tdt).cuda()
+
+
+def _f32(t):
+  return t.detach().float().cpu().numpy()
+
+
+def _check_vs_oracle(o_gpu, lse_gpu, q, k, v, *, causal=False, causal_offset=None, bias=None, rows=None,
+                     block_keys=64, threshold=8.0, name=""):
+  """o_gpu within one storage-dtype rounding of the oracle's unrounded result, LSE to fp32 noise."""
+  qb, dt = fo.torch_to_bits(q)
+  kb, _ = fo.torch_to_bits(k)
+  vb, _ = fo.torch_to_bits(v)
+  _, o32, lse = fo.oracle_forward(qb, kb, vb, dt, causal=causal, causal_offset=causal_offset, bias=bias, rows=rows,
+                                  block_keys=block_keys, threshold=threshold)
+  got = _f32(o_gpu)
+  r0, r1 = (0, got.shape[2]) if rows is None else rows
+  got, want = got[:, :, r0:r1], o32[:, :, r0:r1]
+  finite = np.isfinite(want)
+  assert np.array_equal(np.isnan(got), np.isnan(want)), f"{name}: NaN pattern differs"
+  ulp = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
+  err = np.abs(got - want)[finite]
+  bound = (ulp * np.maximum(np.abs(want), 2.0 ** -6) + 3e-4)[finite]
+  assert (err <= bound).all(), f"{name}: max err {err.max():.3e} (worst excess {(err - bound).max():.3e})"
+  assert err.mean() <= 0.5 * bound.mean(), f"{name}: mean err {err.mean():.3e} vs bound mean {bound.mean():.3e}"
+  if lse_gpu is not None:
+    lg, lw = _f32(lse_gpu)[:, :, r0:r1], lse[:, :, r0:r1]
+    fin = np.isfinite(lw)
+    assert np.array_equal(np.isneginf(lg), np.isneginf(lw)), f"{name}: LSE -inf pattern"
+    np.testing.assert_allclose(lg[fin], lw[fin], atol=2e-4, rtol=2e-5, err_msg=name)
+
+
+def _close(a, b, dtype, name=""):
+  tol = TOL[dtype]
+  a, b = a.float(), b.float()
+  assert torch.equal(torch.isnan(a), torch.isnan(b)), name
+  m = ~torch.isnan(b)
+  assert torch.all((a - b).abs()[m] <= tol + tol * b.abs()[m]), f"{name}: {(a - b).abs()[m].max().item():.3e}"
+
+
+def _rand(shape, dtype=torch.bfloat16, seed=0):
+  g = torch.Generator(device="cuda").manual_seed(seed)
+  return torch.randn(shape, dtype=dtype, device="cuda", generator=g)
+
+
+# ----------------------------------------------------------------------------- committed fixtures
+def test_small_cases_vs_oracle_and_sdpa_fixtures(hip, small_cases):
+  for c in small_cases:
+    q, k, v = (_t(c[n], c["dtype"]) for n in "qkv")
+    bias = case_bias(c)
+    bias_t = None
+    if bias is not None:
+      if "mask_bits" in c:
+        bias_t = _t(c["mask_bits"], c["dtype"])
+      elif c["mask"].dtype == np.bool_:
+        bias_t = torch.from_numpy(bias).to(q.dtype).cuda()  # bool -> 0/-inf in q.dtype (functional.py:891-898)
+      else:
+        bias_t = torch.from_numpy(bias).cuda()
+    o, lse = hip.forward(q, k, v, bias_t, c["causal"], 1.0 / c["D"] ** 0.5, causal_offset=c["causal_offset"])
+    bc = hip.tile_config(hip.padded_head_dim(c["D"]))["block_keys"]
+    _check_vs_oracle(o, lse, q, k, v, causal=c["causal"], causal_offset=c["causal_offset"], bias=bias, block_keys=bc,
+                     name=c["name"])
+    want = _t(c["o_sdpa"], c["dtype"])
+    _close(o, want, q.dtype, c["name"])
+    assert (o.float() - want.float()).abs().max().item() <= 1.2e-2, c["name"]
+    np.testing.assert_allclose(_f32(lse), c["lse_f64"], atol=3e-4, rtol=3e-5, err_msg=c["name"])
+
+
+# ----------------------------------------------------------------------------- fast path == safe path
+@pytest.mark.parametrize("D", [64, 128, 320, 512, 640, 1024])
+def test_dma_and_transpose_read_path_is_bit_identical_to_register_staged_twin(hip, D):
+  """Same arithmetic, two data paths: LDS-DMA + ds_read_b64_tr_b16 vs plain loads + scalar gathers."""
+  q, k, v = _rand((2, 4, 200, D), seed=1), _rand((2, 2, 333, D), seed=2), _rand((2, 2, 333, D), seed=3)
+  for causal in (False, True):
+    a, la = hip.forward(q, k, v, None, causal, 0.05)
+    b, lb = hip.forward(q, k, v, None, causal, 0.05, flags=hip.FLAG_DEBUG_SAFE_PATH)
+    assert torch.equal(a, b) and torch.equal(la, lb), (D, causal)
+
+
+def test_xcd_remap_does_not_change_results(hip):
+  q, k, v = _rand((2, 8, 700, 512), seed=4), _rand((2, 8, 900, 512), seed=5), _rand((2, 8, 900, 512), seed=6)
+  a, _ = hip.forward(q, k, v, None, True, 0.044)
+  b, _ = hip.forward(q, k, v, None, True, 0.044, flags=hip.FLAG_NO_XCD_REMAP)
+  assert torch.equal(a, b)
+
+
+# ----------------------------------------------------------------------------- shapes
+@pytest.mark.parametrize("D", list(range(64, 1025, 64)) + [264, 1000])
+def test_every_head_dim(hip, D):
+  q, k, v = _rand((1, 2, 130, D), seed=D), _rand((1, 1, 257, D), seed=D + 1), _rand((1, 1, 257, D), seed=D + 2)
+  o, lse = hip.forward(q, k, v, None, False, 1.0 / D ** 0.5)
+  assert o.shape == q.shape
+  bc = hip.tile_config(hip.padded_head_dim(D))["block_keys"]
+  _check_vs_oracle(o, lse, q, k, v, block_keys=bc, name=f"D{D}")
+
+
+@pytest.mark.parametrize("Nq,Nkv", [(1, 1), (1, 4096), (7, 513), (15, 64), (127, 129), (128, 128), (129, 65), (513, 1000),
+                                   (1000, 31), (640, 2049), (64, 63), (65, 32), (33, 33)])
+@pytest.mark.parametrize("D", [320, 512, 768])
+def test_boundary_sequence_lengths(hip, Nq, Nkv, D):
+  q, k, v = _rand((1, 2, Nq, D), seed=Nq), _rand((1, 2, Nkv, D), seed=Nkv + 7), _rand((1, 2, Nkv, D), seed=Nkv + 9)
+  o, lse = hip.forward(q, k, v, None, False, 1.0 / D ** 0.5)
+  bc = hip.tile_config(D)["block_keys"]
+  _check_vs_oracle(o, lse, q, k, v, block_keys=bc, name=f"{Nq}x{Nkv}xD{D}")
+
+
+@pytest.mark.parametrize("Hq,Hkv", [(8, 8), (8, 2), (8, 1), (6, 3)])
+def test_gqa_mqa_vs_repeat_interleave(hip, Hq, Hkv):
+  q, k, v = _rand((2, Hq, 300, 512), seed=11), _rand((2, Hkv, 420, 512), seed=12), _rand((2, Hkv, 420, 512), seed=13)
+  o, _ = hip.forward(q, k, v, None, False, 0.0442)
+  g = Hq // Hkv
+  ref, _ = hip.forward(q, k.repeat_interleave(g, 1), v.repeat_interleave(g, 1), None, False, 0.0442)
+  assert torch.equal(o, ref)  # same arithmetic, only the head mapping differs
+  _check_vs_oracle(o, None, q, k, v, name=f"gqa{Hq}/{Hkv}")
+
+
+def test_strided_views_are_honoured_without_copies(hip):
+  B, H, N, D = 2, 4, 260, 512
+  qs = _rand((B, N, H, D), seed=21)  # [B, N, H, D] storage, transposed view: the typical caller
+  ks, vs = _rand((B, N, H, D), seed=22), _rand((B, N, H, D), seed=23)
+  q, k, v = qs.transpose(1, 2), ks.transpose(1, 2), vs.transpose(1, 2)
+  assert not q.is_contiguous()
+  o, lse = hip.forward(q, k, v, None, True, 0.0442)
+  oc, lc = hip.forward(q.contiguous(), k.contiguous(), v.contiguous(), None, True, 0.0442)
+  assert torch.equal(o, oc) and torch.equal(lse, lc)
+  # batch-expanded K/V (stride 0 over batch) — one KV cache shared by every batch element
+  ke, ve = k[:1].expand(B, H, N, D), v[:1].expand(B, H, N, D)
+  o2, _ = hip.forward(q, ke, ve, None, False, 0.0442)
+  o3, _ = hip.forward(q, ke.contiguous(), ve.contiguous(), None, False, 0.0442)
+  assert torch.equal(o2, o3)
+
+
+# ----------------------------------------------------------------------------- causal
+@pytest.mark.parametrize("Nq,Nkv", [(512, 512), (191, 191), (100, 1000), (513, 640), (1, 777), (129, 129)])
+@pytest.mark.parametrize("D", [320, 512, 1024])
+def test_causal_tail_aligned(hip, Nq, Nkv, D):
+  q, k, v = _rand((1, 2, Nq, D), seed=31), _rand((1, 2, Nkv, D), seed=32), _rand((1, 2, Nkv, D), seed=33)
+  o, lse = hip.forward(q, k, v, None, True, 1.0 / D ** 0.5)
+  bc = hip.tile_config(D)["block_keys"]
+  _check_vs_oracle(o, lse, q, k, v, causal=True, block_keys=bc, name=f"causal {Nq}x{Nkv} D{D}")
+  rows = torch.arange(Nq, device="cuda")[:, None]
+  cols = torch.arange(Nkv, device="cuda")[None, :]
+  ref = F.scaled_dot_product_attention(q, k, v, attn_mask=cols <= rows + (Nkv - Nq))  # tests/test_ffpa_fwd.py:1268-1304
+  _close(o, ref, q.dtype)
+
+
+def test_causal_top_left_offset_matches_sdpa_is_causal(hip):
+  """causal_offset = 0 is PyTorch's alignment; Nq > Nkv is BASELINE config 4's shape class."""
+  q, k, v = _rand((1, 4, 700, 320), seed=41), _rand((1, 2, 300, 320), seed=42), _rand((1, 2, 300, 320), seed=43)
+  o, lse = hip.forward(q, k, v, None, True, 320 ** -0.5, causal_offset=0)
+  ref = F.scaled_dot_product_attention(q, k, v, is_causal=True, enable_gqa=True)
+  _close(o, ref, q.dtype)
+  _check_vs_oracle(o, lse, q, k, v, causal=True, causal_offset=0, name="topleft")
+
+
+def test_negative_causal_offset_gives_nan_rows_like_a_fully_masked_sdpa_row(hip):
+  q, k, v = _rand((1, 1, 200, 320), seed=44), _rand((1, 1, 150, 320), seed=45), _rand((1, 1, 150, 320), seed=46)
+  o, lse = hip.forward(q, k, v, None, True, 0.05)  # tail aligned with Nq > Nkv: rows 0..49 see nothing
+  assert torch.isnan(o[0, 0, :50]).all() and torch.isinf(lse[0, 0, :50]).all()
+  assert torch.isfinite(o[0, 0, 50:]).all()
+  _check_vs_oracle(o, lse, q, k, v, causal=True, name="neg-offset")
+
+
+# ----------------------------------------------------------------------------- masks / bias
+@pytest.mark.parametrize("shape", [(1, 1, 1, 600), (2, 1, 1, 600), (1, 4, 1, 600), (1, 1, 520, 600), (2, 4, 520, 600),
+                                   (2, 1, 520, 1), (1, 4, 520, 600)])
+@pytest.mark.parametrize("kind", ["bool", "add_q", "add_f32"])
+def test_masks_all_broadcast_shapes(hip, shape, kind):
+  B, H, Nq, Nkv, D = 2, 4, 520, 600, 320
+  q, k, v = _rand((B, H, Nq, D), seed=51), _rand((B, H, Nkv, D), seed=52), _rand((B, H, Nkv, D), seed=53)
+  g = torch.Generator(device="cuda").manual_seed(sum(shape) * 7 + len(kind))
+  if kind == "bool":
+    mask = torch.rand(shape, device="cuda", generator=g) > 0.25
+    mask[..., 0] = True
+    bias = torch.zeros(shape, dtype=q.dtype, device="cuda").masked_fill(~mask, float("-inf"))
+    sdpa_mask = mask
+  elif kind == "add_q":
+    bias = (torch.randn(shape, device="cuda", generator=g) * 0.5).to(q.dtype)
+    sdpa_mask = bias
+  else:
+    bias = torch.randn(shape, device="cuda", generator=g) * 0.5
+    sdpa_mask = bias
+  o, lse = hip.forward(q, k, v, bias, False, D ** -0.5)
+  ref = F.scaled_dot_product_attention(q, k, v, attn_mask=sdpa_mask)
+  _close(o, ref, q.dtype, f"{shape} {kind}")
+  _check_vs_oracle(o, lse, q, k, v, bias=_f32(bias), name=f"{shape} {kind}")
+
+
+def test_partially_and_fully_masked_rows(hip):
+  B, H, Nq, Nkv, D = 1, 2, 513, 300, 512
+  q, k, v = _rand((B, H, Nq, D), seed=61), _rand((B, H, Nkv, D), seed=62), _rand((B, H, Nkv, D), seed=63)
+  mask = torch.ones(1, 1, Nq, Nkv, dtype=torch.bool, device="cuda")
+  mask[0, 0, 5, :] = False           # fully masked -> NaN row (SDPA semantics)
+  mask[0, 0, 9, :128] = False        # masked for the first tiles only: must stay finite
+  mask[0, 0, 300, 1:] = False        # a single visible key: O = V[0]
+  bias = torch.zeros(mask.shape, dtype=q.dtype, device="cuda").masked_fill(~mask, float("-inf"))
+  o, lse = hip.forward(q, k, v, bias, False, D ** -0.5)
+  assert torch.isnan(o[:, :, 5]).all() and torch.isfinite(o[:, :, 9]).all()
+  assert torch.equal(o[0, :, 300], v[0, :, 0])
+  _check_vs_oracle(o, lse, q, k, v, bias=_f32(bias), name="masked rows")
+
+
+# ----------------------------------------------------------------------------- lazy rescale
+@pytest.mark.parametrize("D", [512, 1024])
+def test_forced_rescale_branch_and_threshold_sweep(hip, D):
+  """Spike keys far above everything before them, late in the sequence (cdna guide rule 26)."""
+  q, k, v = _rand((1, 2, 256, D), seed=71), _rand((1, 2, 1500, D), seed=72), _rand((1, 2, 1500, D), seed=73)
+  k = k.clone()
+  for row, key, gain in ((3, 700, 0.6), (3, 1300, 1.3), (40, 1499, 0.9), (200, 65, 0.8)):
+    k[0, :, key] = (q[0, :, row].float() * gain).to(k.dtype)
+  scale = D ** -0.5
+  bc = hip.tile_config(D)["block_keys"]
+  outs = []
+  for thr in (0.0, 8.0, 40.0):
+    o, lse = hip.forward(q, k, v, None, False, scale, rescale_threshold=thr)
+    _check_vs_oracle(o, lse, q, k, v, threshold=thr, block_keys=bc, name=f"thr{thr}")
+    outs.append(o.float())
+  assert (outs[0] - outs[1]).abs().max() < 1.6e-2 and (outs[0] - outs[2]).abs().max() < 1.6e-2
+  s = (q[0, 0, 3].float() @ k[0, 0].float().T) * scale * 1.4427
+  assert (s.max() - s[:64].max()).item() > 16  # the branch really fires
+
+
+# ----------------------------------------------------------------------------- fp16
+def test_fp16(hip):
+  q, k, v = (_rand((1, 4, 600, 512), torch.float16, seed=s) for s in (81, 82, 83))
+  o, lse = hip.forward(q, k, v, None, True, 512 ** -0.5)
+  _check_vs_oracle(o, lse, q, k, v, causal=True, name="fp16")
+  ref = F.scaled_dot_product_attention(q, k, v, is_causal=True)
+  _close(o, ref, q.dtype)
+
+
+# ----------------------------------------------------------------------------- BASELINE sizes
+def _baseline_inputs(B, Hq, Hkv, Nq, Nkv, D):
+  torch.manual_seed(0)  # "seed 0; q then k then v" (tests/test_ffpa_fwd.py:116-121)
+  q = torch.randn(B, Hq, Nq, D, dtype=torch.bfloat16, device="cuda")
+  k = torch.randn(B, Hkv, Nkv, D, dtype=torch.bfloat16, device="cuda")
+  v = torch.randn(B, Hkv, Nkv, D, dtype=torch.bfloat16, device="cuda")
+  return q, k, v
+
+
+@pytest.mark.parametrize("D", [512, 1024])
+def test_baseline_config_2_and_3_full_size(hip, D):
+  """B=1 H=32 N=8192 D=512 / 1024: vs SDPA on the same inputs (max-abs <= 1e-2), vs the oracle on
+  sampled rows of sampled heads, determinism, and exact V-scaling."""
+  q, k, v = _baseline_inputs(1, 32, 32, 8192, 8192, D)
+  scale = D ** -0.5
+  o, lse = hip.forward(q, k, v, None, False, scale)
+  ref = F.scaled_dot_product_attention(q, k, v)
+  err = (o.float() - ref.float()).abs()
+  assert err.max().item() <= NORTH_STAR_MAX_ABS, err.max().item()
+  _close(o, ref, q.dtype)
+  bc = hip.tile_config(D)["block_keys"]
+  for head, rows in ((0, (0, 48)), (17, (4090, 4130)), (31, (8150, 8192))):
+    sl = slice(head, head + 1)
+    _check_vs_oracle(o[:, sl], lse[:, sl], q[:, sl], k[:, sl], v[:, sl], rows=rows, block_keys=bc, name=f"h{head}")
+  o2, lse2 = hip.forward(q, k, v, None, False, scale)
+  assert torch.equal(o, o2) and torch.equal(lse, lse2)          # run-to-run deterministic
+  o4, _ = hip.forward(q, k, v * 4, None, False, scale)           # P unchanged, V scaled by 2^2: exact
+  assert torch.equal(o4, o * 4)
+
+
+def test_baseline_config_4_gqa_cross_causal_mask(hip):
+  """B=2 Hq=32/Hkv=8 Nq=8192 Nkv=2048 D=320, SDPA-style (top-left) causal mask — both as the
+  structured causal_offset=0 path and as an explicit boolean mask through the bias path."""
+  q, k, v = _baseline_inputs(2, 32, 8, 8192, 2048, 320)
+  scale = 320 ** -0.5
+  ref = F.scaled_dot_product_attention(q, k, v, is_causal=True, enable_gqa=True)
+  o, lse = hip.forward(q, k, v, None, True, scale, causal_offset=0)
+  assert (o.float() - ref.float()).abs().max().item() <= NORTH_STAR_MAX_ABS
+  mask = torch.ones(8192, 2048, dtype=torch.bool, device="cuda").tril()
+  bias = torch.zeros(1, 1, 8192, 2048, dtype=q.dtype, device="cuda").masked_fill(~mask, float("-inf"))
+  om, _ = hip.forward(q, k, v, bias, False, scale)
+  assert (om.float() - ref.float()).abs().max().item() <= NORTH_STAR_MAX_ABS
+  assert (om.float() - o.float()).abs().max().item() <= 4e-3
+  for head, rows in ((0, (0, 40)), (13, (2040, 2080)), (31, (8160, 8192))):
+    sl, kv = slice(head, head + 1), slice(head // 4, head // 4 + 1)
+    _check_vs_oracle(o[:1, sl], lse[:1, sl], q[:1, sl], k[:1, kv], v[:1, kv], causal=True, causal_offset=0, rows=rows,
+                     name=f"cfg4 h{head}")
+
+
+def test_key_permutation_invariance_at_full_length(hip):
+  q, k, v = _baseline_inputs(1, 2, 2, 1024, 8192, 512)
+  o, lse = hip.forward(q, k, v, None, False, 512 ** -0.5)
+  perm = torch.randperm(8192, device="cuda")
+  op, lsep = hip.forward(q, k[:, :, perm], v[:, :, perm], None, False, 512 ** -0.5)
+  assert (o.float() - op.float()).abs().max().item() <= 4e-3   # only summation order / rounding moves
+  assert (lse - lsep).abs().max().item() <= 1e-4
+  ones = torch.ones_like(v)
+  oc, _ = hip.forward(q, k, ones, None, False, 512 ** -0.5)    # softmax rows sum to one
+  assert (oc.float() - 1).abs().max().item() <= 2 ** -7
+
+
+# ----------------------------------------------------------------------------- public API on the GPU
+def test_public_api_routes_large_d_to_the_kernel(hip, monkeypatch):
+  from ffpa_attn_amd import ffpa_attn_func
+
+  q, k, v = _rand((1, 4, 640, 512), seed=91), _rand((1, 2, 900, 512), seed=92), _rand((1, 2, 900, 512), seed=93)
+  calls = []
+  real = torch._C._nn.scaled_dot_product_attention
+  monkeypatch.setattr(torch._C._nn, "scaled_dot_product_attention", lambda *a, **kw: calls.append(1) or real(*a, **kw))
+  out = ffpa_attn_func(q, k, v, is_causal=True, enable_gqa=True)
+  assert not calls, "large-D must not reach native SDPA (tests/test_monkey_patch.py:127-133)"
+  direct, _ = hip.forward(q, k, v, None, True, 512 ** -0.5)
+  assert torch.equal(out, direct)
+  mask = torch.rand(1, 1, 640, 900, device="cuda") > 0.3
+  mask[..., 0] = True
+  outm = ffpa_attn_func(q, k, v, attn_mask=mask, enable_gqa=True)
+  monkeypatch.undo()
+  _close(outm, F.scaled_dot_product_attention(q, k, v, attn_mask=mask, enable_gqa=True), q.dtype)
+  # short / small-D shapes fall back (functional.py:717-724)
+  small = _rand((1, 4, 640, 128), seed=94)
+  assert torch.equal(ffpa_attn_func(small, small, small), F.scaled_dot_product_attention(small, small, small))
+  short = _rand((1, 4, 100, 512), seed=95)
+  assert torch.equal(ffpa_attn_func(short, k[:, :1].expand(1, 4, 900, 512), v[:, :1].expand(1, 4, 900, 512)),
+                     F.scaled_dot_product_attention(short, k[:, :1].expand(1, 4, 900, 512), v[:, :1].expand(1, 4, 900, 512)))
+
+
+def test_monkey_patched_sdpa_and_torch_compile(hip, monkeypatch):
+  from ffpa_attn_amd import ffpa_attn_func
+
+  q, k, v = (_rand((1, 4, 768, 320), seed=s) for s in (101, 102, 103))
+  eager = ffpa_attn_func(q, k, v, is_causal=True)
+  compiled = torch.compile(ffpa_attn_func, fullgraph=False)(q, k, v, is_causal=True)  # tests/test_ffpa_compile.py:52-89
+  assert torch.equal(eager, compiled)
+  monkeypatch.setattr(F, "scaled_dot_product_attention", ffpa_attn_func)
+  assert torch.equal(F.scaled_dot_product_attention(q, k, v, is_causal=True), eager)
+
+
+def test_op_schema_and_lse_contract(hip):
+  q, k, v = (_rand((2, 4, 520, 320), seed=s) for s in (111, 112, 113))
+  o, lse = torch.ops.ffpa_attn._fwd_hip(q, k, v, q.new_empty((0,)), 0, 1, 0, 320 ** -0.5, 0.0, 0, 0)
+  assert o.shape == q.shape and o.dtype == q.dtype
+  assert lse.shape == (2, 4, 520) and lse.dtype == torch.float32 and lse.is_contiguous()  # cuda/__init__.py:100-112
+  s = (q.float() @ k.float().transpose(-1, -2)) * 320 ** -0.5
+  assert (lse - torch.logsumexp(s, -1)).abs().max().item() < 2e-4
