@@ -21,15 +21,15 @@ bench)
   timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench exit $?"; cat gpurun_out/bench.json ;;
 prof)
   rm -rf gpurun_out/prof
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -o trace -- python $OLDPWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-sdpa) > gpurun_out/prof.log 2>&1
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof -o trace -- python $OLDPWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-sdpa) > gpurun_out/prof.log 2>&1
   echo "prof exit $?"; find gpurun_out/prof -name "*stats*" | head; ;;
 pmc)
   rm -rf gpurun_out/pmc
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $OLDPWD/gpurun_out/pmc -o pmc1 -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sdpa) > gpurun_out/pmc1.log 2>&1
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $OLDPWD/gpurun_out/pmc -o pmc1 -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sdpa) > gpurun_out/pmc1.log 2>&1
   echo "pmc1 exit $?"
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum TCC_MISS_sum -d $OLDPWD/gpurun_out/pmc -o pmc2 -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sdpa) > gpurun_out/pmc2.log 2>&1
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE TCC_HIT_sum TCC_MISS_sum -d $OLDPWD/gpurun_out/pmc -o pmc2 -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sdpa) > gpurun_out/pmc2.log 2>&1
   echo "pmc2 exit $?"
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS -d $OLDPWD/gpurun_out/pmc -o pmc3 -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sdpa) > gpurun_out/pmc3.log 2>&1
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS -d $OLDPWD/gpurun_out/pmc -o pmc3 -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sdpa) > gpurun_out/pmc3.log 2>&1
   echo "pmc3 exit $?" ;;
 esac
 done
