@@ -97,12 +97,48 @@ def build(force: bool = False, jobs: int | None = None, save_temps: bool = False
   return LIB_PATH
 
 
+def build_variant(tag: str, defs: list[str], jobs: int | None = None, head_dims: list[int] | None = None) -> str:
+  """Developer tool: build ``variants/libffpa_attn_hip_<tag>.so`` with extra ``-D`` tunables (see the
+  FFPA_* macros at the top of csrc/ffpa_fwd_kernel.h) for A/B timing with tools/gpu_ab.py.  Head dims
+  not listed in ``head_dims`` are still compiled (the C-ABI table references all of them) but without
+  the test-only twins."""
+  hipcc = _hipcc()
+  odir = os.path.join(OBJ_DIR, f"var_{tag}")
+  os.makedirs(odir, exist_ok=True)
+  vdir = os.path.join(HERE, "variants")
+  os.makedirs(vdir, exist_ok=True)
+  lib = os.path.join(vdir, f"libffpa_attn_hip_{tag}.so")
+  newest = _sources_mtime()
+  stamp = os.path.join(odir, "defs.txt")
+  same_defs = os.path.exists(stamp) and open(stamp).read() == " ".join(defs)
+  if same_defs and os.path.exists(lib) and os.path.getmtime(lib) >= newest:
+    return lib
+  tasks, objs = [], []
+  for d in HEAD_DIMS:
+    obj = os.path.join(odir, f"ffpa_fwd_d{d}.o")
+    objs.append(obj)
+    tasks.append([hipcc, *CXXFLAGS, *defs, f"-DFFPA_INST_D={d}", "-c", os.path.join(CSRC, "ffpa_fwd_inst.hip"), "-o", obj])
+  capi = os.path.join(odir, "ffpa_capi.o")
+  objs.append(capi)
+  tasks.append([hipcc, *CXXFLAGS, "-c", os.path.join(CSRC, "ffpa_capi.hip"), "-o", capi])
+  with ThreadPoolExecutor(max_workers=jobs or (os.cpu_count() or 4)) as pool:
+    list(pool.map(_run, tasks))
+  _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib, *objs, "-Wl,-rpath,/opt/rocm/lib"])
+  with open(stamp, "w") as f:
+    f.write(" ".join(defs))
+  return lib
+
+
 def main() -> None:
   ap = argparse.ArgumentParser(description=__doc__)
   ap.add_argument("--force", action="store_true")
   ap.add_argument("--jobs", type=int, default=None)
   ap.add_argument("--save-temps", action="store_true")
+  ap.add_argument("--variant", nargs="+", metavar=("TAG", "DEF"), help="build variants/libffpa_attn_hip_TAG.so with -D defs")
   args = ap.parse_args()
+  if args.variant:
+    print(build_variant(args.variant[0], [d if d.startswith("-D") else "-D" + d for d in args.variant[1:]], jobs=args.jobs))
+    return
   print(build(force=args.force, jobs=args.jobs, save_temps=args.save_temps))
 
 

@@ -32,6 +32,23 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// ---- build-time tunables (defaults = the shipped configuration; tools/gpu_ab.py builds variants) ----
+#ifndef FFPA_PF1
+#define FFPA_PF1 6  // QK: LDS reads run this many MFMAs ahead of their consumer
+#endif
+#ifndef FFPA_PF2
+#define FFPA_PF2 4  // PV: ditto (two transpose reads per MFMA)
+#endif
+#ifndef FFPA_DMA_INTERLEAVE
+#define FFPA_DMA_INTERLEAVE 1  // 1: issue LDS-DMA pieces between the MFMAs; 0: bursts after the barriers
+#endif
+#ifndef FFPA_DMA_STEP
+#define FFPA_DMA_STEP 2  // interleaved mode: one DMA piece every this many MFMAs (ND == 1)
+#endif
+#ifndef FFPA_ABL
+#define FFPA_ABL 0  // developer ablations (WRONG RESULTS): 1 = no in-loop DMA, 2 = no exp in softmax
+#endif
+
 namespace ffpa {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -131,47 +148,85 @@ __device__ __forceinline__ int v_slot_swizzle(int key) {  // in 16-byte slots
 // lane i of piece p lands at lds_tile + p*1024 + i*16 (the hardware's lane-linear rule), so
 // the swizzle goes on the per-lane SOURCE offset.  `rsrc` describes the (batch, kv-head)
 // slice; offsets inside it are 32-bit (the host rejects slices of 4 GiB or more).
+// One 1 KiB LDS-DMA piece: buffer_load_dwordx4 ... lds (16 B per lane, destination M0 + lane*16).
+// Issued through inline asm on purpose: hipcc cannot tell that the DMA's LDS write does not alias a
+// later ds_read_b64_tr_b16 and would put `s_waitcnt vmcnt(0)` in front of every transpose read that
+// follows a builtin DMA (measured: 561 vs 1030 TFLOP/s).  The asm is invisible to that pass, so the
+// kernel drains the DMA queue itself (dma_wait_all) before each workgroup barrier.  Compiler-counted
+// vmcnt waits for its own loads stay correct (loads retire in order; hidden younger ops only make a
+// counted wait conservative).  M0 is written in the same statement that consumes it.
+__device__ __forceinline__ void lds_dma_16(u32x4 rsrc, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory");
+}
+// s_waitcnt vmcnt(0) as a BUILTIN (gfx9 encoding 0x0F70: vmcnt = 0, expcnt / lgkmcnt = no wait): the
+// compiler's own scoreboard then knows its earlier loads (the Q fragments) have retired and emits no
+// counted vmcnt waits inside the tile loop — those would also wait on the hidden DMA pieces.
+__device__ __forceinline__ void dma_wait_all() {
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  asm volatile("" ::: "memory");
+}
+
+// Raw buffer descriptor over `bytes` bytes at `base` (gfx950: word3 0x00020000 = 32-bit raw dwords).
+__device__ __forceinline__ u32x4 make_rsrc(const void* base, uint32_t bytes) {
+  const uint64_t a = (uint64_t)base;
+  u32x4 r = {(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+  return r;
+}
+
 template <typename T, int D, int BC, bool IS_V, bool SAFE>
-__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, const T* __restrict__ base,
+__device__ __forceinline__ void stage_piece(u32x4 rsrc, const T* __restrict__ base,
+                                            uint32_t row_bytes, int key0, int nkv,
+                                            FFPA_LDS char* lds_tile, int wave, int lane, int i) {
+  constexpr int SPR = D / 8;  // 16-byte slots per row
+  constexpr int PPW = BC * D * 2 / 4096;
+  const int p = wave * PPW + i;
+  uint32_t voff, soff;
+  if constexpr ((D * 2) % 1024 == 0) {
+    // a row is a whole number of pieces: the row (and its swizzle) is wave-uniform
+    constexpr int RPP = D * 2 / 1024;
+    const int key = p / RPP;
+    int krow = key0 + key;
+    krow = krow < nkv ? krow : nkv - 1;
+    const int sw = IS_V ? v_slot_swizzle<D>(key) : k_slot_swizzle<D>(key);
+    voff = (uint32_t)((lane ^ sw) << 4);
+    soff = (uint32_t)krow * row_bytes + (uint32_t)(p % RPP) * 1024u;
+  } else {
+    const int g = p * 64 + lane;
+    const int key = g / SPR;
+    const int slot = g - key * SPR;
+    const int src_slot = slot ^ (IS_V ? v_slot_swizzle<D>(key) : k_slot_swizzle<D>(key));
+    int krow = key0 + key;
+    krow = krow < nkv ? krow : nkv - 1;
+    voff = (uint32_t)krow * row_bytes + (uint32_t)(src_slot << 4);
+    soff = 0;
+  }
+  if constexpr (!SAFE) {
+    lds_dma_16(rsrc, (uint32_t)(uintptr_t)(lds_tile + p * 1024), voff, soff);
+  } else {
+    const u32x4 x = *(const u32x4*)((const char*)base + (size_t)voff + (size_t)soff);
+    *(FFPA_LDS u32x4*)(lds_tile + p * 1024 + lane * 16) = x;
+  }
+}
+
+// Keep the per-lane offset arithmetic inside the tile loop: hoisted, it costs dozens of long-lived
+// VGPRs that get spilled, and every reload drains the DMA queue (vmcnt(0)).
+__device__ __forceinline__ int opaque_lane(int lane) {
+  asm volatile("" : "+v"(lane));
+  return lane;
+}
+
+template <typename T, int D, int BC, bool IS_V, bool SAFE>
+__device__ __forceinline__ void stage_tile(u32x4 rsrc, const T* __restrict__ base,
                                            uint32_t row_bytes, int key0, int nkv,
                                            FFPA_LDS char* lds_tile, int wave, int lane) {
-  constexpr int SPR = D / 8;  // 16-byte slots per row
-  constexpr int PIECES = BC * D * 2 / 1024;
-  constexpr int PPW = PIECES / 4;
-  static_assert(PIECES % 4 == 0, "tile must split evenly over 4 waves");
-  // keep the per-lane offset arithmetic inside the tile loop: hoisted, it costs dozens of
-  // long-lived VGPRs that get spilled, and every reload drains the DMA queue (vmcnt(0)).
-  asm volatile("" : "+v"(lane));
+  constexpr int PPW = BC * D * 2 / 4096;
+  static_assert((BC * D * 2) % 4096 == 0, "tile must split evenly into 1 KiB pieces over 4 waves");
+  lane = opaque_lane(lane);
 #pragma unroll
-  for (int i = 0; i < PPW; ++i) {
-    const int p = wave * PPW + i;
-    uint32_t voff, soff;
-    if constexpr ((D * 2) % 1024 == 0) {
-      // a row is a whole number of pieces: the row (and its swizzle) is wave-uniform
-      constexpr int RPP = D * 2 / 1024;
-      const int key = p / RPP;
-      int krow = key0 + key;
-      krow = krow < nkv ? krow : nkv - 1;
-      const int sw = IS_V ? v_slot_swizzle<D>(key) : k_slot_swizzle<D>(key);
-      voff = (uint32_t)((lane ^ sw) << 4);
-      soff = (uint32_t)krow * row_bytes + (uint32_t)(p % RPP) * 1024u;
-    } else {
-      const int g = p * 64 + lane;
-      const int key = g / SPR;
-      const int slot = g - key * SPR;
-      const int src_slot = slot ^ (IS_V ? v_slot_swizzle<D>(key) : k_slot_swizzle<D>(key));
-      int krow = key0 + key;
-      krow = krow < nkv ? krow : nkv - 1;
-      voff = (uint32_t)krow * row_bytes + (uint32_t)(src_slot << 4);
-      soff = 0;
-    }
-    if constexpr (!SAFE) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (FFPA_LDS void*)(lds_tile + p * 1024), 16, voff, soff, 0, 0);
-    } else {
-      const u32x4 x = *(const u32x4*)((const char*)base + (size_t)voff + (size_t)soff);
-      *(FFPA_LDS u32x4*)(lds_tile + p * 1024 + lane * 16) = x;
-    }
-  }
+  for (int i = 0; i < PPW; ++i) stage_piece<T, D, BC, IS_V, SAFE>(rsrc, base, row_bytes, key0, nkv, lds_tile, wave, lane, i);
 }
 
 // Additive bias for the 16 scores one lane holds of a 32-key block:
@@ -206,8 +261,12 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   constexpr int BR = 32 * NQB;
   constexpr int RB = D * 2;        // tile row bytes
   constexpr int TILE = BC * RB;
-  constexpr int PF1 = 6;           // QK: LDS reads run this many MFMAs ahead
-  constexpr int PF2 = 4;           // PV: ditto (two transpose reads per MFMA)
+  constexpr int PF1 = FFPA_PF1;
+  constexpr int PF2 = FFPA_PF2;
+  constexpr int PPW = BC * D * 2 / 4096;  // 1 KiB DMA pieces per wave per tile
+  constexpr bool kInterleave = FFPA_DMA_INTERLEAVE != 0;
+  constexpr int kStep = (ND == 1) ? FFPA_DMA_STEP : 1;  // MFMAs between two DMA pieces
+  static_assert(!kInterleave || PPW * kStep <= (DW / 16) * (BC / 32), "DMA pieces must fit the QK loop");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   FFPA_LDS char* const Kt = (FFPA_LDS char*)smem;
@@ -251,10 +310,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   // buffer descriptors over this (batch, kv-head) slice (0x00020000: raw 32-bit dwords)
   const uint32_t k_row_bytes = (uint32_t)a.sk[2] * 2u;
   const uint32_t v_row_bytes = (uint32_t)a.sv[2] * 2u;
-  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)Kg, 0, (uint32_t)(a.Nkv - 1) * k_row_bytes + (uint32_t)RB, 0x00020000);
-  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)Vg, 0, (uint32_t)(a.Nkv - 1) * v_row_bytes + (uint32_t)RB, 0x00020000);
+  const u32x4 k_rsrc = make_rsrc(Kg, (uint32_t)(a.Nkv - 1) * k_row_bytes + (uint32_t)RB);
+  const u32x4 v_rsrc = make_rsrc(Vg, (uint32_t)(a.Nkv - 1) * v_row_bytes + (uint32_t)RB);
 
   // ---- KV tile range (split_d.cuh:222-228: causal tiles past the diagonal are skipped)
   int nt = (a.Nkv + BC - 1) / BC;
@@ -301,8 +358,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
 
   if (nt > 0) {
     stage_tile<T, D, BC, false, SAFE>(k_rsrc, Kg, k_row_bytes, 0, a.Nkv, Kt, wave, lane);
-    __syncthreads();  // K(0) landed (the barrier's release waits vmcnt(0)) and visible
-    stage_tile<T, D, BC, true, SAFE>(v_rsrc, Vg, v_row_bytes, 0, a.Nkv, Vt, wave, lane);
+    dma_wait_all();
+    __syncthreads();  // K(0) landed and visible
+    if constexpr (!kInterleave) stage_tile<T, D, BC, true, SAFE>(v_rsrc, Vg, v_row_bytes, 0, a.Nkv, Vt, wave, lane);
   }
 
   for (int j = 0; j < nt; ++j) {
@@ -319,6 +377,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
         const int s = n / NKB, kb = n % NKB;
         return *(FFPA_LDS const v8*)(kaddr[s & 7] + (s >> 3) * 256 + kb * 32 * RB);
       };
+      const int dlane = opaque_lane(lane);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int n = 0; n < PF1 && n < N1; ++n) kf[n] = k_frag(n);
@@ -326,6 +385,11 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
       for (int n = 0; n < N1; ++n) {
         __builtin_amdgcn_sched_barrier(0);
         if (n + PF1 < N1) kf[n + PF1] = k_frag(n + PF1);
+        if constexpr (kInterleave && !(FFPA_ABL & 1)) {
+          // V(j) streams in under this tile's QK^T (the V buffer is free since barrier B of tile j-1)
+          if (n % kStep == 0 && n / kStep < PPW)
+            stage_piece<T, D, BC, true, SAFE>(v_rsrc, Vg, v_row_bytes, k0, a.Nkv, Vt, wave, dlane, n / kStep);
+        }
         const int s = n / NKB, kb = n % NKB;
         if (s == 0) E::mfma_v_first(sacc[kb], kf[n], qf[s]);
         else E::mfma_v_acc(sacc[kb], kf[n], qf[s]);
@@ -346,8 +410,11 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
     }
 
     // barrier A: every wave is done reading K(j); V(j) has landed; partials visible
+    dma_wait_all();
     __syncthreads();
-    if (j + 1 < nt) stage_tile<T, D, BC, false, SAFE>(k_rsrc, Kg, k_row_bytes, k0 + BC, a.Nkv, Kt, wave, lane);
+    if constexpr (!kInterleave && !(FFPA_ABL & 1)) {
+      if (j + 1 < nt) stage_tile<T, D, BC, false, SAFE>(k_rsrc, Kg, k_row_bytes, k0 + BC, a.Nkv, Kt, wave, lane);
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     // lane holds x[kb][r] = score(row qrow, key k0 + 32 kb + (r&3) + 8 (r>>2) + 4 h)
@@ -434,7 +501,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(x[kb][r] - m_use);
+        const float p = (FFPA_ABL & 2) ? (x[kb][r] - m_use) : __builtin_amdgcn_exp2f(x[kb][r] - m_use);
         psum += p;  // row sum from the unrounded P (prefill.cuh:755-756)
         // contraction slot (h, r & 7) of step 2 kb + (r >> 3) <-> this register: any
         // permutation of the key index is free as long as V^T uses the same one.
@@ -465,6 +532,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
           return r;
         }
       };
+      const int dlane = opaque_lane(lane);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int n = 0; n < PF2 && n < N2; ++n) vf[n] = v_frag(n);
@@ -472,14 +540,24 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
       for (int n = 0; n < N2; ++n) {
         __builtin_amdgcn_sched_barrier(0);
         if (n + PF2 < N2) vf[n + PF2] = v_frag(n + PF2);
+        if constexpr (kInterleave && !(FFPA_ABL & 1)) {
+          // K(j+1) streams in under this tile's PV (the K buffer is free since barrier A).  After the
+          // last tile this prefetches a clamped, unused tile: cheaper than a branch per piece, and
+          // barrier B still drains it before the workgroup can exit.
+          if (n % kStep == 0 && n / kStep < PPW)
+            stage_piece<T, D, BC, false, SAFE>(k_rsrc, Kg, k_row_bytes, k0 + BC, a.Nkv, Kt, wave, dlane, n / kStep);
+        }
         oacc[n / NKS] = E::mfma(vf[n], pf[n % NKS], oacc[n / NKS]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
 
     // barrier B: every wave is done reading V(j); K(j+1) has landed and is visible
+    dma_wait_all();
     __syncthreads();
-    if (j + 1 < nt) stage_tile<T, D, BC, true, SAFE>(v_rsrc, Vg, v_row_bytes, k0 + BC, a.Nkv, Vt, wave, lane);
+    if constexpr (!kInterleave && !(FFPA_ABL & 1)) {
+      if (j + 1 < nt) stage_tile<T, D, BC, true, SAFE>(v_rsrc, Vg, v_row_bytes, k0 + BC, a.Nkv, Vt, wave, lane);
+    }
   }
 
   // ================= epilogue (prefill.cuh:1018-1093) =================

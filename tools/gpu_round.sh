@@ -31,6 +31,10 @@ pmc)
   echo "pmc2 exit $?"
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS -d $OLDPWD/gpurun_out/pmc -o pmc3 -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sdpa) > gpurun_out/pmc3.log 2>&1
   echo "pmc3 exit $?" ;;
+ab)
+  timeout 600 python tools/gpu_ab.py $AB_ARGS > gpurun_out/ab.log 2>&1; echo "ab exit $?"; cat gpurun_out/ab.log ;;
+ab2)
+  timeout 600 python tools/gpu_ab.py $AB2_ARGS > gpurun_out/ab2.log 2>&1; echo "ab2 exit $?"; cat gpurun_out/ab2.log ;;
 esac
 done
 ls -la gpurun_out | head -30
