@@ -51,6 +51,20 @@ WORKLOADS = {
 }
 
 
+def measured_traffic(workload: str):
+  """HBM bytes per launch from the committed rocprofv3 PMC pass of THIS command (profiles/): bench.py
+  cannot profile itself, so it reports the figure measured with `rocprofv3 --pmc FETCH_SIZE` (x2: gfx950
+  counts 128-B requests at 64 B, MI355X_MICROARCH.md §HBM) + `--pmc WRITE_SIZE`, or null if absent."""
+  path = os.path.join(ROOT, "profiles", "r01_bench_cfg2_pmc.json")
+  if workload != "cfg2" or not os.path.exists(path):
+    return None
+  try:
+    d = json.load(open(path))["derived"]
+    return int(d["hbm_read_bytes_corrected_x2"] + d.get("hbm_write_bytes", 0))
+  except (KeyError, ValueError):
+    return None
+
+
 def cpu_baseline(seconds_budget: float = 20.0) -> dict:
   """The reference's CPU path (torch CPU SDPA) on a bounded sample of the same workload: H=4 of the
   32 heads of B=1 N=8192 D=512 bf16, warm-up 1 + best of 3."""
@@ -185,7 +199,7 @@ def main() -> None:
         "peak": MFMA_BF16_PEAK_TFLOPS,
         "unit": "TFLOP/s",
         "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
-        "traffic": None,
+        "traffic": measured_traffic(args.workload),
         "kernel": "ffpa_fwd_split_d_kernel",
         "kernel_ms_avg": round(kernel_ms_avg, 4),
         "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 4),

@@ -45,8 +45,23 @@
 #ifndef FFPA_DMA_STEP
 #define FFPA_DMA_STEP 2  // interleaved mode: one DMA piece every this many MFMAs (ND == 1)
 #endif
+#ifndef FFPA_PV_ORDER
+#define FFPA_PV_ORDER 1  // PV MFMA order: 0 = column-block outer (4 back-to-back MFMAs per accumulator),
+#endif                   //               1 = key-step outer (consecutive MFMAs rotate over all accumulators)
+#ifndef FFPA_QK_ORDER
+#define FFPA_QK_ORDER 0  // QK MFMA order: 0 = d-step outer (alternate the two S accumulators), 1 = key-block outer
+#endif
+#ifndef FFPA_V_EARLY
+#define FFPA_V_EARLY 1  // issue the first PV fragment reads right after barrier A (latency hides under softmax)
+#endif
 #ifndef FFPA_ABL
-#define FFPA_ABL 0  // developer ablations (WRONG RESULTS): 1 = no in-loop DMA, 2 = no exp in softmax
+#define FFPA_ABL 0  // developer ablations (WRONG RESULTS): 1 no in-loop DMA, 2 no exp, 4 no barriers, 8 no softmax at all, 16 no DMA drain, 32 no s_nop in the S MFMA, 64 no LDS fragment reads
+#endif
+
+#if (FFPA_ABL & 32)
+#define FFPA_MFMA_PAD ""
+#else
+#define FFPA_MFMA_PAD "s_nop 1\n\t"  // VALU-write -> MFMA-operand wait states (invisible to hipcc inside asm)
 #endif
 
 namespace ffpa {
@@ -95,10 +110,10 @@ struct Elem<__bf16> {
   // MFMA of a kernel, and the 256 AGPRs are exactly the O^T accumulator).  "s_nop 1" covers
   // the VALU-write -> MFMA-operand wait states the compiler cannot see inside asm.
   static __device__ __forceinline__ void mfma_v_first(f32x16& d, v8 a, v8 b) {
-    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+    asm volatile(FFPA_MFMA_PAD "v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
   }
   static __device__ __forceinline__ void mfma_v_acc(f32x16& d, v8 a, v8 b) {
-    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+    asm volatile(FFPA_MFMA_PAD "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
   }
   static __device__ __forceinline__ v4 tr_read(FFPA_LDS const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((FFPA_LDS v4*)p);
@@ -113,10 +128,10 @@ struct Elem<_Float16> {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
   static __device__ __forceinline__ void mfma_v_first(f32x16& d, v8 a, v8 b) {
-    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+    asm volatile(FFPA_MFMA_PAD "v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
   }
   static __device__ __forceinline__ void mfma_v_acc(f32x16& d, v8 a, v8 b) {
-    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+    asm volatile(FFPA_MFMA_PAD "v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
   }
   static __device__ __forceinline__ v4 tr_read(FFPA_LDS const char* p) {
     typedef __attribute__((ext_vector_type(4))) short s4;
@@ -264,7 +279,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   constexpr int PF1 = FFPA_PF1;
   constexpr int PF2 = FFPA_PF2;
   constexpr int PPW = BC * D * 2 / 4096;  // 1 KiB DMA pieces per wave per tile
-  constexpr bool kInterleave = FFPA_DMA_INTERLEAVE != 0;
+  constexpr bool kInterleave = FFPA_DMA_INTERLEAVE != 0 && (ND == 1 || FFPA_DMA_INTERLEAVE == 2);  // D > 512 measured faster with bursts
   constexpr int kStep = (ND == 1) ? FFPA_DMA_STEP : 1;  // MFMAs between two DMA pieces
   static_assert(!kInterleave || PPW * kStep <= (DW / 16) * (BC / 32), "DMA pieces must fit the QK loop");
 
@@ -374,7 +389,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
       constexpr int N1 = KS * NKB;
       v8 kf[N1];
       auto k_frag = [&](int n) -> v8 {
-        const int s = n / NKB, kb = n % NKB;
+        const int s = FFPA_QK_ORDER ? n % KS : n / NKB, kb = FFPA_QK_ORDER ? n / KS : n % NKB;
+        if constexpr ((FFPA_ABL & 64) != 0) return qf[(s + 1) % KS];
         return *(FFPA_LDS const v8*)(kaddr[s & 7] + (s >> 3) * 256 + kb * 32 * RB);
       };
       const int dlane = opaque_lane(lane);
@@ -390,7 +406,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
           if (n % kStep == 0 && n / kStep < PPW)
             stage_piece<T, D, BC, true, SAFE>(v_rsrc, Vg, v_row_bytes, k0, a.Nkv, Vt, wave, dlane, n / kStep);
         }
-        const int s = n / NKB, kb = n % NKB;
+        const int s = FFPA_QK_ORDER ? n % KS : n / NKB, kb = FFPA_QK_ORDER ? n / KS : n % NKB;
         if (s == 0) E::mfma_v_first(sacc[kb], kf[n], qf[s]);
         else E::mfma_v_acc(sacc[kb], kf[n], qf[s]);
       }
@@ -410,12 +426,42 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
     }
 
     // barrier A: every wave is done reading K(j); V(j) has landed; partials visible
-    dma_wait_all();
-    __syncthreads();
+    if constexpr (!(FFPA_ABL & 16)) dma_wait_all();
+    if constexpr (!(FFPA_ABL & 4)) __syncthreads();
     if constexpr (!kInterleave && !(FFPA_ABL & 1)) {
       if (j + 1 < nt) stage_tile<T, D, BC, false, SAFE>(k_rsrc, Kg, k_row_bytes, k0 + BC, a.Nkv, Kt, wave, lane);
     }
     __builtin_amdgcn_sched_barrier(0);
+
+    // V^T fragments for the PV loop below.  V(j) is visible from barrier A on, so the first PF2
+    // fragments are requested here and their LDS latency hides under the softmax VALU work.
+    constexpr int N2 = NDB * NKS;
+    v8 vf[N2];
+    auto v_frag = [&](int n) -> v8 {
+      const int db = FFPA_PV_ORDER ? n % NDB : n / NKS, ks = FFPA_PV_ORDER ? n / NDB : n % NKS;
+      if constexpr ((FFPA_ABL & 64) != 0) return qf[(db + ks) % KS];
+      if constexpr (!SAFE) {
+        FFPA_LDS const char* vp = vaddr[db & 3] + (db >> 2) * 256 + (ks * 16) * RB;
+        const v4 lo = E::tr_read(vp);
+        const v4 hi = E::tr_read(vp + 8 * RB);
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      } else {
+        v8 r;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const int key = ks * 16 + 8 * (jj >> 2) + 4 * h + (jj & 3);
+          const int byte = (dh * DW + db * 32 + l31) * 2;
+          const int off = byte ^ (v_slot_swizzle<D>(key) * 16);
+          r[jj] = *(FFPA_LDS const T*)(Vt + key * RB + off);
+        }
+        return r;
+      }
+    };
+    if constexpr (FFPA_V_EARLY) {
+#pragma unroll
+      for (int n = 0; n < PF2 && n < N2; ++n) vf[n] = v_frag(n);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 
     // lane holds x[kb][r] = score(row qrow, key k0 + 32 kb + (r&3) + 8 (r>>2) + 4 h)
     float x[NKB][16];
@@ -460,11 +506,13 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
 
     // ================= online softmax (prefill.cuh:671-870, log2 domain) =================
     float tmax = x[0][0];
+    if constexpr (!(FFPA_ABL & 8)) {
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
+      for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, x[kb][r]);
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, x[kb][r]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    }
     const float m_new = fmaxf(m_run, tmax);
     // lazy rescale: keep the stale max while it grew by <= thr (prefill.cuh:684-755);
     // the first finite max always takes the branch (m_run = -inf).
@@ -493,7 +541,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
       l_run *= alpha;
       m_run = grow ? m_new : m_run;
     }
-    const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
+    float m_use = (m_run == -INFINITY) ? 0.f : m_run;
+    if constexpr ((FFPA_ABL & 8) != 0) m_use = 0.f;
 
     v8 pf[NKS];
     float psum = 0.f;
@@ -501,8 +550,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = (FFPA_ABL & 2) ? (x[kb][r] - m_use) : __builtin_amdgcn_exp2f(x[kb][r] - m_use);
-        psum += p;  // row sum from the unrounded P (prefill.cuh:755-756)
+        const float p = (FFPA_ABL & 8) ? x[kb][r] : (FFPA_ABL & 2) ? (x[kb][r] - m_use) : __builtin_amdgcn_exp2f(x[kb][r] - m_use);
+        if constexpr (!(FFPA_ABL & 8)) psum += p;  // row sum from the unrounded P (prefill.cuh:755-756)
         // contraction slot (h, r & 7) of step 2 kb + (r >> 3) <-> this register: any
         // permutation of the key index is free as long as V^T uses the same one.
         pf[kb * 2 + (r >> 3)][r & 7] = (T)p;
@@ -511,31 +560,12 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
 
     // ================= O^T += V^T.P^T =================
     {
-      constexpr int N2 = NDB * NKS;
-      v8 vf[N2];
-      auto v_frag = [&](int n) -> v8 {
-        const int db = n / NKS, ks = n % NKS;
-        if constexpr (!SAFE) {
-          FFPA_LDS const char* vp = vaddr[db & 3] + (db >> 2) * 256 + (ks * 16) * RB;
-          const v4 lo = E::tr_read(vp);
-          const v4 hi = E::tr_read(vp + 8 * RB);
-          return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        } else {
-          v8 r;
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj) {
-            const int key = ks * 16 + 8 * (jj >> 2) + 4 * h + (jj & 3);
-            const int byte = (dh * DW + db * 32 + l31) * 2;
-            const int off = byte ^ (v_slot_swizzle<D>(key) * 16);
-            r[jj] = *(FFPA_LDS const T*)(Vt + key * RB + off);
-          }
-          return r;
-        }
-      };
       const int dlane = opaque_lane(lane);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!FFPA_V_EARLY) {
 #pragma unroll
-      for (int n = 0; n < PF2 && n < N2; ++n) vf[n] = v_frag(n);
+        for (int n = 0; n < PF2 && n < N2; ++n) vf[n] = v_frag(n);
+      }
 #pragma unroll
       for (int n = 0; n < N2; ++n) {
         __builtin_amdgcn_sched_barrier(0);
@@ -547,14 +577,17 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
           if (n % kStep == 0 && n / kStep < PPW)
             stage_piece<T, D, BC, false, SAFE>(k_rsrc, Kg, k_row_bytes, k0 + BC, a.Nkv, Kt, wave, dlane, n / kStep);
         }
-        oacc[n / NKS] = E::mfma(vf[n], pf[n % NKS], oacc[n / NKS]);
+        {
+          const int db = FFPA_PV_ORDER ? n % NDB : n / NKS, ks = FFPA_PV_ORDER ? n / NDB : n % NKS;
+          oacc[db] = E::mfma(vf[n], pf[ks], oacc[db]);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
 
     // barrier B: every wave is done reading V(j); K(j+1) has landed and is visible
-    dma_wait_all();
-    __syncthreads();
+    if constexpr (!(FFPA_ABL & 16)) dma_wait_all();
+    if constexpr (!(FFPA_ABL & 4)) __syncthreads();
     if constexpr (!kInterleave && !(FFPA_ABL & 1)) {
       if (j + 1 < nt) stage_tile<T, D, BC, true, SAFE>(v_rsrc, Vg, v_row_bytes, k0 + BC, a.Nkv, Vt, wave, lane);
     }

@@ -31,6 +31,15 @@ pmc)
   echo "pmc2 exit $?"
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS -d $OLDPWD/gpurun_out/pmc -o pmc3 -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sdpa) > gpurun_out/pmc3.log 2>&1
   echo "pmc3 exit $?" ;;
+pmcsq)
+  rm -rf gpurun_out/pmc
+  (cd /tmp && timeout 180 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $OLDPWD/gpurun_out/pmc -o pmc1 -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sdpa) > gpurun_out/pmc1.log 2>&1
+  echo "pmc1 exit $?"
+  (cd /tmp && timeout 180 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU -d $OLDPWD/gpurun_out/pmc -o pmc3 -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sdpa) > gpurun_out/pmc3.log 2>&1
+  echo "pmc3 exit $?" ;;
+pmcfetch)
+  (cd /tmp && timeout 90 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OLDPWD/gpurun_out/pmc -o pmc2 -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sdpa) > gpurun_out/pmc2.log 2>&1
+  echo "pmcfetch exit $?" ;;
 ab)
   timeout 600 python tools/gpu_ab.py $AB_ARGS > gpurun_out/ab.log 2>&1; echo "ab exit $?"; cat gpurun_out/ab.log ;;
 ab2)
