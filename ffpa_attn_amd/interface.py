@@ -13,24 +13,52 @@ import torch
 from .functional import FFPAAttnMeta
 
 
+class _FFPAAttnFunc(torch.autograd.Function):
+  """HIP forward + SDPA-style backward (the reference's ``_FFPAAttnFunc`` with ``forward_backend`` =
+  native kernel and ``backward_backend="sdpa"``, functional.py:964-1172).  O and the natural-log LSE
+  ``[B, Hq, Nq]`` are saved only when a gradient is needed (functional.py:1066-1077)."""
+
+  @staticmethod
+  def forward(ctx, query, key, value, attn_bias, meta: FFPAAttnMeta):
+    from .hip import ffpa_attn_forward_hip
+
+    thr = getattr(meta.forward_meta, "rescale_threshold", None)
+    out, lse = ffpa_attn_forward_hip(
+      query,
+      key,
+      value,
+      attn_bias,
+      causal=meta.attn_meta.is_causal,
+      softmax_scale=meta.attn_meta.scale,
+      dropout_p=meta.attn_meta.dropout_p,
+      rescale_threshold=-1.0 if thr is None else float(thr),
+    )
+    needs_grad = meta.attn_meta.is_grad_enabled and any(
+      t is not None and t.requires_grad for t in (query, key, value, attn_bias)
+    )
+    if needs_grad:
+      ctx.save_for_backward(query, key, value, out, lse, attn_bias)
+      ctx.causal = meta.attn_meta.is_causal
+      ctx.scale = meta.attn_meta.scale
+    return out
+
+  @staticmethod
+  def backward(ctx, grad_out):
+    from .backward import attention_backward
+
+    query, key, value, out, lse, attn_bias = ctx.saved_tensors
+    want_bias = attn_bias is not None and ctx.needs_input_grad[3]
+    dq, dk, dv, dbias = attention_backward(
+      grad_out.contiguous(), query, key, value, out, lse, causal=ctx.causal, scale=ctx.scale, attn_bias=attn_bias,
+      want_bias_grad=want_bias,
+    )
+    return dq, dk, dv, dbias, None
+
+
 @torch._dynamo.disable
 def _ffpa_apply(query, key, value, attn_bias, meta: FFPAAttnMeta) -> torch.Tensor:
   """Graph-break boundary, as the reference's ``_ffpa_apply`` (functional.py:1195-1216)."""
-  from .hip import ffpa_attn_forward_hip
-
-  fwd = meta.forward_meta
-  thr = getattr(fwd, "rescale_threshold", None)
-  out, _lse = ffpa_attn_forward_hip(
-    query,
-    key,
-    value,
-    attn_bias,
-    causal=meta.attn_meta.is_causal,
-    softmax_scale=meta.attn_meta.scale,
-    dropout_p=meta.attn_meta.dropout_p,
-    rescale_threshold=-1.0 if thr is None else float(thr),
-  )
-  return out
+  return _FFPAAttnFunc.apply(query, key, value, attn_bias, meta)
 
 
 def ffpa_attn_func(

@@ -392,3 +392,51 @@ def test_op_schema_and_lse_contract(hip):
   assert lse.shape == (2, 4, 520) and lse.dtype == torch.float32 and lse.is_contiguous()  # cuda/__init__.py:100-112
   s = (q.float() @ k.float().transpose(-1, -2)) * 320 ** -0.5
   assert (lse - torch.logsumexp(s, -1)).abs().max().item() < 2e-4
+
+
+# ----------------------------------------------------------------------------- backward hookup (§8f rank 2)
+@pytest.mark.parametrize("impl", ["auto", "recompute"])
+@pytest.mark.parametrize("case", ["self", "gqa_causal_cross", "bias"])
+def test_backward_through_saved_o_and_lse(hip, impl, case, monkeypatch):
+  """Gradients from (O, LSE) of the HIP forward vs torch autograd through fp32 math attention
+  (the reference checks its sdpa-backward the same way, tests/test_ffpa_bwd.py)."""
+  from ffpa_attn_amd import backward as bw
+  from ffpa_attn_amd import ffpa_attn_func
+
+  D = 512
+  if case == "self":
+    Hq, Hkv, Nq, Nkv, causal = 4, 4, 640, 640, False
+  elif case == "gqa_causal_cross":
+    Hq, Hkv, Nq, Nkv, causal = 4, 2, 600, 777, True
+  else:
+    Hq, Hkv, Nq, Nkv, causal = 2, 2, 520, 640, False
+  q = _rand((1, Hq, Nq, D), seed=121).requires_grad_()
+  k = _rand((1, Hkv, Nkv, D), seed=122).requires_grad_()
+  v = _rand((1, Hkv, Nkv, D), seed=123).requires_grad_()
+  bias = None
+  if case == "bias":
+    bias = (_rand((1, 1, Nq, Nkv), seed=124) * 0.5).requires_grad_()
+  go = _rand((1, Hq, Nq, D), seed=125)
+
+  if impl == "recompute":
+    orig = bw.attention_backward
+    monkeypatch.setattr(bw, "attention_backward", lambda *a, **kw: orig(*a, **{**kw, "force": "recompute"}))
+  out = ffpa_attn_func(q, k, v, attn_mask=bias, is_causal=causal, enable_gqa=(Hq != Hkv))
+  grads = torch.autograd.grad(out, [q, k, v] + ([bias] if bias is not None else []), go)
+
+  qf, kf, vf = (t.detach().float().requires_grad_() for t in (q, k, v))
+  bf = bias.detach().float().requires_grad_() if bias is not None else None
+  g = Hq // Hkv
+  s = (qf @ kf.repeat_interleave(g, 1).transpose(-1, -2)) * D ** -0.5
+  if bf is not None:
+    s = s + bf
+  if causal:
+    rows = torch.arange(Nq, device="cuda")[:, None]
+    cols = torch.arange(Nkv, device="cuda")[None, :]
+    s = s.masked_fill(cols > rows + (Nkv - Nq), float("-inf"))
+  ref = torch.softmax(s, -1) @ vf.repeat_interleave(g, 1)
+  rgrads = torch.autograd.grad(ref, [qf, kf, vf] + ([bf] if bf is not None else []), go.float())
+  for name, a, b in zip(("dq", "dk", "dv", "dbias"), grads, rgrads):
+    scale = b.abs().max().item()
+    err = (a.float() - b).abs().max().item()
+    assert err <= 3e-2 * scale + 1e-3, f"{case}/{impl} {name}: err {err:.3e} vs max {scale:.3e}"
