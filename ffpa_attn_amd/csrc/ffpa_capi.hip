@@ -27,8 +27,8 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
-typedef int (*launch_fn)(int, int, const ffpa::FwdArgs&, hipStream_t);
-typedef void (*config_fn)(int*, int*, int*);
+typedef int (*launch_fn)(int, int, int, const ffpa::FwdArgs&, hipStream_t);
+typedef void (*config_fn)(int, int*, int*, int*);
 
 struct DimEntry {
   int d;
@@ -46,6 +46,72 @@ const DimEntry* find_dim(int d) {
   for (const DimEntry& e : kDims)
     if (e.d == d) return &e;
   return nullptr;
+}
+
+// Launch plan: which tile variant, and over how many workgroups the KV axis is split.
+struct Plan {
+  int variant, br, bc, lds, nqt, nt, splits, tiles_per_split;
+  size_t ws_bytes;
+};
+
+int device_cu_count() {
+  static int cached[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
+Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
+  Plan pl = {};
+  // <= 32 query rows per (batch, head): one 32-row block per workgroup with D split over all four waves;
+  // the reference switches to its split-KV decode kernels only for Nq == 1 (native/launch.cuh:306-340)
+  pl.variant = (p->seqlen_q <= 32 && !(p->flags & FFPA_FLAG_DEBUG_SAFE_PATH)) ? 1 : 0;
+  de->config(pl.variant, &pl.br, &pl.bc, &pl.lds);
+  pl.nqt = (p->seqlen_q + pl.br - 1) / pl.br;
+  pl.nt = (p->seqlen_kv + pl.bc - 1) / pl.bc;
+  pl.splits = 1;
+  if (pl.variant == 1 && p->num_splits != 1) {
+    // occupancy heuristic (cf. select_decode_num_splits, native/launch.cuh:17-67): aim at two workgroups
+    // per CU, keep at least 4 KV tiles per split so the merge stays cheap
+    const int64_t base = (int64_t)p->batch * p->heads_q * pl.nqt;
+    int64_t want = (2LL * device_cu_count() + base - 1) / base;
+    const int64_t cap = pl.nt / 4 > 0 ? pl.nt / 4 : 1;
+    if (want > cap) want = cap;
+    if (p->num_splits > 1 && want > p->num_splits) want = p->num_splits;
+    if (want < 1) want = 1;
+    const size_t per_split = (size_t)p->batch * p->heads_q * p->seqlen_q * ((size_t)p->head_dim + 1) * sizeof(float);
+    if (p->workspace == nullptr) want = 1;
+    else if ((uint64_t)want * per_split > p->workspace_bytes) want = (int64_t)(p->workspace_bytes / per_split);
+    if (want < 1) want = 1;
+    pl.splits = (int)want;
+  }
+  pl.tiles_per_split = (pl.nt + pl.splits - 1) / pl.splits;
+  if (pl.tiles_per_split < 1) pl.tiles_per_split = 1;
+  pl.splits = (pl.nt + pl.tiles_per_split - 1) / pl.tiles_per_split;
+  if (pl.splits < 1) pl.splits = 1;
+  pl.ws_bytes = pl.splits > 1 ? (size_t)pl.splits * p->batch * p->heads_q * p->seqlen_q * ((size_t)p->head_dim + 1) * sizeof(float) : 0;
+  return pl;
+}
+
+// Shape / dtype checks shared by the launch and the queries.  Returns FFPA_OK or a status.
+int check_basic(const ffpa_fwd_params* p, const DimEntry** de_out) {
+  if (p == nullptr) return fail(FFPA_ERR_NULL_POINTER, "params is NULL");
+  if (p->struct_size != sizeof(ffpa_fwd_params) || p->abi_version != FFPA_ATTN_ABI_VERSION)
+    return fail(FFPA_ERR_BAD_ABI, "ffpa_fwd_params ABI mismatch: size %u (want %zu), version %u (want %d)",
+                p->struct_size, sizeof(ffpa_fwd_params), p->abi_version, FFPA_ATTN_ABI_VERSION);
+  if (p->batch <= 0 || p->heads_q <= 0 || p->heads_kv <= 0 || p->seqlen_q <= 0 || p->seqlen_kv <= 0)
+    return fail(FFPA_ERR_BAD_SHAPE, "non-positive dimension: B=%d Hq=%d Hkv=%d Nq=%d Nkv=%d", p->batch, p->heads_q,
+                p->heads_kv, p->seqlen_q, p->seqlen_kv);
+  const DimEntry* de = find_dim(p->head_dim);
+  if (de == nullptr)
+    return fail(FFPA_ERR_BAD_HEADDIM, "headdim not support! D=%d (built: multiples of 64 in [64, 1024])", p->head_dim);
+  *de_out = de;
+  return FFPA_OK;
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -106,10 +172,13 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   if (!isfinite(p->softmax_scale)) return fail(FFPA_ERR_BAD_SHAPE, "softmax_scale is not finite");
   const int safe = (p->flags & FFPA_FLAG_DEBUG_SAFE_PATH) ? 1 : 0;
 
-  int br = 0, bc = 0, lds = 0;
-  de->config(&br, &bc, &lds);
-  const int64_t nqt = ((int64_t)p->seqlen_q + br - 1) / br;
-  const int64_t grid = (int64_t)p->batch * p->heads_q * nqt;
+  if (p->causal_row_mod < 0) return fail(FFPA_ERR_BAD_SHAPE, "causal_row_mod must be >= 0");
+  if (p->workspace != nullptr && !aligned16(p->workspace))
+    return fail(FFPA_ERR_MISALIGNED, "workspace must be 16-byte aligned");
+  const Plan pl = make_plan(p, de);
+  const int lds = pl.lds;
+  const int64_t nqt = pl.nqt;
+  const int64_t grid = (int64_t)p->batch * p->heads_q * nqt * pl.splits;
   if (grid > 0x7fffffffLL) return fail(FFPA_ERR_BAD_SHAPE, "grid of %lld workgroups is too large", (long long)grid);
 
   ffpa::FwdArgs a;
@@ -140,8 +209,23 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   a.scale_log2 = p->softmax_scale * 1.4426950408889634f;  // FFPA_M_LOG2E, csrc/cuffpa/common.cuh:9-18
   a.thr = p->rescale_threshold < 0.f ? 8.0f : p->rescale_threshold;
   a.flags = p->flags;
+  a.nsplit = pl.splits;
+  a.tiles_per_split = pl.tiles_per_split;
+  a.causal_row_mod = p->causal_row_mod;
+  if (pl.splits > 1) {
+    a.ws_o = static_cast<float*>(p->workspace);
+    a.ws_lse = a.ws_o + (size_t)pl.splits * p->batch * p->heads_q * p->seqlen_q * p->head_dim;
+  }
 
-  const int st = de->launch(p->dtype, safe, a, static_cast<hipStream_t>(stream));
+  int st = de->launch(p->dtype, safe, pl.variant, a, static_cast<hipStream_t>(stream));
+  if (st == 0 && pl.splits > 1) {
+    const unsigned rows = (unsigned)((int64_t)p->batch * p->heads_q * p->seqlen_q);
+    if (p->dtype == FFPA_DTYPE_BF16)
+      hipLaunchKernelGGL(ffpa::ffpa_fwd_merge_kernel<__bf16>, dim3(rows), dim3(64), 0, static_cast<hipStream_t>(stream), a, p->head_dim);
+    else
+      hipLaunchKernelGGL(ffpa::ffpa_fwd_merge_kernel<_Float16>, dim3(rows), dim3(64), 0, static_cast<hipStream_t>(stream), a, p->head_dim);
+    st = (int)hipGetLastError();
+  }
   if (st == -3) return fail(FFPA_ERR_UNSUPPORTED, "debug safe-path kernel is not built for D=%d / this dtype", p->head_dim);
   if (st == -2)
     return fail(FFPA_ERR_LAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed (is this a gfx950?)", lds);
@@ -151,7 +235,28 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   return FFPA_OK;
 }
 
-size_t ffpa_attn_fwd_workspace_bytes(const ffpa_fwd_params* /*params*/) { return 0; }
+size_t ffpa_attn_fwd_workspace_bytes(const ffpa_fwd_params* params) {
+  const DimEntry* de = nullptr;
+  if (check_basic(params, &de) != FFPA_OK) return 0;
+  // size for the split count the heuristic would pick with unlimited scratch
+  ffpa_fwd_params q = *params;
+  q.workspace = reinterpret_cast<void*>(16);
+  q.workspace_bytes = ~0ull;
+  return make_plan(&q, de).ws_bytes;
+}
+
+int ffpa_attn_fwd_plan(const ffpa_fwd_params* params, int out[4]) {
+  const DimEntry* de = nullptr;
+  const int rc = check_basic(params, &de);
+  if (rc != FFPA_OK) return rc;
+  if (out == nullptr) return fail(FFPA_ERR_NULL_POINTER, "out is NULL");
+  const Plan pl = make_plan(params, de);
+  out[0] = pl.variant;
+  out[1] = pl.br;
+  out[2] = pl.bc;
+  out[3] = pl.splits;
+  return FFPA_OK;
+}
 
 int ffpa_attn_query(int what) {
   switch (what) {
@@ -171,7 +276,7 @@ int ffpa_attn_fwd_tile_config(int head_dim, int* block_rows, int* block_keys, in
   const DimEntry* de = find_dim(head_dim);
   if (de == nullptr) return fail(FFPA_ERR_BAD_HEADDIM, "headdim not support! D=%d", head_dim);
   int br = 0, bc = 0, lds = 0;
-  de->config(&br, &bc, &lds);
+  de->config(0, &br, &bc, &lds);
   if (block_rows) *block_rows = br;
   if (block_keys) *block_keys = bc;
   if (lds_bytes) *lds_bytes = lds;

@@ -14,7 +14,7 @@ namespace ffpa {
 template <typename T, int D, int ND, bool SAFE>
 static int launch_one(const FwdArgs& a, hipStream_t stream) {
   constexpr int BC = (ND == 1) ? 64 : 32;
-  constexpr int LDS = 2 * BC * D * 2 + (ND == 2 ? 4 * 4096 : 0);
+  constexpr int LDS = 2 * BC * D * 2 + (ND > 1 ? 4 * 4096 : 0);
   auto kern = ffpa_fwd_split_d_kernel<T, D, ND, SAFE>;
   static bool attr_done[64] = {};
   int dev = 0;
@@ -26,7 +26,7 @@ static int launch_one(const FwdArgs& a, hipStream_t stream) {
     }
     attr_done[dev] = true;
   }
-  const unsigned grid = (unsigned)a.B * (unsigned)a.Hq * (unsigned)a.nqt;
+  const unsigned grid = (unsigned)a.B * (unsigned)a.Hq * (unsigned)a.nqt * (unsigned)a.nsplit;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, stream, a);
   return (int)hipGetLastError();
 }
@@ -34,9 +34,18 @@ static int launch_one(const FwdArgs& a, hipStream_t stream) {
 #define FFPA_CAT2(a, b) a##b
 #define FFPA_CAT(a, b) FFPA_CAT2(a, b)
 
-int FFPA_CAT(launch_fwd_d, FFPA_INST_D)(int dtype, int safe, const FwdArgs& a, hipStream_t stream) {
+int FFPA_CAT(launch_fwd_d, FFPA_INST_D)(int dtype, int safe, int variant, const FwdArgs& a, hipStream_t stream) {
   constexpr int D = FFPA_INST_D;
   constexpr int ND = (D <= 512) ? 1 : 2;
+  if (variant == 1) {
+    // short-query launches: D split over all 4 waves (one 32-row block per workgroup) when the D/4
+    // slice is a whole number of 32-column O blocks, else over 2 waves (two row blocks)
+    constexpr int NDS = (D % 128 == 0) ? 4 : 2;
+    if (safe) return -3;
+    if (dtype == 0) return launch_one<__bf16, D, NDS, false>(a, stream);
+    if (dtype == 1) return launch_one<_Float16, D, NDS, false>(a, stream);
+    return -4;
+  }
 #ifdef FFPA_INST_SAFE
   if (safe) {
     if (dtype == 0) return launch_one<__bf16, D, ND, true>(a, stream);
@@ -50,13 +59,13 @@ int FFPA_CAT(launch_fwd_d, FFPA_INST_D)(int dtype, int safe, const FwdArgs& a, h
   return -4;
 }
 
-void FFPA_CAT(tile_config_d, FFPA_INST_D)(int* br, int* bc, int* lds) {
+void FFPA_CAT(tile_config_d, FFPA_INST_D)(int variant, int* br, int* bc, int* lds) {
   constexpr int D = FFPA_INST_D;
-  constexpr int ND = (D <= 512) ? 1 : 2;
-  constexpr int BC = (ND == 1) ? 64 : 32;
+  const int ND = variant == 1 ? ((D % 128 == 0) ? 4 : 2) : ((D <= 512) ? 1 : 2);
+  const int BC = (ND == 1) ? 64 : 32;
   *br = 32 * (4 / ND);
   *bc = BC;
-  *lds = 2 * BC * D * 2 + (ND == 2 ? 4 * 4096 : 0);
+  *lds = 2 * BC * D * 2 + (ND > 1 ? 4 * 4096 : 0);
 }
 
 }  // namespace ffpa

@@ -94,6 +94,15 @@ struct FwdArgs {
   float scale_log2;   // softmax_scale * log2(e)
   float thr;          // lazy-rescale threshold, log2 units (0 = exact recurrence)
   unsigned flags;
+  // split-KV (short-query / decode launches): workgroup (tile, split) handles KV tiles
+  // [split * tiles_per_split, ...) and writes a normalised fp32 partial + its LSE to the workspace
+  int nsplit;           // 1 = no split (write O / LSE directly)
+  int tiles_per_split;
+  float* ws_o;          // [nsplit, B, Hq, Nq, D] fp32
+  float* ws_lse;        // [nsplit, B, Hq, Nq]    fp32
+  // rows of several query heads of one KV group packed into one row axis (host reshape): the causal
+  // limit of packed row r is (r % causal_row_mod) + causal_offset; 0 = rows are plain query rows
+  int causal_row_mod;
 };
 
 template <typename T>
@@ -264,12 +273,12 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   using E = Elem<T>;
   using v8 = typename E::v8;
   using v4 = typename E::v4;
-  static_assert(ND == 1 || ND == 2, "D is split over at most two waves");
+  static_assert(ND == 1 || ND == 2 || ND == 4, "D is split over 1, 2 or all 4 waves");
   static_assert(D % 64 == 0, "head dim must be a multiple of 64");
   constexpr int DW = D / ND;       // output columns owned by one wave
   constexpr int NDB = DW / 32;     // 32-column O^T blocks per wave
   constexpr int KS = DW / 16;      // QK contraction steps per wave
-  constexpr int BC = (ND == 1) ? 64 : 32;
+  constexpr int BC = (ND == 1) ? 64 : 32;   // ND == 4 (short-query launches): small tiles, 2 workgroups / CU
   constexpr int NKB = BC / 32;     // 32-key S^T blocks per tile
   constexpr int NKS = BC / 16;     // PV contraction steps per tile
   constexpr int NQB = 4 / ND;      // 32-row blocks per workgroup
@@ -293,8 +302,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31;
   const int h = lane >> 5;
-  const int qb = (ND == 1) ? wave : (wave >> 1);
-  const int dh = (ND == 1) ? 0 : (wave & 1);
+  const int qb = wave / ND;  // row block of this wave
+  const int dh = wave % ND;  // which D/ND slice of the head dim it owns
 
   // ---- workgroup -> (batch, head, row tile).  Block b runs on XCD b % 8; give every
   // XCD a contiguous range of virtual ids so that the row tiles of one head (which
@@ -308,6 +317,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
     const int rem = total & 7;
     vid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
   }
+  const int split = vid % a.nsplit;
+  vid /= a.nsplit;
   const int bh = vid / a.nqt;
   int qt = vid - bh * a.nqt;
   if (a.causal) qt = a.nqt - 1 - qt;  // longest rows first
@@ -331,9 +342,15 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   // ---- KV tile range (split_d.cuh:222-228: causal tiles past the diagonal are skipped)
   int nt = (a.Nkv + BC - 1) / BC;
   if (a.causal) {
-    const int64_t last = (int64_t)q0 + BR - 1 + a.causal_offset;
+    const int last_row = a.causal_row_mod ? a.causal_row_mod - 1 : q0 + BR - 1;
+    const int64_t last = (int64_t)last_row + a.causal_offset;
     const int ntc = last < 0 ? 0 : (int)(last / BC) + 1;
     nt = nt < ntc ? nt : ntc;
+  }
+  const int t0 = split * a.tiles_per_split;  // this workgroup's share of the KV tiles
+  {
+    const int t1 = t0 + a.tiles_per_split;
+    nt = nt < t1 ? nt : t1;
   }
 
   // ---- Q fragments: B operand of S^T = K.Q^T.  lane (row l31, half h) holds
@@ -371,14 +388,14 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
     for (int i = 0; i < 4; ++i) vaddr[i] = Vt + (4 * h + j4) * RB + ((vcol + i * 64) ^ vsw);
   }
 
-  if (nt > 0) {
-    stage_tile<T, D, BC, false, SAFE>(k_rsrc, Kg, k_row_bytes, 0, a.Nkv, Kt, wave, lane);
+  if (nt > t0) {
+    stage_tile<T, D, BC, false, SAFE>(k_rsrc, Kg, k_row_bytes, t0 * BC, a.Nkv, Kt, wave, lane);
     dma_wait_all();
-    __syncthreads();  // K(0) landed and visible
-    if constexpr (!kInterleave) stage_tile<T, D, BC, true, SAFE>(v_rsrc, Vg, v_row_bytes, 0, a.Nkv, Vt, wave, lane);
+    __syncthreads();  // K(t0) landed and visible
+    if constexpr (!kInterleave) stage_tile<T, D, BC, true, SAFE>(v_rsrc, Vg, v_row_bytes, t0 * BC, a.Nkv, Vt, wave, lane);
   }
 
-  for (int j = 0; j < nt; ++j) {
+  for (int j = t0; j < nt; ++j) {
     const int k0 = j * BC;
 
     // ================= S^T = K.Q^T over this wave's part of D =================
@@ -416,7 +433,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
       __builtin_amdgcn_sched_barrier(0);
     }
 
-    if constexpr (ND == 2) {  // publish this wave's partial S^T (lane-linear, conflict free)
+    if constexpr (ND > 1) {  // publish this wave's partial S^T (lane-linear, conflict free)
       FFPA_LDS char* xw = Xb + wave * 4096 + lane * 16;
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
@@ -473,6 +490,22 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
 #pragma unroll
         for (int e = 0; e < 4; ++e) x[0][4 * r4 + e] = (sacc[0][4 * r4 + e] + t[e]) * a.scale_log2;
       }
+    } else if constexpr (ND == 4) {
+      // sum the four D-quarter partials in a fixed order so that all four waves of the row block see
+      // bit-identical scores (their softmax state must agree: each owns a different slice of O^T)
+      FFPA_LDS const char* xr = Xb + (wave & ~3) * 4096 + lane * 16;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        f32x4 acc4 = *(FFPA_LDS const f32x4*)(xr + r4 * 1024);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+          const f32x4 t = *(FFPA_LDS const f32x4*)(xr + w * 4096 + r4 * 1024);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc4[e] += t[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[0][4 * r4 + e] = acc4[e] * a.scale_log2;
+      }
     } else {
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb)
@@ -492,9 +525,10 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
       }
     }
     const bool tail = k0 + BC > a.Nkv;
-    const bool diag = a.causal && ((int64_t)k0 + BC - 1 > (int64_t)wq0 + a.causal_offset);
+    const bool diag = a.causal && ((int64_t)k0 + BC - 1 > (int64_t)(a.causal_row_mod ? 0 : wq0) + a.causal_offset);
     if (tail || diag) {
-      const int64_t lim = a.causal ? (int64_t)qrow + a.causal_offset : (int64_t)a.Nkv;
+      const int crow = a.causal_row_mod ? qrow % a.causal_row_mod : qrow;
+      const int64_t lim = a.causal ? (int64_t)crow + a.causal_offset : (int64_t)a.Nkv;
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -519,7 +553,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
     const bool grow = m_new > m_run + a.thr;
     if (__any(grow)) {
       const float alpha = grow ? __builtin_amdgcn_exp2f(m_run - m_new) : 1.f;
-      if (j > 0) {
+      if (j > t0) {
         // Rare path.  O^T lives in AGPRs, which the VALU cannot address: scale it in place
         // through one temporary VGPR.  Written as asm on "+a" operands so the accumulator
         // never acquires a VGPR live range (which makes hipcc spill the whole hot loop).
@@ -597,21 +631,72 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = __builtin_amdgcn_rcpf(l_tot);  // fully masked row: 0 * inf = NaN, as SDPA
   if (qrow < a.Nq) {
-    T* op = (T*)a.o + b * a.so[0] + hq * a.so[1] + (int64_t)qrow * a.so[2] + dh * DW + 4 * h;
+    if (a.nsplit > 1) {
+      // split-KV partial: normalised fp32 O and its LSE; an empty / fully masked share contributes
+      // nothing (O = 0, LSE = -inf).  Merged by ffpa_fwd_merge_kernel.
+      const bool dead = !(l_tot > 0.f);
+      const int64_t prow = (((int64_t)split * a.B + b) * a.Hq + hq) * a.Nq + qrow;
+      float* wp = a.ws_o + prow * D + dh * DW + 4 * h;
 #pragma unroll
-    for (int db = 0; db < NDB; ++db)
+      for (int db = 0; db < NDB; ++db)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        v4 w;
+        for (int i = 0; i < 4; ++i) {
+          f32x4 w;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) w[t] = (T)(oacc[db][4 * i + t] * inv);
-        *(v4*)(op + db * 32 + 8 * i) = w;
+          for (int t = 0; t < 4; ++t) w[t] = dead ? 0.f : oacc[db][4 * i + t] * inv;
+          *(f32x4*)(wp + db * 32 + 8 * i) = w;
+        }
+      if (h == 0 && dh == 0) a.ws_lse[prow] = dead ? -INFINITY : __logf(l_tot) + m_run * 0.6931471805599453f;
+    } else {
+      T* op = (T*)a.o + b * a.so[0] + hq * a.so[1] + (int64_t)qrow * a.so[2] + dh * DW + 4 * h;
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v4 w;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) w[t] = (T)(oacc[db][4 * i + t] * inv);
+          *(v4*)(op + db * 32 + 8 * i) = w;
+        }
+      if (a.lse != nullptr && h == 0 && dh == 0) {
+        // natural-log LSE = ln(l) + m*ln2 (prefill.cuh:1063-1073)
+        a.lse[((int64_t)b * a.Hq + hq) * a.Nq + qrow] = __logf(l_tot) + m_run * 0.6931471805599453f;
       }
-    if (a.lse != nullptr && h == 0 && dh == 0) {
-      // natural-log LSE = ln(l) + m*ln2 (prefill.cuh:1063-1073)
-      a.lse[((int64_t)b * a.Hq + hq) * a.Nq + qrow] = __logf(l_tot) + m_run * 0.6931471805599453f;
     }
   }
+}
+
+// Merge the split-KV partials of one launch (the reference's decode stage 2,
+// csrc/cuffpa/native/sm_80/split_kv.cuh:329-455): O = sum_s w_s O_s / sum_s w_s with
+// w_s = exp(LSE_s - max_s LSE_s), LSE = max + ln(sum_s w_s).  One workgroup of 64 lanes per row.
+template <typename T>
+__global__ __launch_bounds__(64) void ffpa_fwd_merge_kernel(const FwdArgs a, int D) {
+  const int64_t row = blockIdx.x;  // (b * Hq + hq) * Nq + qrow
+  const int64_t rows = (int64_t)a.B * a.Hq * a.Nq;
+  float mx = -INFINITY;
+  for (int s = 0; s < a.nsplit; ++s) mx = fmaxf(mx, a.ws_lse[s * rows + row]);
+  float wsum = 0.f;
+  for (int s = 0; s < a.nsplit; ++s) wsum += (mx == -INFINITY) ? 0.f : __expf(a.ws_lse[s * rows + row] - mx);
+  const float inv = 1.f / wsum;  // every share empty -> 0 * inf = NaN, like an unsplit fully masked row
+  const int qrow = (int)(row % a.Nq);
+  const int64_t bh = row / a.Nq;
+  const int hq = (int)(bh % a.Hq);
+  const int b = (int)(bh / a.Hq);
+  T* op = (T*)a.o + b * a.so[0] + hq * a.so[1] + (int64_t)qrow * a.so[2];
+  for (int d = threadIdx.x * 4; d < D; d += 64 * 4) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < a.nsplit; ++s) {
+      const float w = (mx == -INFINITY) ? 0.f : __expf(a.ws_lse[s * rows + row] - mx);
+      const f32x4 t = *(const f32x4*)(a.ws_o + (s * rows + row) * D + d);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += w * t[e];
+    }
+    typename Elem<T>::v4 w4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w4[e] = (T)(acc[e] * inv);
+    *(typename Elem<T>::v4*)(op + d) = w4;
+  }
+  if (a.lse != nullptr && threadIdx.x == 0) a.lse[row] = (mx == -INFINITY) ? -INFINITY : mx + __logf(wsum);
 }
 
 }  // namespace ffpa

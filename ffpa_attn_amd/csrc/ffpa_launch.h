@@ -11,8 +11,8 @@ struct FwdArgs;
   X(576) X(640) X(704) X(768) X(832) X(896) X(960) X(1024)
 
 #define FFPA_DECL(D)                                                                  \
-  int launch_fwd_d##D(int dtype, int safe, const FwdArgs& a, hipStream_t stream);     \
-  void tile_config_d##D(int* br, int* bc, int* lds);
+  int launch_fwd_d##D(int dtype, int safe, int variant, const FwdArgs& a, hipStream_t stream); \
+  void tile_config_d##D(int variant, int* br, int* bc, int* lds);
 FFPA_FOR_EACH_HEAD_DIM(FFPA_DECL)
 #undef FFPA_DECL
 

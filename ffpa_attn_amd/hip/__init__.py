@@ -86,6 +86,10 @@ class FfpaFwdParams(ctypes.Structure):
     ("flags", ctypes.c_uint32),
     ("philox_seed", ctypes.c_uint64),
     ("philox_offset", ctypes.c_uint64),
+    ("workspace", ctypes.c_void_p),
+    ("workspace_bytes", ctypes.c_uint64),
+    ("num_splits", ctypes.c_int32),
+    ("causal_row_mod", ctypes.c_int32),
   ]
 
 
@@ -95,6 +99,7 @@ _lib_lock = threading.Lock()
 EXPORTS = (
   "ffpa_attn_fwd",
   "ffpa_attn_fwd_workspace_bytes",
+  "ffpa_attn_fwd_plan",
   "ffpa_attn_query",
   "ffpa_attn_fwd_tile_config",
   "ffpa_attn_last_error",
@@ -123,6 +128,8 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.ffpa_attn_fwd.restype = ctypes.c_int
     lib.ffpa_attn_fwd_workspace_bytes.argtypes = [ctypes.POINTER(FfpaFwdParams)]
     lib.ffpa_attn_fwd_workspace_bytes.restype = ctypes.c_size_t
+    lib.ffpa_attn_fwd_plan.argtypes = [ctypes.POINTER(FfpaFwdParams), ctypes.POINTER(ctypes.c_int)]
+    lib.ffpa_attn_fwd_plan.restype = ctypes.c_int
     lib.ffpa_attn_query.argtypes = [ctypes.c_int]
     lib.ffpa_attn_query.restype = ctypes.c_int
     lib.ffpa_attn_fwd_tile_config.argtypes = [
@@ -185,11 +192,20 @@ def forward(
   philox_offset: int = 0,
   flags: int = 0,
   return_lse: bool = True,
+  num_splits: int = 0,
+  plan_out: dict | None = None,
 ) -> tuple[torch.Tensor, torch.Tensor | None]:
   """Run the gfx950 kernel on the current stream of ``q.device``; returns ``(o, lse)``.
 
   Inputs are ``[B, H, N, D]`` bf16/fp16 device tensors.  ``causal_offset=None`` selects the
   reference's tail-aligned causal mask (``Nkv - Nq``, split_d.cuh:222-228).
+
+  Short-query calls (the reference's decode regime, ``Nq`` in 1..7 reaches FFPA: functional.py:722-723):
+  with GQA and no bias, the ``group`` query heads of a KV head are packed into the row axis
+  (``q`` viewed as ``[B, Hkv, group*Nq, D]`` — K/V are then streamed once per KV head instead of once
+  per query head), the library splits the KV axis over workgroups (``num_splits``: 0 = heuristic,
+  1 = never) and merges by LSE; the scratch for the partials is allocated here with torch.
+  ``plan_out``, if given, receives the launch plan (variant, block_rows, block_keys, splits, packed).
   """
   if not q.is_cuda:
     raise NotImplementedError(
@@ -200,10 +216,22 @@ def forward(
     raise TypeError(f"ffpa_attn::_fwd_hip only supports fp16/bf16 q/k/v of one dtype, got {q.dtype}, {k.dtype}, {v.dtype}")
   B, Hq, Nq, D = q.shape
   _, Hkv, Nkv, _ = k.shape
+  out_shape = (B, Hq, Nq)
+  if causal_offset is None:
+    causal_offset = Nkv - Nq
   Dp = padded_head_dim(D)
   if Dp != D:
     pad = (0, Dp - D)
     q, k, v = (torch.nn.functional.pad(t, pad) for t in (q, k, v))
+  group = Hq // Hkv if Hkv and Hq % Hkv == 0 else 1
+  has_bias = attn_bias is not None and attn_bias.numel() > 0
+  causal_row_mod = 0
+  packed = group > 1 and Nq <= 7 and group * Nq <= 32 and not has_bias
+  if packed:
+    # [B, Hq, Nq, D] -> [B, Hkv, group*Nq, D]: packed row r = (head in group) * Nq + (query row)
+    q = q.contiguous().view(B, Hkv, group * Nq, Dp)
+    causal_row_mod = Nq
+    Hq, Nq = Hkv, group * Nq
   q, k, v = _dense_rows(q), _dense_rows(k), _dense_rows(v)
   o = torch.empty((B, Hq, Nq, Dp), dtype=q.dtype, device=q.device)
   lse = torch.empty((B, Hq, Nq), dtype=torch.float32, device=q.device) if return_lse else None
@@ -239,7 +267,9 @@ def forward(
     p.bias_dtype = 0
   p.dtype = _DTYPE[q.dtype]
   p.causal = 1 if causal else 0
-  p.causal_offset = int(Nkv - Nq if causal_offset is None else causal_offset)
+  p.causal_offset = int(causal_offset)
+  p.causal_row_mod = int(causal_row_mod)
+  p.num_splits = int(num_splits)
   p.softmax_scale = float(softmax_scale)
   p.rescale_threshold = float(rescale_threshold)
   p.dropout_p = float(dropout_p)
@@ -248,10 +278,23 @@ def forward(
   p.philox_offset = int(philox_offset) & 0xFFFFFFFFFFFFFFFF
 
   with torch.cuda.device(q.device):
+    ws_bytes = lib.ffpa_attn_fwd_workspace_bytes(ctypes.byref(p)) if num_splits != 1 else 0
+    workspace = None
+    if ws_bytes:
+      workspace = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=q.device)  # caching allocator
+      p.workspace = workspace.data_ptr()
+      p.workspace_bytes = ws_bytes
+    if plan_out is not None:
+      plan = (ctypes.c_int * 4)()
+      if lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0:
+        plan_out.update(variant=plan[0], block_rows=plan[1], block_keys=plan[2], splits=plan[3], packed=bool(packed))
     stream = torch.cuda.current_stream(q.device).cuda_stream
     rc = lib.ffpa_attn_fwd(ctypes.byref(p), ctypes.c_void_p(stream))
   if rc != 0:
     raise _STATUS_EXC.get(rc, RuntimeError)(f"ffpa_attn_fwd: {lib.ffpa_attn_last_error().decode()} (status {rc})")
+  if packed:
+    o = o.view(*out_shape, Dp)
+    lse = lse.view(out_shape) if lse is not None else None
   if Dp != D:
     o = o[..., :D]
   return o, lse

@@ -111,6 +111,18 @@ typedef struct ffpa_fwd_params {
 
   uint64_t philox_seed;   /* reserved for dropout (prefill.cuh:398-546) */
   uint64_t philox_offset;
+
+  /* Short-query (decode) launches, seqlen_q <= 32: the KV axis is split over workgroups and merged by
+   * LSE, the role of the reference's split_kv_decode_s1/s2 kernels (native/sm_80/split_kv.cuh:22-455,
+   * heuristic native/launch.cuh:17-67).  The caller owns the scratch (the reference allocates it inside
+   * the launcher, native/launch.cuh:314-318): size from ffpa_attn_fwd_workspace_bytes(). */
+  void* workspace;          /* device scratch, 16-byte aligned; NULL => no split        */
+  uint64_t workspace_bytes;
+  int32_t num_splits;       /* 0 = library heuristic, 1 = never split, n = at most n     */
+  /* Rows of several query heads of one KV group packed into the row axis by the caller (q viewed as
+   * [B, Hkv, group*Nq, D]): the causal limit of packed row r is (r % causal_row_mod) + causal_offset.
+   * 0 = rows are plain query rows. */
+  int32_t causal_row_mod;
 } ffpa_fwd_params;
 
 /*
@@ -121,10 +133,17 @@ typedef struct ffpa_fwd_params {
 int ffpa_attn_fwd(const ffpa_fwd_params* params, void* stream);
 
 /*
- * Scratch bytes the call needs (caller allocates; 0 in ABI v1).  Replaces the
- * in-launcher allocations of native/launch.cuh:314-318,503-509.
+ * Scratch bytes the call would use with the split count it would choose (0 when it does not split).
+ * Replaces the in-launcher allocations of native/launch.cuh:314-318,503-509.
  */
 size_t ffpa_attn_fwd_workspace_bytes(const ffpa_fwd_params* params);
+
+/*
+ * The launch plan for `params` (for benches / roofline maths / tests): out[0] = kernel variant
+ * (0 = prefill tiles, 1 = short-query tiles), out[1] = query rows per workgroup, out[2] = keys per
+ * tile, out[3] = number of KV splits given params->workspace_bytes.  Returns an ffpa_status.
+ */
+int ffpa_attn_fwd_plan(const ffpa_fwd_params* params, int out[4]);
 
 /* Capability / build queries.  Replaces the module attributes
  * CUDA_FWD_AVAILABLE, F16_ACC_AVAILABLE, ... (csrc/cuffpa/ffpa_api.cc:283-305). */

@@ -40,7 +40,7 @@ def test_struct_layout_matches_header(lib):
   p.abi_version = hip.ABI_VERSION
   assert lib.ffpa_attn_fwd(ctypes.byref(p), None) == 10
   assert b"ABI mismatch" in lib.ffpa_attn_last_error()
-  assert ctypes.sizeof(hip.FfpaFwdParams) == 256
+  assert ctypes.sizeof(hip.FfpaFwdParams) == 280
 
 
 def test_ctypes_mirror_matches_the_c_header(tmp_path):
@@ -70,6 +70,30 @@ def test_queries(lib):
   assert lib.ffpa_attn_query(99) == -1
   assert lib.ffpa_attn_version().startswith(b"ffpa-attn-amd")
   assert lib.ffpa_attn_fwd_workspace_bytes(None) == 0
+
+
+def test_short_query_plan_and_workspace(lib):
+  """<= 32 query rows: short-query tiles + KV splits sized by the caller's scratch (no GPU needed for the plan)."""
+  plan = (ctypes.c_int * 4)()
+  p = _params(seqlen_q=1, seqlen_kv=8192, heads_q=4, heads_kv=4)
+  assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0
+  assert list(plan) == [1, 32, 32, 1]  # no workspace -> no split
+  need = lib.ffpa_attn_fwd_workspace_bytes(ctypes.byref(p))
+  assert need > 0 and need % (4 * 1 * 4 * 1 * (512 + 1)) == 0
+  p.workspace, p.workspace_bytes = 16, need
+  assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0
+  splits = plan[3]
+  assert splits > 1 and need == splits * 4 * 1 * 4 * 1 * (512 + 1)
+  assert -(-8192 // 32) // splits >= 4  # at least 4 KV tiles per split
+  p.num_splits = 1
+  assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0 and plan[3] == 1
+  p.num_splits = 3
+  assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0 and 1 < plan[3] <= 3
+  big = _params(seqlen_q=4096, seqlen_kv=4096)
+  assert lib.ffpa_attn_fwd_plan(ctypes.byref(big), plan) == 0 and list(plan) == [0, 128, 64, 1]
+  assert lib.ffpa_attn_fwd_workspace_bytes(ctypes.byref(big)) == 0
+  d1024 = _params(seqlen_q=4096, seqlen_kv=4096, head_dim=1024)
+  assert lib.ffpa_attn_fwd_plan(ctypes.byref(d1024), plan) == 0 and list(plan) == [0, 64, 32, 1]
 
 
 def test_tile_configs():

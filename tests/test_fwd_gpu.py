@@ -440,3 +440,53 @@ def test_backward_through_saved_o_and_lse(hip, impl, case, monkeypatch):
     scale = b.abs().max().item()
     err = (a.float() - b).abs().max().item()
     assert err <= 3e-2 * scale + 1e-3, f"{case}/{impl} {name}: err {err:.3e} vs max {scale:.3e}"
+
+
+# ----------------------------------------------------------------------------- short-query / decode path (§8f rank 3)
+@pytest.mark.parametrize("D", [128, 320, 512, 1024])
+@pytest.mark.parametrize("Nq,Hq,Hkv", [(1, 8, 8), (1, 8, 2), (1, 32, 4), (2, 8, 2), (7, 4, 1), (7, 8, 8), (20, 4, 4), (32, 4, 2)])
+def test_short_query_split_kv(hip, D, Nq, Hq, Hkv):
+  """Nq <= 32: D split over all four waves, KV split over workgroups + LSE merge, GQA heads packed into
+  rows for Nq <= 7 (the reference's decode tests: tests/test_ffpa_fwd.py:929-1018)."""
+  Nkv = 3000
+  q, k, v = _rand((2, Hq, Nq, D), seed=131), _rand((2, Hkv, Nkv, D), seed=132), _rand((2, Hkv, Nkv, D), seed=133)
+  plan = {}
+  o, lse = hip.forward(q, k, v, None, False, D ** -0.5, plan_out=plan)
+  assert plan["variant"] == 1 and plan["splits"] > 1
+  assert plan["packed"] == (Hq != Hkv and Nq <= 7 and (Hq // Hkv) * Nq <= 32)
+  _check_vs_oracle(o, lse, q, k, v, block_keys=32, name=f"short {Nq}x{Hq}/{Hkv} D{D}")
+  o1, lse1 = hip.forward(q, k, v, None, False, D ** -0.5, num_splits=1)  # unsplit: same answer up to rounding
+  assert (o.float() - o1.float()).abs().max().item() <= 4e-3
+  assert (lse - lse1).abs().max().item() <= 1e-4
+  o3, _ = hip.forward(q, k, v, None, False, D ** -0.5, num_splits=3, plan_out=plan)
+  assert 1 < plan["splits"] <= 3
+  assert (o3.float() - o1.float()).abs().max().item() <= 4e-3
+
+
+@pytest.mark.parametrize("Nq,Hq,Hkv", [(1, 8, 2), (7, 4, 1), (5, 8, 8), (24, 4, 4)])
+def test_short_query_causal_and_tails(hip, Nq, Hq, Hkv):
+  D, Nkv = 512, 1111
+  q, k, v = _rand((1, Hq, Nq, D), seed=141), _rand((1, Hkv, Nkv, D), seed=142), _rand((1, Hkv, Nkv, D), seed=143)
+  o, lse = hip.forward(q, k, v, None, True, D ** -0.5)                       # tail aligned
+  _check_vs_oracle(o, lse, q, k, v, causal=True, block_keys=32, name="short causal tail")
+  o0, lse0 = hip.forward(q, k, v, None, True, D ** -0.5, causal_offset=0)    # top-left: row i sees keys 0..i
+  _check_vs_oracle(o0, lse0, q, k, v, causal=True, causal_offset=0, block_keys=32, name="short causal topleft")
+  assert torch.equal(o0[:, :, 0], v[:, :, 0].repeat_interleave(Hq // Hkv, 1))  # row 0 sees only key 0
+
+
+def test_short_query_bias_is_not_packed(hip):
+  q, k, v = _rand((1, 8, 3, 512), seed=151), _rand((1, 2, 900, 512), seed=152), _rand((1, 2, 900, 512), seed=153)
+  bias = (torch.randn(1, 8, 3, 900, device="cuda") * 0.5).to(q.dtype)
+  plan = {}
+  o, lse = hip.forward(q, k, v, bias, False, 512 ** -0.5, plan_out=plan)
+  assert plan["variant"] == 1 and not plan["packed"]
+  _check_vs_oracle(o, lse, q, k, v, bias=_f32(bias), block_keys=32, name="short bias")
+
+
+def test_decode_through_public_api(hip):
+  from ffpa_attn_amd import ffpa_attn_func
+
+  q, k, v = _rand((2, 16, 1, 512), seed=161), _rand((2, 4, 4096, 512), seed=162), _rand((2, 4, 4096, 512), seed=163)
+  out = ffpa_attn_func(q, k, v, enable_gqa=True)
+  ref = F.scaled_dot_product_attention(q, k, v, enable_gqa=True)
+  _close(out, ref, q.dtype)

@@ -40,6 +40,13 @@ pmcsq)
 pmcfetch)
   (cd /tmp && timeout 90 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OLDPWD/gpurun_out/pmc -o pmc2 -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sdpa) > gpurun_out/pmc2.log 2>&1
   echo "pmcfetch exit $?" ;;
+dist1)
+  timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-sdpa > gpurun_out/dist1.json 2> gpurun_out/dist1.err; echo "dist1 exit $?"; cat gpurun_out/dist1.json; tail -3 gpurun_out/dist1.err
+  timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-sdpa --gather > gpurun_out/dist1g.json 2>> gpurun_out/dist1.err; echo "dist1 gather exit $?" ;;
+work)
+  for w in cfg3 cfg2_causal cfg4; do timeout 300 python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_$w.json 2>> gpurun_out/bench.err; echo "$w exit $?"; cat gpurun_out/bench_$w.json; done ;;
+decode)
+  timeout 600 python tools/gpu_decode_bench.py > gpurun_out/decode.log 2>&1; echo "decode exit $?"; grep DECODE gpurun_out/decode.log; tail -3 gpurun_out/decode.log | grep -v DECODE ;;
 ab)
   timeout 600 python tools/gpu_ab.py $AB_ARGS > gpurun_out/ab.log 2>&1; echo "ab exit $?"; cat gpurun_out/ab.log ;;
 ab2)
