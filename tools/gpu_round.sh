@@ -45,6 +45,8 @@ dist1)
   timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-sdpa --gather > gpurun_out/dist1g.json 2>> gpurun_out/dist1.err; echo "dist1 gather exit $?" ;;
 work)
   for w in cfg3 cfg2_causal cfg4; do timeout 300 python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_$w.json 2>> gpurun_out/bench.err; echo "$w exit $?"; cat gpurun_out/bench_$w.json; done ;;
+biasperf)
+  timeout 600 python tools/gpu_bias_bench.py > gpurun_out/bias.log 2>&1; echo "bias exit $?"; grep BIAS gpurun_out/bias.log; tail -2 gpurun_out/bias.log | grep -v BIAS ;;
 decode)
   timeout 600 python tools/gpu_decode_bench.py > gpurun_out/decode.log 2>&1; echo "decode exit $?"; grep DECODE gpurun_out/decode.log; tail -3 gpurun_out/decode.log | grep -v DECODE ;;
 ab)
