@@ -61,7 +61,7 @@ def _aten_efficient_backward(grad_out, q, k, v, o, lse, causal, scale, attn_bias
 
 
 def _chunked_recompute_backward(grad_out, q, k, v, o, lse, causal, scale, attn_bias, want_bias_grad,
-                                budget_bytes: int = 1 << 30):
+                                budget_bytes: int = 1 << 30, dropout=None):
   """dV = P^T dO;  dS = P o (dO V^T - rowsum(dO o O));  dQ = scale dS K;  dK = scale dS^T Q, with
   P = exp(scale QK^T + bias - LSE) recomputed per block of query rows in fp32."""
   B, Hq, Nq, D = q.shape
@@ -77,7 +77,13 @@ def _chunked_recompute_backward(grad_out, q, k, v, o, lse, causal, scale, attn_b
   dbias_full = None
   if want_bias_grad and attn_bias is not None:
     dbias_full = torch.zeros(B, Hq, Nq, Nkv, dtype=torch.float32, device=q.device)
-  chunk = max(16, min(Nq, budget_bytes // max(1, B * Hq * Nkv * 4 * 3)))
+  chunk = max(16, min(Nq, budget_bytes // max(1, B * Hq * Nkv * 4 * (3 if dropout is None else 12))))
+  if dropout is not None:
+    from .philox import dropout_keep_mask
+
+    p_drop, seed, offset = dropout
+    keep_scale = 1.0 / (1.0 - p_drop)
+    bh = (torch.arange(B, device=q.device).view(B, 1, 1, 1) * Hq + torch.arange(Hq, device=q.device).view(1, Hq, 1, 1))
   cols = torch.arange(Nkv, device=q.device).view(1, -1)
   for r0 in range(0, Nq, chunk):
     r1 = min(Nq, r0 + chunk)
@@ -92,8 +98,17 @@ def _chunked_recompute_backward(grad_out, q, k, v, o, lse, causal, scale, attn_b
     p = torch.exp(s - lse[:, :, r0:r1, None])
     p = torch.nan_to_num(p, nan=0.0)  # fully masked rows: LSE = -inf
     goc = go[:, :, r0:r1]
-    dv += p.transpose(-1, -2) @ goc
-    ds = p * (goc @ vx.transpose(-1, -2) - delta[:, :, r0:r1, None])
+    if dropout is None:
+      dv += p.transpose(-1, -2) @ goc
+      dp = goc @ vx.transpose(-1, -2)
+    else:
+      # forward: O = (keep o round(P) / (1-p)) V / l with the row sum undropped; d/dP of that
+      rows_i = torch.arange(r0, r1, device=q.device).view(1, 1, -1, 1)
+      idx = (bh * Nq + rows_i) * Nkv + cols.view(1, 1, 1, -1)
+      keep = dropout_keep_mask(seed, offset, idx, p_drop).to(torch.float32) * keep_scale
+      dv += (p * keep).transpose(-1, -2) @ goc
+      dp = (goc @ vx.transpose(-1, -2)) * keep
+    ds = p * (dp - delta[:, :, r0:r1, None])
     dq[:, :, r0:r1] = (ds @ kx) * scale
     dk += (ds.transpose(-1, -2) @ qc) * scale
     if dbias_full is not None:
@@ -108,10 +123,13 @@ _aten_ok: dict = {}
 
 
 def attention_backward(grad_out, q, k, v, o, lse, *, causal: bool, scale: float, attn_bias=None,
-                       want_bias_grad: bool = False, force: str | None = None):
+                       want_bias_grad: bool = False, force: str | None = None, dropout=None):
   """``(dq, dk, dv, d_attn_bias)`` for the forward ``o, lse = ffpa(q, k, v)``.  ``force`` = ``"aten"`` /
   ``"recompute"`` pins one implementation (tests); otherwise aten first, recompute if it refuses."""
   key = (q.dtype, q.size(-1))
+  if dropout is not None:
+    # the fused aten backward would regenerate a DIFFERENT mask on ROCm: rebuild the kernel's own (philox.py)
+    return _chunked_recompute_backward(grad_out, q, k, v, o, lse, causal, scale, attn_bias, want_bias_grad, dropout=dropout)
   if force != "recompute" and _aten_ok.get(key, True):
     try:
       out = _aten_efficient_backward(grad_out, q, k, v, o, lse, causal, scale, attn_bias, want_bias_grad)

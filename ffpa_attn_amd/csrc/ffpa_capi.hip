@@ -166,9 +166,10 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
     return fail(FFPA_ERR_BAD_DTYPE, "unknown bias_dtype %d", p->bias_dtype);
   for (int i = 0; i < 4; ++i)
     if (p->bias && p->bias_stride[i] < 0) return fail(FFPA_ERR_BAD_STRIDE, "bias stride[%d] is negative", i);
-  if (p->dropout_p != 0.f)
-    return fail(FFPA_ERR_UNSUPPORTED, "dropout_p=%g: dropout is not built into ABI v%d", (double)p->dropout_p,
-                FFPA_ATTN_ABI_VERSION);
+  if (!(p->dropout_p >= 0.f && p->dropout_p < 1.f))
+    return fail(FFPA_ERR_BAD_SHAPE, "dropout_p=%g must be in [0, 1)", (double)p->dropout_p);
+  if (p->dropout_p > 0.f && p->causal_row_mod != 0)
+    return fail(FFPA_ERR_UNSUPPORTED, "dropout with packed query heads (causal_row_mod) is not supported");
   if (!isfinite(p->softmax_scale)) return fail(FFPA_ERR_BAD_SHAPE, "softmax_scale is not finite");
   const int safe = (p->flags & FFPA_FLAG_DEBUG_SAFE_PATH) ? 1 : 0;
 
@@ -212,6 +213,10 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   a.nsplit = pl.splits;
   a.tiles_per_split = pl.tiles_per_split;
   a.causal_row_mod = p->causal_row_mod;
+  a.dropout_p = p->dropout_p;
+  a.keep_scale = p->dropout_p > 0.f ? 1.f / (1.f - p->dropout_p) : 1.f;
+  a.philox_seed = p->philox_seed;
+  a.philox_offset = p->philox_offset;
   if (pl.splits > 1) {
     a.ws_o = static_cast<float*>(p->workspace);
     a.ws_lse = a.ws_o + (size_t)pl.splits * p->batch * p->heads_q * p->seqlen_q * p->head_dim;
@@ -266,7 +271,7 @@ int ffpa_attn_query(int what) {
     case FFPA_QUERY_MAX_HEAD_DIM: return 1024;
     case FFPA_QUERY_HEAD_DIM_MULTIPLE: return 64;
     case FFPA_QUERY_FP16_AVAILABLE: return 1;
-    case FFPA_QUERY_DROPOUT_AVAILABLE: return 0;
+    case FFPA_QUERY_DROPOUT_AVAILABLE: return 1;
     case FFPA_QUERY_DEBUG_KERNELS: return 1;
     default: return -1;
   }

@@ -11,11 +11,11 @@
 
 namespace ffpa {
 
-template <typename T, int D, int ND, bool SAFE>
+template <typename T, int D, int ND, bool SAFE, bool DROP = false>
 static int launch_one(const FwdArgs& a, hipStream_t stream) {
   constexpr int BC = (ND == 1) ? 64 : 32;
   constexpr int LDS = 2 * BC * D * 2 + (ND > 1 ? 4 * 4096 : 0);
-  auto kern = ffpa_fwd_split_d_kernel<T, D, ND, SAFE>;
+  auto kern = ffpa_fwd_split_d_kernel<T, D, ND, SAFE, DROP>;
   static bool attr_done[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return -1;
@@ -42,18 +42,29 @@ int FFPA_CAT(launch_fwd_d, FFPA_INST_D)(int dtype, int safe, int variant, const 
     // slice is a whole number of 32-column O blocks, else over 2 waves (two row blocks)
     constexpr int NDS = (D % 128 == 0) ? 4 : 2;
     if (safe) return -3;
+    if (a.dropout_p > 0.f) {
+      if (dtype == 0) return launch_one<__bf16, D, NDS, false, true>(a, stream);
+      if (dtype == 1) return launch_one<_Float16, D, NDS, false, true>(a, stream);
+      return -4;
+    }
     if (dtype == 0) return launch_one<__bf16, D, NDS, false>(a, stream);
     if (dtype == 1) return launch_one<_Float16, D, NDS, false>(a, stream);
     return -4;
   }
 #ifdef FFPA_INST_SAFE
   if (safe) {
+    if (a.dropout_p > 0.f) return -3;
     if (dtype == 0) return launch_one<__bf16, D, ND, true>(a, stream);
     return -3;
   }
 #else
   if (safe) return -3;
 #endif
+  if (a.dropout_p > 0.f) {
+    if (dtype == 0) return launch_one<__bf16, D, ND, false, true>(a, stream);
+    if (dtype == 1) return launch_one<_Float16, D, ND, false, true>(a, stream);
+    return -4;
+  }
   if (dtype == 0) return launch_one<__bf16, D, ND, false>(a, stream);
   if (dtype == 1) return launch_one<_Float16, D, ND, false>(a, stream);
   return -4;

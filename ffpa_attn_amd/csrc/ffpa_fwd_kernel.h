@@ -32,6 +32,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+
 // ---- build-time tunables (defaults = the shipped configuration; tools/gpu_ab.py builds variants) ----
 #ifndef FFPA_PF1
 #define FFPA_PF1 6  // QK: LDS reads run this many MFMAs ahead of their consumer
@@ -51,6 +53,9 @@
 #ifndef FFPA_QK_ORDER
 #define FFPA_QK_ORDER 0  // QK MFMA order: 0 = d-step outer (alternate the two S accumulators), 1 = key-block outer
 #endif
+#ifndef FFPA_DMA_IMM
+#define FFPA_DMA_IMM 0  // 1: D == 512 DMA pieces with immediate LDS offset / swizzle (5 instrs per piece; measured neutral)
+#endif
 #ifndef FFPA_V_EARLY
 #define FFPA_V_EARLY 1  // issue the first PV fragment reads right after barrier A (latency hides under softmax)
 #endif
@@ -69,6 +74,18 @@ namespace ffpa {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{}) — the
+// index is a constant expression inside the body (inline-asm "i" operands need one; an unrolled loop
+// variable is not enough for the front end).
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
 
 #define FFPA_LDS __attribute__((address_space(3)))
 #define FFPA_GLB __attribute__((address_space(1)))
@@ -103,6 +120,11 @@ struct FwdArgs {
   // rows of several query heads of one KV group packed into one row axis (host reshape): the causal
   // limit of packed row r is (r % causal_row_mod) + causal_offset; 0 = rows are plain query rows
   int causal_row_mod;
+  // dropout (prefill.cuh:398-546): keep iff u > p, u from Philox4x32-10 at the logical element offset
+  float dropout_p;          // 0 = off
+  float keep_scale;         // 1 / (1 - p)
+  unsigned long long philox_seed;
+  unsigned long long philox_offset;
 };
 
 template <typename T>
@@ -188,6 +210,20 @@ __device__ __forceinline__ void lds_dma_16(u32x4 rsrc, uint32_t lds_addr, uint32
 // s_waitcnt vmcnt(0) as a BUILTIN (gfx9 encoding 0x0F70: vmcnt = 0, expcnt / lgkmcnt = no wait): the
 // compiler's own scoreboard then knows its earlier loads (the Q fragments) have retired and emits no
 // counted vmcnt waits inside the tile loop — those would also wait on the hidden DMA pieces.
+// D == 512 form: a K / V row is exactly one 1 KiB piece, so for piece I of this wave the LDS address is
+// wave_base + I*1024 and the source swizzle is a compile-time XOR constant.  M0 is produced by the
+// s_add itself (no precomputed SGPR per piece), the v_xor that forms the per-lane source offset doubles
+// as the SALU-writes-M0 wait state, and the row offset arrives as a running scalar: 5 instructions per
+// piece (s_add + s_min outside) instead of 7.
+template <int LDS_IMM, int XOR_IMM>
+__device__ __forceinline__ void lds_dma_16_imm(u32x4 rsrc, uint32_t lds_wave_base, uint32_t lane16, uint32_t soff) {
+  uint32_t voff;
+  asm volatile("s_add_u32 m0, %1, %2\n\tv_xor_b32 %0, %3, %4\n\tbuffer_load_dwordx4 %0, %5, %6 offen lds"
+               : "=&v"(voff)
+               : "s"(lds_wave_base), "i"(LDS_IMM), "i"(XOR_IMM), "v"(lane16), "s"(rsrc), "s"(soff)
+               : "memory", "scc");
+}
+
 __device__ __forceinline__ void dma_wait_all() {
   __builtin_amdgcn_s_waitcnt(0x0F70);
   asm volatile("" ::: "memory");
@@ -253,6 +289,52 @@ __device__ __forceinline__ void stage_tile(u32x4 rsrc, const T* __restrict__ bas
   for (int i = 0; i < PPW; ++i) stage_piece<T, D, BC, IS_V, SAFE>(rsrc, base, row_bytes, key0, nkv, lds_tile, wave, lane, i);
 }
 
+// Philox4x32-10 (Salmon et al., SC'11) on counter (quad_lo, quad_hi, 0, 0) with key = seed: the generator
+// behind torch / cuRAND / Triton dropout.  The reference keys it by the logical score index so that masks
+// line up with SDPA's (csrc/cuffpa/native/prefill.cuh:398-452): element e uses word e & 3 of block e >> 2.
+__device__ __forceinline__ void philox4x32_10(unsigned long long seed, unsigned long long quad, uint32_t (&out)[4]) {
+  uint32_t c0 = (uint32_t)quad, c1 = (uint32_t)(quad >> 32), c2 = 0u, c3 = 0u;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int round = 0; round < 10; ++round) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0;
+    c2 = hi0 ^ c3 ^ k1;
+    c1 = lo1;
+    c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0;
+  out[1] = c1;
+  out[2] = c2;
+  out[3] = c3;
+}
+
+// keep-scale (1/(1-p) or 0) for the 4 consecutive elements e0 .. e0+3 of one score row
+__device__ __forceinline__ void dropout_keep4(unsigned long long seed, unsigned long long e0, float p, float keep_scale,
+                                              float (&keep)[4]) {
+  uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t blk[4];
+  const unsigned a = (unsigned)(e0 & 3ull);
+  philox4x32_10(seed, e0 >> 2, blk);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = blk[i];
+  if (a != 0) {  // the group straddles two Philox blocks
+    philox4x32_10(seed, (e0 >> 2) + 1, blk);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[4 + i] = blk[i];
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    // word a + t of the 8-word window, selected without run-time indexing (that would go to scratch)
+    const uint32_t word = a == 0 ? w[t] : a == 1 ? w[t + 1] : a == 2 ? w[t + 2] : w[t + 3];
+    const float u = ((float)word + 1.0f) * 2.3283064365386963e-10f;  // (0, 1]  (prefill.cuh:437-440)
+    keep[t] = (u > p) ? keep_scale : 0.f;
+  }
+}
+
 // Additive bias for the 16 scores one lane holds of a 32-key block:
 // x[r] += bias[row][k0 + (r&3) + 8 (r>>2) + 4 h] * log2(e)   (prefill.cuh:556-658; here the
 // bias is added after the scale instead of being pre-divided by it — same value).
@@ -268,7 +350,10 @@ __device__ __forceinline__ void add_bias_block(float (&x)[16], const void* bias,
   }
 }
 
-template <typename T, int D, int ND, bool SAFE>
+// DROP selects the dropout-capable build of the kernel: kept out of the default instantiation because its
+// Philox temporaries push hipcc into spilling Q fragments inside the QK^T loop (and every reload drains the
+// DMA queue); dropout launches pay that, plain launches do not.
+template <typename T, int D, int ND, bool SAFE, bool DROP = false>
 __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) {
   using E = Elem<T>;
   using v8 = typename E::v8;
@@ -291,6 +376,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   constexpr bool kInterleave = FFPA_DMA_INTERLEAVE != 0 && (ND == 1 || FFPA_DMA_INTERLEAVE == 2);  // D > 512 measured faster with bursts
   constexpr int kStep = (ND == 1) ? FFPA_DMA_STEP : 1;  // MFMAs between two DMA pieces
   static_assert(!kInterleave || PPW * kStep <= (DW / 16) * (BC / 32), "DMA pieces must fit the QK loop");
+  // immediate-form DMA: one piece == one row (D == 512) and 16 pieces per wave so that the row's swizzle
+  // (key & 15 / key & 3) equals the piece index
+  constexpr bool kImm = FFPA_DMA_IMM != 0 && kInterleave && !SAFE && D == 512 && PPW == 16;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   FFPA_LDS char* const Kt = (FFPA_LDS char*)smem;
@@ -388,6 +476,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
     for (int i = 0; i < 4; ++i) vaddr[i] = Vt + (4 * h + j4) * RB + ((vcol + i * 64) ^ vsw);
   }
 
+  const uint32_t k_wave_lds = (uint32_t)(uintptr_t)(Kt + wave * PPW * 1024);  // this wave's pieces of a tile
+  const uint32_t v_wave_lds = (uint32_t)(uintptr_t)(Vt + wave * PPW * 1024);
   if (nt > t0) {
     stage_tile<T, D, BC, false, SAFE>(k_rsrc, Kg, k_row_bytes, t0 * BC, a.Nkv, Kt, wave, lane);
     dma_wait_all();
@@ -414,19 +504,31 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int n = 0; n < PF1 && n < N1; ++n) kf[n] = k_frag(n);
-#pragma unroll
-      for (int n = 0; n < N1; ++n) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (n + PF1 < N1) kf[n + PF1] = k_frag(n + PF1);
-        if constexpr (kInterleave && !(FFPA_ABL & 1)) {
-          // V(j) streams in under this tile's QK^T (the V buffer is free since barrier B of tile j-1)
-          if (n % kStep == 0 && n / kStep < PPW)
-            stage_piece<T, D, BC, true, SAFE>(v_rsrc, Vg, v_row_bytes, k0, a.Nkv, Vt, wave, dlane, n / kStep);
-        }
-        const int s = FFPA_QK_ORDER ? n % KS : n / NKB, kb = FFPA_QK_ORDER ? n / KS : n % NKB;
-        if (s == 0) E::mfma_v_first(sacc[kb], kf[n], qf[s]);
-        else E::mfma_v_acc(sacc[kb], kf[n], qf[s]);
+      // interleaved DMA of V(j): running scalar row offset of the next piece (clamped to the last key)
+      uint32_t v_soff = 0, v_last = 0;
+      if constexpr (kImm) {
+        v_soff = (uint32_t)(k0 + wave * PPW) * v_row_bytes;
+        v_last = (uint32_t)(a.Nkv - 1) * v_row_bytes;
       }
+      static_for<N1>([&](auto ic) {
+        constexpr int n = decltype(ic)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (n + PF1 < N1) kf[n + PF1] = k_frag(n + PF1);
+        if constexpr (kInterleave && !(FFPA_ABL & 1) && n % kStep == 0 && n / kStep < PPW) {
+          // V(j) streams in under this tile's QK^T (the V buffer is free since barrier B of tile j-1)
+          constexpr int i = n / kStep;
+          if constexpr (kImm) {
+            const uint32_t so = v_soff < v_last ? v_soff : v_last;
+            lds_dma_16_imm<i * 1024, (i & 3) << 6>(v_rsrc, v_wave_lds, dlane << 4, so);
+            v_soff += v_row_bytes;
+          } else {
+            stage_piece<T, D, BC, true, SAFE>(v_rsrc, Vg, v_row_bytes, k0, a.Nkv, Vt, wave, dlane, i);
+          }
+        }
+        constexpr int s = FFPA_QK_ORDER ? n % KS : n / NKB, kb = FFPA_QK_ORDER ? n / KS : n % NKB;
+        if constexpr (s == 0) E::mfma_v_first(sacc[kb], kf[n], qf[s]);
+        else E::mfma_v_acc(sacc[kb], kf[n], qf[s]);
+      });
       // MFMA result -> VALU reader wait states (invisible to the compiler inside asm)
       if constexpr (NKB == 2) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sacc[0]), "+v"(sacc[1]));
       else asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sacc[0]));
@@ -591,6 +693,25 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
         pf[kb * 2 + (r >> 3)][r & 7] = (T)p;
       }
     l_run += psum;
+    if constexpr (DROP) {
+      // applied to the ROUNDED P, after the row sum (LSE is undropped): prefill.cuh:508-546
+      const unsigned long long erow =
+          a.philox_offset + (((unsigned long long)b * a.Hq + hq) * a.Nq + (unsigned long long)qrow_c) * (unsigned long long)a.Nkv;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_barrier(0);  // one Philox group at a time: bounded register pressure
+          float keep[4];
+          dropout_keep4(a.philox_seed, erow + (unsigned long long)(k0 + kb * 32 + 8 * i + 4 * h), a.dropout_p, a.keep_scale, keep);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int r = 4 * i + t;
+            const float dropped = (float)pf[kb * 2 + (r >> 3)][r & 7] * keep[t];
+            pf[kb * 2 + (r >> 3)][r & 7] = (T)dropped;
+          }
+        }
+    }
 
     // ================= O^T += V^T.P^T =================
     {
@@ -600,22 +721,31 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
 #pragma unroll
         for (int n = 0; n < PF2 && n < N2; ++n) vf[n] = v_frag(n);
       }
-#pragma unroll
-      for (int n = 0; n < N2; ++n) {
+      uint32_t k_soff = 0, k_last = 0;
+      if constexpr (kImm) {
+        k_soff = (uint32_t)(k0 + BC + wave * PPW) * k_row_bytes;
+        k_last = (uint32_t)(a.Nkv - 1) * k_row_bytes;
+      }
+      static_for<N2>([&](auto ic) {
+        constexpr int n = decltype(ic)::value;
         __builtin_amdgcn_sched_barrier(0);
-        if (n + PF2 < N2) vf[n + PF2] = v_frag(n + PF2);
-        if constexpr (kInterleave && !(FFPA_ABL & 1)) {
+        if constexpr (n + PF2 < N2) vf[n + PF2] = v_frag(n + PF2);
+        if constexpr (kInterleave && !(FFPA_ABL & 1) && n % kStep == 0 && n / kStep < PPW) {
           // K(j+1) streams in under this tile's PV (the K buffer is free since barrier A).  After the
           // last tile this prefetches a clamped, unused tile: cheaper than a branch per piece, and
           // barrier B still drains it before the workgroup can exit.
-          if (n % kStep == 0 && n / kStep < PPW)
-            stage_piece<T, D, BC, false, SAFE>(k_rsrc, Kg, k_row_bytes, k0 + BC, a.Nkv, Kt, wave, dlane, n / kStep);
+          constexpr int i = n / kStep;
+          if constexpr (kImm) {
+            const uint32_t so = k_soff < k_last ? k_soff : k_last;
+            lds_dma_16_imm<i * 1024, (i & 15) << 4>(k_rsrc, k_wave_lds, dlane << 4, so);
+            k_soff += k_row_bytes;
+          } else {
+            stage_piece<T, D, BC, false, SAFE>(k_rsrc, Kg, k_row_bytes, k0 + BC, a.Nkv, Kt, wave, dlane, i);
+          }
         }
-        {
-          const int db = FFPA_PV_ORDER ? n % NDB : n / NKS, ks = FFPA_PV_ORDER ? n / NDB : n % NKS;
-          oacc[db] = E::mfma(vf[n], pf[ks], oacc[db]);
-        }
-      }
+        constexpr int db = FFPA_PV_ORDER ? n % NDB : n / NKS, ks = FFPA_PV_ORDER ? n / NDB : n % NKS;
+        oacc[db] = E::mfma(vf[n], pf[ks], oacc[db]);
+      });
       __builtin_amdgcn_sched_barrier(0);
     }
 

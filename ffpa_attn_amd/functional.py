@@ -95,8 +95,7 @@ class FFPAAttnMeta:
   # ------------------------------------------------------------------ fallback predicate
   def fallback(self, query: torch.Tensor, key: torch.Tensor, attn_mask, dropout_p: float) -> bool:
     """True when the call must go to ``torch._C._nn.scaled_dot_product_attention``
-    (functional.py:676-724).  One row is specific to this build and documented in DESIGN.md: dropout is
-    not implemented by the HIP kernel yet (autograd calls keep the HIP forward; backward.py)."""
+    (functional.py:676-724)."""
     assert query.dim() == 4, "Expected query shape [B, Nh_q, Nq, D]"
     assert key.dim() == 4, "Expected key shape [B, Nh_kv, Nkv, D]"
     _, _, Nq, D = query.shape
@@ -117,9 +116,6 @@ class FFPAAttnMeta:
       return True
     if not query.is_cuda:
       return False  # large-D CPU tensors reach the op and raise NotImplementedError, like the reference
-    if dropout_p > 0.0:
-      warning_once("ffpa_attn_func: dropout_p > 0 is not implemented by the HIP kernel yet; using SDPA")
-      return True
     return False
 
   # ------------------------------------------------------------------ validation

@@ -226,7 +226,7 @@ def forward(
   group = Hq // Hkv if Hkv and Hq % Hkv == 0 else 1
   has_bias = attn_bias is not None and attn_bias.numel() > 0
   causal_row_mod = 0
-  packed = group > 1 and Nq <= 7 and group * Nq <= 32 and not has_bias
+  packed = group > 1 and Nq <= 7 and group * Nq <= 32 and not has_bias and dropout_p == 0.0
   if packed:
     # [B, Hq, Nq, D] -> [B, Hkv, group*Nq, D]: packed row r = (head in group) * Nq + (query row)
     q = q.contiguous().view(B, Hkv, group * Nq, Dp)

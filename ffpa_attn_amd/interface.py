@@ -13,6 +13,20 @@ import torch
 from .functional import FFPAAttnMeta
 
 
+def _reserve_dropout_rng(query: torch.Tensor, key: torch.Tensor, dropout_p: float) -> tuple[int, int]:
+  """(seed, offset) for this call's dropout, advancing the device generator by one Philox output per logical
+  score, rounded up to a multiple of four — what SDPA's efficient attention reserves and what the reference
+  does (functional.py:518-540)."""
+  if dropout_p <= 0.0:
+    return 0, 0
+  with torch.cuda.device(query.device):
+    seed = int(torch.cuda.initial_seed())
+    offset = int(torch.cuda._get_rng_state_offset())
+    elems = query.size(0) * query.size(1) * query.size(2) * key.size(2)
+    torch.cuda._set_rng_state_offset(offset + (elems + 3) // 4 * 4)
+  return seed, offset
+
+
 class _FFPAAttnFunc(torch.autograd.Function):
   """HIP forward + SDPA-style backward (the reference's ``_FFPAAttnFunc`` with ``forward_backend`` =
   native kernel and ``backward_backend="sdpa"``, functional.py:964-1172).  O and the natural-log LSE
@@ -23,6 +37,7 @@ class _FFPAAttnFunc(torch.autograd.Function):
     from .hip import ffpa_attn_forward_hip
 
     thr = getattr(meta.forward_meta, "rescale_threshold", None)
+    seed, offset = _reserve_dropout_rng(query, key, meta.attn_meta.dropout_p)
     out, lse = ffpa_attn_forward_hip(
       query,
       key,
@@ -31,6 +46,8 @@ class _FFPAAttnFunc(torch.autograd.Function):
       causal=meta.attn_meta.is_causal,
       softmax_scale=meta.attn_meta.scale,
       dropout_p=meta.attn_meta.dropout_p,
+      philox_seed=seed,
+      philox_offset=offset,
       rescale_threshold=-1.0 if thr is None else float(thr),
     )
     needs_grad = meta.attn_meta.is_grad_enabled and any(
@@ -40,6 +57,7 @@ class _FFPAAttnFunc(torch.autograd.Function):
       ctx.save_for_backward(query, key, value, out, lse, attn_bias)
       ctx.causal = meta.attn_meta.is_causal
       ctx.scale = meta.attn_meta.scale
+      ctx.dropout = (meta.attn_meta.dropout_p, seed, offset) if meta.attn_meta.dropout_p > 0.0 else None
     return out
 
   @staticmethod
@@ -50,7 +68,7 @@ class _FFPAAttnFunc(torch.autograd.Function):
     want_bias = attn_bias is not None and ctx.needs_input_grad[3]
     dq, dk, dv, dbias = attention_backward(
       grad_out.contiguous(), query, key, value, out, lse, causal=ctx.causal, scale=ctx.scale, attn_bias=attn_bias,
-      want_bias_grad=want_bias,
+      want_bias_grad=want_bias, dropout=ctx.dropout,
     )
     return dq, dk, dv, dbias, None
 

@@ -106,10 +106,14 @@ typedef struct ffpa_fwd_params {
   float rescale_threshold; /* lazy-rescale threshold in log2 units; <0 => default
                               8.0 (FFPA_RESCALE_THRESHOLD, csrc/cuffpa/common.cuh:14);
                               0 => exact recurrence                                */
-  float dropout_p;         /* must be 0 in ABI v1 (FFPA_ERR_UNSUPPORTED otherwise) */
+  float dropout_p;         /* [0, 1): P <- keep ? P/(1-p) : 0 after the row sum (prefill.cuh:508-546) */
   uint32_t flags;
 
-  uint64_t philox_seed;   /* reserved for dropout (prefill.cuh:398-546) */
+  /* Philox4x32-10 key and base counter: element (b,hq,q,k) uses word e&3 of block e>>2 with
+   * e = philox_offset + ((b*Hq + hq)*Nq + q)*Nkv + k; keep iff (word+1)*2^-32 > dropout_p — the
+   * SDPA-efficient-attention-compatible convention of prefill.cuh:398-452.  The caller reserves the
+   * ceil4(B*Hq*Nq*Nkv) offsets from its generator (functional.py:518-540). */
+  uint64_t philox_seed;
   uint64_t philox_offset;
 
   /* Short-query (decode) launches, seqlen_q <= 32: the KV axis is split over workgroups and merged by

@@ -112,6 +112,34 @@ static inline float load_elem(const uint16_t* p, int dtype) { return dtype == 0 
 static inline uint16_t store_elem(float f, int dtype) { return dtype == 0 ? f32_to_bf16(f) : f32_to_f16(f); }
 static inline float round_elem(float f, int dtype) { return load_elem(&(uint16_t){store_elem(f, dtype)}, dtype); }
 
+/* Philox4x32-10 on counter (quad_lo, quad_hi, 0, 0), key = seed (csrc/cuffpa/native/prefill.cuh:398-422). */
+void ffpa_oracle_philox(uint64_t seed, uint64_t quad, uint32_t out[4]) {
+  uint32_t c0 = (uint32_t)quad, c1 = (uint32_t)(quad >> 32), c2 = 0u, c3 = 0u;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  for (int round = 0; round < 10; ++round) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0;
+  out[1] = c1;
+  out[2] = c2;
+  out[3] = c3;
+}
+
+/* keep iff u > p with u = (word + 1) * 2^-32 in fp32 (prefill.cuh:437-452,508-546) */
+static inline int dropout_keeps(uint64_t seed, uint64_t element, float p) {
+  uint32_t w[4];
+  ffpa_oracle_philox(seed, element >> 2, w);
+  const float u = ((float)w[element & 3] + 1.0f) * 2.3283064365386963e-10f;
+  return u > p;
+}
+
 #define FFPA_LOG2E 1.4426950408889634f
 #define FFPA_LN2 0.6931471805599453f
 
@@ -124,16 +152,17 @@ static inline float round_elem(float f, int dtype) { return load_elem(&(uint16_t
  * it only changes fp32 summation order and when the lazy rescale fires.
  * Returns 0, or -1 on bad arguments / allocation failure.
  */
-int ffpa_oracle_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* o_f32, float* lse,
-                    const float* bias, const int64_t* bias_stride, int B, int Hq, int Hkv, int Nq, int Nkv, int D,
-                    int dtype, float scale, int causal, int causal_offset, float thr, int block_keys, int row_begin,
-                    int row_end) {
+int ffpa_oracle_fwd_dropout(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* o_f32, float* lse,
+                            const float* bias, const int64_t* bias_stride, int B, int Hq, int Hkv, int Nq, int Nkv, int D,
+                            int dtype, float scale, int causal, int causal_offset, float thr, int block_keys,
+                            int row_begin, int row_end, float dropout_p, uint64_t philox_seed, uint64_t philox_offset) {
   if (!q || !k || !v || !o || B <= 0 || Hq <= 0 || Hkv <= 0 || Nq <= 0 || Nkv <= 0 || D <= 0) return -1;
   if (Hq % Hkv != 0 || block_keys <= 0 || (dtype != 0 && dtype != 1)) return -1;
   if (row_begin < 0) row_begin = 0;
   if (row_end > Nq) row_end = Nq;
   const int group = Hq / Hkv; /* split_d.cuh:135-136: kv head = q head / group */
   const float c = scale * FFPA_LOG2E;
+  const float keep_scale = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
   int status = 0;
 
   for (int b = 0; b < B; ++b) {
@@ -210,7 +239,11 @@ int ffpa_oracle_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, uin
             for (int j = 0; j < kn; ++j) {
               const float p = exp2f(x[j] - m_use);
               psum += p;
-              const float p16 = round_elem(p, dtype);
+              float p16 = round_elem(p, dtype);
+              if (dropout_p > 0.f) { /* on the rounded P, after the row sum; rounded again (prefill.cuh:508-546) */
+                const uint64_t e = philox_offset + (((uint64_t)b * Hq + hq) * Nq + (uint64_t)r) * (uint64_t)Nkv + (uint64_t)(k0 + j);
+                p16 = dropout_keeps(philox_seed, e, dropout_p) ? round_elem(p16 * keep_scale, dtype) : 0.f;
+              }
               if (p16 != 0.f) {
                 const float* vr = vf + (size_t)(k0 + j) * D;
                 for (int d = 0; d < D; ++d) acc[d] += p16 * vr[d];
@@ -237,4 +270,12 @@ int ffpa_oracle_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, uin
   return status;
 }
 
-int ffpa_oracle_abi_version(void) { return 1; }
+int ffpa_oracle_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* o_f32, float* lse,
+                    const float* bias, const int64_t* bias_stride, int B, int Hq, int Hkv, int Nq, int Nkv, int D,
+                    int dtype, float scale, int causal, int causal_offset, float thr, int block_keys, int row_begin,
+                    int row_end) {
+  return ffpa_oracle_fwd_dropout(q, k, v, o, o_f32, lse, bias, bias_stride, B, Hq, Hkv, Nq, Nkv, D, dtype, scale, causal,
+                                 causal_offset, thr, block_keys, row_begin, row_end, 0.f, 0, 0);
+}
+
+int ffpa_oracle_abi_version(void) { return 2; }

@@ -56,8 +56,19 @@ def _load() -> ctypes.CDLL:
       ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int,
       ctypes.c_int,
     ]
+    lib.ffpa_oracle_fwd_dropout.restype = ctypes.c_int
+    lib.ffpa_oracle_fwd_dropout.argtypes = lib.ffpa_oracle_fwd.argtypes + [ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64]
+    lib.ffpa_oracle_philox.restype = None
+    lib.ffpa_oracle_philox.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32)]
     _lib = lib
   return _lib
+
+
+def philox4x32_10(seed: int, quad: int) -> tuple[int, int, int, int]:
+  """Philox4x32-10 block for counter (quad_lo, quad_hi, 0, 0) and key = seed."""
+  out = (ctypes.c_uint32 * 4)()
+  _load().ffpa_oracle_philox(seed, quad, out)
+  return tuple(out)
 
 
 # ---- 16-bit helpers (numpy has no bfloat16) -------------------------------------------
@@ -121,6 +132,9 @@ def oracle_forward(
   threshold: float = DEFAULT_THRESHOLD,
   block_keys: int = 64,
   rows: tuple[int, int] | None = None,
+  dropout_p: float = 0.0,
+  philox_seed: int = 0,
+  philox_offset: int = 0,
 ):
   """Run the C oracle.  Inputs are uint16 storage bits, dense ``[B,H,N,D]``.
 
@@ -146,10 +160,11 @@ def oracle_forward(
     bst = _bias_strides(bias, (B, Hq, Nq, Nkv))
     bias_p, bst_p = bias.ctypes.data, bst.ctypes.data
   r0, r1 = (0, Nq) if rows is None else rows
-  rc = lib.ffpa_oracle_fwd(
+  rc = lib.ffpa_oracle_fwd_dropout(
     q_bits.ctypes.data, k_bits.ctypes.data, v_bits.ctypes.data, o.ctypes.data, o32.ctypes.data, lse.ctypes.data,
     bias_p, bst_p, B, Hq, Hkv, Nq, Nkv, D, 0 if dtype == "bf16" else 1, float(scale), int(bool(causal)),
-    int(causal_offset), float(threshold), int(block_keys), int(r0), int(r1),
+    int(causal_offset), float(threshold), int(block_keys), int(r0), int(r1), float(dropout_p), int(philox_seed),
+    int(philox_offset),
   )
   if rc != 0:
     raise RuntimeError(f"ffpa_oracle_fwd failed ({rc})")

@@ -66,7 +66,7 @@ def test_queries(lib):
   assert lib.ffpa_attn_query(0) == hip.ABI_VERSION
   assert lib.ffpa_attn_query(1) == 1
   assert (lib.ffpa_attn_query(2), lib.ffpa_attn_query(3), lib.ffpa_attn_query(4)) == (64, 1024, 64)
-  assert lib.ffpa_attn_query(5) == 1 and lib.ffpa_attn_query(6) == 0
+  assert lib.ffpa_attn_query(5) == 1 and lib.ffpa_attn_query(6) == 1
   assert lib.ffpa_attn_query(99) == -1
   assert lib.ffpa_attn_version().startswith(b"ffpa-attn-amd")
   assert lib.ffpa_attn_fwd_workspace_bytes(None) == 0
@@ -140,7 +140,8 @@ def _params(**over):
     ({"k_stride": [4 * 128 * 512, 128 * 512, 516]}, 5, b"multiple of 8"),
     ({"v_stride": [4 * 128 * 512, 128 * 512, 256]}, 5, b"rows must not overlap"),
     ({"bias_dtype": 2}, 2, b"bias pointer and bias_dtype disagree"),
-    ({"dropout_p": 0.1}, 7, b"dropout"),
+    ({"dropout_p": 1.0}, 4, b"dropout_p"),
+    ({"dropout_p": 0.1, "causal_row_mod": 2}, 7, b"packed query heads"),
     ({"softmax_scale": float("nan")}, 4, b"not finite"),
   ],
 )

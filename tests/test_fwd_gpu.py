@@ -490,3 +490,71 @@ def test_decode_through_public_api(hip):
   out = ffpa_attn_func(q, k, v, enable_gqa=True)
   ref = F.scaled_dot_product_attention(q, k, v, enable_gqa=True)
   _close(out, ref, q.dtype)
+
+
+# ----------------------------------------------------------------------------- dropout (§8f rank 4)
+@pytest.mark.parametrize("D,Nq,Nkv,Hq,Hkv,causal", [(512, 300, 777, 4, 2, False), (320, 129, 515, 2, 2, True),
+                                                    (1024, 100, 300, 2, 1, False), (512, 5, 900, 8, 2, False)])
+def test_dropout_mask_matches_the_oracle_bit_for_bit(hip, D, Nq, Nkv, Hq, Hkv, causal):
+  """Same Philox seed/offset => same mask as the CPU restatement (prefill.cuh:398-546).  A single flipped
+  mask bit would move O by ~p_k/l >> tolerance at these lengths."""
+  q, k, v = _rand((2, Hq, Nq, D), seed=171), _rand((2, Hkv, Nkv, D), seed=172), _rand((2, Hkv, Nkv, D), seed=173)
+  for (p, seed, off) in ((0.1, 1234567, 0), (0.5, 0xFEDCBA9876543210, 1_000_003)):  # offset % 4 != 0 too
+    o, lse = hip.forward(q, k, v, None, causal, D ** -0.5, dropout_p=p, philox_seed=seed, philox_offset=off)
+    qb, dt = fo.torch_to_bits(q)
+    kb, _ = fo.torch_to_bits(k)
+    vb, _ = fo.torch_to_bits(v)
+    bc = 32 if (Nq <= 32 or D > 512) else 64
+    _, o32, lse_ref = fo.oracle_forward(qb, kb, vb, dt, causal=causal, block_keys=bc, dropout_p=p, philox_seed=seed,
+                                        philox_offset=off)
+    err = np.abs(_f32(o) - o32)
+    assert err.max() <= 2.0 ** -8 * np.abs(o32).max() + 6e-3 and err.mean() < 6e-4, (p, err.max(), err.mean())
+    np.testing.assert_allclose(_f32(lse), lse_ref, atol=2e-4, rtol=2e-5)   # LSE is undropped
+    o_nodrop, _ = hip.forward(q, k, v, None, causal, D ** -0.5)
+    assert (o.float() - o_nodrop.float()).abs().max().item() > 0.02            # dropout really happened
+
+
+def test_dropout_public_api_reserves_generator_offsets(hip):
+  from ffpa_attn_amd import ffpa_attn_func
+
+  q, k, v = (_rand((1, 4, 600, 512), seed=s) for s in (181, 182, 183))
+  torch.cuda.manual_seed(99)
+  off0 = torch.cuda._get_rng_state_offset()
+  a = ffpa_attn_func(q, k, v, dropout_p=0.2)
+  assert torch.cuda._get_rng_state_offset() - off0 == (1 * 4 * 600 * 600 + 3) // 4 * 4   # functional.py:535-540
+  b = ffpa_attn_func(q, k, v, dropout_p=0.2)
+  assert not torch.equal(a, b)                 # generator advanced
+  torch.cuda.manual_seed(99)
+  assert torch.equal(ffpa_attn_func(q, k, v, dropout_p=0.2), a)   # same seed + offset => same mask
+  ones = torch.ones_like(v)
+  o = ffpa_attn_func(q * 0, k, ones, dropout_p=0.25)            # uniform attention: O = kept/N/(1-p)
+  assert abs(o.float().mean().item() - 1.0) < 0.02
+
+
+def test_dropout_backward_uses_the_forward_mask(hip):
+  """dq/dk/dv under dropout vs autograd through explicit math with the SAME Philox mask."""
+  from ffpa_attn_amd import ffpa_attn_func
+  from ffpa_attn_amd.philox import dropout_keep_mask
+
+  D, Hq, Hkv, Nq, Nkv, p = 512, 4, 2, 520, 640, 0.2
+  q = _rand((1, Hq, Nq, D), seed=191).requires_grad_()
+  k = _rand((1, Hkv, Nkv, D), seed=192).requires_grad_()
+  v = _rand((1, Hkv, Nkv, D), seed=193).requires_grad_()
+  go = _rand((1, Hq, Nq, D), seed=194)
+  torch.cuda.manual_seed(5)
+  seed, off = torch.cuda.initial_seed(), torch.cuda._get_rng_state_offset()
+  out = ffpa_attn_func(q, k, v, dropout_p=p, enable_gqa=True)
+  grads = torch.autograd.grad(out, [q, k, v], go)
+
+  qf, kf, vf = (t.detach().float().requires_grad_() for t in (q, k, v))
+  g = Hq // Hkv
+  s = (qf @ kf.repeat_interleave(g, 1).transpose(-1, -2)) * D ** -0.5
+  idx = ((torch.arange(Hq, device="cuda").view(1, Hq, 1, 1) * Nq + torch.arange(Nq, device="cuda").view(1, 1, Nq, 1)) * Nkv
+         + torch.arange(Nkv, device="cuda").view(1, 1, 1, Nkv))
+  keep = dropout_keep_mask(seed, off, idx, p).float() / (1 - p)
+  ref = (torch.softmax(s, -1) * keep) @ vf.repeat_interleave(g, 1)
+  assert (out.float() - ref).abs().max().item() < 2e-2
+  rgrads = torch.autograd.grad(ref, [qf, kf, vf], go.float())
+  for name, a, b in zip(("dq", "dk", "dv"), grads, rgrads):
+    scale = b.abs().max().item()
+    assert (a.float() - b).abs().max().item() <= 3e-2 * scale + 1e-3, name
