@@ -53,6 +53,9 @@
 #ifndef FFPA_QK_ORDER
 #define FFPA_QK_ORDER 0  // QK MFMA order: 0 = d-step outer (alternate the two S accumulators), 1 = key-block outer
 #endif
+#ifndef FFPA_K_PRE
+#define FFPA_K_PRE 8  // interleaved mode: this many K(j+1) pieces are issued right after QK^T (they stream under
+#endif                //   the softmax); V(j) is then awaited with a counted vmcnt just before PV.  0 = one barrier A
 #ifndef FFPA_DMA_IMM
 #define FFPA_DMA_IMM 0  // 1: D == 512 DMA pieces with immediate LDS offset / swizzle (5 instrs per piece; measured neutral)
 #endif
@@ -60,7 +63,7 @@
 #define FFPA_V_EARLY 1  // issue the first PV fragment reads right after barrier A (latency hides under softmax)
 #endif
 #ifndef FFPA_ABL
-#define FFPA_ABL 0  // developer ablations (WRONG RESULTS): 1 no in-loop DMA, 2 no exp, 4 no barriers, 8 no softmax at all, 16 no DMA drain, 32 no s_nop in the S MFMA, 64 no LDS fragment reads
+#define FFPA_ABL 0  // developer ablations (WRONG RESULTS): 1 no in-loop DMA, 2 no exp, 4 no barriers, 8 no softmax at all, 16 no DMA drain, 32 no s_nop in the S MFMA, 64 no LDS fragment reads, 128 no MFMA (DMA + barriers only), 256 no QK MFMA, 512 no PV MFMA
 #endif
 
 #if (FFPA_ABL & 32)
@@ -229,6 +232,15 @@ __device__ __forceinline__ void dma_wait_all() {
   asm volatile("" ::: "memory");
 }
 
+// s_waitcnt vmcnt(N), N <= 15: everything but the N youngest VMEM operations has retired (loads retire in
+// order).  Builtin form for the same reason as dma_wait_all.
+template <int N>
+__device__ __forceinline__ void dma_wait_except() {
+  static_assert(N >= 0 && N <= 15, "vmcnt low field");
+  __builtin_amdgcn_s_waitcnt(0x0F70 | N);
+  asm volatile("" ::: "memory");
+}
+
 // Raw buffer descriptor over `bytes` bytes at `base` (gfx950: word3 0x00020000 = 32-bit raw dwords).
 __device__ __forceinline__ u32x4 make_rsrc(const void* base, uint32_t bytes) {
   const uint64_t a = (uint64_t)base;
@@ -378,6 +390,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   static_assert(!kInterleave || PPW * kStep <= (DW / 16) * (BC / 32), "DMA pieces must fit the QK loop");
   // immediate-form DMA: one piece == one row (D == 512) and 16 pieces per wave so that the row's swizzle
   // (key & 15 / key & 3) equals the piece index
+  constexpr int kPre = (kInterleave && FFPA_K_PRE > 0 && FFPA_K_PRE <= PPW && FFPA_K_PRE <= 15) ? FFPA_K_PRE : 0;
   constexpr bool kImm = FFPA_DMA_IMM != 0 && kInterleave && !SAFE && D == 512 && PPW == 16;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -526,7 +539,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
           }
         }
         constexpr int s = FFPA_QK_ORDER ? n % KS : n / NKB, kb = FFPA_QK_ORDER ? n / KS : n % NKB;
-        if constexpr (s == 0) E::mfma_v_first(sacc[kb], kf[n], qf[s]);
+        if constexpr ((FFPA_ABL & (128 | 256)) != 0) { if constexpr (s == 0) sacc[kb] = (f32x16)(0.f); }
+        else if constexpr (s == 0) E::mfma_v_first(sacc[kb], kf[n], qf[s]);
         else E::mfma_v_acc(sacc[kb], kf[n], qf[s]);
       });
       // MFMA result -> VALU reader wait states (invisible to the compiler inside asm)
@@ -545,8 +559,20 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
     }
 
     // barrier A: every wave is done reading K(j); V(j) has landed; partials visible
-    if constexpr (!(FFPA_ABL & 16)) dma_wait_all();
-    if constexpr (!(FFPA_ABL & 4)) __syncthreads();
+    if constexpr (kPre > 0) {
+      // split form: A1 only frees the K buffer, so the first K(j+1) pieces stream under the softmax;
+      // V(j) (issued before them) is awaited by count right before the PV loop (barrier A2 below).
+      if constexpr (!(FFPA_ABL & 4)) __syncthreads();
+      if constexpr (!(FFPA_ABL & 1)) {
+        const int plane = opaque_lane(lane);
+#pragma unroll
+        for (int i = 0; i < kPre; ++i)
+          stage_piece<T, D, BC, false, SAFE>(k_rsrc, Kg, k_row_bytes, k0 + BC, a.Nkv, Kt, wave, plane, i);
+      }
+    } else {
+      if constexpr (!(FFPA_ABL & 16)) dma_wait_all();
+      if constexpr (!(FFPA_ABL & 4)) __syncthreads();
+    }
     if constexpr (!kInterleave && !(FFPA_ABL & 1)) {
       if (j + 1 < nt) stage_tile<T, D, BC, false, SAFE>(k_rsrc, Kg, k_row_bytes, k0 + BC, a.Nkv, Kt, wave, lane);
     }
@@ -576,7 +602,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
         return r;
       }
     };
-    if constexpr (FFPA_V_EARLY) {
+    if constexpr (FFPA_V_EARLY && kPre == 0) {
 #pragma unroll
       for (int n = 0; n < PF2 && n < N2; ++n) vf[n] = v_frag(n);
       __builtin_amdgcn_sched_barrier(0);
@@ -717,7 +743,12 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
     {
       const int dlane = opaque_lane(lane);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (!FFPA_V_EARLY) {
+      if constexpr (kPre > 0) {
+        // barrier A2: V(j) has landed on every wave (all but the kPre younger K pieces have retired)
+        if constexpr (!(FFPA_ABL & 16)) dma_wait_except<kPre>();
+        if constexpr (!(FFPA_ABL & 4)) __syncthreads();
+      }
+      if constexpr (!FFPA_V_EARLY || kPre > 0) {
 #pragma unroll
         for (int n = 0; n < PF2 && n < N2; ++n) vf[n] = v_frag(n);
       }
@@ -730,11 +761,11 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
         constexpr int n = decltype(ic)::value;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (n + PF2 < N2) vf[n + PF2] = v_frag(n + PF2);
-        if constexpr (kInterleave && !(FFPA_ABL & 1) && n % kStep == 0 && n / kStep < PPW) {
+        if constexpr (kInterleave && !(FFPA_ABL & 1) && n % kStep == 0 && n / kStep + kPre < PPW) {
           // K(j+1) streams in under this tile's PV (the K buffer is free since barrier A).  After the
           // last tile this prefetches a clamped, unused tile: cheaper than a branch per piece, and
           // barrier B still drains it before the workgroup can exit.
-          constexpr int i = n / kStep;
+          constexpr int i = n / kStep + kPre;
           if constexpr (kImm) {
             const uint32_t so = k_soff < k_last ? k_soff : k_last;
             lds_dma_16_imm<i * 1024, (i & 15) << 4>(k_rsrc, k_wave_lds, dlane << 4, so);
@@ -744,7 +775,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
           }
         }
         constexpr int db = FFPA_PV_ORDER ? n % NDB : n / NKS, ks = FFPA_PV_ORDER ? n / NDB : n % NKS;
-        oacc[db] = E::mfma(vf[n], pf[ks], oacc[db]);
+        if constexpr (!(FFPA_ABL & (128 | 512))) oacc[db] = E::mfma(vf[n], pf[ks], oacc[db]);
       });
       __builtin_amdgcn_sched_barrier(0);
     }

@@ -45,6 +45,10 @@ dist1)
   timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-sdpa --gather > gpurun_out/dist1g.json 2>> gpurun_out/dist1.err; echo "dist1 gather exit $?" ;;
 work)
   for w in cfg3 cfg2_causal cfg4; do timeout 300 python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_$w.json 2>> gpurun_out/bench.err; echo "$w exit $?"; cat gpurun_out/bench_$w.json; done ;;
+clocks)
+  rm -rf gpurun_out/clk
+  (cd /tmp && timeout 240 rocprofv3 --kernel-trace --output-format csv --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OLDPWD/gpurun_out/clk -o clk -- python $OLDPWD/tools/gpu_ab.py $CLK_ARGS --rounds 2 --reps 3) > gpurun_out/clk.log 2>&1
+  echo "clocks exit $?"; grep "^AB" gpurun_out/clk.log ;;
 biasperf)
   timeout 600 python tools/gpu_bias_bench.py > gpurun_out/bias.log 2>&1; echo "bias exit $?"; grep BIAS gpurun_out/bias.log; tail -2 gpurun_out/bias.log | grep -v BIAS ;;
 decode)
