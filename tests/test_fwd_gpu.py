@@ -558,3 +558,81 @@ def test_dropout_backward_uses_the_forward_mask(hip):
   for name, a, b in zip(("dq", "dk", "dv"), grads, rgrads):
     scale = b.abs().max().item()
     assert (a.float() - b).abs().max().item() <= 3e-2 * scale + 1e-3, name
+
+
+# ----------------------------------------------------------------------------- randomized sweep
+def _random_case(rng):
+  D = int(rng.choice([64, 128, 192, 264, 320, 384, 448, 512, 520, 576, 640, 768, 1000, 1024]))
+  Hkv = int(rng.choice([1, 2, 3]))
+  group = int(rng.choice([1, 1, 2, 4]))
+  Nq = int(rng.choice([1, 2, 7, 9, 31, 32, 33, 64, 100, 129, 257, 300]))
+  Nkv = int(rng.choice([1, 17, 32, 33, 63, 64, 65, 127, 200, 333, 512, 700]))
+  mode = rng.choice(["plain", "causal_tail", "causal_topleft", "causal_off", "bias_bool", "bias_add", "bias_f32", "dropout"])
+  dtype = torch.float16 if rng.random() < 0.25 else torch.bfloat16
+  strided = rng.random() < 0.3
+  return dict(B=int(rng.choice([1, 2])), Hq=Hkv * group, Hkv=Hkv, Nq=Nq, Nkv=Nkv, D=D, mode=str(mode), dtype=dtype, strided=strided)
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_randomized_against_oracle(hip, seed):
+  rng = np.random.default_rng(1000 + seed)
+  c = _random_case(rng)
+  B, Hq, Hkv, Nq, Nkv, D, dt = c["B"], c["Hq"], c["Hkv"], c["Nq"], c["Nkv"], c["D"], c["dtype"]
+  if c["strided"]:  # [B, N, H, D] storage viewed as [B, H, N, D]
+    q = _rand((B, Nq, Hq, D), dt, seed=seed * 3 + 1).transpose(1, 2)
+    k = _rand((B, Nkv, Hkv, D), dt, seed=seed * 3 + 2).transpose(1, 2)
+    v = _rand((B, Nkv, Hkv, D), dt, seed=seed * 3 + 3).transpose(1, 2)
+  else:
+    q, k, v = _rand((B, Hq, Nq, D), dt, seed=seed * 3 + 1), _rand((B, Hkv, Nkv, D), dt, seed=seed * 3 + 2), _rand((B, Hkv, Nkv, D), dt, seed=seed * 3 + 3)
+  kw, okw, bias = {}, {}, None
+  causal = c["mode"].startswith("causal")
+  if c["mode"] == "causal_topleft":
+    kw["causal_offset"] = okw["causal_offset"] = 0
+  elif c["mode"] == "causal_off":
+    off = int(rng.integers(-3, Nkv + 2))
+    kw["causal_offset"] = okw["causal_offset"] = off
+  elif c["mode"] == "bias_bool":
+    m = torch.rand((B, 1, 1, Nkv), device="cuda") > 0.3
+    m[..., 0] = True
+    bias = torch.zeros(m.shape, dtype=dt, device="cuda").masked_fill(~m, float("-inf"))
+  elif c["mode"] == "bias_add":
+    bias = (torch.randn((1, Hq, Nq, Nkv), device="cuda") * 0.5).to(dt)
+  elif c["mode"] == "bias_f32":
+    bias = torch.randn((B, 1, Nq, 1), device="cuda") * 0.5 + torch.randn((1, 1, 1, Nkv), device="cuda")
+  elif c["mode"] == "dropout":
+    kw.update(dropout_p=0.3, philox_seed=int(rng.integers(0, 2**62)), philox_offset=int(rng.integers(0, 10**9)))
+    okw.update(dropout_p=0.3, philox_seed=kw["philox_seed"], philox_offset=kw["philox_offset"])
+  scale = float(rng.choice([D ** -0.5, 0.03, 0.11]))
+  plan = {}
+  o, lse = hip.forward(q, k, v, bias, causal, scale, plan_out=plan, **kw)
+  assert o.shape == (B, Hq, Nq, D) and lse.shape == (B, Hq, Nq)
+  qb, dname = fo.torch_to_bits(q)
+  kb, _ = fo.torch_to_bits(k)
+  vb, _ = fo.torch_to_bits(v)
+  _, o32, lse_ref = fo.oracle_forward(qb, kb, vb, dname, scale=scale, causal=causal, bias=None if bias is None else _f32(bias),
+                                      block_keys=plan["block_keys"], **okw)
+  got = _f32(o)
+  assert np.array_equal(np.isnan(got), np.isnan(o32)), c
+  fin = np.isfinite(o32)
+  ulp = 2.0 ** -8 if dname == "bf16" else 2.0 ** -11
+  # P entries that sit on a rounding boundary may round the other way in the kernel (different fp32 summation
+  # order / exp2): one flip moves O by ulp * p_k/l * |v|, so the slack scales with the row's largest probability
+  # (these random cases include peaky softmaxes, scale up to 0.11 at D = 1000) — times two for dropout's 1/(1-p).
+  g = Hq // Hkv
+  sc = (q.float() @ k.float().repeat_interleave(g, 1).transpose(-1, -2)) * scale
+  if bias is not None:
+    sc = sc + bias.float()
+  if causal:
+    off = kw.get("causal_offset", Nkv - Nq)
+    rows_i = torch.arange(Nq, device="cuda")[:, None]
+    cols_i = torch.arange(Nkv, device="cuda")[None, :]
+    sc = sc.masked_fill(cols_i > rows_i + off, float("-inf"))
+  pmax = torch.exp(sc.max(-1).values - torch.logsumexp(sc, -1)).nan_to_num(0.0).cpu().numpy()[..., None]
+  vmax = float(v.float().abs().max())
+  flip = 3.0 * ulp * pmax * vmax * (2.0 if c["mode"] == "dropout" else 1.0) + (2.5e-3 if dname == "bf16" else 4e-4)
+  err = np.abs(got - o32)
+  lim = ulp * np.maximum(np.abs(o32), 2.0 ** -6) + flip
+  assert (err[fin] <= np.broadcast_to(lim, err.shape)[fin]).all(), (c, plan, float(err[fin].max()))
+  lfin = np.isfinite(lse_ref)
+  assert np.array_equal(np.isneginf(_f32(lse)), np.isneginf(lse_ref)), c
+  np.testing.assert_allclose(_f32(lse)[lfin], lse_ref[lfin], atol=3e-4, rtol=3e-5, err_msg=str(c))
