@@ -636,3 +636,35 @@ def test_randomized_against_oracle(hip, seed):
   lfin = np.isfinite(lse_ref)
   assert np.array_equal(np.isneginf(_f32(lse)), np.isneginf(lse_ref)), c
   np.testing.assert_allclose(_f32(lse)[lfin], lse_ref[lfin], atol=3e-4, rtol=3e-5, err_msg=str(c))
+
+
+# ----------------------------------------------------------------------------- streams and HIP graphs
+def test_runs_on_the_callers_stream_and_in_a_hip_graph(hip):
+  """The C-ABI launches on the stream it is given (torch's current stream), never synchronises and allocates
+  nothing itself, so a warmed-up call can be captured into a HIP graph and replayed (the decode path included)."""
+  from ffpa_attn_amd import ffpa_attn_func
+
+  q, k, v = _rand((1, 8, 640, 512), seed=201), _rand((1, 2, 2048, 512), seed=202), _rand((1, 2, 2048, 512), seed=203)
+  qd = _rand((4, 8, 1, 512), seed=204)
+  kd, vd = _rand((4, 2, 4096, 512), seed=205), _rand((4, 2, 4096, 512), seed=206)
+  ref = ffpa_attn_func(q, k, v, is_causal=True, enable_gqa=True)
+  refd = ffpa_attn_func(qd, kd, vd, enable_gqa=True)
+  side = torch.cuda.Stream()
+  side.wait_stream(torch.cuda.current_stream())
+  with torch.cuda.stream(side):
+    out = ffpa_attn_func(q, k, v, is_causal=True, enable_gqa=True)
+    outd = ffpa_attn_func(qd, kd, vd, enable_gqa=True)
+  side.synchronize()
+  assert torch.equal(out, ref) and torch.equal(outd, refd)
+
+  static_q, static_qd = q.clone(), qd.clone()
+  g = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(g):
+    go = ffpa_attn_func(static_q, k, v, is_causal=True, enable_gqa=True)
+    god = ffpa_attn_func(static_qd, kd, vd, enable_gqa=True)
+  static_q.copy_(q * 0.5)
+  static_qd.copy_(qd * 0.5)
+  g.replay()
+  torch.cuda.synchronize()
+  assert torch.equal(go, ffpa_attn_func(q * 0.5, k, v, is_causal=True, enable_gqa=True))
+  assert torch.equal(god, ffpa_attn_func(qd * 0.5, kd, vd, enable_gqa=True))
