@@ -213,6 +213,13 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   a.nsplit = pl.splits;
   a.tiles_per_split = pl.tiles_per_split;
   a.causal_row_mod = p->causal_row_mod;
+  if (p->bias != nullptr && p->bias_stride[3] == 1) {
+    // 4-wide bias loads need naturally aligned groups of 4 keys: base and the batch/head/row strides
+    const int esz = p->bias_dtype == FFPA_BIAS_FP32 ? 4 : 2;
+    bool ok = (reinterpret_cast<uintptr_t>(p->bias) % (4 * esz)) == 0;
+    for (int i = 0; i < 3; ++i) ok = ok && (p->bias_stride[i] % 4 == 0);
+    a.bias_vec = ok ? 1 : 0;
+  }
   a.dropout_p = p->dropout_p;
   a.keep_scale = p->dropout_p > 0.f ? 1.f / (1.f - p->dropout_p) : 1.f;
   a.philox_seed = p->philox_seed;

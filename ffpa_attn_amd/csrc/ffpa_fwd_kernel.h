@@ -126,6 +126,7 @@ struct FwdArgs {
   // rows of several query heads of one KV group packed into one row axis (host reshape): the causal
   // limit of packed row r is (r % causal_row_mod) + causal_offset; 0 = rows are plain query rows
   int causal_row_mod;
+  int bias_vec;  // 1: bias key stride is 1 and every (row, 4-key group) is naturally aligned -> 4-wide loads
   // dropout (prefill.cuh:398-546): keep iff u > p, u from Philox4x32-10 at the logical element offset
   float dropout_p;          // 0 = off
   float keep_scale;         // 1 / (1 - p)
@@ -368,6 +369,20 @@ __device__ __forceinline__ void add_bias_block(float (&x)[16], const void* bias,
 // DROP selects the dropout-capable build of the kernel: kept out of the default instantiation because its
 // Philox temporaries push hipcc into spilling Q fragments inside the QK^T loop (and every reload drains the
 // DMA queue); dropout launches pay that, plain launches do not.
+// 4-wide variant for unit key stride: the lane's 16 scores are 4 groups of 4 consecutive keys.
+template <typename BT>
+__device__ __forceinline__ void add_bias_block_vec4(float (&x)[16], const void* bias, int64_t row_off, int key_base) {
+  typedef __attribute__((ext_vector_type(4))) BT bvec4;
+  const BT* bp = (const BT*)bias + row_off + key_base;
+  bvec4 raw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) raw[i] = *(const bvec4*)(bp + 8 * i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) x[4 * i + t] += (float)raw[i][t] * 1.4426950408889634f;
+}
+
 template <typename T, int D, int ND, bool SAFE, bool DROP = false>
 __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) {
   using E = Elem<T>;
@@ -696,6 +711,12 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
         const int kbase = k0 + kb * 32 + 4 * h;
+        if (a.bias_vec && k0 + BC <= a.Nkv) {  // full tile, unit key stride, aligned rows
+          if (a.bias_dtype == 3) add_bias_block_vec4<float>(x[kb], a.bias, brow, kbase);
+          else if (a.bias_dtype == 2) add_bias_block_vec4<__bf16>(x[kb], a.bias, brow, kbase);
+          else add_bias_block_vec4<_Float16>(x[kb], a.bias, brow, kbase);
+          continue;
+        }
         if (a.bias_dtype == 3) add_bias_block<float>(x[kb], a.bias, brow, a.sbias[3], kbase, a.Nkv);
         else if (a.bias_dtype == 2) add_bias_block<__bf16>(x[kb], a.bias, brow, a.sbias[3], kbase, a.Nkv);
         else add_bias_block<_Float16>(x[kb], a.bias, brow, a.sbias[3], kbase, a.Nkv);
