@@ -5,28 +5,29 @@
 // split_d_fwd_sm80 (csrc/cuffpa/native/sm_80/split_d.cuh:96-777) and its helpers
 // (csrc/cuffpa/native/prefill.cuh:671-1093); the mapping onto the machine does not.
 //
-// Machine mapping (see DESIGN.md for the derivation):
-//   * one workgroup = 4 waves = one wave per SIMD, each wave owns the SIMD's whole
-//     512-entry register file.  A wave owns 32 query rows and DW = D/ND output columns:
-//       ND = 1 (D <= 512):  4 waves x 32 rows           -> BR = 128 rows / workgroup
-//       ND = 2 (D  > 512):  2 row blocks x 2 D-halves   -> BR =  64 rows / workgroup
-//   * S^T = K.Q^T  (v_mfma_f32_32x32x16, A = K rows from LDS, B = Q rows from VGPRs):
-//     every lane then owns ONE query column, so the softmax row reductions are in-lane
-//     plus a single lane^32 exchange, and the C layout of S^T is already the B-operand
-//     layout of the second contraction (P never leaves registers).
-//   * O^T += V^T.P^T (A = V^T via ds_read_b64_tr_b16 from a row-major V tile in LDS,
-//     B = P^T from registers, accumulator O^T = 16*DW/32 AGPRs per lane).
-//   * Split-D: the Q.K contraction walks D in 16-wide steps against Q fragments that
-//     stay resident in VGPRs (DW/4 registers); for ND = 2 each wave contracts only its
-//     own half of D and the two partial S^T tiles are summed through LDS.  The O^T
-//     accumulator is split over D the same way, so registers + LDS stay bounded in D.
-//   * K and V tiles ([BC keys][D] bf16, BC = 64 / 32) are brought in by LDS-DMA
-//     (global_load_lds_dwordx4: no VGPR round trip); bank-conflict-avoiding XOR swizzles
-//     are applied on the per-lane SOURCE address because the DMA destination is
-//     lane-linear.  K(j+1) streams in under softmax+PV of tile j, V(j+1) under QK of
-//     tile j+1: two workgroup barriers per KV tile.
-//   * blockIdx is remapped so that all row tiles of one (batch, head) run on the same
-//     XCD at the same time and share K/V through that XCD's L2.
+// Machine mapping (see DESIGN.md for the derivation and the measurements behind each choice):
+//   * one workgroup = 4 waves = one wave per SIMD, each wave owns the SIMD's whole 512-entry register file.
+//     A wave owns 32 query rows and DW = D/ND output columns:
+//       ND = 1 (D <= 512):  4 waves x 32 rows            -> BR = 128 rows / workgroup, BC = 64 keys / tile
+//       ND = 2 (D  > 512):  2 row blocks x 2 D-halves    -> BR =  64, BC = 32
+//       ND = 4 (Nq <= 32):  1 row block  x 4 D-quarters  -> BR =  32, BC = 32 (short-query / decode launches,
+//                                                           with the KV axis split over workgroups)
+//   * S^T = K.Q^T  (v_mfma_f32_32x32x16, A = K rows from LDS, B = Q rows from VGPRs): every lane then owns ONE
+//     query column, so the softmax row reductions are in-lane plus a single lane^32 exchange, and the C layout
+//     of S^T is already the B-operand layout of the second contraction (P never leaves registers).
+//   * O^T += V^T.P^T (A = V^T via ds_read_b64_tr_b16 from a row-major V tile in LDS, B = P^T from registers,
+//     accumulator O^T = 16*DW/32 AGPRs per lane).
+//   * Split-D: the Q.K contraction walks D in 16-wide steps against Q fragments that stay resident in VGPRs
+//     (DW/4 registers); for ND > 1 each wave contracts only its own slice of D and the partial S^T tiles are
+//     summed through LDS.  The O^T accumulator is split over D the same way, so registers + LDS stay bounded
+//     in D.
+//   * K and V tiles ([BC keys][D]) are brought in by LDS-DMA (buffer_load_dwordx4 ... lds: no VGPR round
+//     trip), issued through inline asm between the MFMAs; bank-conflict-avoiding XOR swizzles are applied on
+//     the per-lane SOURCE offset because the DMA destination is lane-linear.  Per KV tile: QK^T(j) with the
+//     V(j) pieces interleaved -> barrier A1 -> first K(j+1) pieces -> softmax -> counted vmcnt + barrier A2 ->
+//     PV(j) with the remaining K(j+1) pieces interleaved -> barrier B.
+//   * blockIdx is remapped so that all row tiles of one (batch, head) run on the same XCD at the same time
+//     and share K/V through that XCD's L2.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -59,14 +60,13 @@
 #ifndef FFPA_K_PRE
 #define FFPA_K_PRE 8  // interleaved mode: this many K(j+1) pieces are issued right after QK^T (they stream under
 #endif                //   the softmax); V(j) is then awaited with a counted vmcnt just before PV.  0 = one barrier A
-#ifndef FFPA_DMA_IMM
-#define FFPA_DMA_IMM 0  // 1: D == 512 DMA pieces with immediate LDS offset / swizzle (5 instrs per piece; measured neutral)
-#endif
 #ifndef FFPA_V_EARLY
 #define FFPA_V_EARLY 1  // issue the first PV fragment reads right after barrier A (latency hides under softmax)
 #endif
 #ifndef FFPA_ABL
-#define FFPA_ABL 0  // developer ablations (WRONG RESULTS): 1 no in-loop DMA, 2 no exp, 4 no barriers, 8 no softmax at all, 16 no DMA drain, 32 no s_nop in the S MFMA, 64 no LDS fragment reads, 128 no MFMA (DMA + barriers only), 256 no QK MFMA, 512 no PV MFMA
+// developer ablations (WRONG RESULTS; tools/gpu_ab.py): 1 no in-loop DMA, 2 no exp, 4 no barriers, 8 no softmax,
+// 16 no DMA drain, 32 no s_nop in the S MFMA, 64 no LDS fragment reads, 128 no MFMA, 256 no QK MFMA, 512 no PV MFMA
+#define FFPA_ABL 0
 #endif
 
 #if (FFPA_ABL & 32)
@@ -82,8 +82,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{}) — the
-// index is a constant expression inside the body (inline-asm "i" operands need one; an unrolled loop
-// variable is not enough for the front end).
+// index is a constant expression inside the body (`if constexpr` on it, static register-array indices).
 template <typename F, int... Is>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
   (f(std::integral_constant<int, Is>{}), ...);
@@ -196,11 +195,6 @@ __device__ __forceinline__ int v_slot_swizzle(int key) {  // in 16-byte slots
   return (D % 128 == 0) ? ((key & 3) << 2) : (((key >> 1) & 1) << 2);
 }
 
-// Stage one [BC][D] tile (keys key0 .. key0+BC-1, clamped to the last valid key) into
-// LDS.  Each wave moves TILE/4 bytes as 1 KiB LDS-DMA pieces (buffer_load_dwordx4 ... lds):
-// lane i of piece p lands at lds_tile + p*1024 + i*16 (the hardware's lane-linear rule), so
-// the swizzle goes on the per-lane SOURCE offset.  `rsrc` describes the (batch, kv-head)
-// slice; offsets inside it are 32-bit (the host rejects slices of 4 GiB or more).
 // One 1 KiB LDS-DMA piece: buffer_load_dwordx4 ... lds (16 B per lane, destination M0 + lane*16).
 // Issued through inline asm on purpose: hipcc cannot tell that the DMA's LDS write does not alias a
 // later ds_read_b64_tr_b16 and would put `s_waitcnt vmcnt(0)` in front of every transpose read that
@@ -214,23 +208,10 @@ __device__ __forceinline__ void lds_dma_16(u32x4 rsrc, uint32_t lds_addr, uint32
                : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
                : "memory");
 }
+
 // s_waitcnt vmcnt(0) as a BUILTIN (gfx9 encoding 0x0F70: vmcnt = 0, expcnt / lgkmcnt = no wait): the
 // compiler's own scoreboard then knows its earlier loads (the Q fragments) have retired and emits no
 // counted vmcnt waits inside the tile loop — those would also wait on the hidden DMA pieces.
-// D == 512 form: a K / V row is exactly one 1 KiB piece, so for piece I of this wave the LDS address is
-// wave_base + I*1024 and the source swizzle is a compile-time XOR constant.  M0 is produced by the
-// s_add itself (no precomputed SGPR per piece), the v_xor that forms the per-lane source offset doubles
-// as the SALU-writes-M0 wait state, and the row offset arrives as a running scalar: 5 instructions per
-// piece (s_add + s_min outside) instead of 7.
-template <int LDS_IMM, int XOR_IMM>
-__device__ __forceinline__ void lds_dma_16_imm(u32x4 rsrc, uint32_t lds_wave_base, uint32_t lane16, uint32_t soff) {
-  uint32_t voff;
-  asm volatile("s_add_u32 m0, %1, %2\n\tv_xor_b32 %0, %3, %4\n\tbuffer_load_dwordx4 %0, %5, %6 offen lds"
-               : "=&v"(voff)
-               : "s"(lds_wave_base), "i"(LDS_IMM), "i"(XOR_IMM), "v"(lane16), "s"(rsrc), "s"(soff)
-               : "memory", "scc");
-}
-
 __device__ __forceinline__ void dma_wait_all() {
   __builtin_amdgcn_s_waitcnt(0x0F70);
   asm volatile("" ::: "memory");
@@ -252,6 +233,11 @@ __device__ __forceinline__ u32x4 make_rsrc(const void* base, uint32_t bytes) {
   return r;
 }
 
+// Piece i of this wave's share of one [BC][D] tile (keys key0 .. key0+BC-1, clamped to the last valid
+// key).  Each wave moves TILE/4 bytes as 1 KiB LDS-DMA pieces: lane l of piece p lands at
+// lds_tile + p*1024 + l*16 (the hardware's lane-linear rule), so the swizzle goes on the per-lane SOURCE
+// offset.  `rsrc` describes the (batch, kv-head) slice; offsets inside it are 32-bit (the host rejects
+// slices of 4 GiB or more).  SAFE = the register-staged twin used by the tests.
 template <typename T, int D, int BC, bool IS_V, bool SAFE>
 __device__ __forceinline__ void stage_piece(u32x4 rsrc, const T* __restrict__ base,
                                             uint32_t row_bytes, int key0, int nkv,
@@ -292,17 +278,6 @@ __device__ __forceinline__ void stage_piece(u32x4 rsrc, const T* __restrict__ ba
 __device__ __forceinline__ int opaque_lane(int lane) {
   asm volatile("" : "+v"(lane));
   return lane;
-}
-
-template <typename T, int D, int BC, bool IS_V, bool SAFE>
-__device__ __forceinline__ void stage_tile(u32x4 rsrc, const T* __restrict__ base,
-                                           uint32_t row_bytes, int key0, int nkv,
-                                           FFPA_LDS char* lds_tile, int wave, int lane) {
-  constexpr int PPW = BC * D * 2 / 4096;
-  static_assert((BC * D * 2) % 4096 == 0, "tile must split evenly into 1 KiB pieces over 4 waves");
-  lane = opaque_lane(lane);
-#pragma unroll
-  for (int i = 0; i < PPW; ++i) stage_piece<T, D, BC, IS_V, SAFE>(rsrc, base, row_bytes, key0, nkv, lds_tile, wave, lane, i);
 }
 
 // Philox4x32-10 (Salmon et al., SC'11) on counter (quad_lo, quad_hi, 0, 0) with key = seed: the generator
@@ -407,14 +382,12 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   constexpr int kStep = (ND == 1) ? FFPA_DMA_STEP : 1;  // MFMAs between two DMA pieces
   static_assert(!kInterleave || PPW * kStep <= (DW / 16) * (BC / 32), "DMA pieces must fit the QK loop");
   // immediate-form DMA: one piece == one row (D == 512) and 16 pieces per wave so that the row's swizzle
-  // (key & 15 / key & 3) equals the piece index
   // Head dims whose rows are not a whole number of 1 KiB pieces need ~12 VALU instructions per piece for the
   // per-lane source offset (constant division, swizzle, clamp).  The offsets are tile-invariant: where the
   // register budget allows they are hoisted into PPW + PPW VGPRs and only the tail tile recomputes them.
   constexpr bool kRowUniform = (D * 2) % 1024 == 0;
   constexpr bool kHoist = FFPA_HOIST != 0 && !kRowUniform && !SAFE && !DROP && ND == 1 && D <= 384;  // measured: +4 % at D = 320, -5 % on the ND = 2 burst path
   constexpr int kPre = (kInterleave && FFPA_K_PRE > 0 && FFPA_K_PRE <= PPW && FFPA_K_PRE <= 15) ? FFPA_K_PRE : 0;
-  constexpr bool kImm = FFPA_DMA_IMM != 0 && kInterleave && !SAFE && D == 512 && PPW == 16;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   FFPA_LDS char* const Kt = (FFPA_LDS char*)smem;
@@ -554,8 +527,6 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
     for (int i = 0; i < 4; ++i) vaddr[i] = Vt + (4 * h + j4) * RB + ((vcol + i * 64) ^ vsw);
   }
 
-  const uint32_t k_wave_lds = (uint32_t)(uintptr_t)(Kt + wave * PPW * 1024);  // this wave's pieces of a tile
-  const uint32_t v_wave_lds = (uint32_t)(uintptr_t)(Vt + wave * PPW * 1024);
   if (nt > t0) {
     issue_k_tile(t0 * BC);
     dma_wait_all();
@@ -582,26 +553,13 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int n = 0; n < PF1 && n < N1; ++n) kf[n] = k_frag(n);
-      // interleaved DMA of V(j): running scalar row offset of the next piece (clamped to the last key)
-      uint32_t v_soff = 0, v_last = 0;
-      if constexpr (kImm) {
-        v_soff = (uint32_t)(k0 + wave * PPW) * v_row_bytes;
-        v_last = (uint32_t)(a.Nkv - 1) * v_row_bytes;
-      }
       static_for<N1>([&](auto ic) {
         constexpr int n = decltype(ic)::value;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (n + PF1 < N1) kf[n + PF1] = k_frag(n + PF1);
         if constexpr (kInterleave && !(FFPA_ABL & 1) && n % kStep == 0 && n / kStep < PPW) {
           // V(j) streams in under this tile's QK^T (the V buffer is free since barrier B of tile j-1)
-          constexpr int i = n / kStep;
-          if constexpr (kImm) {
-            const uint32_t so = v_soff < v_last ? v_soff : v_last;
-            lds_dma_16_imm<i * 1024, (i & 3) << 6>(v_rsrc, v_wave_lds, dlane << 4, so);
-            v_soff += v_row_bytes;
-          } else {
-            issue_v(i, k0, dlane);
-          }
+          issue_v(n / kStep, k0, dlane);
         }
         constexpr int s = FFPA_QK_ORDER ? n % KS : n / NKB, kb = FFPA_QK_ORDER ? n / KS : n % NKB;
         if constexpr ((FFPA_ABL & (128 | 256)) != 0) { if constexpr (s == 0) sacc[kb] = (f32x16)(0.f); }
@@ -822,11 +780,6 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
 #pragma unroll
         for (int n = 0; n < PF2 && n < N2; ++n) vf[n] = v_frag(n);
       }
-      uint32_t k_soff = 0, k_last = 0;
-      if constexpr (kImm) {
-        k_soff = (uint32_t)(k0 + BC + wave * PPW) * k_row_bytes;
-        k_last = (uint32_t)(a.Nkv - 1) * k_row_bytes;
-      }
       static_for<N2>([&](auto ic) {
         constexpr int n = decltype(ic)::value;
         __builtin_amdgcn_sched_barrier(0);
@@ -835,14 +788,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
           // K(j+1) streams in under this tile's PV (the K buffer is free since barrier A).  After the
           // last tile this prefetches a clamped, unused tile: cheaper than a branch per piece, and
           // barrier B still drains it before the workgroup can exit.
-          constexpr int i = n / kStep + kPre;
-          if constexpr (kImm) {
-            const uint32_t so = k_soff < k_last ? k_soff : k_last;
-            lds_dma_16_imm<i * 1024, (i & 15) << 4>(k_rsrc, k_wave_lds, dlane << 4, so);
-            k_soff += k_row_bytes;
-          } else {
-            issue_k(i, k0 + BC, dlane);
-          }
+          issue_k(n / kStep + kPre, k0 + BC, dlane);
         }
         constexpr int db = FFPA_PV_ORDER ? n % NDB : n / NKS, ks = FFPA_PV_ORDER ? n / NDB : n % NKS;
         if constexpr (!(FFPA_ABL & (128 | 512))) oacc[db] = E::mfma(vf[n], pf[ks], oacc[db]);
