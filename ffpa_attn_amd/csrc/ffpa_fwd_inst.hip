@@ -13,7 +13,7 @@ namespace ffpa {
 
 template <typename T, int D, int ND, bool SAFE, bool DROP = false>
 static int launch_one(const FwdArgs& a, hipStream_t stream) {
-  constexpr int BC = (ND == 1) ? 64 : 32;
+  constexpr int BC = (ND == 1) ? ((D <= FFPA_BC128_MAX_D) ? 128 : 64) : 32;
   constexpr int LDS = 2 * BC * D * 2 + (ND > 1 ? 4 * 4096 : 0);
   auto kern = ffpa_fwd_split_d_kernel<T, D, ND, SAFE, DROP>;
   static bool attr_done[64] = {};
@@ -73,7 +73,7 @@ int FFPA_CAT(launch_fwd_d, FFPA_INST_D)(int dtype, int safe, int variant, const 
 void FFPA_CAT(tile_config_d, FFPA_INST_D)(int variant, int* br, int* bc, int* lds) {
   constexpr int D = FFPA_INST_D;
   const int ND = variant == 1 ? ((D % 128 == 0) ? 4 : 2) : ((D <= 512) ? 1 : 2);
-  const int BC = (ND == 1) ? 64 : 32;
+  const int BC = (ND == 1) ? ((D <= FFPA_BC128_MAX_D) ? 128 : 64) : 32;
   *br = 32 * (4 / ND);
   *bc = BC;
   *lds = 2 * BC * D * 2 + (ND > 1 ? 4 * 4096 : 0);

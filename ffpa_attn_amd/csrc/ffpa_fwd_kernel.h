@@ -54,6 +54,9 @@
 #ifndef FFPA_QK_ORDER
 #define FFPA_QK_ORDER 0  // QK MFMA order: 0 = d-step outer (alternate the two S accumulators), 1 = key-block outer
 #endif
+#ifndef FFPA_BC128_MAX_D
+#define FFPA_BC128_MAX_D 320  // ND == 1 head dims up to this use 128-key tiles (2*128*D*2 B of LDS <= 160 KiB)
+#endif
 #ifndef FFPA_HOIST
 #define FFPA_HOIST 1  // hoist the tile-invariant per-lane DMA source offsets (head dims with non-1KiB rows)
 #endif
@@ -368,7 +371,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   constexpr int DW = D / ND;       // output columns owned by one wave
   constexpr int NDB = DW / 32;     // 32-column O^T blocks per wave
   constexpr int KS = DW / 16;      // QK contraction steps per wave
-  constexpr int BC = (ND == 1) ? 64 : 32;   // ND == 4 (short-query launches): small tiles, 2 workgroups / CU
+  // keys per tile: 128 for small head dims (fewer barriers / phase fills per key), 64 up to D = 512, 32 when D
+  // is split over waves (ND == 4, short-query launches: small tiles, 2 workgroups / CU)
+  constexpr int BC = (ND == 1) ? ((D <= FFPA_BC128_MAX_D) ? 128 : 64) : 32;
   constexpr int NKB = BC / 32;     // 32-key S^T blocks per tile
   constexpr int NKS = BC / 16;     // PV contraction steps per tile
   constexpr int NQB = 4 / ND;      // 32-row blocks per workgroup
@@ -518,13 +523,19 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
     for (int i = 0; i < 8; ++i) kaddr[i] = Kt + l31 * RB + (((c0 + 2 * i + h) ^ kx) << 4);
   }
   // V^T fragment of column block db = 4 q + i, step ks, half hh: vaddr[i] + 256 q + (16 ks + 8 hh)*RB
-  FFPA_LDS const char* vaddr[4];
+  // (ds_read immediates are 16 bits: key steps whose row offset would overflow use a second base, +64 rows)
+  constexpr int kVHiKs = (65535 - 768 - 8 * RB) / (16 * RB) + 1;  // first key step that needs the high base
+  constexpr bool kVHi = NKS > kVHiKs;
+  FFPA_LDS const char* vaddr[kVHi ? 8 : 4];
   {
     const int j4 = (lane & 15) >> 2;
     const int vsw = v_slot_swizzle<D>(j4) * 16;
     const int vcol = dh * DW * 2 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;  // bytes
 #pragma unroll
-    for (int i = 0; i < 4; ++i) vaddr[i] = Vt + (4 * h + j4) * RB + ((vcol + i * 64) ^ vsw);
+    for (int i = 0; i < 4; ++i) {
+      vaddr[i] = Vt + (4 * h + j4) * RB + ((vcol + i * 64) ^ vsw);
+      if constexpr (kVHi) vaddr[4 + i] = vaddr[i] + 64 * RB;
+    }
   }
 
   if (nt > t0) {
@@ -608,7 +619,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
       const int db = FFPA_PV_ORDER ? n % NDB : n / NKS, ks = FFPA_PV_ORDER ? n / NDB : n % NKS;
       if constexpr ((FFPA_ABL & 64) != 0) return qf[(db + ks) % KS];
       if constexpr (!SAFE) {
-        FFPA_LDS const char* vp = vaddr[db & 3] + (db >> 2) * 256 + (ks * 16) * RB;
+        FFPA_LDS const char* vp = (kVHi && ks >= 4) ? vaddr[4 + (db & 3)] + (db >> 2) * 256 + ((ks - 4) * 16) * RB
+                                                     : vaddr[db & 3] + (db >> 2) * 256 + (ks * 16) * RB;
         const v4 lo = E::tr_read(vp);
         const v4 hi = E::tr_read(vp + 8 * RB);
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);

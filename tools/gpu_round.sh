@@ -45,6 +45,10 @@ dist1)
   timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-sdpa --gather > gpurun_out/dist1g.json 2>> gpurun_out/dist1.err; echo "dist1 gather exit $?" ;;
 work)
   for w in cfg3 cfg2_causal cfg4; do timeout 300 python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_$w.json 2>> gpurun_out/bench.err; echo "$w exit $?"; cat gpurun_out/bench_$w.json; done ;;
+pmc4)
+  rm -rf gpurun_out/pmc4
+  (cd /tmp && timeout 180 rocprofv3 --kernel-trace --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_VALU_MFMA_BUSY_CYCLES -d $OLDPWD/gpurun_out/pmc4 -o p -- python $OLDPWD/bench.py --workload ${PMC_WORKLOAD:-cfg4} --steps 3 --warmup 1 --no-cpu-baseline --no-sdpa) > gpurun_out/pmc4.log 2>&1
+  echo "pmc4 exit $?" ;;
 clocks)
   rm -rf gpurun_out/clk
   (cd /tmp && timeout 240 rocprofv3 --kernel-trace --output-format csv --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OLDPWD/gpurun_out/clk -o clk -- python $OLDPWD/tools/gpu_ab.py $CLK_ARGS --rounds 2 --reps 3) > gpurun_out/clk.log 2>&1
