@@ -100,7 +100,8 @@ def test_tile_configs():
   for d in range(64, 1025, 64):
     c = hip.tile_config(d)
     if d <= 512:
-      assert (c["block_rows"], c["block_keys"]) == (128, 64) and c["lds_bytes"] == 2 * 64 * d * 2
+      bc = 128 if d <= 320 else 64  # 128-key tiles while K+V of a tile stay within 160 KiB
+      assert (c["block_rows"], c["block_keys"]) == (128, bc) and c["lds_bytes"] == 2 * bc * d * 2
     else:
       assert (c["block_rows"], c["block_keys"]) == (64, 32) and c["lds_bytes"] == 2 * 32 * d * 2 + 16384
     assert c["lds_bytes"] <= 160 * 1024  # one CU's LDS
