@@ -54,6 +54,9 @@
 #ifndef FFPA_QK_ORDER
 #define FFPA_QK_ORDER 0  // QK MFMA order: 0 = d-step outer (alternate the two S accumulators), 1 = key-block outer
 #endif
+#ifndef FFPA_ROW_DMA
+#define FFPA_ROW_DMA 1  // D = 512: wave-uniform rows, 4 scalar instructions per DMA piece (+0.9 %)
+#endif
 #ifndef FFPA_BC128_MAX_D
 #define FFPA_BC128_MAX_D 320  // ND == 1 head dims up to this use 128-key tiles (2*128*D*2 B of LDS <= 160 KiB)
 #endif
@@ -210,6 +213,25 @@ __device__ __forceinline__ void lds_dma_16(u32x4 rsrc, uint32_t lds_addr, uint32
                :
                : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
                : "memory");
+}
+
+// Row-uniform form (one LDS image row == whole pieces: D = 512, 1024).  Everything but the per-lane swizzled
+// column offset `voff` is scalar: destination = lds_base + LCONST (+ IMM), source row offset =
+// min(tile_off + row_off, last_off) — the clamp to the last valid key — and IMM advances source and
+// destination together for the second KiB of a 2 KiB row.  4 instructions, no VALU, no wait state to pad
+// (two SALU instructions sit between the M0 write and its use).
+template <int LCONST, int IMM>
+__device__ __forceinline__ void lds_dma_row(u32x4 rsrc, uint32_t lds_base, uint32_t voff, uint32_t tile_off,
+                                            uint32_t row_off, uint32_t last_off) {
+  uint32_t t;
+  asm volatile(
+      "s_add_u32 m0, %1, %7\n\t"
+      "s_add_u32 %0, %4, %5\n\t"
+      "s_min_u32 %0, %0, %6\n\t"
+      "buffer_load_dwordx4 %2, %3, %0 offen offset:%8 lds"
+      : "=&s"(t)
+      : "s"(lds_base), "v"(voff), "s"(rsrc), "s"(tile_off), "s"(row_off), "s"(last_off), "n"(LCONST), "n"(IMM)
+      : "memory", "scc");
 }
 
 // s_waitcnt vmcnt(0) as a BUILTIN (gfx9 encoding 0x0F70: vmcnt = 0, expcnt / lgkmcnt = no wait): the
@@ -386,12 +408,17 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   constexpr bool kInterleave = FFPA_DMA_INTERLEAVE != 0 && (ND == 1 || FFPA_DMA_INTERLEAVE == 2);  // D > 512 measured faster with bursts
   constexpr int kStep = (ND == 1) ? FFPA_DMA_STEP : 1;  // MFMAs between two DMA pieces
   static_assert(!kInterleave || PPW * kStep <= (DW / 16) * (BC / 32), "DMA pieces must fit the QK loop");
-  // immediate-form DMA: one piece == one row (D == 512) and 16 pieces per wave so that the row's swizzle
   // Head dims whose rows are not a whole number of 1 KiB pieces need ~12 VALU instructions per piece for the
   // per-lane source offset (constant division, swizzle, clamp).  The offsets are tile-invariant: where the
   // register budget allows they are hoisted into PPW + PPW VGPRs and only the tail tile recomputes them.
   constexpr bool kRowUniform = (D * 2) % 1024 == 0;
   constexpr bool kHoist = FFPA_HOIST != 0 && !kRowUniform && !SAFE && !DROP && ND == 1 && D <= 384;  // measured: +4 % at D = 320, -5 % on the ND = 2 burst path
+  // Row-uniform head dims: wave w stages keys 16 a + 4 w + b (a < BC/16, b < 4) so that only four K and
+  // four V swizzled lane offsets exist (K: slot ^ (4 w + b); V: slot ^ 4 b) and live in 8 VGPRs.
+  constexpr bool kRowDma = FFPA_ROW_DMA != 0 && kRowUniform && !SAFE && kInterleave;  // bursts (D = 1024): measured 1.3 % slower
+  constexpr int RPP = kRowUniform ? RB / 1024 : 1;  // pieces per row
+  constexpr int KPW = BC / 4;                       // keys staged per wave per tile
+  static_assert(!kRowDma || (D % 128 == 0 && KPW * RPP == PPW && BC % 16 == 0), "row DMA layout");
   constexpr int kPre = (kInterleave && FFPA_K_PRE > 0 && FFPA_K_PRE <= PPW && FFPA_K_PRE <= 15) ? FFPA_K_PRE : 0;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -454,19 +481,53 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
       vrel[i] = (uint32_t)key * v_row_bytes + (uint32_t)((slot ^ v_slot_swizzle<D>(key)) << 4);
     }
   }
-  auto issue_k = [&](int i, int key0, int dlane) {
+  uint32_t kvo[kRowDma ? 4 : 1], vvo[kRowDma ? 4 : 1];        // per-lane swizzled column offsets
+  uint32_t kro[kRowDma ? KPW : 1], vro[kRowDma ? KPW : 1];    // scalar: row offset of staged key jk
+  uint32_t k_last = 0, v_last = 0, k_lds = 0, v_lds = 0;
+  if constexpr (kRowDma) {
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+      kvo[bb] = (uint32_t)((lane ^ (4 * wave + bb)) << 4);
+      vvo[bb] = (uint32_t)((lane ^ (4 * bb)) << 4);
+    }
+#pragma unroll
+    for (int jk = 0; jk < KPW; ++jk) {
+      const uint32_t key = (uint32_t)(16 * (jk >> 2) + 4 * wave + (jk & 3));
+      kro[jk] = key * k_row_bytes;
+      vro[jk] = key * v_row_bytes;
+    }
+    k_last = (uint32_t)(a.Nkv - 1) * k_row_bytes;
+    v_last = (uint32_t)(a.Nkv - 1) * v_row_bytes;
+    k_lds = (uint32_t)(uintptr_t)Kt + (uint32_t)(4 * wave * RB);
+    v_lds = (uint32_t)(uintptr_t)Vt + (uint32_t)(4 * wave * RB);
+  }
+  auto issue_k = [&](auto ic, int key0, int dlane) {
+    constexpr int i = decltype(ic)::value;
+    if constexpr (kRowDma) {
+      constexpr int jk = i / RPP, half = i % RPP;
+      lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(k_rsrc, k_lds, kvo[jk & 3], (uint32_t)key0 * k_row_bytes,
+                                                                 kro[jk], k_last);
+      return;
+    }
     if constexpr (kHoist) {
       if (key0 + BC <= a.Nkv) {
-        lds_dma_16(k_rsrc, (uint32_t)(uintptr_t)(Kt + (wave * (BC * D * 2 / 4096) + i) * 1024), krel[i], (uint32_t)key0 * k_row_bytes);
+        lds_dma_16(k_rsrc, (uint32_t)(uintptr_t)(Kt + (wave * PPW + i) * 1024), krel[i], (uint32_t)key0 * k_row_bytes);
         return;
       }
     }
     stage_piece<T, D, BC, false, SAFE>(k_rsrc, Kg, k_row_bytes, key0, a.Nkv, Kt, wave, dlane, i);
   };
-  auto issue_v = [&](int i, int key0, int dlane) {
+  auto issue_v = [&](auto ic, int key0, int dlane) {
+    constexpr int i = decltype(ic)::value;
+    if constexpr (kRowDma) {
+      constexpr int jk = i / RPP, half = i % RPP;
+      lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(v_rsrc, v_lds, vvo[jk & 3], (uint32_t)key0 * v_row_bytes,
+                                                                 vro[jk], v_last);
+      return;
+    }
     if constexpr (kHoist) {
       if (key0 + BC <= a.Nkv) {
-        lds_dma_16(v_rsrc, (uint32_t)(uintptr_t)(Vt + (wave * (BC * D * 2 / 4096) + i) * 1024), vrel[i], (uint32_t)key0 * v_row_bytes);
+        lds_dma_16(v_rsrc, (uint32_t)(uintptr_t)(Vt + (wave * PPW + i) * 1024), vrel[i], (uint32_t)key0 * v_row_bytes);
         return;
       }
     }
@@ -474,13 +535,11 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   };
   auto issue_k_tile = [&](int key0) {
     const int dl = opaque_lane(lane);
-#pragma unroll
-    for (int i = 0; i < BC * D * 2 / 4096; ++i) issue_k(i, key0, dl);
+    static_for<PPW>([&](auto ic) { issue_k(ic, key0, dl); });
   };
   auto issue_v_tile = [&](int key0) {
     const int dl = opaque_lane(lane);
-#pragma unroll
-    for (int i = 0; i < BC * D * 2 / 4096; ++i) issue_v(i, key0, dl);
+    static_for<PPW>([&](auto ic) { issue_v(ic, key0, dl); });
   };
 
   // ---- KV tile range (split_d.cuh:222-228: causal tiles past the diagonal are skipped)
@@ -570,7 +629,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
         if constexpr (n + PF1 < N1) kf[n + PF1] = k_frag(n + PF1);
         if constexpr (kInterleave && !(FFPA_ABL & 1) && n % kStep == 0 && n / kStep < PPW) {
           // V(j) streams in under this tile's QK^T (the V buffer is free since barrier B of tile j-1)
-          issue_v(n / kStep, k0, dlane);
+          issue_v(std::integral_constant<int, n / kStep>{}, k0, dlane);
         }
         constexpr int s = FFPA_QK_ORDER ? n % KS : n / NKB, kb = FFPA_QK_ORDER ? n / KS : n % NKB;
         if constexpr ((FFPA_ABL & (128 | 256)) != 0) { if constexpr (s == 0) sacc[kb] = (f32x16)(0.f); }
@@ -599,8 +658,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
       if constexpr (!(FFPA_ABL & 4)) __syncthreads();
       if constexpr (!(FFPA_ABL & 1)) {
         const int plane = opaque_lane(lane);
-#pragma unroll
-        for (int i = 0; i < kPre; ++i) issue_k(i, k0 + BC, plane);
+        static_for<kPre>([&](auto ic) { issue_k(ic, k0 + BC, plane); });
       }
     } else {
       if constexpr (!(FFPA_ABL & 16)) dma_wait_all();
@@ -800,7 +858,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
           // K(j+1) streams in under this tile's PV (the K buffer is free since barrier A).  After the
           // last tile this prefetches a clamped, unused tile: cheaper than a branch per piece, and
           // barrier B still drains it before the workgroup can exit.
-          issue_k(n / kStep + kPre, k0 + BC, dlane);
+          issue_k(std::integral_constant<int, n / kStep + kPre>{}, k0 + BC, dlane);
         }
         constexpr int db = FFPA_PV_ORDER ? n % NDB : n / NKS, ks = FFPA_PV_ORDER ? n / NDB : n % NKS;
         if constexpr (!(FFPA_ABL & (128 | 512))) oacc[db] = E::mfma(vf[n], pf[ks], oacc[db]);
