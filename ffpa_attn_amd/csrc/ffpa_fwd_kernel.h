@@ -242,12 +242,12 @@ __device__ __forceinline__ void dma_wait_all() {
   asm volatile("" ::: "memory");
 }
 
-// s_waitcnt vmcnt(N), N <= 15: everything but the N youngest VMEM operations has retired (loads retire in
-// order).  Builtin form for the same reason as dma_wait_all.
+// s_waitcnt vmcnt(N): everything but the N youngest VMEM operations has retired (loads retire in order).
+// gfx9 encoding: vmcnt[3:0] in bits 3:0, vmcnt[5:4] in bits 15:14.  Builtin form for the same reason as above.
 template <int N>
 __device__ __forceinline__ void dma_wait_except() {
-  static_assert(N >= 0 && N <= 15, "vmcnt low field");
-  __builtin_amdgcn_s_waitcnt(0x0F70 | N);
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
   asm volatile("" ::: "memory");
 }
 
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   constexpr int RPP = kRowUniform ? RB / 1024 : 1;  // pieces per row
   constexpr int KPW = BC / 4;                       // keys staged per wave per tile
   static_assert(!kRowDma || (D % 128 == 0 && KPW * RPP == PPW && BC % 16 == 0), "row DMA layout");
-  constexpr int kPre = (kInterleave && FFPA_K_PRE > 0 && FFPA_K_PRE <= PPW && FFPA_K_PRE <= 15) ? FFPA_K_PRE : 0;
+  constexpr int kPre = (kInterleave && FFPA_K_PRE > 0 && FFPA_K_PRE <= PPW) ? FFPA_K_PRE : 0;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   FFPA_LDS char* const Kt = (FFPA_LDS char*)smem;
