@@ -337,6 +337,27 @@ def test_baseline_config_4_gqa_cross_causal_mask(hip):
                      name=f"cfg4 h{head}")
 
 
+def test_baseline_config_5_unsharded_on_one_gpu(hip):
+  """B=8 H=32 N=8192 D=512 in ONE launch: 2^30 elements (2 GiB) per tensor, so batch / head offsets pass
+  2^31 bytes.  Every (batch, head) unit must equal the same unit run alone (units are independent: this is
+  what sharding over ranks relies on), also through a token-major [B,N,H,D] view (rows 32 KiB apart)."""
+  B, H, N, D = 8, 32, 8192, 512
+  g = torch.Generator(device="cuda").manual_seed(5)
+  x = torch.randn(3, B, N, H, D, device="cuda", dtype=torch.bfloat16, generator=g)  # token-major storage
+  q, k, v = (t.transpose(1, 2) for t in x)          # [B,H,N,D] views, row stride H*D
+  scale = D ** -0.5
+  o, lse = hip.forward(q, k, v, None, False, scale)
+  assert o.shape == (B, H, N, D)
+  for b, h in ((0, 0), (3, 17), (7, 31)):
+    qs, ks, vs = (t[b:b + 1, h:h + 1].contiguous() for t in (q, k, v))
+    o1, lse1 = hip.forward(qs, ks, vs, None, False, scale)
+    assert torch.equal(o[b:b + 1, h:h + 1], o1) and torch.equal(lse[b:b + 1, h:h + 1], lse1), (b, h)
+  ref = F.scaled_dot_product_attention(q[7:8, 30:32], k[7:8, 30:32], v[7:8, 30:32])
+  assert (o[7:8, 30:32].float() - ref.float()).abs().max().item() <= NORTH_STAR_MAX_ABS
+  del x, q, k, v, o
+  torch.cuda.empty_cache()
+
+
 def test_key_permutation_invariance_at_full_length(hip):
   q, k, v = _baseline_inputs(1, 2, 2, 1024, 8192, 512)
   o, lse = hip.forward(q, k, v, None, False, 512 ** -0.5)
