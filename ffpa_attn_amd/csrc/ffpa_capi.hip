@@ -152,11 +152,11 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   if ((rc = check_strides("q", p->q_stride)) || (rc = check_strides("k", p->k_stride)) ||
       (rc = check_strides("v", p->v_stride)) || (rc = check_strides("o", p->o_stride)))
     return rc;
-  // K / V tiles are fetched with 32-bit buffer offsets inside one (batch, kv-head) slice
+  // K / V tiles are fetched with 32-bit buffer offsets relative to the tile's first row: one tile (<= 128
+  // rows) must span < 4 GiB; the slice itself may be of any size
   for (const int64_t* st : {p->k_stride, p->v_stride}) {
-    const int64_t slice_bytes = ((int64_t)(p->seqlen_kv - 1) * st[2] + p->head_dim) * 2;
-    if (st[2] < p->head_dim || slice_bytes >= (1LL << 32))
-      return fail(FFPA_ERR_BAD_STRIDE, "k/v row stride %lld: one (batch, head) slice must be < 4 GiB and rows must not overlap",
+    if (st[2] < p->head_dim || st[2] >= (1LL << 24))
+      return fail(FFPA_ERR_BAD_STRIDE, "k/v row stride %lld: rows must not overlap and must be < 2^24 elements apart",
                   (long long)st[2]);
   }
   if ((p->bias == nullptr) != (p->bias_dtype == FFPA_BIAS_NONE))

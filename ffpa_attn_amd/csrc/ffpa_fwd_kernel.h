@@ -215,22 +215,21 @@ __device__ __forceinline__ void lds_dma_16(u32x4 rsrc, uint32_t lds_addr, uint32
                : "memory");
 }
 
-// Row-uniform form (one LDS image row == whole pieces: D = 512, 1024).  Everything but the per-lane swizzled
-// column offset `voff` is scalar: destination = lds_base + LCONST (+ IMM), source row offset =
-// min(tile_off + row_off, last_off) — the clamp to the last valid key — and IMM advances source and
-// destination together for the second KiB of a 2 KiB row.  4 instructions, no VALU, no wait state to pad
-// (two SALU instructions sit between the M0 write and its use).
+// Row-uniform form (one LDS image row == whole pieces: D = 512).  Everything but the per-lane swizzled
+// column offset `voff` is scalar: destination = lds_base + LCONST (+ IMM), source row offset inside the tile =
+// min(row_off, last_off) — the clamp to the last valid key — and IMM advances source and destination together
+// for the second KiB of a 2 KiB row.  3 instructions, no VALU, no wait state to pad (the s_min sits between
+// the M0 write and its use).
 template <int LCONST, int IMM>
-__device__ __forceinline__ void lds_dma_row(u32x4 rsrc, uint32_t lds_base, uint32_t voff, uint32_t tile_off,
-                                            uint32_t row_off, uint32_t last_off) {
+__device__ __forceinline__ void lds_dma_row(u32x4 rsrc, uint32_t lds_base, uint32_t voff, uint32_t row_off,
+                                            uint32_t last_off) {
   uint32_t t;
   asm volatile(
-      "s_add_u32 m0, %1, %7\n\t"
-      "s_add_u32 %0, %4, %5\n\t"
-      "s_min_u32 %0, %0, %6\n\t"
-      "buffer_load_dwordx4 %2, %3, %0 offen offset:%8 lds"
+      "s_add_u32 m0, %1, %6\n\t"
+      "s_min_u32 %0, %4, %5\n\t"
+      "buffer_load_dwordx4 %2, %3, %0 offen offset:%7 lds"
       : "=&s"(t)
-      : "s"(lds_base), "v"(voff), "s"(rsrc), "s"(tile_off), "s"(row_off), "s"(last_off), "n"(LCONST), "n"(IMM)
+      : "s"(lds_base), "v"(voff), "s"(rsrc), "s"(row_off), "s"(last_off), "n"(LCONST), "n"(IMM)
       : "memory", "scc");
 }
 
@@ -258,13 +257,33 @@ __device__ __forceinline__ u32x4 make_rsrc(const void* base, uint32_t bytes) {
   return r;
 }
 
-// Piece i of this wave's share of one [BC][D] tile (keys key0 .. key0+BC-1, clamped to the last valid
-// key).  Each wave moves TILE/4 bytes as 1 KiB LDS-DMA pieces: lane l of piece p lands at
+// Source of one KV tile: a descriptor whose base is the tile's first row, so that every DMA offset is
+// tile-relative and 32-bit no matter how large the (batch, head) slice is (a token-major [B,N,H,D] cache
+// passes 4 GiB at 128k tokens); only BC rows must span < 4 GiB.  `rows` = valid rows from the base (>= 1):
+// a tile that starts at or past the end (the unused prefetch after the last tile) re-reads the last row.
+struct TileSrc {
+  u32x4 rsrc;
+  const char* base;
+  int rows;
+};
+template <int BC, int RB>
+__device__ __forceinline__ TileSrc tile_src(const void* slice, uint32_t row_bytes, int key0, int nkv) {
+  const int kc = key0 < nkv - 1 ? key0 : nkv - 1;
+  int rows = nkv - kc;
+  rows = rows < BC ? rows : BC;
+  TileSrc t;
+  t.base = (const char*)slice + (uint64_t)(uint32_t)kc * row_bytes;
+  t.rows = rows;
+  t.rsrc = make_rsrc(t.base, (uint32_t)(rows - 1) * row_bytes + (uint32_t)RB);
+  return t;
+}
+
+// Piece i of this wave's share of one [BC][D] tile (rows key0 .. key0+BC-1 from `base`, clamped to row
+// nkv-1; the kernel passes a tile-relative base: key0 = 0, nkv = valid rows).  Each wave moves TILE/4 bytes as 1 KiB LDS-DMA pieces: lane l of piece p lands at
 // lds_tile + p*1024 + l*16 (the hardware's lane-linear rule), so the swizzle goes on the per-lane SOURCE
-// offset.  `rsrc` describes the (batch, kv-head) slice; offsets inside it are 32-bit (the host rejects
-// slices of 4 GiB or more).  SAFE = the register-staged twin used by the tests.
+// offset.  SAFE = the register-staged twin used by the tests.
 template <typename T, int D, int BC, bool IS_V, bool SAFE>
-__device__ __forceinline__ void stage_piece(u32x4 rsrc, const T* __restrict__ base,
+__device__ __forceinline__ void stage_piece(u32x4 rsrc, const char* __restrict__ base,
                                             uint32_t row_bytes, int key0, int nkv,
                                             FFPA_LDS char* lds_tile, int wave, int lane, int i) {
   constexpr int SPR = D / 8;  // 16-byte slots per row
@@ -293,7 +312,7 @@ __device__ __forceinline__ void stage_piece(u32x4 rsrc, const T* __restrict__ ba
   if constexpr (!SAFE) {
     lds_dma_16(rsrc, (uint32_t)(uintptr_t)(lds_tile + p * 1024), voff, soff);
   } else {
-    const u32x4 x = *(const u32x4*)((const char*)base + (size_t)voff + (size_t)soff);
+    const u32x4 x = *(const u32x4*)(base + (size_t)voff + (size_t)soff);
     *(FFPA_LDS u32x4*)(lds_tile + p * 1024 + lane * 16) = x;
   }
 }
@@ -462,11 +481,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
 
   const T* __restrict__ Kg = (const T*)a.k + b * a.sk[0] + hkv * a.sk[1];
   const T* __restrict__ Vg = (const T*)a.v + b * a.sv[0] + hkv * a.sv[1];
-  // buffer descriptors over this (batch, kv-head) slice (0x00020000: raw 32-bit dwords)
   const uint32_t k_row_bytes = (uint32_t)a.sk[2] * 2u;
   const uint32_t v_row_bytes = (uint32_t)a.sv[2] * 2u;
-  const u32x4 k_rsrc = make_rsrc(Kg, (uint32_t)(a.Nkv - 1) * k_row_bytes + (uint32_t)RB);
-  const u32x4 v_rsrc = make_rsrc(Vg, (uint32_t)(a.Nkv - 1) * v_row_bytes + (uint32_t)RB);
 
   // ---- DMA issue helpers (piece i of this wave for the tile starting at key0)
   uint32_t krel[kHoist ? BC * D * 2 / 4096 : 1], vrel[kHoist ? BC * D * 2 / 4096 : 1];
@@ -483,7 +499,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   }
   uint32_t kvo[kRowDma ? 4 : 1], vvo[kRowDma ? 4 : 1];        // per-lane swizzled column offsets
   uint32_t kro[kRowDma ? KPW : 1], vro[kRowDma ? KPW : 1];    // scalar: row offset of staged key jk
-  uint32_t k_last = 0, v_last = 0, k_lds = 0, v_lds = 0;
+  uint32_t k_lds = 0, v_lds = 0;
   if constexpr (kRowDma) {
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) {
@@ -496,42 +512,43 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
       kro[jk] = key * k_row_bytes;
       vro[jk] = key * v_row_bytes;
     }
-    k_last = (uint32_t)(a.Nkv - 1) * k_row_bytes;
-    v_last = (uint32_t)(a.Nkv - 1) * v_row_bytes;
     k_lds = (uint32_t)(uintptr_t)Kt + (uint32_t)(4 * wave * RB);
     v_lds = (uint32_t)(uintptr_t)Vt + (uint32_t)(4 * wave * RB);
   }
+  // All three forms address the tile through tile_src(): offsets are relative to the tile's first row.
   auto issue_k = [&](auto ic, int key0, int dlane) {
     constexpr int i = decltype(ic)::value;
+    const TileSrc ts = tile_src<BC, RB>(Kg, k_row_bytes, key0, a.Nkv);
     if constexpr (kRowDma) {
       constexpr int jk = i / RPP, half = i % RPP;
-      lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(k_rsrc, k_lds, kvo[jk & 3], (uint32_t)key0 * k_row_bytes,
-                                                                 kro[jk], k_last);
+      lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(ts.rsrc, k_lds, kvo[jk & 3], kro[jk],
+                                                                 (uint32_t)(ts.rows - 1) * k_row_bytes);
       return;
     }
     if constexpr (kHoist) {
-      if (key0 + BC <= a.Nkv) {
-        lds_dma_16(k_rsrc, (uint32_t)(uintptr_t)(Kt + (wave * PPW + i) * 1024), krel[i], (uint32_t)key0 * k_row_bytes);
+      if (ts.rows == BC) {
+        lds_dma_16(ts.rsrc, (uint32_t)(uintptr_t)(Kt + (wave * PPW + i) * 1024), krel[i], 0u);
         return;
       }
     }
-    stage_piece<T, D, BC, false, SAFE>(k_rsrc, Kg, k_row_bytes, key0, a.Nkv, Kt, wave, dlane, i);
+    stage_piece<T, D, BC, false, SAFE>(ts.rsrc, ts.base, k_row_bytes, 0, ts.rows, Kt, wave, dlane, i);
   };
   auto issue_v = [&](auto ic, int key0, int dlane) {
     constexpr int i = decltype(ic)::value;
+    const TileSrc ts = tile_src<BC, RB>(Vg, v_row_bytes, key0, a.Nkv);
     if constexpr (kRowDma) {
       constexpr int jk = i / RPP, half = i % RPP;
-      lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(v_rsrc, v_lds, vvo[jk & 3], (uint32_t)key0 * v_row_bytes,
-                                                                 vro[jk], v_last);
+      lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(ts.rsrc, v_lds, vvo[jk & 3], vro[jk],
+                                                                 (uint32_t)(ts.rows - 1) * v_row_bytes);
       return;
     }
     if constexpr (kHoist) {
-      if (key0 + BC <= a.Nkv) {
-        lds_dma_16(v_rsrc, (uint32_t)(uintptr_t)(Vt + (wave * PPW + i) * 1024), vrel[i], (uint32_t)key0 * v_row_bytes);
+      if (ts.rows == BC) {
+        lds_dma_16(ts.rsrc, (uint32_t)(uintptr_t)(Vt + (wave * PPW + i) * 1024), vrel[i], 0u);
         return;
       }
     }
-    stage_piece<T, D, BC, true, SAFE>(v_rsrc, Vg, v_row_bytes, key0, a.Nkv, Vt, wave, dlane, i);
+    stage_piece<T, D, BC, true, SAFE>(ts.rsrc, ts.base, v_row_bytes, 0, ts.rows, Vt, wave, dlane, i);
   };
   auto issue_k_tile = [&](int key0) {
     const int dl = opaque_lane(lane);

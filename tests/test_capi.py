@@ -140,6 +140,7 @@ def _params(**over):
     ({"seqlen_kv": 0}, 4, b"non-positive"),
     ({"k_stride": [4 * 128 * 512, 128 * 512, 516]}, 5, b"multiple of 8"),
     ({"v_stride": [4 * 128 * 512, 128 * 512, 256]}, 5, b"rows must not overlap"),
+    ({"k_stride": [4 * 128 * 512, 128 * 512, 1 << 24]}, 5, b"2^24 elements"),
     ({"bias_dtype": 2}, 2, b"bias pointer and bias_dtype disagree"),
     ({"dropout_p": 1.0}, 4, b"dropout_p"),
     ({"dropout_p": 0.1, "causal_row_mod": 2}, 7, b"packed query heads"),

@@ -358,6 +358,32 @@ def test_baseline_config_5_unsharded_on_one_gpu(hip):
   torch.cuda.empty_cache()
 
 
+def test_kv_slices_larger_than_4_gib(hip):
+  """Token-major [B,N,H,D] K/V with H*D = 16384 and N = 140k: each head's slice spans 4.6 GB, past any 32-bit
+  offset from the slice base.  Tile-relative addressing must give exactly what dense per-head copies give."""
+  N, H, D = 140_000, 32, 512
+  g = torch.Generator(device="cuda").manual_seed(6)
+  kv = torch.randn(2, 1, N, H, D, device="cuda", dtype=torch.bfloat16, generator=g)   # 2 x 4.6 GB
+  k, v = (t.transpose(1, 2)[:, ::31] for t in kv)       # heads 0 and 31: [1,2,N,D] views, row stride 16384
+  assert (k.size(2) - 1) * k.stride(2) * 2 >= 1 << 32
+  q = torch.randn(1, 2, 256, D, device="cuda", dtype=torch.bfloat16, generator=g)
+  scale = D ** -0.5
+  o, lse = hip.forward(q, k, v, None, False, scale)
+  od, lsed = hip.forward(q, k.contiguous(), v.contiguous(), None, False, scale)
+  assert torch.equal(o, od) and torch.equal(lse, lsed)
+  oc, _ = hip.forward(q, k, v, None, True, scale, causal_offset=N - 256)                # tail tiles at the far end
+  ocd, _ = hip.forward(q, k.contiguous(), v.contiguous(), None, True, scale, causal_offset=N - 256)
+  assert torch.equal(oc, ocd)
+  q1 = q[:, :, :1]
+  o1, _ = hip.forward(q1, k, v, None, False, scale)                                     # split-KV decode path
+  o1d, _ = hip.forward(q1, k.contiguous(), v.contiguous(), None, False, scale)
+  assert torch.equal(o1, o1d)
+  ref = F.scaled_dot_product_attention(q, k.contiguous(), v.contiguous())
+  assert (o.float() - ref.float()).abs().max().item() <= NORTH_STAR_MAX_ABS
+  del kv, k, v
+  torch.cuda.empty_cache()
+
+
 def test_key_permutation_invariance_at_full_length(hip):
   q, k, v = _baseline_inputs(1, 2, 2, 1024, 8192, 512)
   o, lse = hip.forward(q, k, v, None, False, 512 ** -0.5)

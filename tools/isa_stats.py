@@ -1,0 +1,46 @@
+"""Per-kernel register / scratch statistics from the --save-temps assembly (python -m ffpa_attn_amd.build --save-temps).
+
+Usage: python tools/isa_stats.py [D ...]     (default: every head dim found)
+Prints, per kernel instantiation: VGPRs, AGPRs, SGPRs, scratch bytes, and how many scratch / v_readlane
+instructions sit inside the KV-tile loop (between the first and the last MFMA of the kernel).
+"""
+import glob, os, re, sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ffpa_attn_amd", "csrc", "build")
+
+
+def kernels(path):
+  name, body = None, []
+  for line in open(path):
+    m = re.match(r"^(_ZN4ffpa\w+):", line)
+    if m:
+      if name:
+        yield name, body
+      name, body = m.group(1), []
+    if name:
+      body.append(line)
+  if name:
+    yield name, body
+
+
+def main():
+  dims = sys.argv[1:] or sorted((os.path.basename(d)[7:] for d in glob.glob(os.path.join(ROOT, "temps_d*"))), key=int)
+  for d in dims:
+    path = glob.glob(os.path.join(ROOT, f"temps_d{d}", "*gfx950.s"))
+    if not path:
+      continue
+    for name, body in kernels(path[0]):
+      text = "".join(body)
+      get = lambda k: (re.search(rf"; {k}: (\d+)", text) or [None, "?"])[1]
+      mf = [i for i, l in enumerate(body) if "v_mfma" in l]
+      loop = body[mf[0]:mf[-1]] if mf else []
+      n_scr = sum("scratch_" in l for l in loop)
+      n_rl = sum("v_readlane" in l or "v_writelane" in l for l in loop)
+      short = re.sub(r"_ZN4ffpa23ffpa_fwd_split_d_kernelI(\w+?)EEvNS_7FwdArgsE", r"\1", name)
+      short = short.replace("DF16b", "bf16 ").replace("DF16_", "fp16 ").replace("Li", " ").replace("ELb", " b").replace("E", "")
+      print(f"D={d:>4} {short:<28} vgpr {get('NumVgprs'):>3} agpr {get('NumAgprs'):>3} sgpr {get('NumSgprs'):>3} "
+            f"scratch {get('ScratchSize'):>4} B | in MFMA span: scratch ops {n_scr}, lane spills {n_rl}, mfma {len(mf)}")
+
+
+if __name__ == "__main__":
+  main()
