@@ -10,6 +10,8 @@ register-staged twin, forced lazy-rescale inputs, strided views and size-indepen
 the BASELINE sizes.
 """
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -620,7 +622,11 @@ def _random_case(rng):
   return dict(B=int(rng.choice([1, 2])), Hq=Hkv * group, Hkv=Hkv, Nq=Nq, Nkv=Nkv, D=D, mode=str(mode), dtype=dtype, strided=strided)
 
 
-@pytest.mark.parametrize("seed", range(48))
+# FFPA_FUZZ_SEEDS=a:b widens the sweep for a one-off fuzz run (the default 48 cases keep the suite short)
+_FUZZ = os.environ.get("FFPA_FUZZ_SEEDS", "0:48").split(":")
+
+
+@pytest.mark.parametrize("seed", range(int(_FUZZ[0]), int(_FUZZ[1])))
 def test_randomized_against_oracle(hip, seed):
   rng = np.random.default_rng(1000 + seed)
   c = _random_case(rng)
