@@ -21,7 +21,7 @@ bench)
   timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench exit $?"; cat gpurun_out/bench.json ;;
 prof)
   rm -rf gpurun_out/prof
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof -o trace -- python $OLDPWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-sdpa) > gpurun_out/prof.log 2>&1
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof -o trace -- python $OLDPWD/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-sdpa) > gpurun_out/prof.log 2>&1
   echo "prof exit $?"; find gpurun_out/prof -name "*stats*" | head; ;;
 pmc)
   rm -rf gpurun_out/pmc
@@ -40,6 +40,9 @@ pmcsq)
 pmcfetch)
   (cd /tmp && timeout 90 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OLDPWD/gpurun_out/pmc -o pmc2 -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sdpa) > gpurun_out/pmc2.log 2>&1
   echo "pmcfetch exit $?" ;;
+pmcwrite)
+  (cd /tmp && timeout 90 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OLDPWD/gpurun_out/pmc -o pmc4 -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sdpa) > gpurun_out/pmc4w.log 2>&1
+  echo "pmcwrite exit $?" ;;
 dist1)
   timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-sdpa > gpurun_out/dist1.json 2> gpurun_out/dist1.err; echo "dist1 exit $?"; cat gpurun_out/dist1.json; tail -3 gpurun_out/dist1.err
   timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-sdpa --gather > gpurun_out/dist1g.json 2>> gpurun_out/dist1.err; echo "dist1 gather exit $?" ;;
