@@ -214,11 +214,17 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   a.tiles_per_split = pl.tiles_per_split;
   a.causal_row_mod = p->causal_row_mod;
   if (p->bias != nullptr && p->bias_stride[3] == 1) {
-    // 4-wide bias loads need naturally aligned groups of 4 keys: base and the batch/head/row strides
+    // vector bias loads (16 consecutive keys per lane): W elements per load need W-element aligned base and
+    // batch / head / row strides.  16-byte loads when possible (W = 8 for 16-bit, 4 for fp32), else 8-byte.
     const int esz = p->bias_dtype == FFPA_BIAS_FP32 ? 4 : 2;
-    bool ok = (reinterpret_cast<uintptr_t>(p->bias) % (4 * esz)) == 0;
-    for (int i = 0; i < 3; ++i) ok = ok && (p->bias_stride[i] % 4 == 0);
-    a.bias_vec = ok ? 1 : 0;
+    for (int w : {16 / esz, 4}) {
+      bool ok = (reinterpret_cast<uintptr_t>(p->bias) % (size_t)(w * esz)) == 0;
+      for (int i = 0; i < 3; ++i) ok = ok && (p->bias_stride[i] % w == 0);
+      if (ok) {
+        a.bias_vec = w;
+        break;
+      }
+    }
   }
   a.dropout_p = p->dropout_p;
   a.keep_scale = p->dropout_p > 0.f ? 1.f / (1.f - p->dropout_p) : 1.f;

@@ -131,7 +131,7 @@ struct FwdArgs {
   // rows of several query heads of one KV group packed into one row axis (host reshape): the causal
   // limit of packed row r is (r % causal_row_mod) + causal_offset; 0 = rows are plain query rows
   int causal_row_mod;
-  int bias_vec;  // 1: bias key stride is 1 and every (row, 4-key group) is naturally aligned -> 4-wide loads
+  int bias_vec;  // W in {0, 4, 8}: bias key stride is 1 and base / strides are W-element aligned -> W-wide loads
   // dropout (prefill.cuh:398-546): keep iff u > p, u from Philox4x32-10 at the logical element offset
   float dropout_p;          // 0 = off
   float keep_scale;         // 1 / (1 - p)
@@ -379,29 +379,30 @@ __device__ __forceinline__ void add_bias_block(float (&x)[16], const void* bias,
   const BT* bp = (const BT*)bias + row_off;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    int key = key_base + (r & 3) + 8 * (r >> 2);
+    int key = key_base + r;
     key = key < nkv ? key : nkv - 1;
     x[r] += (float)bp[key * stride_key] * 1.4426950408889634f;
   }
 }
 
+// Vector variant for unit key stride: the lane's 16 scores of a key block are 16 CONSECUTIVE keys (the key <->
+// MFMA-row map of the kernel is chosen for exactly that), read as 16 / W loads of W elements.
+template <typename BT, int W>
+__device__ __forceinline__ void add_bias_block_vec(float (&x)[16], const void* bias, int64_t row_off, int key_base) {
+  typedef __attribute__((ext_vector_type(W))) BT bvec;
+  const BT* bp = (const BT*)bias + row_off + key_base;
+  bvec raw[16 / W];
+#pragma unroll
+  for (int i = 0; i < 16 / W; ++i) raw[i] = *(const bvec*)(bp + W * i);
+#pragma unroll
+  for (int i = 0; i < 16 / W; ++i)
+#pragma unroll
+    for (int t = 0; t < W; ++t) x[W * i + t] += (float)raw[i][t] * 1.4426950408889634f;
+}
+
 // DROP selects the dropout-capable build of the kernel: kept out of the default instantiation because its
 // Philox temporaries push hipcc into spilling Q fragments inside the QK^T loop (and every reload drains the
 // DMA queue); dropout launches pay that, plain launches do not.
-// 4-wide variant for unit key stride: the lane's 16 scores are 4 groups of 4 consecutive keys.
-template <typename BT>
-__device__ __forceinline__ void add_bias_block_vec4(float (&x)[16], const void* bias, int64_t row_off, int key_base) {
-  typedef __attribute__((ext_vector_type(4))) BT bvec4;
-  const BT* bp = (const BT*)bias + row_off + key_base;
-  bvec4 raw[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) raw[i] = *(const bvec4*)(bp + 8 * i);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) x[4 * i + t] += (float)raw[i][t] * 1.4426950408889634f;
-}
-
 template <typename T, int D, int ND, bool SAFE, bool DROP = false>
 __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) {
   using E = Elem<T>;
@@ -588,20 +589,27 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   float m_run = -INFINITY;  // running row max, log2 domain (includes softmax_scale)
   float l_run = 0.f;        // this lane's share of the row sum (other share: lane ^ 32)
 
+  // ---- key <-> MFMA-row map.  Row a of S^T = K.Q^T (A operand lane a) is fed key pi(a) =
+  // 16 (a/4 % 2) + a%4 + 4 (a/8) of the 32-key block, so that the C layout — row (r&3) + 8 (r>>2) + 4 h in
+  // register r of lane half h — leaves each lane with the 16 CONTIGUOUS keys 16 h + r: masks, bias tiles and
+  // dropout counters are then plain runs of keys.  V^T below uses the same map (the key index is a contraction
+  // index of the second product, so any permutation is free as long as both agree).
   // ---- per-lane LDS addresses, hoisted so that the MFMA loops carry only immediates.
   // K fragment of step s = 8 q + i, key block kb:  kaddr[i] + 256 q + kb*32*RB
   //   (slot (c0 + 2 s + h) ^ kx: adding 16 q slots commutes with a 4-bit XOR)
   FFPA_LDS const char* kaddr[8];
   {
-    const int kx = k_slot_swizzle<D>(l31);
+    const int kpi = 16 * ((l31 >> 2) & 1) + (l31 & 3) + 4 * (l31 >> 3);
+    const int kx = k_slot_swizzle<D>(kpi);
     const int c0 = dh * (DW / 8);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) kaddr[i] = Kt + l31 * RB + (((c0 + 2 * i + h) ^ kx) << 4);
+    for (int i = 0; i < 8; ++i) kaddr[i] = Kt + kpi * RB + (((c0 + 2 * i + h) ^ kx) << 4);
   }
-  // V^T fragment of column block db = 4 q + i, step ks, half hh: vaddr[i] + 256 q + (16 ks + 8 hh)*RB
-  // (ds_read immediates are 16 bits: key steps whose row offset would overflow use a second base, +64 rows)
-  constexpr int kVHiKs = (65535 - 768 - 8 * RB) / (16 * RB) + 1;  // first key step that needs the high base
-  constexpr bool kVHi = NKS > kVHiKs;
+  // V^T fragment of column block db = 4 q + i, key step ks: contraction slot (h, e) <-> key
+  // 32 (ks/2) + 16 h + 8 (ks%2) + e; two transpose reads (e < 4, e >= 4) at
+  // vaddr[i] + 256 q + (32 (ks/2) + 8 (ks%2) + {0, 4}) * RB.  ds_read immediates are 16 bits: key steps whose
+  // row offset would overflow use a second base, +64 rows.
+  constexpr bool kVHi = NKS > 4 && (32 * ((NKS - 1) >> 1) + 12) * RB + 768 > 65535;
   FFPA_LDS const char* vaddr[kVHi ? 8 : 4];
   {
     const int j4 = (lane & 15) >> 2;
@@ -609,7 +617,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
     const int vcol = dh * DW * 2 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;  // bytes
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      vaddr[i] = Vt + (4 * h + j4) * RB + ((vcol + i * 64) ^ vsw);
+      vaddr[i] = Vt + (16 * h + j4) * RB + ((vcol + i * 64) ^ vsw);
       if constexpr (kVHi) vaddr[4 + i] = vaddr[i] + 64 * RB;
     }
   }
@@ -694,16 +702,16 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
       const int db = FFPA_PV_ORDER ? n % NDB : n / NKS, ks = FFPA_PV_ORDER ? n / NDB : n % NKS;
       if constexpr ((FFPA_ABL & 64) != 0) return qf[(db + ks) % KS];
       if constexpr (!SAFE) {
-        FFPA_LDS const char* vp = (kVHi && ks >= 4) ? vaddr[4 + (db & 3)] + (db >> 2) * 256 + ((ks - 4) * 16) * RB
-                                                     : vaddr[db & 3] + (db >> 2) * 256 + (ks * 16) * RB;
+        const int krow = (kVHi && ks >= 4) ? 32 * ((ks - 4) >> 1) + 8 * (ks & 1) : 32 * (ks >> 1) + 8 * (ks & 1);
+        FFPA_LDS const char* vp = ((kVHi && ks >= 4) ? vaddr[4 + (db & 3)] : vaddr[db & 3]) + (db >> 2) * 256 + krow * RB;
         const v4 lo = E::tr_read(vp);
-        const v4 hi = E::tr_read(vp + 8 * RB);
+        const v4 hi = E::tr_read(vp + 4 * RB);
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       } else {
         v8 r;
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
-          const int key = ks * 16 + 8 * (jj >> 2) + 4 * h + (jj & 3);
+          const int key = 32 * (ks >> 1) + 16 * h + 8 * (ks & 1) + jj;
           const int byte = (dh * DW + db * 32 + l31) * 2;
           const int off = byte ^ (v_slot_swizzle<D>(key) * 16);
           r[jj] = *(FFPA_LDS const T*)(Vt + key * RB + off);
@@ -717,7 +725,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
       __builtin_amdgcn_sched_barrier(0);
     }
 
-    // lane holds x[kb][r] = score(row qrow, key k0 + 32 kb + (r&3) + 8 (r>>2) + 4 h)
+    // lane holds x[kb][r] = score(row qrow, key k0 + 32 kb + 16 h + r)
     float x[NKB][16];
     if constexpr (ND == 2) {
       FFPA_LDS const char* xr = Xb + (wave ^ 1) * 4096 + lane * 16;
@@ -755,11 +763,16 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
       const int64_t brow = b * a.sbias[0] + hq * a.sbias[1] + (int64_t)qrow_c * a.sbias[2];
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
-        const int kbase = k0 + kb * 32 + 4 * h;
-        if (a.bias_vec && k0 + BC <= a.Nkv) {  // full tile, unit key stride, aligned rows
-          if (a.bias_dtype == 3) add_bias_block_vec4<float>(x[kb], a.bias, brow, kbase);
-          else if (a.bias_dtype == 2) add_bias_block_vec4<__bf16>(x[kb], a.bias, brow, kbase);
-          else add_bias_block_vec4<_Float16>(x[kb], a.bias, brow, kbase);
+        const int kbase = k0 + kb * 32 + 16 * h;
+        if (a.bias_vec && k0 + BC <= a.Nkv) {  // full tile, unit key stride, rows aligned to the vector width
+          if (a.bias_dtype == 3) add_bias_block_vec<float, 4>(x[kb], a.bias, brow, kbase);
+          else if (a.bias_vec == 8) {
+            if (a.bias_dtype == 2) add_bias_block_vec<__bf16, 8>(x[kb], a.bias, brow, kbase);
+            else add_bias_block_vec<_Float16, 8>(x[kb], a.bias, brow, kbase);
+          } else {
+            if (a.bias_dtype == 2) add_bias_block_vec<__bf16, 4>(x[kb], a.bias, brow, kbase);
+            else add_bias_block_vec<_Float16, 4>(x[kb], a.bias, brow, kbase);
+          }
           continue;
         }
         if (a.bias_dtype == 3) add_bias_block<float>(x[kb], a.bias, brow, a.sbias[3], kbase, a.Nkv);
@@ -776,7 +789,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
       for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int key = k0 + kb * 32 + 16 * h + r;
           if (key >= a.Nkv || key > lim) x[kb][r] = -INFINITY;
         }
     }
@@ -829,8 +842,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
       for (int r = 0; r < 16; ++r) {
         const float p = (FFPA_ABL & 8) ? x[kb][r] : (FFPA_ABL & 2) ? (x[kb][r] - m_use) : __builtin_amdgcn_exp2f(x[kb][r] - m_use);
         if constexpr (!(FFPA_ABL & 8)) psum += p;  // row sum from the unrounded P (prefill.cuh:755-756)
-        // contraction slot (h, r & 7) of step 2 kb + (r >> 3) <-> this register: any
-        // permutation of the key index is free as long as V^T uses the same one.
+        // contraction slot (h, r & 7) of key step 2 kb + (r >> 3) <-> this register (key 32 kb + 16 h + r)
         pf[kb * 2 + (r >> 3)][r & 7] = (T)p;
       }
     l_run += psum;
@@ -844,7 +856,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
         for (int i = 0; i < 4; ++i) {
           __builtin_amdgcn_sched_barrier(0);  // one Philox group at a time: bounded register pressure
           float keep[4];
-          dropout_keep4(a.philox_seed, erow + (unsigned long long)(k0 + kb * 32 + 8 * i + 4 * h), a.dropout_p, a.keep_scale, keep);
+          dropout_keep4(a.philox_seed, erow + (unsigned long long)(k0 + kb * 32 + 16 * h + 4 * i), a.dropout_p, a.keep_scale, keep);
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const int r = 4 * i + t;

@@ -2,9 +2,11 @@
 
 Re-derives, in plain Python, where the LDS-DMA puts every 16-byte slot of a K / V tile and which
 bytes each lane's ds_read_b128 / ds_read_b64_tr_b16 touches, and checks that
-  * K fragment (lane l, step s, key block kb) = K[kb*32 + l%32][dh*DW + 16 s + 8 (l/32) .. +8]
+  * K fragment (lane l, step s, key block kb) = K[kb*32 + pi(l%32)][dh*DW + 16 s + 8 (l/32) .. +8] with
+    pi(a) = 16 (a/4 % 2) + a%4 + 4 (a/8): MFMA row a of S^T = K.Q^T is fed key pi(a), so that the C layout
+    (row (r&3) + 8 (r>>2) + 4 (l/32) in register r) hands lane half h = l/32 the 16 CONTIGUOUS keys 16 h + r
   * V^T fragment (lane l, column block db, step ks, element jj) =
-        V[16 ks + 8 (jj/4) + 4 (l/32) + jj%4][dh*DW + 32 db + l%32]
+        V[32 (ks/2) + 16 (l/32) + 8 (ks%2) + jj][dh*DW + 32 db + l%32]   (the same key <-> slot map)
     under the transpose-read rule  result[lane i][e] = data of lane 4e + i/4, element i%4
     (cdna_hip_programming.md §2 "ds_read_b64_tr_b16")
 and reports the worst bank conflict per LDS instruction group (MI355X_MICROARCH.md §LDS).
@@ -21,9 +23,13 @@ def v_sw(D, key):
   return ((key & 3) << 2) if D % 128 == 0 else (((key >> 1) & 1) << 2)
 
 
-def check(D):
-  ND = 1 if D <= 512 else 2
-  DW, BC = D // ND, (64 if ND == 1 else 32)
+def pi(a):
+  return 16 * ((a >> 2) & 1) + (a & 3) + 4 * (a >> 3)
+
+
+def check(D, ND=None):
+  ND = ND or (1 if D <= 512 else 2)
+  DW, BC = D // ND, ((128 if D <= 320 else 64) if ND == 1 else 32)
   RB, SPR = D * 2, D // 8
   PIECES = BC * D * 2 // 1024
   PPW = PIECES // 4
@@ -64,14 +70,14 @@ def check(D):
         addrs = []
         for lane in range(64):
           l31, h = lane & 31, lane >> 5
-          kx = k_sw(D, l31)
+          kx = k_sw(D, pi(l31))
           c0 = dh * (DW // 8)
-          kaddr = l31 * RB + (((c0 + 2 * (s & 7) + h) ^ kx) << 4)
+          kaddr = pi(l31) * RB + (((c0 + 2 * (s & 7) + h) ^ kx) << 4)
           a = kaddr + (s >> 3) * 256 + kb * 32 * RB
           addrs.append(a)
           for e in range(8):
             key, sb = kimg[a + 2 * e]
-            assert key == kb * 32 + l31 and sb == (dh * DW + 16 * s + 8 * h + e) * 2, (D, lane, s, kb, e, key, sb)
+            assert key == kb * 32 + pi(l31) and sb == (dh * DW + 16 * s + 8 * h + e) * 2, (D, lane, s, kb, e, key, sb)
         # ds_read_b128: 4 groups of 16 lanes, bank = (a/4) % 64, 4 dwords each
         for grp in ([0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
                     [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]):
@@ -89,8 +95,8 @@ def check(D):
             h, j4 = lane >> 5, (lane & 15) >> 2
             vsw = v_sw(D, j4) * 16
             vcol = dh * DW * 2 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8
-            vaddr = (4 * h + j4) * RB + ((vcol + (db & 3) * 64) ^ vsw)
-            lane_addr.append(vaddr + (db >> 2) * 256 + (ks * 16 + 8 * hh) * RB)
+            vaddr = (16 * h + j4) * RB + ((vcol + (db & 3) * 64) ^ vsw)
+            lane_addr.append(vaddr + (db >> 2) * 256 + (32 * (ks >> 1) + 8 * (ks & 1) + 4 * hh) * RB)
           for lane in range(64):
             l31, h = lane & 31, lane >> 5
             i, base = lane & 15, lane & ~15
@@ -98,7 +104,7 @@ def check(D):
               src_lane = base + 4 * e + (i >> 2)
               key, sb = vimg[lane_addr[src_lane] + 2 * (i & 3)]
               jj = 4 * hh + e
-              want_key = ks * 16 + 8 * (jj >> 2) + 4 * h + (jj & 3)
+              want_key = 32 * (ks >> 1) + 16 * h + 8 * (ks & 1) + jj
               want_col = dh * DW + db * 32 + l31
               assert (key, sb) == (want_key, want_col * 2), (D, lane, db, ks, hh, e, key, sb, want_key, want_col)
           # ds_read_b64_tr_b16: 2 groups of 32 lanes, bank = (a/4) % 64, 2 dwords each
@@ -109,8 +115,15 @@ def check(D):
               banks.setdefault((a // 8) % 32, set()).add(a)
             worst_v = max(worst_v, max(len(v) for v in banks.values()))
   print(f"D={D:5d} ND={ND} BC={BC}: K/V fragment maps OK; worst bank conflict: ds_read_b128 {worst_k}-way, tr_b16 {worst_v}-way")
+  return worst_k, worst_v
+
+
+def variants(D):
+  """(D, ND) pairs the library instantiates: the prefill tiles and the short-query (split over 2 / 4 waves) tiles."""
+  return [(D, 1 if D <= 512 else 2), (D, 4 if D % 128 == 0 else 2)]
 
 
 if __name__ == "__main__":
   for D in ([int(x) for x in sys.argv[1:]] or [64, 128, 192, 256, 320, 384, 448, 512, 576, 640, 704, 768, 832, 896, 960, 1024]):
-    check(D)
+    for d, nd in dict.fromkeys(variants(D)):
+      check(d, nd)
