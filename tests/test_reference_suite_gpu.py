@@ -207,6 +207,30 @@ def test_decode_gqa(hip, route, dtype, Nq, D):
   _check(route, hip, *_qkv(2, 32, 8, Nq, 4096, D, dtype))
 
 
+# --------------------------------------------------------------------------- backward through the saved O / LSE (backward_backend="sdpa")
+def _grads(fn, q, k, v, go):
+  q, k, v = (t.detach().clone().requires_grad_() for t in (q, k, v))
+  return torch.autograd.grad(fn(q, k, v), [q, k, v], go)
+
+
+@BY_DTYPE
+@pytest.mark.parametrize("Hq,Hkv,N,D,causal", [(8, 8, 4096, 320, False), (8, 8, 4096, 512, False), (16, 16, 8192, 320, False),
+                                               (4, 4, 4096, 320, True), (4, 4, 8192, 512, True),
+                                               (32, 4, 8192, 320, False), (8, 1, 8192, 320, False), (32, 8, 4096, 512, True)])
+def test_backward_matches_sdpa_autograd(hip, dtype, Hq, Hkv, N, D, causal):
+  """dQ / dK / dV of ffpa_attn_func (HIP forward, PyTorch efficient-attention backward on its O and LSE) vs autograd
+  through SDPA on the same inputs — the reference's backward grids (tests/test_ffpa_bwd.py:896-903,935-941,1070-1072)."""
+  from ffpa_attn_amd import ffpa_attn_func
+  q, k, v = _qkv(1, Hq, Hkv, N, N, D, dtype)
+  go = torch.randn(q.shape, dtype=dtype, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+  gqa = Hq != Hkv
+  got = _grads(lambda a, b, c: ffpa_attn_func(a, b, c, is_causal=causal, enable_gqa=gqa), q, k, v, go)
+  want = _grads(lambda a, b, c: torch.nn.functional.scaled_dot_product_attention(a, b, c, is_causal=causal, enable_gqa=gqa), q, k, v, go)
+  for name, a, b in zip(("dq", "dk", "dv"), got, want):
+    assert a.dtype == dtype and a.shape == b.shape
+    torch.testing.assert_close(a, b, **_tol(dtype), msg=lambda m: f"{name}: {m}")
+
+
 # --------------------------------------------------------------------------- the api route really is the kernel where the rules say so
 def test_api_route_reaches_native_sdpa_only_where_the_reference_falls_back(hip, monkeypatch):
   from ffpa_attn_amd import ffpa_attn_func
