@@ -85,7 +85,7 @@ def cpu_baseline(seconds_budget: float = 20.0) -> dict:
     torch._C._nn.scaled_dot_product_attention(q, k, v)
     best = min(best, time.perf_counter() - t0)
     reps += 1
-  return {
+  out = {
     "value": round(flops / best / 1e12, 4),
     "unit": "TFLOPS",
     "cores": torch.get_num_threads(),
@@ -93,6 +93,20 @@ def cpu_baseline(seconds_budget: float = 20.0) -> dict:
     "sample": f"torch CPU SDPA (the reference's CPU path: ffpa_attn_func falls back to it) on B=1 H={H} N=8192 "
               f"D=512 bf16, best of {reps} after 1 warm-up, {best * 1e3:.1f} ms per pass",
   }
+  try:  # the oracle (scalar C restatement of the kernel's recurrence), for scale: one thread, 64 rows of one head
+    from oracle import ffpa_oracle as fo
+    rows = 64
+    qb, dname = fo.torch_to_bits(q[:, :1, :rows].contiguous())
+    kb, _ = fo.torch_to_bits(k[:, :1].contiguous())
+    vb, _ = fo.torch_to_bits(v[:, :1].contiguous())
+    t0 = time.perf_counter()
+    fo.oracle_forward(qb, kb, vb, dname, scale=512 ** -0.5)
+    dt = time.perf_counter() - t0
+    out["oracle_port"] = {"value": round(attention_fwd_flops(1, 1, rows, 8192, 512) / dt / 1e12, 6), "unit": "TFLOPS", "cores": 1,
+                          "kind": "port", "sample": f"oracle/ffpa_oracle.c on {rows} rows x 8192 keys of one head, D=512, {dt * 1e3:.0f} ms"}
+  except Exception as exc:  # the oracle is test infrastructure: its absence must not break the bench line
+    out["oracle_port"] = {"error": str(exc)[:120]}
+  return out
 
 
 def main() -> None:
