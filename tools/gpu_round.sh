@@ -56,6 +56,10 @@ clocks)
   rm -rf gpurun_out/clk
   (cd /tmp && timeout 240 rocprofv3 --kernel-trace --output-format csv --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OLDPWD/gpurun_out/clk -o clk -- python $OLDPWD/tools/gpu_ab.py $CLK_ARGS --rounds 2 --reps 3) > gpurun_out/clk.log 2>&1
   echo "clocks exit $?"; grep "^AB" gpurun_out/clk.log ;;
+pmcab)
+  rm -rf gpurun_out/pmcab
+  (cd /tmp && timeout 240 rocprofv3 --kernel-trace --output-format csv --pmc ${PMCAB_COUNTERS:-SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY} -d $OLDPWD/gpurun_out/pmcab -o ab -- python $OLDPWD/tools/gpu_ab.py $PMCAB_ARGS --rounds 2 --reps 3) > gpurun_out/pmcab.log 2>&1
+  echo "pmcab exit $?"; python tools/parse_pmc_ab.py gpurun_out/pmcab/ab_counter_collection.csv 3 $PMCAB_TAGS ;;
 biasperf)
   timeout 600 python tools/gpu_bias_bench.py > gpurun_out/bias.log 2>&1; echo "bias exit $?"; grep BIAS gpurun_out/bias.log; tail -2 gpurun_out/bias.log | grep -v BIAS ;;
 decode)

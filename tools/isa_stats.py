@@ -36,10 +36,24 @@ def main():
       loop = body[mf[0]:mf[-1]] if mf else []
       n_scr = sum("scratch_" in l for l in loop)
       n_rl = sum("v_readlane" in l or "v_writelane" in l for l in loop)
+      # inside the MFMA loops proper: clusters of MFMAs less than 60 lines apart
+      hot_rl = hot_scr = 0
+      if mf:
+        start = prev = mf[0]
+        spans = []
+        for i in mf[1:]:
+          if i - prev > 60:
+            spans.append((start, prev))
+            start = i
+          prev = i
+        spans.append((start, prev))
+        for a0, b0 in spans:
+          hot_rl += sum("v_readlane" in l or "v_writelane" in l for l in body[a0:b0])
+          hot_scr += sum("scratch_" in l for l in body[a0:b0])
       short = re.sub(r"_ZN4ffpa23ffpa_fwd_split_d_kernelI(\w+?)EEvNS_7FwdArgsE", r"\1", name)
       short = short.replace("DF16b", "bf16 ").replace("DF16_", "fp16 ").replace("Li", " ").replace("ELb", " b").replace("E", "")
       print(f"D={d:>4} {short:<28} vgpr {get('NumVgprs'):>3} agpr {get('NumAgprs'):>3} sgpr {get('NumSgprs'):>3} "
-            f"scratch {get('ScratchSize'):>4} B | in MFMA span: scratch ops {n_scr}, lane spills {n_rl}, mfma {len(mf)}")
+            f"scratch {get('ScratchSize'):>4} B | first..last MFMA: scratch ops {n_scr}, lane spills {n_rl} | inside MFMA loops: scratch {hot_scr}, lane spills {hot_rl} | mfma {len(mf)}")
 
 
 if __name__ == "__main__":
