@@ -86,6 +86,7 @@ namespace ffpa {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{}) — the
 // index is a constant expression inside the body (`if constexpr` on it, static register-array indices).
@@ -924,15 +925,30 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
         }
       if (h == 0 && dh == 0) a.ws_lse[prow] = dead ? -INFINITY : __logf(l_tot) + m_run * 0.6931471805599453f;
     } else {
-      T* op = (T*)a.o + b * a.so[0] + hq * a.so[1] + (int64_t)qrow * a.so[2] + dh * DW + 4 * h;
+      // The lane owns 4-element groups d = 32 db + 8 i + 4 h + (0..3); its partner lane ^ 32 owns the other half
+      // of each 8-element run.  The two trade groups (v_permlane32_swap: this lane's odd group for the partner's
+      // even one) so that each stores whole 16-byte runs: the epilogue is store-issue bound, and this halves the
+      // number of store instructions.
+      T* op = (T*)a.o + b * a.so[0] + hq * a.so[1] + (int64_t)qrow * a.so[2] + dh * DW + 8 * h;
 #pragma unroll
       for (int db = 0; db < NDB; ++db)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          v4 w;
+        for (int pr = 0; pr < 2; ++pr) {
+          v4 even, odd;  // groups i = 2 pr and i = 2 pr + 1
 #pragma unroll
-          for (int t = 0; t < 4; ++t) w[t] = (T)(oacc[db][4 * i + t] * inv);
-          *(v4*)(op + db * 32 + 8 * i) = w;
+          for (int t = 0; t < 4; ++t) {
+            even[t] = (T)(oacc[db][8 * pr + t] * inv);
+            odd[t] = (T)(oacc[db][8 * pr + 4 + t] * inv);
+          }
+          const u32x2 e2 = __builtin_bit_cast(u32x2, even), o2 = __builtin_bit_cast(u32x2, odd);
+          u32x4 run;  // h = 0: [own even | partner's even]   h = 1: [partner's odd | own odd]
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(e2[w], o2[w], false, false);
+            run[w] = sw[0];
+            run[2 + w] = sw[1];
+          }
+          *(u32x4*)(op + db * 32 + pr * 16) = run;
         }
       if (a.lse != nullptr && h == 0 && dh == 0) {
         // natural-log LSE = ln(l) + m*ln2 (prefill.cuh:1063-1073)
