@@ -217,20 +217,17 @@ __device__ __forceinline__ void lds_dma_16(u32x4 rsrc, uint32_t lds_addr, uint32
 }
 
 // Row-uniform form (one LDS image row == whole pieces: D = 512).  Everything but the per-lane swizzled
-// column offset `voff` is scalar: destination = lds_base + LCONST (+ IMM), source row offset inside the tile =
-// min(row_off, last_off) — the clamp to the last valid key — and IMM advances source and destination together
-// for the second KiB of a 2 KiB row.  3 instructions, no VALU, no wait state to pad (the s_min sits between
-// the M0 write and its use).
+// column offset `voff` is scalar: destination = lds_base + LCONST (+ IMM), source row offset `row_off` inside
+// the tile, and IMM advances source and destination together for the second KiB of a 2 KiB row.  No VALU;
+// rows past the tile's last key are zero-filled by the descriptor's range check.
 template <int LCONST, int IMM>
-__device__ __forceinline__ void lds_dma_row(u32x4 rsrc, uint32_t lds_base, uint32_t voff, uint32_t row_off,
-                                            uint32_t last_off) {
-  uint32_t t;
+__device__ __forceinline__ void lds_dma_row(u32x4 rsrc, uint32_t lds_base, uint32_t voff, uint32_t row_off) {
   asm volatile(
-      "s_add_u32 m0, %1, %6\n\t"
-      "s_min_u32 %0, %4, %5\n\t"
-      "buffer_load_dwordx4 %2, %3, %0 offen offset:%7 lds"
-      : "=&s"(t)
-      : "s"(lds_base), "v"(voff), "s"(rsrc), "s"(row_off), "s"(last_off), "n"(LCONST), "n"(IMM)
+      "s_add_u32 m0, %0, %4\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %1, %2, %3 offen offset:%5 lds"
+      :
+      : "s"(lds_base), "v"(voff), "s"(rsrc), "s"(row_off), "n"(LCONST), "n"(IMM)
       : "memory", "scc");
 }
 
@@ -260,8 +257,11 @@ __device__ __forceinline__ u32x4 make_rsrc(const void* base, uint32_t bytes) {
 
 // Source of one KV tile: a descriptor whose base is the tile's first row, so that every DMA offset is
 // tile-relative and 32-bit no matter how large the (batch, head) slice is (a token-major [B,N,H,D] cache
-// passes 4 GiB at 128k tokens); only BC rows must span < 4 GiB.  `rows` = valid rows from the base (>= 1):
-// a tile that starts at or past the end (the unused prefetch after the last tile) re-reads the last row.
+// passes 4 GiB at 128k tokens); only BC rows must span < 4 GiB.  num_records covers exactly the `rows` valid
+// rows: gfx950 range-checks voffset + soffset against it and an out-of-range LDS-DMA lane writes ZEROS to LDS
+// (tools/probes/lds_dma_oob.hip), i.e. rows past the last key are zero-filled like the reference's cp.async
+// staging (prefill.cuh:123-137) — no clamping, no tail branch.  A tile that starts at or past the end (the
+// unused prefetch after the last tile) has rows = 0: all zeros, no memory traffic.
 struct TileSrc {
   u32x4 rsrc;
   const char* base;
@@ -269,51 +269,50 @@ struct TileSrc {
 };
 template <int BC, int RB>
 __device__ __forceinline__ TileSrc tile_src(const void* slice, uint32_t row_bytes, int key0, int nkv) {
-  const int kc = key0 < nkv - 1 ? key0 : nkv - 1;
+  // min / max only: a select here is lowered to VALU by hipcc and the descriptor then lands in VGPRs
+  const int kc = key0 < nkv ? key0 : nkv;
   int rows = nkv - kc;
-  rows = rows < BC ? rows : BC;
+  rows = rows < BC ? rows : BC;  // 0 when the tile starts at or past the end
+  const uint32_t span = (uint32_t)(rows < 1 ? rows : 1) * ((uint32_t)(rows - 1) * row_bytes + (uint32_t)RB);
   TileSrc t;
   t.base = (const char*)slice + (uint64_t)(uint32_t)kc * row_bytes;
   t.rows = rows;
-  t.rsrc = make_rsrc(t.base, (uint32_t)(rows - 1) * row_bytes + (uint32_t)RB);
+  t.rsrc = make_rsrc(t.base, span);
   return t;
 }
 
-// Piece i of this wave's share of one [BC][D] tile (rows key0 .. key0+BC-1 from `base`, clamped to row
-// nkv-1; the kernel passes a tile-relative base: key0 = 0, nkv = valid rows).  Each wave moves TILE/4 bytes as 1 KiB LDS-DMA pieces: lane l of piece p lands at
+// Piece i of this wave's share of one [BC][D] tile whose first row is `base` and which has `rows` valid rows
+// (the rest reads as zeros).  Each wave moves TILE/4 bytes as 1 KiB LDS-DMA pieces: lane l of piece p lands at
 // lds_tile + p*1024 + l*16 (the hardware's lane-linear rule), so the swizzle goes on the per-lane SOURCE
 // offset.  SAFE = the register-staged twin used by the tests.
 template <typename T, int D, int BC, bool IS_V, bool SAFE>
-__device__ __forceinline__ void stage_piece(u32x4 rsrc, const char* __restrict__ base,
-                                            uint32_t row_bytes, int key0, int nkv,
+__device__ __forceinline__ void stage_piece(u32x4 rsrc, const char* __restrict__ base, uint32_t row_bytes, int rows,
                                             FFPA_LDS char* lds_tile, int wave, int lane, int i) {
   constexpr int SPR = D / 8;  // 16-byte slots per row
   constexpr int PPW = BC * D * 2 / 4096;
   const int p = wave * PPW + i;
   uint32_t voff, soff;
+  int key;
   if constexpr ((D * 2) % 1024 == 0) {
     // a row is a whole number of pieces: the row (and its swizzle) is wave-uniform
     constexpr int RPP = D * 2 / 1024;
-    const int key = p / RPP;
-    int krow = key0 + key;
-    krow = krow < nkv ? krow : nkv - 1;
+    key = p / RPP;
     const int sw = IS_V ? v_slot_swizzle<D>(key) : k_slot_swizzle<D>(key);
     voff = (uint32_t)((lane ^ sw) << 4);
-    soff = (uint32_t)krow * row_bytes + (uint32_t)(p % RPP) * 1024u;
+    soff = (uint32_t)key * row_bytes + (uint32_t)(p % RPP) * 1024u;
   } else {
     const int g = p * 64 + lane;
-    const int key = g / SPR;
+    key = g / SPR;
     const int slot = g - key * SPR;
     const int src_slot = slot ^ (IS_V ? v_slot_swizzle<D>(key) : k_slot_swizzle<D>(key));
-    int krow = key0 + key;
-    krow = krow < nkv ? krow : nkv - 1;
-    voff = (uint32_t)krow * row_bytes + (uint32_t)(src_slot << 4);
+    voff = (uint32_t)key * row_bytes + (uint32_t)(src_slot << 4);
     soff = 0;
   }
   if constexpr (!SAFE) {
     lds_dma_16(rsrc, (uint32_t)(uintptr_t)(lds_tile + p * 1024), voff, soff);
   } else {
-    const u32x4 x = *(const u32x4*)(base + (size_t)voff + (size_t)soff);
+    u32x4 x = {0u, 0u, 0u, 0u};
+    if (key < rows) x = *(const u32x4*)(base + (size_t)voff + (size_t)soff);
     *(FFPA_LDS u32x4*)(lds_tile + p * 1024 + lane * 16) = x;
   }
 }
@@ -430,8 +429,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   constexpr int kStep = (ND == 1) ? FFPA_DMA_STEP : 1;  // MFMAs between two DMA pieces
   static_assert(!kInterleave || PPW * kStep <= (DW / 16) * (BC / 32), "DMA pieces must fit the QK loop");
   // Head dims whose rows are not a whole number of 1 KiB pieces need ~12 VALU instructions per piece for the
-  // per-lane source offset (constant division, swizzle, clamp).  The offsets are tile-invariant: where the
-  // register budget allows they are hoisted into PPW + PPW VGPRs and only the tail tile recomputes them.
+  // per-lane source offset (constant division, swizzle).  The offsets are tile-invariant: where the register
+  // budget allows they are hoisted into PPW + PPW VGPRs.
   constexpr bool kRowUniform = (D * 2) % 1024 == 0;
   constexpr bool kHoist = FFPA_HOIST != 0 && !kRowUniform && !SAFE && !DROP && ND == 1 && D <= 384;  // measured: +4 % at D = 320, -5 % on the ND = 2 burst path
   // Row-uniform head dims: wave w stages keys 16 a + 4 w + b (a < BC/16, b < 4) so that only four K and
@@ -517,40 +516,31 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
     k_lds = (uint32_t)(uintptr_t)Kt + (uint32_t)(4 * wave * RB);
     v_lds = (uint32_t)(uintptr_t)Vt + (uint32_t)(4 * wave * RB);
   }
-  // All three forms address the tile through tile_src(): offsets are relative to the tile's first row.
+  // All three forms address the tile through tile_src(): offsets are relative to the tile's first row and the
+  // descriptor zero-fills rows past the last key.
   auto issue_k = [&](auto ic, int key0, int dlane) {
     constexpr int i = decltype(ic)::value;
     const TileSrc ts = tile_src<BC, RB>(Kg, k_row_bytes, key0, a.Nkv);
     if constexpr (kRowDma) {
       constexpr int jk = i / RPP, half = i % RPP;
-      lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(ts.rsrc, k_lds, kvo[jk & 3], kro[jk],
-                                                                 (uint32_t)(ts.rows - 1) * k_row_bytes);
-      return;
+      lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(ts.rsrc, k_lds, kvo[jk & 3], kro[jk]);
+    } else if constexpr (kHoist) {
+      lds_dma_16(ts.rsrc, (uint32_t)(uintptr_t)(Kt + (wave * PPW + i) * 1024), krel[i], 0u);
+    } else {
+      stage_piece<T, D, BC, false, SAFE>(ts.rsrc, ts.base, k_row_bytes, ts.rows, Kt, wave, dlane, i);
     }
-    if constexpr (kHoist) {
-      if (ts.rows == BC) {
-        lds_dma_16(ts.rsrc, (uint32_t)(uintptr_t)(Kt + (wave * PPW + i) * 1024), krel[i], 0u);
-        return;
-      }
-    }
-    stage_piece<T, D, BC, false, SAFE>(ts.rsrc, ts.base, k_row_bytes, 0, ts.rows, Kt, wave, dlane, i);
   };
   auto issue_v = [&](auto ic, int key0, int dlane) {
     constexpr int i = decltype(ic)::value;
     const TileSrc ts = tile_src<BC, RB>(Vg, v_row_bytes, key0, a.Nkv);
     if constexpr (kRowDma) {
       constexpr int jk = i / RPP, half = i % RPP;
-      lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(ts.rsrc, v_lds, vvo[jk & 3], vro[jk],
-                                                                 (uint32_t)(ts.rows - 1) * v_row_bytes);
-      return;
+      lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(ts.rsrc, v_lds, vvo[jk & 3], vro[jk]);
+    } else if constexpr (kHoist) {
+      lds_dma_16(ts.rsrc, (uint32_t)(uintptr_t)(Vt + (wave * PPW + i) * 1024), vrel[i], 0u);
+    } else {
+      stage_piece<T, D, BC, true, SAFE>(ts.rsrc, ts.base, v_row_bytes, ts.rows, Vt, wave, dlane, i);
     }
-    if constexpr (kHoist) {
-      if (ts.rows == BC) {
-        lds_dma_16(ts.rsrc, (uint32_t)(uintptr_t)(Vt + (wave * PPW + i) * 1024), vrel[i], 0u);
-        return;
-      }
-    }
-    stage_piece<T, D, BC, true, SAFE>(ts.rsrc, ts.base, v_row_bytes, 0, ts.rows, Vt, wave, dlane, i);
   };
   auto issue_k_tile = [&](int key0) {
     const int dl = opaque_lane(lane);
@@ -886,8 +876,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
         if constexpr (n + PF2 < N2) vf[n + PF2] = v_frag(n + PF2);
         if constexpr (kInterleave && !(FFPA_ABL & 1) && n % kStep == 0 && n / kStep + kPre < PPW) {
           // K(j+1) streams in under this tile's PV (the K buffer is free since barrier A).  After the
-          // last tile this prefetches a clamped, unused tile: cheaper than a branch per piece, and
-          // barrier B still drains it before the workgroup can exit.
+          // last tile that is an empty tile (every lane out of range: zeros, no memory traffic): cheaper
+          // than a branch per piece, and barrier B still drains it before the workgroup can exit.
           issue_k(std::integral_constant<int, n / kStep + kPre>{}, k0 + BC, dlane);
         }
         constexpr int db = FFPA_PV_ORDER ? n % NDB : n / NKS, ks = FFPA_PV_ORDER ? n / NDB : n % NKS;
