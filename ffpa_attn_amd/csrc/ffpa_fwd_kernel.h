@@ -54,6 +54,12 @@
 #ifndef FFPA_QK_ORDER
 #define FFPA_QK_ORDER 0  // QK MFMA order: 0 = d-step outer (alternate the two S accumulators), 1 = key-block outer
 #endif
+#ifndef FFPA_HOIST_MAX_D
+#define FFPA_HOIST_MAX_D 448      // ND == 1: hoist the per-lane DMA source offsets up to this head dim
+#endif
+#ifndef FFPA_HOIST_ND2_MAX_D
+#define FFPA_HOIST_ND2_MAX_D 896  // ND == 2 (split-D, burst DMA): up to this head dim (D = 960 spills: -16 %)
+#endif
 #ifndef FFPA_ROW_DMA
 #define FFPA_ROW_DMA 1  // D = 512: wave-uniform rows, 4 scalar instructions per DMA piece (+0.9 %)
 #endif
@@ -432,7 +438,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   // per-lane source offset (constant division, swizzle).  The offsets are tile-invariant: where the register
   // budget allows they are hoisted into PPW + PPW VGPRs.
   constexpr bool kRowUniform = (D * 2) % 1024 == 0;
-  constexpr bool kHoist = FFPA_HOIST != 0 && !kRowUniform && !SAFE && !DROP && ND == 1 && D <= 384;  // measured: +4 % at D = 320, -5 % on the ND = 2 burst path
+  constexpr bool kHoist = FFPA_HOIST != 0 && !kRowUniform && !SAFE && !DROP && (ND == 1 ? D <= FFPA_HOIST_MAX_D : (ND == 2 && D <= FFPA_HOIST_ND2_MAX_D));
   // Row-uniform head dims: wave w stages keys 16 a + 4 w + b (a < BC/16, b < 4) so that only four K and
   // four V swizzled lane offsets exist (K: slot ^ (4 w + b); V: slot ^ 4 b) and live in 8 VGPRs.
   constexpr bool kRowDma = FFPA_ROW_DMA != 0 && kRowUniform && !SAFE && kInterleave;  // bursts (D = 1024): measured 1.3 % slower
