@@ -77,15 +77,19 @@
 #endif
 #ifndef FFPA_ABL
 // developer ablations (WRONG RESULTS; tools/gpu_ab.py): 1 no in-loop DMA, 2 no exp, 4 no barriers, 8 no softmax,
-// 16 no DMA drain, 32 no s_nop in the S MFMA, 64 no LDS fragment reads, 128 no MFMA, 256 no QK MFMA, 512 no PV MFMA
+// 16 no DMA drain, 32 s_nop 1 in front of every S MFMA, 64 no LDS fragment reads, 128 no MFMA, 256 no QK MFMA, 512 no PV MFMA
 #define FFPA_ABL 0
 #endif
 
-#if (FFPA_ABL & 32)
-#define FFPA_MFMA_PAD ""
-#else
-#define FFPA_MFMA_PAD "s_nop 1\n\t"  // VALU-write -> MFMA-operand wait states (invisible to hipcc inside asm)
-#endif
+// The S^T MFMAs are inline asm, so hipcc's hazard recognizer does not see their operands (a VALU write needs 2
+// wait states before an MFMA reads the register).  In the product kernels their A operand comes from ds_read
+// (ordered by lgkmcnt), B (the Q fragments) is written once per workgroup by global loads, and C is the previous
+// MFMA of the chain: no VALU write precedes any of them, so nothing is padded in (a `s_nop 1` per MFMA cost 1.4 %
+// at D = 512, 2.7 % at D = 320).  tools/check_mfma_hazards.py proves the "no VALU write within the last two
+// instructions" property on the generated ISA of every instantiation.  The register-staged SAFE twins (tests
+// only) do get the pad: there hipcc parks Q fragments in spare AGPRs and restores them right before the MFMA.
+// FFPA_ABL bit 32 pads every kernel.
+#define FFPA_MFMA_PAD "s_nop 1\n\t"
 
 namespace ffpa {
 
@@ -159,11 +163,15 @@ struct Elem<__bf16> {
   // VGPR-form MFMA for the S^T accumulator (hipcc selects the AGPR form for every builtin
   // MFMA of a kernel, and the 256 AGPRs are exactly the O^T accumulator).  "s_nop 1" covers
   // the VALU-write -> MFMA-operand wait states the compiler cannot see inside asm.
+  template <bool PAD>
   static __device__ __forceinline__ void mfma_v_first(f32x16& d, v8 a, v8 b) {
-    asm volatile(FFPA_MFMA_PAD "v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+    if constexpr (PAD) asm volatile(FFPA_MFMA_PAD "v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
   }
+  template <bool PAD>
   static __device__ __forceinline__ void mfma_v_acc(f32x16& d, v8 a, v8 b) {
-    asm volatile(FFPA_MFMA_PAD "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+    if constexpr (PAD) asm volatile(FFPA_MFMA_PAD "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
   }
   static __device__ __forceinline__ v4 tr_read(FFPA_LDS const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((FFPA_LDS v4*)p);
@@ -177,11 +185,15 @@ struct Elem<_Float16> {
   static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
+  template <bool PAD>
   static __device__ __forceinline__ void mfma_v_first(f32x16& d, v8 a, v8 b) {
-    asm volatile(FFPA_MFMA_PAD "v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+    if constexpr (PAD) asm volatile(FFPA_MFMA_PAD "v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
   }
+  template <bool PAD>
   static __device__ __forceinline__ void mfma_v_acc(f32x16& d, v8 a, v8 b) {
-    asm volatile(FFPA_MFMA_PAD "v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+    if constexpr (PAD) asm volatile(FFPA_MFMA_PAD "v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
   }
   static __device__ __forceinline__ v4 tr_read(FFPA_LDS const char* p) {
     typedef __attribute__((ext_vector_type(4))) short s4;
@@ -437,6 +449,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   // Head dims whose rows are not a whole number of 1 KiB pieces need ~12 VALU instructions per piece for the
   // per-lane source offset (constant division, swizzle).  The offsets are tile-invariant: where the register
   // budget allows they are hoisted into PPW + PPW VGPRs.
+  constexpr bool kPad = SAFE || (FFPA_ABL & 32) != 0;  // s_nop 1 in front of the asm MFMAs (see FFPA_MFMA_PAD)
   constexpr bool kRowUniform = (D * 2) % 1024 == 0;
   constexpr bool kHoist = FFPA_HOIST != 0 && !kRowUniform && !SAFE && !DROP && (ND == 1 ? D <= FFPA_HOIST_MAX_D : (ND == 2 && D <= FFPA_HOIST_ND2_MAX_D));
   // Row-uniform head dims: wave w stages keys 16 a + 4 w + b (a < BC/16, b < 4) so that only four K and
@@ -655,8 +668,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
         }
         constexpr int s = FFPA_QK_ORDER ? n % KS : n / NKB, kb = FFPA_QK_ORDER ? n / KS : n % NKB;
         if constexpr ((FFPA_ABL & (128 | 256)) != 0) { if constexpr (s == 0) sacc[kb] = (f32x16)(0.f); }
-        else if constexpr (s == 0) E::mfma_v_first(sacc[kb], kf[n], qf[s]);
-        else E::mfma_v_acc(sacc[kb], kf[n], qf[s]);
+        else if constexpr (s == 0) E::template mfma_v_first<kPad>(sacc[kb], kf[n], qf[s]);
+        else E::template mfma_v_acc<kPad>(sacc[kb], kf[n], qf[s]);
       });
       // MFMA result -> VALU reader wait states (invisible to the compiler inside asm)
       if constexpr (NKB == 2) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sacc[0]), "+v"(sacc[1]));

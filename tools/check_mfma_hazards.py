@@ -1,0 +1,66 @@
+"""Static check of the inline-asm MFMAs in the generated ISA (python -m ffpa_attn_amd.build --save-temps).
+
+The S^T MFMAs are emitted through inline asm, invisible to hipcc's hazard recognizer.  The kernel relies on
+"no VALU instruction writes an operand register of an asm MFMA within the few instructions before it".  This
+script parses every asm MFMA of every kernel instantiation and looks back over the preceding WINDOW
+instructions (s_waitcnt / s_nop count as instructions, they only help) for a VALU (v_*) instruction whose
+destination overlaps the MFMA's A, B or C source registers.  Exit status 1 if any is found.
+
+Usage: python tools/check_mfma_hazards.py [D ...]
+"""
+import glob, os, re, sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ffpa_attn_amd", "csrc", "build")
+WINDOW = 2  # the hazard needs 2 wait states; every instruction in between provides at least one
+REG = re.compile(r"v\[(\d+):(\d+)\]|v(\d+)")
+
+
+def regs(tok):
+  m = REG.fullmatch(tok.strip())
+  if not m:
+    return None
+  if m.group(3) is not None:
+    return (int(m.group(3)), int(m.group(3)))
+  return (int(m.group(1)), int(m.group(2)))
+
+
+def overlap(a, b):
+  return a and b and a[0] <= b[1] and b[0] <= a[1]
+
+
+def main():
+  dims = sys.argv[1:] or sorted((os.path.basename(d)[7:] for d in glob.glob(os.path.join(ROOT, "temps_d*"))), key=int)
+  bad = total = 0
+  for d in dims:
+    for path in glob.glob(os.path.join(ROOT, f"temps_d{d}", "*gfx950.s")):
+      lines = open(path).read().split("\n")
+      in_asm = False
+      for i, l in enumerate(lines):
+        t = l.strip()
+        if t.startswith(";;#ASMSTART"):
+          in_asm = True
+        elif t.startswith(";;#ASMEND"):
+          in_asm = False
+        if not (in_asm and t.startswith("v_mfma")):
+          continue
+        total += 1
+        ops = [x.strip() for x in t.split(None, 1)[1].split(",")]
+        srcs = [regs(x) for x in ops[1:4]]
+        seen, j = 0, i - 1
+        while j >= 0 and seen < WINDOW:
+          p = lines[j].strip()
+          j -= 1
+          if not p or p.startswith((";", ".", "//")) or p.endswith(":"):
+            continue
+          seen += 1
+          if p.startswith("v_") and not p.startswith("v_mfma"):
+            dst = regs(p.split(None, 1)[1].split(",")[0]) if len(p.split(None, 1)) > 1 else None
+            if any(overlap(dst, s) for s in srcs):
+              bad += 1
+              print(f"HAZARD D={d} line {i + 1}: `{p}` writes an operand of `{t}`")
+  print(f"{total} asm MFMAs checked over D = {', '.join(dims)}: {bad} preceded by a VALU write to an operand")
+  return 1 if bad else 0
+
+
+if __name__ == "__main__":
+  sys.exit(main())
