@@ -82,6 +82,7 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
     int64_t want = (2LL * device_cu_count() + base - 1) / base;
     const int64_t cap = pl.nt / 4 > 0 ? pl.nt / 4 : 1;
     if (want > cap) want = cap;
+    if (want > ffpa::kMergeMaxSplits) want = ffpa::kMergeMaxSplits;  // the merge kernel keeps the split weights in LDS
     if (p->num_splits > 1 && want > p->num_splits) want = p->num_splits;
     if (want < 1) want = 1;
     const size_t per_split = (size_t)p->batch * p->heads_q * p->seqlen_q * ((size_t)p->head_dim + 1) * sizeof(float);
@@ -239,9 +240,9 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   if (st == 0 && pl.splits > 1) {
     const unsigned rows = (unsigned)((int64_t)p->batch * p->heads_q * p->seqlen_q);
     if (p->dtype == FFPA_DTYPE_BF16)
-      hipLaunchKernelGGL(ffpa::ffpa_fwd_merge_kernel<__bf16>, dim3(rows), dim3(64), 0, static_cast<hipStream_t>(stream), a, p->head_dim);
+      hipLaunchKernelGGL(ffpa::ffpa_fwd_merge_kernel<__bf16>, dim3(rows, (unsigned)(p->head_dim + 255) / 256), dim3(64), 0, static_cast<hipStream_t>(stream), a, p->head_dim);
     else
-      hipLaunchKernelGGL(ffpa::ffpa_fwd_merge_kernel<_Float16>, dim3(rows), dim3(64), 0, static_cast<hipStream_t>(stream), a, p->head_dim);
+      hipLaunchKernelGGL(ffpa::ffpa_fwd_merge_kernel<_Float16>, dim3(rows, (unsigned)(p->head_dim + 255) / 256), dim3(64), 0, static_cast<hipStream_t>(stream), a, p->head_dim);
     st = (int)hipGetLastError();
   }
   if (st == -3) return fail(FFPA_ERR_UNSUPPORTED, "debug safe-path kernel is not built for D=%d / this dtype", p->head_dim);

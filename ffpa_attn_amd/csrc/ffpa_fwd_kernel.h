@@ -969,35 +969,65 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
 
 // Merge the split-KV partials of one launch (the reference's decode stage 2,
 // csrc/cuffpa/native/sm_80/split_kv.cuh:329-455): O = sum_s w_s O_s / sum_s w_s with
-// w_s = exp(LSE_s - max_s LSE_s), LSE = max + ln(sum_s w_s).  One workgroup of 64 lanes per row.
+// w_s = exp(LSE_s - max_s LSE_s), LSE = max + ln(sum_s w_s).  One 64-lane workgroup per (row, 256-column chunk):
+// the lanes first share out the splits (max, weights -> LDS, sum: wave reductions), then each accumulates its 4
+// columns over the splits with the loads of 8 splits in flight at a time.  (The first version walked the splits
+// serially per lane and recomputed the weights per chunk: 60 us for a 64-split launch, 2.6x the main kernel.)
+constexpr int kMergeMaxSplits = 1024;
 template <typename T>
 __global__ __launch_bounds__(64) void ffpa_fwd_merge_kernel(const FwdArgs a, int D) {
+  __shared__ float wsh[kMergeMaxSplits];
   const int64_t row = blockIdx.x;  // (b * Hq + hq) * Nq + qrow
   const int64_t rows = (int64_t)a.B * a.Hq * a.Nq;
+  const int lane = threadIdx.x;
   float mx = -INFINITY;
-  for (int s = 0; s < a.nsplit; ++s) mx = fmaxf(mx, a.ws_lse[s * rows + row]);
+  for (int s = lane; s < a.nsplit; s += 64) mx = fmaxf(mx, a.ws_lse[s * rows + row]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
   float wsum = 0.f;
-  for (int s = 0; s < a.nsplit; ++s) wsum += (mx == -INFINITY) ? 0.f : __expf(a.ws_lse[s * rows + row] - mx);
+  for (int s = lane; s < a.nsplit; s += 64) {
+    const float w = (mx == -INFINITY) ? 0.f : __expf(a.ws_lse[s * rows + row] - mx);
+    wsh[s] = w;
+    wsum += w;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o);
+  __syncthreads();
   const float inv = 1.f / wsum;  // every share empty -> 0 * inf = NaN, like an unsplit fully masked row
-  const int qrow = (int)(row % a.Nq);
-  const int64_t bh = row / a.Nq;
-  const int hq = (int)(bh % a.Hq);
-  const int b = (int)(bh / a.Hq);
-  T* op = (T*)a.o + b * a.so[0] + hq * a.so[1] + (int64_t)qrow * a.so[2];
-  for (int d = threadIdx.x * 4; d < D; d += 64 * 4) {
+  const int d = blockIdx.y * 256 + lane * 4;
+  if (d < D) {
+    const float* src = a.ws_o + row * D + d;
+    const int64_t sstride = rows * D;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < a.nsplit; ++s) {
-      const float w = (mx == -INFINITY) ? 0.f : __expf(a.ws_lse[s * rows + row] - mx);
-      const f32x4 t = *(const f32x4*)(a.ws_o + (s * rows + row) * D + d);
+    int s = 0;
+    for (; s + 8 <= a.nsplit; s += 8) {
+      f32x4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = *(const f32x4*)(src + (s + u) * sstride);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float w = wsh[s + u];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += w * t[u][e];
+      }
+    }
+    for (; s < a.nsplit; ++s) {
+      const f32x4 t = *(const f32x4*)(src + s * sstride);
+      const float w = wsh[s];
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[e] += w * t[e];
     }
+    const int qrow = (int)(row % a.Nq);
+    const int64_t bh = row / a.Nq;
+    const int hq = (int)(bh % a.Hq);
+    const int b = (int)(bh / a.Hq);
+    T* op = (T*)a.o + b * a.so[0] + hq * a.so[1] + (int64_t)qrow * a.so[2];
     typename Elem<T>::v4 w4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) w4[e] = (T)(acc[e] * inv);
     *(typename Elem<T>::v4*)(op + d) = w4;
   }
-  if (a.lse != nullptr && threadIdx.x == 0) a.lse[row] = (mx == -INFINITY) ? -INFINITY : mx + __logf(wsum);
+  if (a.lse != nullptr && lane == 0 && blockIdx.y == 0) a.lse[row] = (mx == -INFINITY) ? -INFINITY : mx + __logf(wsum);
 }
 
 }  // namespace ffpa
