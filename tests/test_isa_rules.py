@@ -1,0 +1,38 @@
+"""Static rules on the generated gfx950 ISA (needs `python -m ffpa_attn_amd.build --save-temps`, which
+__graft_entry__.build() runs; skipped when the assembly files are not there)."""
+import glob
+import importlib.util
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TEMPS = glob.glob(os.path.join(ROOT, "ffpa_attn_amd", "csrc", "build", "temps_d*", "*gfx950.s"))
+
+
+def _tool(name):
+  spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  return mod
+
+
+@pytest.mark.skipif(not TEMPS, reason="no --save-temps assembly in csrc/build")
+def test_asm_mfma_operands_have_no_valu_writer_inside_the_hazard_window(monkeypatch, capsys):
+  """The product kernels issue their S^T MFMAs through inline asm WITHOUT wait-state padding (worth 1.4-2.7 %);
+  that is only legal while no VALU instruction writes an A / B / C operand within the two instructions before."""
+  monkeypatch.setattr(sys, "argv", ["check_mfma_hazards"])
+  assert _tool("check_mfma_hazards").main() == 0, capsys.readouterr().out[-2000:]
+  out = capsys.readouterr().out
+  assert "asm MFMAs checked" in out and " 0 preceded" in out
+
+
+@pytest.mark.skipif(not TEMPS, reason="no --save-temps assembly in csrc/build")
+def test_headline_kernel_has_no_spill_code_inside_its_mfma_loops(capsys, monkeypatch):
+  """D = 512 bf16 prefill kernel: 256 + 256 registers, no scratch and no SGPR lane spills inside the MFMA loops."""
+  monkeypatch.setattr(sys, "argv", ["isa_stats", "512"])
+  _tool("isa_stats").main()
+  lines = [l for l in capsys.readouterr().out.splitlines() if "bf16  512 1 b0 b0" in l]
+  assert len(lines) == 1, lines
+  assert "vgpr 256 agpr 256" in lines[0] and "inside MFMA loops: scratch 0, lane spills 0" in lines[0], lines[0]
