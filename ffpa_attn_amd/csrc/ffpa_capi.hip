@@ -75,12 +75,17 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
   pl.nqt = (p->seqlen_q + pl.br - 1) / pl.br;
   pl.nt = (p->seqlen_kv + pl.bc - 1) / pl.bc;
   pl.splits = 1;
-  if (pl.variant == 1 && p->num_splits != 1) {
-    // occupancy heuristic (cf. select_decode_num_splits, native/launch.cuh:17-67): aim at two workgroups
-    // per CU, keep at least 4 KV tiles per split so the merge stays cheap
-    const int64_t base = (int64_t)p->batch * p->heads_q * pl.nqt;
-    int64_t want = (2LL * device_cu_count() + base - 1) / base;
-    const int64_t cap = pl.nt / 4 > 0 ? pl.nt / 4 : 1;
+  // KV-split launches (partials + LSE merge).  Short-query tiles: occupancy heuristic cf. select_decode_num_splits
+  // (native/launch.cuh:17-67) — aim at two workgroups per CU, at least 4 KV tiles per split so the merge stays
+  // cheap.  Prefill tiles split too when the launch would leave more than half of the chip idle (chunked prefill
+  // against a long context with few heads per GPU): one workgroup per CU, at least 8 KV tiles per split.
+  const int64_t base = (int64_t)p->batch * p->heads_q * pl.nqt;
+  const int64_t cus = device_cu_count();
+  const bool underfilled = pl.variant == 0 && !(p->flags & FFPA_FLAG_DEBUG_SAFE_PATH) && base * 2 <= cus;
+  if ((pl.variant == 1 || underfilled) && p->num_splits != 1) {
+    int64_t want = pl.variant == 1 ? (2 * cus + base - 1) / base : cus / base;
+    const int min_tiles = pl.variant == 1 ? 4 : 8;
+    const int64_t cap = pl.nt / min_tiles > 0 ? pl.nt / min_tiles : 1;
     if (want > cap) want = cap;
     if (want > ffpa::kMergeMaxSplits) want = ffpa::kMergeMaxSplits;  // the merge kernel keeps the split weights in LDS
     if (p->num_splits > 1 && want > p->num_splits) want = p->num_splits;

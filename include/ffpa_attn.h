@@ -116,7 +116,8 @@ typedef struct ffpa_fwd_params {
   uint64_t philox_seed;
   uint64_t philox_offset;
 
-  /* Short-query (decode) launches, seqlen_q <= 32: the KV axis is split over workgroups and merged by
+  /* Short-query (decode) launches, seqlen_q <= 32 — and prefill launches that would fill less than half of
+   * the CUs: the KV axis is split over workgroups and merged by
    * LSE, the role of the reference's split_kv_decode_s1/s2 kernels (native/sm_80/split_kv.cuh:22-455,
    * heuristic native/launch.cuh:17-67).  The caller owns the scratch (the reference allocates it inside
    * the launcher, native/launch.cuh:314-318): size from ffpa_attn_fwd_workspace_bytes(). */

@@ -89,11 +89,35 @@ def test_short_query_plan_and_workspace(lib):
   assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0 and plan[3] == 1
   p.num_splits = 3
   assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0 and 1 < plan[3] <= 3
-  big = _params(seqlen_q=4096, seqlen_kv=4096)
+  big = _params(seqlen_q=4096, seqlen_kv=4096, heads_q=32, heads_kv=8)   # 1024 workgroups: fills the chip
   assert lib.ffpa_attn_fwd_plan(ctypes.byref(big), plan) == 0 and list(plan) == [0, 128, 64, 1]
   assert lib.ffpa_attn_fwd_workspace_bytes(ctypes.byref(big)) == 0
-  d1024 = _params(seqlen_q=4096, seqlen_kv=4096, head_dim=1024)
+  d1024 = _params(seqlen_q=4096, seqlen_kv=4096, head_dim=1024, heads_q=32, heads_kv=8)
   assert lib.ffpa_attn_fwd_plan(ctypes.byref(d1024), plan) == 0 and list(plan) == [0, 64, 32, 1]
+
+
+def test_underfilled_prefill_plan_splits_the_kv_axis(lib):
+  """Prefill tiles whose launch would leave more than half of the CUs idle (chunked prefill against a long
+  context with few heads) split the KV axis too: >= 8 KV tiles per split, one workgroup per CU in total
+  (256 CUs are assumed when no device is present)."""
+  plan = (ctypes.c_int * 4)()
+  p = _params(seqlen_q=512, seqlen_kv=65536, heads_q=8, heads_kv=8)        # 8 heads x 4 row tiles = 32 workgroups
+  assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0 and list(plan) == [0, 128, 64, 1]   # no scratch
+  need = lib.ffpa_attn_fwd_workspace_bytes(ctypes.byref(p))
+  assert need == 8 * (1 * 8 * 512 * (512 + 1) * 4)
+  p.workspace, p.workspace_bytes = 16, need
+  assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0 and list(plan) == [0, 128, 64, 8]
+  p.workspace_bytes = need // 2                                             # less scratch -> fewer splits
+  assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0 and plan[3] == 4
+  short_ctx = _params(seqlen_q=512, seqlen_kv=1024, heads_q=8, heads_kv=8)  # 16 KV tiles: at most 2 splits
+  short_ctx.workspace, short_ctx.workspace_bytes = 16, 1 << 40
+  assert lib.ffpa_attn_fwd_plan(ctypes.byref(short_ctx), plan) == 0 and plan[3] == 2
+  half = _params(seqlen_q=4096, seqlen_kv=4096, heads_q=4, heads_kv=4)      # 128 workgroups = half the chip
+  half.workspace, half.workspace_bytes = 16, 1 << 40
+  assert lib.ffpa_attn_fwd_plan(ctypes.byref(half), plan) == 0 and plan[3] == 2
+  full = _params(seqlen_q=4096, seqlen_kv=4096, heads_q=8, heads_kv=8)      # 256 workgroups: no split
+  full.workspace, full.workspace_bytes = 16, 1 << 40
+  assert lib.ffpa_attn_fwd_plan(ctypes.byref(full), plan) == 0 and plan[3] == 1
 
 
 def test_tile_configs():

@@ -523,6 +523,32 @@ def test_short_query_causal_and_tails(hip, Nq, Hq, Hkv):
   assert torch.equal(o0[:, :, 0], v[:, :, 0].repeat_interleave(Hq // Hkv, 1))  # row 0 sees only key 0
 
 
+@pytest.mark.parametrize("D,Hq,Hkv,Nq,Nkv,causal", [(512, 4, 4, 512, 16384, False), (512, 8, 2, 640, 9000, True), (320, 2, 1, 1024, 8192, True),
+                                                    (1024, 2, 2, 512, 8192, False)])
+def test_underfilled_prefill_splits_the_kv_axis(hip, D, Hq, Hkv, Nq, Nkv, causal):
+  """Prefill tiles with few workgroups (chunked prefill, long context, few heads): the plan splits the KV axis and
+  merges by LSE.  Must agree with the unsplit launch to rounding and with SDPA at the north-star bound."""
+  q, k, v = _rand((1, Hq, Nq, D), seed=401), _rand((1, Hkv, Nkv, D), seed=402), _rand((1, Hkv, Nkv, D), seed=403)
+  scale = D ** -0.5
+  plan = {}
+  o, lse = hip.forward(q, k, v, None, causal, scale, plan_out=plan)
+  assert plan["variant"] == 0 and plan["splits"] > 1, plan
+  o1, lse1 = hip.forward(q, k, v, None, causal, scale, num_splits=1)
+  assert (o.float() - o1.float()).abs().max().item() <= 4e-3 and (lse - lse1).abs().max().item() <= 1e-4
+  g = Hq // Hkv
+  mask = None
+  if causal:
+    rows, cols = torch.arange(Nq, device="cuda")[:, None], torch.arange(Nkv, device="cuda")[None, :]
+    mask = cols <= rows + (Nkv - Nq)
+  ref = F.scaled_dot_product_attention(q, k.repeat_interleave(g, 1), v.repeat_interleave(g, 1), attn_mask=mask)
+  assert (o.float() - ref.float()).abs().max().item() <= NORTH_STAR_MAX_ABS
+  bias = (_rand((1, 1, Nq, Nkv), seed=404) * 0.5)
+  ob, _ = hip.forward(q, k, v, bias, False, scale, plan_out=plan)
+  assert plan["splits"] > 1
+  ob1, _ = hip.forward(q, k, v, bias, False, scale, num_splits=1)
+  assert (ob.float() - ob1.float()).abs().max().item() <= 4e-3
+
+
 def test_short_query_bias_is_not_packed(hip):
   q, k, v = _rand((1, 8, 3, 512), seed=151), _rand((1, 2, 900, 512), seed=152), _rand((1, 2, 900, 512), seed=153)
   bias = (torch.randn(1, 8, 3, 900, device="cuda") * 0.5).to(q.dtype)
