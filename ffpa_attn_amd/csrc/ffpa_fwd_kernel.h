@@ -8,13 +8,15 @@
 // Machine mapping (see DESIGN.md for the derivation and the measurements behind each choice):
 //   * one workgroup = 4 waves = one wave per SIMD, each wave owns the SIMD's whole 512-entry register file.
 //     A wave owns 32 query rows and DW = D/ND output columns:
-//       ND = 1 (D <= 512):  4 waves x 32 rows            -> BR = 128 rows / workgroup, BC = 64 keys / tile
+//       ND = 1 (D <= 512):  4 waves x 32 rows            -> BR = 128 rows / workgroup, BC = 128 keys / tile for
+//                                                           D <= 320, 64 above
 //       ND = 2 (D  > 512):  2 row blocks x 2 D-halves    -> BR =  64, BC = 32
 //       ND = 4 (Nq <= 32):  1 row block  x 4 D-quarters  -> BR =  32, BC = 32 (short-query / decode launches,
 //                                                           with the KV axis split over workgroups)
 //   * S^T = K.Q^T  (v_mfma_f32_32x32x16, A = K rows from LDS, B = Q rows from VGPRs): every lane then owns ONE
 //     query column, so the softmax row reductions are in-lane plus a single lane^32 exchange, and the C layout
-//     of S^T is already the B-operand layout of the second contraction (P never leaves registers).
+//     of S^T is already the B-operand layout of the second contraction (P never leaves registers).  MFMA row a
+//     is fed key pi(a), chosen so that each lane holds 16 CONSECUTIVE keys of every 32-key block.
 //   * O^T += V^T.P^T (A = V^T via ds_read_b64_tr_b16 from a row-major V tile in LDS, B = P^T from registers,
 //     accumulator O^T = 16*DW/32 AGPRs per lane).
 //   * Split-D: the Q.K contraction walks D in 16-wide steps against Q fragments that stay resident in VGPRs
@@ -23,7 +25,8 @@
 //     in D.
 //   * K and V tiles ([BC keys][D]) are brought in by LDS-DMA (buffer_load_dwordx4 ... lds: no VGPR round
 //     trip), issued through inline asm between the MFMAs; bank-conflict-avoiding XOR swizzles are applied on
-//     the per-lane SOURCE offset because the DMA destination is lane-linear.  Per KV tile: QK^T(j) with the
+//     the per-lane SOURCE offset because the DMA destination is lane-linear; rows past the last key are
+//     zero-filled by the buffer descriptor's range check.  Per KV tile: QK^T(j) with the
 //     V(j) pieces interleaved -> barrier A1 -> first K(j+1) pieces -> softmax -> counted vmcnt + barrier A2 ->
 //     PV(j) with the remaining K(j+1) pieces interleaved -> barrier B.
 //   * blockIdx is remapped so that all row tiles of one (batch, head) run on the same XCD at the same time
@@ -61,7 +64,7 @@
 #define FFPA_HOIST_ND2_MAX_D 896  // ND == 2 (split-D, burst DMA): up to this head dim (D = 960 spills: -16 %)
 #endif
 #ifndef FFPA_ROW_DMA
-#define FFPA_ROW_DMA 1  // D = 512: wave-uniform rows, 4 scalar instructions per DMA piece (+0.9 %)
+#define FFPA_ROW_DMA 1  // D = 512: wave-uniform rows, 3 scalar-only instructions per DMA piece
 #endif
 #ifndef FFPA_BC128_MAX_D
 #define FFPA_BC128_MAX_D 320  // ND == 1 head dims up to this use 128-key tiles (2*128*D*2 B of LDS <= 160 KiB)
