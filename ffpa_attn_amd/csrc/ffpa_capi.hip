@@ -180,6 +180,10 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   const int safe = (p->flags & FFPA_FLAG_DEBUG_SAFE_PATH) ? 1 : 0;
 
   if (p->causal_row_mod < 0) return fail(FFPA_ERR_BAD_SHAPE, "causal_row_mod must be >= 0");
+  if (p->kv_bounds != nullptr && p->causal_row_mod != 0)
+    return fail(FFPA_ERR_UNSUPPORTED, "kv_bounds with packed query heads (causal_row_mod) is not supported");
+  if (p->kv_bounds != nullptr && (p->kv_bounds_stride[0] < 0 || p->kv_bounds_stride[1] < 0))
+    return fail(FFPA_ERR_BAD_STRIDE, "kv_bounds strides must be >= 0");
   if (p->workspace != nullptr && !aligned16(p->workspace))
     return fail(FFPA_ERR_MISALIGNED, "workspace must be 16-byte aligned");
   const Plan pl = make_plan(p, de);
@@ -219,6 +223,9 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   a.nsplit = pl.splits;
   a.tiles_per_split = pl.tiles_per_split;
   a.causal_row_mod = p->causal_row_mod;
+  a.kv_bounds = p->kv_bounds;
+  a.s_bounds[0] = p->kv_bounds ? p->kv_bounds_stride[0] : 0;
+  a.s_bounds[1] = p->kv_bounds ? p->kv_bounds_stride[1] : 0;
   if (p->bias != nullptr && p->bias_stride[3] == 1) {
     // vector bias loads (16 consecutive keys per lane): W elements per load need W-element aligned base and
     // batch / head / row strides.  16-byte loads when possible (W = 8 for 16-bit, 4 for fp32), else 8-byte.
@@ -267,6 +274,32 @@ size_t ffpa_attn_fwd_workspace_bytes(const ffpa_fwd_params* params) {
   q.workspace = reinterpret_cast<void*>(16);
   q.workspace_bytes = ~0ull;
   return make_plan(&q, de).ws_bytes;
+}
+
+int ffpa_attn_mask_kv_bounds(const void* bias, int bias_dtype, const int64_t bias_stride[4], int bb, int hb, int nq,
+                             int nkv, int32_t* out, void* stream) {
+  if (bias == nullptr || out == nullptr || bias_stride == nullptr) return fail(FFPA_ERR_NULL_POINTER, "bias / out / strides are NULL");
+  if (bias_dtype < FFPA_BIAS_FP16 || bias_dtype > FFPA_BIAS_FP32) return fail(FFPA_ERR_BAD_DTYPE, "unknown bias_dtype %d", bias_dtype);
+  if (bb <= 0 || hb <= 0 || nq <= 0 || nkv <= 0) return fail(FFPA_ERR_BAD_SHAPE, "non-positive mask dimension");
+  for (int i = 0; i < 4; ++i)
+    if (bias_stride[i] < 0) return fail(FFPA_ERR_BAD_STRIDE, "bias stride[%d] is negative", i);
+  ffpa::MaskBoundsArgs m;
+  m.bias = bias;
+  for (int i = 0; i < 4; ++i) m.sb[i] = bias_stride[i];
+  m.hb = hb;
+  m.nq = nq;
+  m.nkv = nkv;
+  m.nblk = (nq + 31) / 32;
+  m.out = out;
+  const int64_t grid = (int64_t)bb * hb * m.nblk;
+  if (grid > 0x7fffffffLL) return fail(FFPA_ERR_BAD_SHAPE, "mask of %lld row blocks is too large", (long long)grid);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (bias_dtype == FFPA_BIAS_FP32) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_kernel<float>, dim3((unsigned)grid), dim3(256), 0, st, m);
+  else if (bias_dtype == FFPA_BIAS_BF16) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_kernel<__bf16>, dim3((unsigned)grid), dim3(256), 0, st, m);
+  else hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_kernel<_Float16>, dim3((unsigned)grid), dim3(256), 0, st, m);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(FFPA_ERR_LAUNCH, "mask bounds launch failed: %s", hipGetErrorString(e));
+  return FFPA_OK;
 }
 
 int ffpa_attn_fwd_plan(const ffpa_fwd_params* params, int out[4]) {

@@ -145,6 +145,9 @@ struct FwdArgs {
   // rows of several query heads of one KV group packed into one row axis (host reshape): the causal
   // limit of packed row r is (r % causal_row_mod) + causal_offset; 0 = rows are plain query rows
   int causal_row_mod;
+  // optional [first, end) visible-key bounds per block of 32 query rows (see ffpa_fwd_params.kv_bounds)
+  const int* kv_bounds;
+  int64_t s_bounds[2];  // element strides: batch, head (0 = broadcast)
   int bias_vec;  // W in {0, 4, 8}: bias key stride is 1 and base / strides are W-element aligned -> W-wide loads
   // dropout (prefill.cuh:398-546): keep iff u > p, u from Philox4x32-10 at the logical element offset
   float dropout_p;          // 0 = off
@@ -581,10 +584,27 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
     const int ntc = last < 0 ? 0 : (int)(last / BC) + 1;
     nt = nt < ntc ? nt : ntc;
   }
-  const int t0 = split * a.tiles_per_split;  // this workgroup's share of the KV tiles
+  int t0 = split * a.tiles_per_split;  // this workgroup's share of the KV tiles
   {
     const int t1 = t0 + a.tiles_per_split;
     nt = nt < t1 ? nt : t1;
+  }
+  if (a.kv_bounds != nullptr) {
+    // the caller's mask leaves only keys [first, end) visible to the 32-row blocks of this row tile
+    const int* bp = a.kv_bounds + b * a.s_bounds[0] + hq * a.s_bounds[1];
+    int first = 0x7fffffff, end = 0;
+#pragma unroll
+    for (int blk = 0; blk < BR / 32; ++blk) {
+      const int r32 = q0 / 32 + blk;
+      if (r32 * 32 < a.Nq) {
+        const int lo = bp[2 * r32], hi = bp[2 * r32 + 1];
+        first = first < lo ? first : lo;
+        end = end > hi ? end : hi;
+      }
+    }
+    const int tf = first / BC, te = (end + BC - 1) / BC;
+    t0 = t0 > tf ? t0 : tf;
+    nt = nt < te ? nt : te;
   }
 
   // ---- Q fragments: B operand of S^T = K.Q^T.  lane (row l31, half h) holds
@@ -1031,6 +1051,81 @@ __global__ __launch_bounds__(64) void ffpa_fwd_merge_kernel(const FwdArgs a, int
     *(typename Elem<T>::v4*)(op + d) = w4;
   }
   if (a.lse != nullptr && lane == 0 && blockIdx.y == 0) a.lse[row] = (mx == -INFINITY) ? -INFINITY : mx + __logf(wsum);
+}
+
+// Visible-key bounds of an additive mask (ffpa_fwd_params.kv_bounds): one workgroup per (batch, head, block of 32
+// query rows) scans its 32 x Nkv slab once (coalesced along the keys) and writes {first, end} of the keys that are
+// not -inf for at least one row of the block ({Nkv, 0} when there is none).  HBM-bound, 2-4 bytes per mask element.
+template <typename BT>
+__device__ __forceinline__ bool mask_elem_visible(BT x);
+template <>
+__device__ __forceinline__ bool mask_elem_visible<float>(float x) { return __builtin_bit_cast(uint32_t, x) != 0xff800000u; }
+template <>
+__device__ __forceinline__ bool mask_elem_visible<__bf16>(__bf16 x) { return __builtin_bit_cast(uint16_t, x) != (uint16_t)0xff80u; }
+template <>
+__device__ __forceinline__ bool mask_elem_visible<_Float16>(_Float16 x) { return __builtin_bit_cast(uint16_t, x) != (uint16_t)0xfc00u; }
+
+struct MaskBoundsArgs {
+  const void* bias;
+  int64_t sb[4];  // element strides: batch, head, row, key (0 = broadcast)
+  int hb, nq, nkv, nblk;
+  int* out;       // [bb, hb, nblk, 2]
+};
+
+template <typename BT>
+__global__ __launch_bounds__(256) void ffpa_mask_kv_bounds_kernel(const MaskBoundsArgs m) {
+  __shared__ int red[2][4];
+  const int blk = blockIdx.x % m.nblk;
+  const int bh = blockIdx.x / m.nblk;
+  const int h = bh % m.hb, b = bh / m.hb;
+  const BT* base = (const BT*)m.bias + b * m.sb[0] + h * m.sb[1];
+  const int r0 = blk * 32;
+  const int r1 = r0 + 32 < m.nq ? r0 + 32 : m.nq;
+  int first = m.nkv, end = 0;
+  // all 32 rows of a column are loaded before any is tested: 32 (x2 columns) independent loads in flight per lane
+  for (int c0 = threadIdx.x; c0 < m.nkv; c0 += 512) {
+    BT x[2][32];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = c0 + 256 * u < m.nkv ? c0 + 256 * u : c0;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        const int rr = r0 + r < r1 ? r0 + r : r1 - 1;
+        x[u][r] = base[(int64_t)rr * m.sb[2] + (int64_t)c * m.sb[3]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = c0 + 256 * u;
+      bool vis = false;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) vis = vis || mask_elem_visible<BT>(x[u][r]);
+      if (vis && c < m.nkv) {
+        first = first < c ? first : c;
+        end = end > c + 1 ? end : c + 1;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int f2 = __shfl_xor(first, o), e2 = __shfl_xor(end, o);
+    first = first < f2 ? first : f2;
+    end = end > e2 ? end : e2;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = first;
+    red[1][threadIdx.x >> 6] = end;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      first = first < red[0][w] ? first : red[0][w];
+      end = end > red[1][w] ? end : red[1][w];
+    }
+    m.out[2 * (int64_t)blockIdx.x] = first;
+    m.out[2 * (int64_t)blockIdx.x + 1] = end;
+  }
 }
 
 }  // namespace ffpa

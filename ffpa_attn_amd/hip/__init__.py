@@ -30,7 +30,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_PKG, "libffpa_attn_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # enum ffpa_status (include/ffpa_attn.h)
 _STATUS_EXC = {
@@ -90,6 +90,8 @@ class FfpaFwdParams(ctypes.Structure):
     ("workspace_bytes", ctypes.c_uint64),
     ("num_splits", ctypes.c_int32),
     ("causal_row_mod", ctypes.c_int32),
+    ("kv_bounds", ctypes.c_void_p),
+    ("kv_bounds_stride", ctypes.c_int64 * 2),
   ]
 
 
@@ -99,6 +101,7 @@ _lib_lock = threading.Lock()
 EXPORTS = (
   "ffpa_attn_fwd",
   "ffpa_attn_fwd_workspace_bytes",
+  "ffpa_attn_mask_kv_bounds",
   "ffpa_attn_fwd_plan",
   "ffpa_attn_query",
   "ffpa_attn_fwd_tile_config",
@@ -126,6 +129,9 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib = ctypes.CDLL(p)
     lib.ffpa_attn_fwd.argtypes = [ctypes.POINTER(FfpaFwdParams), ctypes.c_void_p]
     lib.ffpa_attn_fwd.restype = ctypes.c_int
+    lib.ffpa_attn_mask_kv_bounds.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.ffpa_attn_mask_kv_bounds.restype = ctypes.c_int
     lib.ffpa_attn_fwd_workspace_bytes.argtypes = [ctypes.POINTER(FfpaFwdParams)]
     lib.ffpa_attn_fwd_workspace_bytes.restype = ctypes.c_size_t
     lib.ffpa_attn_fwd_plan.argtypes = [ctypes.POINTER(FfpaFwdParams), ctypes.POINTER(ctypes.c_int)]
@@ -177,6 +183,47 @@ def _dense_rows(t: torch.Tensor) -> torch.Tensor:
   return t if ok else t.contiguous()
 
 
+def mask_kv_bounds(attn_bias: torch.Tensor, nq: int, nkv: int) -> torch.Tensor:
+  """Visible-key bounds of an additive mask for the kernel's tile clipping: int32 ``[Bb, Hb, ceil(Nq/32), 2]`` holding,
+  per block of 32 query rows, ``[first, end)`` such that every key outside is -inf for every row of the block
+  (``{Nkv, 0}`` for a block without any visible key).  On the GPU: one fused pass of the library over the mask
+  (``ffpa_attn_mask_kv_bounds``); elsewhere (tests) the same thing in torch ops."""
+  bb, hb = attn_bias.size(0), attn_bias.size(1)
+  nblk = (nq + 31) // 32
+  if attn_bias.is_cuda and attn_bias.dtype in _BIAS_DTYPE:
+    lib = load_library()
+    out = torch.empty((bb, hb, nblk, 2), dtype=torch.int32, device=attn_bias.device)
+    strides = (ctypes.c_int64 * 4)(*[attn_bias.stride(d) if attn_bias.size(d) > 1 else 0 for d in range(4)])
+    with torch.cuda.device(attn_bias.device):
+      rc = lib.ffpa_attn_mask_kv_bounds(ctypes.c_void_p(attn_bias.data_ptr()), _BIAS_DTYPE[attn_bias.dtype], strides, bb, hb, nq, nkv,
+                                        ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream(attn_bias.device).cuda_stream))
+    if rc != 0:
+      raise _STATUS_EXC.get(rc, RuntimeError)(lib.ffpa_attn_last_error().decode())
+    return out
+  vis = ~torch.isneginf(attn_bias)                                     # [Bb, Hb, Nq|1, Nkv|1]
+  col_any = vis.expand(bb, hb, nq, nkv)
+  pad = nblk * 32 - nq
+  if pad:
+    col_any = torch.nn.functional.pad(col_any, (0, 0, 0, pad))         # padded rows see nothing
+  col_any = col_any.reshape(bb, hb, nblk, 32, nkv).any(dim=3)          # any over the rows of a block: [Bb, Hb, nblk, Nkv]
+  idx = torch.arange(nkv, device=attn_bias.device, dtype=torch.int32)
+  first = torch.where(col_any, idx, torch.full_like(idx, nkv)).amin(dim=-1)
+  end = torch.where(col_any, idx + 1, torch.zeros_like(idx)).amax(dim=-1)
+  return torch.stack((first, end), dim=-1).to(torch.int32).contiguous()
+
+
+def _want_mask_bounds(attn_bias: torch.Tensor, b: int, hq: int, nq: int, nkv: int) -> bool:
+  """The scan reads the mask once (2-4 B per element): worth it for every mask that has real row and key axes and a
+  problem with tiles to skip, unless each (batch, head) pair brings its own mask (then the scan is as big as the
+  mask reads of the attention itself).  FFPA_HIP_MASK_BOUNDS=0/1 forces it off / on."""
+  env = os.environ.get("FFPA_HIP_MASK_BOUNDS")
+  if env is not None:
+    return env not in ("0", "")
+  if attn_bias.size(2) != nq or attn_bias.size(3) != nkv or nkv < 512 or nq < 128:
+    return False
+  return b * hq >= 2 * attn_bias.size(0) * attn_bias.size(1)
+
+
 def forward(
   q: torch.Tensor,
   k: torch.Tensor,
@@ -194,6 +241,7 @@ def forward(
   return_lse: bool = True,
   num_splits: int = 0,
   plan_out: dict | None = None,
+  kv_bounds: torch.Tensor | bool | None = None,
 ) -> tuple[torch.Tensor, torch.Tensor | None]:
   """Run the gfx950 kernel on the current stream of ``q.device``; returns ``(o, lse)``.
 
@@ -206,6 +254,10 @@ def forward(
   per query head), the library splits the KV axis over workgroups (``num_splits``: 0 = heuristic,
   1 = never) and merges by LSE; the scratch for the partials is allocated here with torch.
   ``plan_out``, if given, receives the launch plan (variant, block_rows, block_keys, splits, packed).
+
+  ``kv_bounds``: visible-key bounds of the mask (``mask_kv_bounds``) — the kernel then skips the KV tiles the mask
+  hides entirely (an explicit causal mask costs what ``is_causal`` costs); ``None`` derives them from ``attn_bias``
+  when that is worth a scan of the mask, ``False`` never, ``True`` always, or pass a precomputed tensor.
   """
   if not q.is_cuda:
     raise NotImplementedError(
@@ -262,6 +314,16 @@ def forward(
     p.bias = attn_bias.data_ptr()
     p.bias_dtype = _BIAS_DTYPE[attn_bias.dtype]
     p.bias_stride[:] = strides
+    if kv_bounds is True or (kv_bounds is None and _want_mask_bounds(attn_bias, B, Hq, Nq, Nkv)):
+      kv_bounds = mask_kv_bounds(attn_bias, Nq, Nkv)
+    if isinstance(kv_bounds, torch.Tensor):
+      nblk = (Nq + 31) // 32
+      if kv_bounds.dtype != torch.int32 or kv_bounds.dim() != 4 or kv_bounds.shape[2:] != (nblk, 2) or not kv_bounds.is_contiguous():
+        raise ValueError(f"kv_bounds must be a contiguous int32 [B|1, Hq|1, {nblk}, 2] tensor")
+      if kv_bounds.size(0) not in (1, B) or kv_bounds.size(1) not in (1, Hq) or kv_bounds.device != q.device:
+        raise ValueError("kv_bounds batch / head dims must be 1 or match q, on q's device")
+      p.kv_bounds = kv_bounds.data_ptr()
+      p.kv_bounds_stride[:] = [kv_bounds.stride(0) if kv_bounds.size(0) > 1 else 0, kv_bounds.stride(1) if kv_bounds.size(1) > 1 else 0]
   else:
     p.bias = None
     p.bias_dtype = 0

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FFPA_ATTN_ABI_VERSION 1
+#define FFPA_ATTN_ABI_VERSION 2
 
 /* status codes (0 == success).  The Python host maps them onto the exception
  * classes the reference raises (TORCH_CHECK -> RuntimeError,
@@ -128,6 +128,16 @@ typedef struct ffpa_fwd_params {
    * [B, Hkv, group*Nq, D]): the causal limit of packed row r is (r % causal_row_mod) + causal_offset.
    * 0 = rows are plain query rows. */
   int32_t causal_row_mod;
+
+  /* Optional visible-key bounds derived from the mask by the caller (NULL = none): for every block of 32
+   * query rows, [first, end) such that EVERY key outside it is masked (bias == -inf) for EVERY row of the
+   * block.  int32 pairs, shape [Bb, Hb, ceil(Nq / 32), 2] with element strides kv_bounds_stride = {batch, head}
+   * (0 = broadcast); an empty block is {Nkv, 0}.  The kernel clips its KV-tile loop to the union of its
+   * blocks' ranges: results are unchanged (the skipped tiles contribute exp(-inf) = 0), an explicit causal /
+   * sliding-window / padding mask just stops costing the tiles it masks out entirely.  The reference has no
+   * counterpart (it always walks every tile: native/sm_80/split_d.cuh:222-228 clips for is_causal only). */
+  const int32_t* kv_bounds;
+  int64_t kv_bounds_stride[2];
 } ffpa_fwd_params;
 
 /*
@@ -149,6 +159,14 @@ size_t ffpa_attn_fwd_workspace_bytes(const ffpa_fwd_params* params);
  * tile, out[3] = number of KV splits given params->workspace_bytes.  Returns an ffpa_status.
  */
 int ffpa_attn_fwd_plan(const ffpa_fwd_params* params, int out[4]);
+
+/*
+ * Visible-key bounds of an additive mask, in the layout ffpa_fwd_params.kv_bounds expects: one fused pass over
+ * `bias` ([bb, hb, nq|1, nkv|1] with element strides bias_stride, 0 = broadcast; enum ffpa_bias_dtype) writes
+ * out[bb][hb][ceil(nq / 32)][2] (int32, contiguous) on `stream`.  Returns an ffpa_status.
+ */
+int ffpa_attn_mask_kv_bounds(const void* bias, int bias_dtype, const int64_t bias_stride[4], int bb, int hb,
+                             int nq, int nkv, int32_t* out, void* stream);
 
 /* Capability / build queries.  Replaces the module attributes
  * CUDA_FWD_AVAILABLE, F16_ACC_AVAILABLE, ... (csrc/cuffpa/ffpa_api.cc:283-305). */

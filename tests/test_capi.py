@@ -40,7 +40,7 @@ def test_struct_layout_matches_header(lib):
   p.abi_version = hip.ABI_VERSION
   assert lib.ffpa_attn_fwd(ctypes.byref(p), None) == 10
   assert b"ABI mismatch" in lib.ffpa_attn_last_error()
-  assert ctypes.sizeof(hip.FfpaFwdParams) == 280
+  assert ctypes.sizeof(hip.FfpaFwdParams) == 304
 
 
 def test_ctypes_mirror_matches_the_c_header(tmp_path):
@@ -168,6 +168,7 @@ def _params(**over):
     ({"bias_dtype": 2}, 2, b"bias pointer and bias_dtype disagree"),
     ({"dropout_p": 1.0}, 4, b"dropout_p"),
     ({"dropout_p": 0.1, "causal_row_mod": 2}, 7, b"packed query heads"),
+    ({"kv_bounds": 64, "causal_row_mod": 2}, 7, b"kv_bounds with packed"),
     ({"softmax_scale": float("nan")}, 4, b"not finite"),
   ],
 )

@@ -549,6 +549,64 @@ def test_underfilled_prefill_splits_the_kv_axis(hip, D, Hq, Hkv, Nq, Nkv, causal
   assert (ob.float() - ob1.float()).abs().max().item() <= 4e-3
 
 
+@pytest.mark.parametrize("D", [512, 320, 1024])
+def test_mask_derived_tile_clipping_changes_nothing_but_the_time(hip, D):
+  """kv_bounds (visible-key range per 32-row block, derived from the mask): tiles the mask hides entirely are
+  skipped.  Results must be BIT-identical to walking every tile — for causal, sliding-window, padding and
+  batch/head-dependent masks, rows without any visible key (NaN) included."""
+  B, Hq, Hkv, Nq, Nkv = 2, 4, 2, 700, 1500
+  q, k, v = _rand((B, Hq, Nq, D), seed=501), _rand((B, Hkv, Nkv, D), seed=502), _rand((B, Hkv, Nkv, D), seed=503)
+  scale = D ** -0.5
+  rows, cols = torch.arange(Nq, device="cuda")[:, None], torch.arange(Nkv, device="cuda")[None, :]
+  masks = {
+      "causal": cols <= rows + (Nkv - Nq),
+      "window": (cols <= rows + 400) & (cols >= rows + 100),
+      "padding": (cols < 900).expand(Nq, Nkv),
+      "holes": ((cols <= rows + 300) & (rows >= 64)),                     # first 64 rows see nothing -> NaN rows
+  }
+  for name, m in masks.items():
+    bias = torch.zeros(1, 1, Nq, Nkv, dtype=q.dtype, device="cuda").masked_fill(~m, float("-inf"))
+    o_all, lse_all = hip.forward(q, k, v, bias, False, scale, kv_bounds=False)
+    o_clip, lse_clip = hip.forward(q, k, v, bias, False, scale, kv_bounds=True)
+    assert torch.equal(torch.nan_to_num(o_all.float(), nan=7.0), torch.nan_to_num(o_clip.float(), nan=7.0)), name
+    assert torch.equal(lse_all, lse_clip) or torch.equal(torch.nan_to_num(lse_all, nan=7.0), torch.nan_to_num(lse_clip, nan=7.0)), name
+    assert torch.isnan(o_all).any().item() == (name == "holes")
+  # per-(batch, head) masks and precomputed bounds
+  mbh = torch.rand(B, Hq, 1, Nkv, device="cuda") > 0.5
+  mbh = (mbh & (cols[None, None] < 1000)).expand(B, Hq, Nq, Nkv).contiguous()
+  mbh[..., 0] = True
+  bias = torch.zeros(B, Hq, Nq, Nkv, dtype=q.dtype, device="cuda").masked_fill(~mbh, float("-inf"))
+  bounds = hip.mask_kv_bounds(bias, Nq, Nkv)
+  assert bounds.shape == (B, Hq, (Nq + 31) // 32, 2) and int(bounds[..., 1].max()) <= 1000
+  o_all, _ = hip.forward(q, k, v, bias, False, scale, kv_bounds=False)
+  o_clip, _ = hip.forward(q, k, v, bias, False, scale, kv_bounds=bounds)
+  assert torch.equal(o_all, o_clip)
+  ref = F.scaled_dot_product_attention(q, k, v, attn_mask=mbh, enable_gqa=True)
+  _close(o_clip, ref, q.dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_mask_bounds_kernel_matches_the_torch_restatement(hip, dtype):
+  """ffpa_attn_mask_kv_bounds (one fused pass on the GPU) vs the torch-op statement of the same thing on the CPU."""
+  g = torch.Generator(device="cuda").manual_seed(7)
+  for (bb, hb, nq, nkv, rows_bcast) in ((1, 1, 700, 1500, False), (2, 3, 97, 1111, False), (1, 2, 64, 5000, True), (1, 1, 33, 31, False)):
+    shape = (bb, hb, 1 if rows_bcast else nq, nkv)
+    keep = torch.rand(shape, device="cuda", generator=g) > 0.7
+    r = torch.arange(shape[2], device="cuda")[:, None]
+    c = torch.arange(nkv, device="cuda")[None, :]
+    keep = keep & (c <= r * 2 + nkv // 3) & (c >= r // 2)               # banded + random holes
+    if not rows_bcast and nq > 40:
+      keep[..., 32:64, :] = False                                       # an empty 32-row block
+    bias = (torch.randn(shape, device="cuda", generator=g) * 0.1).to(dtype).masked_fill(~keep, float("-inf"))
+    got = hip.mask_kv_bounds(bias, nq, nkv)
+    want = hip.mask_kv_bounds(bias.cpu(), nq, nkv)
+    assert got.dtype == torch.int32 and torch.equal(got.cpu(), want), (dtype, shape)
+  strided = torch.zeros(1, 1, 128, 2048, dtype=dtype, device="cuda").masked_fill(
+      torch.arange(2048, device="cuda")[None, :] > torch.arange(128, device="cuda")[:, None] * 4 + 77, float("-inf"))
+  view = strided[..., ::2]                                               # key stride 2
+  assert torch.equal(hip.mask_kv_bounds(view, 128, 1024).cpu(), hip.mask_kv_bounds(view.cpu(), 128, 1024))
+
+
 def test_short_query_bias_is_not_packed(hip):
   q, k, v = _rand((1, 8, 3, 512), seed=151), _rand((1, 2, 900, 512), seed=152), _rand((1, 2, 900, 512), seed=153)
   bias = (torch.randn(1, 8, 3, 900, device="cuda") * 0.5).to(q.dtype)

@@ -76,3 +76,21 @@ def test_mask_normalisation_shapes():
   assert b.shape == (2, 1, 1, 700) and torch.isinf(b).all()
   b = m.normalize_attn_mask(q, k, torch.zeros(2, 4, 1, 700))
   assert b.dtype == torch.float32 and b.shape == (2, 4, 1, 700)
+
+
+def test_mask_kv_bounds_per_32_row_block():
+  """Host side of the mask-derived tile clipping: [first, end) of the keys visible to ANY row of each 32-row block."""
+  from ffpa_attn_amd.hip import mask_kv_bounds
+  Nq, Nkv = 100, 300
+  m = torch.ones(Nq, Nkv, dtype=torch.bool).tril(diagonal=50)
+  m[40:70] = False
+  bias = torch.zeros(1, 1, Nq, Nkv).masked_fill(~m, float("-inf"))
+  assert mask_kv_bounds(bias, Nq, Nkv)[0, 0].tolist() == [[0, 82], [0, 90], [0, 146], [0, 150]]
+  win = torch.ones(64, 512, dtype=torch.bool).tril(diagonal=200).triu(diagonal=150)       # sliding window
+  b = mask_kv_bounds(torch.zeros(2, 1, 64, 512).masked_fill(~win, float("-inf")), 64, 512)
+  assert b.shape == (2, 1, 2, 2) and b.dtype == torch.int32
+  assert b[1, 0].tolist() == [[150, 232], [182, 264]]
+  none = mask_kv_bounds(torch.full((1, 1, 32, 64), float("-inf")), 32, 64)                # nothing visible: empty range
+  assert none[0, 0].tolist() == [[64, 0]]
+  pad = mask_kv_bounds(torch.zeros(1, 1, 1, 100).index_fill_(3, torch.arange(60, 100), float("-inf")), 40, 100)   # key padding
+  assert pad[0, 0].tolist() == [[0, 60], [0, 60]]

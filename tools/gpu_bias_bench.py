@@ -35,3 +35,22 @@ res["cfg4 key-padding bias [1,1,1,Nkv]"] = (t(lambda: hip.forward(q, k, v, kp, F
 res["cfg4 SDPA is_causal"] = (t(lambda: torch.nn.functional.scaled_dot_product_attention(q, k, v, is_causal=True, enable_gqa=True), 3), fl_c)
 for name, (ms, f) in res.items():
   print("BIAS " + json.dumps({"case": name, "ms": round(ms, 4), "tflops": round(f / ms / 1e9, 1)}), flush=True)
+
+# ---- mask-derived tile clipping (kv_bounds): explicit causal mask at config-2 size, and config 4
+for (Bx, Hqx, Hkvx, Nqx, Nkvx, Dx) in ((1, 32, 32, 8192, 8192, 512), (2, 32, 8, 8192, 2048, 320)):
+  qx = torch.randn(Bx, Hqx, Nqx, Dx, dtype=torch.bfloat16, device="cuda")
+  kx = torch.randn(Bx, Hkvx, Nkvx, Dx, dtype=torch.bfloat16, device="cuda")
+  vx = torch.randn_like(kx)
+  mx = torch.ones(Nqx, Nkvx, dtype=torch.bool, device="cuda").tril()
+  bx = torch.zeros(1, 1, Nqx, Nkvx, dtype=torch.bfloat16, device="cuda").masked_fill(~mx, float("-inf"))
+  flc = attention_fwd_flops(Bx, Hqx, Nqx, Nkvx, Dx, True, causal_offset=0)
+  bounds = hip.mask_kv_bounds(bx, Nqx, Nkvx)
+  cases = {
+      "mask, every tile": lambda: hip.forward(qx, kx, vx, bx, False, Dx ** -0.5, kv_bounds=False),
+      "mask, clipped (bounds precomputed)": lambda: hip.forward(qx, kx, vx, bx, False, Dx ** -0.5, kv_bounds=bounds),
+      "mask, clipped (bounds derived per call)": lambda: hip.forward(qx, kx, vx, bx, False, Dx ** -0.5, kv_bounds=True),
+      "structured causal_offset=0": lambda: hip.forward(qx, kx, vx, None, True, Dx ** -0.5, causal_offset=0),
+  }
+  for name, fn in cases.items():
+    ms = t(fn)
+    print("BIAS " + json.dumps({"case": f"B{Bx} Hq{Hqx}/Hkv{Hkvx} Nq{Nqx} Nkv{Nkvx} D{Dx} tril: {name}", "ms": round(ms, 4), "tflops": round(flc / ms / 1e9, 1)}), flush=True)
