@@ -294,9 +294,19 @@ int ffpa_attn_mask_kv_bounds(const void* bias, int bias_dtype, const int64_t bia
   const int64_t grid = (int64_t)bb * hb * m.nblk;
   if (grid > 0x7fffffffLL) return fail(FFPA_ERR_BAD_SHAPE, "mask of %lld row blocks is too large", (long long)grid);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (bias_dtype == FFPA_BIAS_FP32) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_kernel<float>, dim3((unsigned)grid), dim3(256), 0, st, m);
-  else if (bias_dtype == FFPA_BIAS_BF16) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_kernel<__bf16>, dim3((unsigned)grid), dim3(256), 0, st, m);
-  else hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_kernel<_Float16>, dim3((unsigned)grid), dim3(256), 0, st, m);
+  const int w = bias_dtype == FFPA_BIAS_FP32 ? 4 : 8;  // elements per 16-byte load
+  const bool vec = bias_stride[3] == 1 && nkv % w == 0 && reinterpret_cast<uintptr_t>(bias) % 16 == 0 &&
+                   bias_stride[0] % w == 0 && bias_stride[1] % w == 0 && bias_stride[2] % w == 0;
+  const dim3 g((unsigned)grid), blk(256);
+  if (vec) {
+    if (bias_dtype == FFPA_BIAS_FP32) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_vec_kernel<float>, g, blk, 0, st, m);
+    else if (bias_dtype == FFPA_BIAS_BF16) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_vec_kernel<__bf16>, g, blk, 0, st, m);
+    else hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_vec_kernel<_Float16>, g, blk, 0, st, m);
+  } else {
+    if (bias_dtype == FFPA_BIAS_FP32) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_kernel<float>, g, blk, 0, st, m);
+    else if (bias_dtype == FFPA_BIAS_BF16) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_kernel<__bf16>, g, blk, 0, st, m);
+    else hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_kernel<_Float16>, g, blk, 0, st, m);
+  }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(FFPA_ERR_LAUNCH, "mask bounds launch failed: %s", hipGetErrorString(e));
   return FFPA_OK;

@@ -1128,4 +1128,58 @@ __global__ __launch_bounds__(256) void ffpa_mask_kv_bounds_kernel(const MaskBoun
   }
 }
 
+// 16-byte variant (unit key stride, 16-byte aligned rows, Nkv a multiple of the vector width): each lane owns W = 8
+// (16-bit) or 4 (fp32) consecutive keys, so a wave reads 1 KiB of a row per load instead of 128 B.
+template <typename BT>
+__global__ __launch_bounds__(256) void ffpa_mask_kv_bounds_vec_kernel(const MaskBoundsArgs m) {
+  constexpr int W = 16 / (int)sizeof(BT);
+  typedef __attribute__((ext_vector_type(W))) BT bvec;
+  __shared__ int red[2][4];
+  const int blk = blockIdx.x % m.nblk;
+  const int bh = blockIdx.x / m.nblk;
+  const int h = bh % m.hb, b = bh / m.hb;
+  const BT* base = (const BT*)m.bias + b * m.sb[0] + h * m.sb[1];
+  const int r0 = blk * 32;
+  const int r1 = r0 + 32 < m.nq ? r0 + 32 : m.nq;
+  int first = m.nkv, end = 0;
+  for (int c = threadIdx.x * W; c < m.nkv; c += 256 * W) {
+    bvec x[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      const int rr = r0 + r < r1 ? r0 + r : r1 - 1;
+      x[r] = *(const bvec*)(base + (int64_t)rr * m.sb[2] + c);
+    }
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+      bool vis = false;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) vis = vis || mask_elem_visible<BT>(x[r][e]);
+      if (vis) {
+        first = first < c + e ? first : c + e;
+        end = end > c + e + 1 ? end : c + e + 1;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int f2 = __shfl_xor(first, o), e2 = __shfl_xor(end, o);
+    first = first < f2 ? first : f2;
+    end = end > e2 ? end : e2;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = first;
+    red[1][threadIdx.x >> 6] = end;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      first = first < red[0][w] ? first : red[0][w];
+      end = end > red[1][w] ? end : red[1][w];
+    }
+    m.out[2 * (int64_t)blockIdx.x] = first;
+    m.out[2 * (int64_t)blockIdx.x + 1] = end;
+  }
+}
+
 }  // namespace ffpa
