@@ -585,6 +585,25 @@ def test_mask_derived_tile_clipping_changes_nothing_but_the_time(hip, D):
   _close(o_clip, ref, q.dtype)
 
 
+def test_public_api_clips_masked_tiles_automatically(hip, monkeypatch):
+  """ffpa_attn_func(attn_mask=<bool mask>) derives the bounds by itself (a [Nq, Nkv] mask shared by all heads); same
+  bits as with the scan disabled, and the scan really ran."""
+  from ffpa_attn_amd import ffpa_attn_func
+  import ffpa_attn_amd.hip as hmod
+  q, k, v = _rand((1, 8, 1024, 512), seed=601), _rand((1, 8, 2048, 512), seed=602), _rand((1, 8, 2048, 512), seed=603)
+  rows, cols = torch.arange(1024, device="cuda")[:, None], torch.arange(2048, device="cuda")[None, :]
+  mask = (cols <= rows + 1024) & (cols + 512 >= rows)
+  calls = []
+  real = hmod.mask_kv_bounds
+  monkeypatch.setattr(hmod, "mask_kv_bounds", lambda *a, **kw: calls.append(1) or real(*a, **kw))
+  out = ffpa_attn_func(q, k, v, attn_mask=mask)
+  assert calls == [1]
+  monkeypatch.setenv("FFPA_HIP_MASK_BOUNDS", "0")
+  out_all = ffpa_attn_func(q, k, v, attn_mask=mask)
+  assert calls == [1] and torch.equal(out, out_all)
+  _close(out, F.scaled_dot_product_attention(q, k, v, attn_mask=mask), q.dtype)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 def test_mask_bounds_kernel_matches_the_torch_restatement(hip, dtype):
   """ffpa_attn_mask_kv_bounds (one fused pass on the GPU) vs the torch-op statement of the same thing on the CPU."""
