@@ -26,7 +26,7 @@
 //   * K and V tiles ([BC keys][D]) are brought in by LDS-DMA (buffer_load_dwordx4 ... lds: no VGPR round
 //     trip), issued through inline asm between the MFMAs; bank-conflict-avoiding XOR swizzles are applied on
 //     the per-lane SOURCE offset because the DMA destination is lane-linear; rows past the last key are
-//     zero-filled by the buffer descriptor's range check.  Per KV tile: QK^T(j) with the
+//     zero-filled by the buffer descriptor's range check.  Per KV tile (ND <= 2; the ND = 4 tiles use bursts): QK^T(j) with the
 //     V(j) pieces interleaved -> barrier A1 -> first K(j+1) pieces -> softmax -> counted vmcnt + barrier A2 ->
 //     PV(j) with the remaining K(j+1) pieces interleaved -> barrier B.
 //   * blockIdx is remapped so that all row tiles of one (batch, head) run on the same XCD at the same time
@@ -46,7 +46,7 @@
 #define FFPA_PF2 4  // PV: ditto (two transpose reads per MFMA)
 #endif
 #ifndef FFPA_DMA_INTERLEAVE
-#define FFPA_DMA_INTERLEAVE 1  // 1: issue LDS-DMA pieces between the MFMAs; 0: bursts after the barriers
+#define FFPA_DMA_INTERLEAVE 1  // 1: issue LDS-DMA pieces between the MFMAs (2: on the ND = 4 tiles too); 0: bursts after the barriers
 #endif
 #ifndef FFPA_DMA_STEP
 #define FFPA_DMA_STEP 2  // interleaved mode: one DMA piece every this many MFMAs (ND == 1)
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   constexpr int PF1 = FFPA_PF1;
   constexpr int PF2 = FFPA_PF2;
   constexpr int PPW = BC * D * 2 / 4096;  // 1 KiB DMA pieces per wave per tile
-  constexpr bool kInterleave = FFPA_DMA_INTERLEAVE != 0 && (ND == 1 || FFPA_DMA_INTERLEAVE == 2);  // D > 512 measured faster with bursts
+  constexpr bool kInterleave = FFPA_DMA_INTERLEAVE != 0 && (ND <= 2 || FFPA_DMA_INTERLEAVE == 2);  // short-query (ND = 4) tiles keep bursts
   constexpr int kStep = (ND == 1) ? FFPA_DMA_STEP : 1;  // MFMAs between two DMA pieces
   static_assert(!kInterleave || PPW * kStep <= (DW / 16) * (BC / 32), "DMA pieces must fit the QK loop");
   // Head dims whose rows are not a whole number of 1 KiB pieces need ~12 VALU instructions per piece for the
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   constexpr bool kHoist = FFPA_HOIST != 0 && !kRowUniform && !SAFE && !DROP && (ND == 1 ? D <= FFPA_HOIST_MAX_D : (ND == 2 && D <= FFPA_HOIST_ND2_MAX_D));
   // Row-uniform head dims: wave w stages keys 16 a + 4 w + b (a < BC/16, b < 4) so that only four K and
   // four V swizzled lane offsets exist (K: slot ^ (4 w + b); V: slot ^ 4 b) and live in 8 VGPRs.
-  constexpr bool kRowDma = FFPA_ROW_DMA != 0 && kRowUniform && !SAFE && kInterleave;  // bursts (D = 1024): measured 1.3 % slower
+  constexpr bool kRowDma = FFPA_ROW_DMA != 0 && kRowUniform && !SAFE && kInterleave;  // (burst-mode kernels keep stage_piece)
   constexpr int RPP = kRowUniform ? RB / 1024 : 1;  // pieces per row
   constexpr int KPW = BC / 4;                       // keys staged per wave per tile
   static_assert(!kRowDma || (D % 128 == 0 && KPW * RPP == PPW && BC % 16 == 0), "row DMA layout");
