@@ -51,6 +51,9 @@
 #ifndef FFPA_DMA_STEP
 #define FFPA_DMA_STEP 2  // interleaved mode: one DMA piece every this many MFMAs (ND == 1)
 #endif
+#ifndef FFPA_DMA_STEP_ND2
+#define FFPA_DMA_STEP_ND2 2  // ditto for the split-D kernels (+2 % over 1)
+#endif
 #ifndef FFPA_PV_ORDER
 #define FFPA_PV_ORDER 1  // PV MFMA order: 0 = column-block outer (4 back-to-back MFMAs per accumulator),
 #endif                   //               1 = key-step outer (consecutive MFMAs rotate over all accumulators)
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   constexpr int PF2 = FFPA_PF2;
   constexpr int PPW = BC * D * 2 / 4096;  // 1 KiB DMA pieces per wave per tile
   constexpr bool kInterleave = FFPA_DMA_INTERLEAVE != 0 && (ND <= 2 || FFPA_DMA_INTERLEAVE == 2);  // short-query (ND = 4) tiles keep bursts
-  constexpr int kStep = (ND == 1) ? FFPA_DMA_STEP : 1;  // MFMAs between two DMA pieces
+  constexpr int kStep = (ND == 1) ? FFPA_DMA_STEP : (ND == 2) ? FFPA_DMA_STEP_ND2 : 1;  // MFMAs between two DMA pieces
   static_assert(!kInterleave || PPW * kStep <= (DW / 16) * (BC / 32), "DMA pieces must fit the QK loop");
   // Head dims whose rows are not a whole number of 1 KiB pieces need ~12 VALU instructions per piece for the
   // per-lane source offset (constant division, swizzle).  The offsets are tile-invariant: where the register
