@@ -67,7 +67,7 @@
 #define FFPA_HOIST_MAX_D 448      // ND == 1: hoist the per-lane DMA source offsets up to this head dim
 #endif
 #ifndef FFPA_HOIST_ND2_MAX_D
-#define FFPA_HOIST_ND2_MAX_D 896  // ND == 2 (split-D, burst DMA): up to this head dim (D = 960 spills: -16 %)
+#define FFPA_HOIST_ND2_MAX_D 960  // ND == 2 (split-D): every head dim whose rows are not whole pieces
 #endif
 #ifndef FFPA_ROW_DMA
 #define FFPA_ROW_DMA 1  // D = 512: wave-uniform rows, 3 scalar-only instructions per DMA piece
