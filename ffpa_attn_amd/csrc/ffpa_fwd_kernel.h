@@ -49,7 +49,7 @@
 #define FFPA_DMA_INTERLEAVE 1  // 1: issue LDS-DMA pieces between the MFMAs (2: on the ND = 4 tiles too); 0: bursts after the barriers
 #endif
 #ifndef FFPA_DMA_STEP
-#define FFPA_DMA_STEP 2  // interleaved mode: one DMA piece every this many MFMAs (ND == 1)
+#define FFPA_DMA_STEP 4  // interleaved mode: one DMA piece every this many MFMAs (ND == 1): spreads the tile evenly over the loop
 #endif
 #ifndef FFPA_DMA_STEP_ND2
 #define FFPA_DMA_STEP_ND2 2  // ditto for the split-D kernels (+2 % over 1)
