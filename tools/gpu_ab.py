@@ -8,7 +8,6 @@ process (cdna guide §5.4 rule 24) with HIP events; the report gives median / mi
 variant, plus max |O - O_main| to flag variants that changed results (ablations do, by design).
 """
 import argparse
-import json
 import os
 import sys
 

@@ -11,7 +11,6 @@ bytes each lane's ds_read_b128 / ds_read_b64_tr_b16 touches, and checks that
     (cdna_hip_programming.md §2 "ds_read_b64_tr_b16")
 and reports the worst bank conflict per LDS instruction group (MI355X_MICROARCH.md §LDS).
 """
-import itertools
 import sys
 
 
