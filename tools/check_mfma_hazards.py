@@ -59,7 +59,22 @@ def main():
               bad += 1
               print(f"HAZARD D={d} line {i + 1}: `{p}` writes an operand of `{t}`")
   print(f"{total} asm MFMAs checked over D = {', '.join(dims)}: {bad} preceded by a VALU write to an operand")
-  return 1 if bad else 0
+  # M0 is carried from one LDS-DMA asm statement to the next: nothing outside the asm blocks may write it
+  m0_bad = 0
+  for d in dims:
+    for path in glob.glob(os.path.join(ROOT, f"temps_d{d}", "*gfx950.s")):
+      in_asm = False
+      for i, l in enumerate(open(path).read().split("\n")):
+        t = l.strip()
+        if t.startswith(";;#ASMSTART"):
+          in_asm = True
+        elif t.startswith(";;#ASMEND"):
+          in_asm = False
+        elif not in_asm and re.match(r"^(s_|v_readfirstlane|v_readlane)\S*\s+m0\b", t):
+          m0_bad += 1
+          print(f"M0 D={d} line {i + 1}: `{t}` writes m0 outside the LDS-DMA asm")
+  print(f"M0 writers outside inline asm: {m0_bad}")
+  return 1 if (bad or m0_bad) else 0
 
 
 if __name__ == "__main__":
