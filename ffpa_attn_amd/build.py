@@ -99,9 +99,9 @@ def build(force: bool = False, jobs: int | None = None, save_temps: bool = False
 
 def build_variant(tag: str, defs: list[str], jobs: int | None = None, head_dims: list[int] | None = None) -> str:
   """Developer tool: build ``variants/libffpa_attn_hip_<tag>.so`` with extra ``-D`` tunables (see the
-  FFPA_* macros at the top of csrc/ffpa_fwd_kernel.h) for A/B timing with tools/gpu_ab.py.  Head dims
-  not listed in ``head_dims`` are still compiled (the C-ABI table references all of them) but without
-  the test-only twins."""
+  FFPA_* macros at the top of csrc/ffpa_fwd_kernel.h) for A/B timing with tools/gpu_ab.py.  With
+  ``head_dims`` only those head dims are recompiled with the tunables; the rest of the C-ABI table
+  links the objects of the main build (which must exist), so a variant costs seconds."""
   hipcc = _hipcc()
   odir = os.path.join(OBJ_DIR, f"var_{tag}")
   os.makedirs(odir, exist_ok=True)
@@ -110,11 +110,17 @@ def build_variant(tag: str, defs: list[str], jobs: int | None = None, head_dims:
   lib = os.path.join(vdir, f"libffpa_attn_hip_{tag}.so")
   newest = _sources_mtime()
   stamp = os.path.join(odir, "defs.txt")
-  same_defs = os.path.exists(stamp) and open(stamp).read() == " ".join(defs)
+  key = " ".join(defs) + " | " + ",".join(str(d) for d in (head_dims or HEAD_DIMS))
+  same_defs = os.path.exists(stamp) and open(stamp).read() == key
   if same_defs and os.path.exists(lib) and os.path.getmtime(lib) >= newest:
     return lib
+  if head_dims:
+    build(verbose=False)  # the untouched head dims come from the main build
   tasks, objs = [], []
   for d in HEAD_DIMS:
+    if head_dims and d not in head_dims:
+      objs.append(os.path.join(OBJ_DIR, f"ffpa_fwd_d{d}.o"))
+      continue
     obj = os.path.join(odir, f"ffpa_fwd_d{d}.o")
     objs.append(obj)
     tasks.append([hipcc, *CXXFLAGS, *defs, f"-DFFPA_INST_D={d}", "-c", os.path.join(CSRC, "ffpa_fwd_inst.hip"), "-o", obj])
@@ -125,7 +131,7 @@ def build_variant(tag: str, defs: list[str], jobs: int | None = None, head_dims:
     list(pool.map(_run, tasks))
   _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib, *objs, "-Wl,-rpath,/opt/rocm/lib"])
   with open(stamp, "w") as f:
-    f.write(" ".join(defs))
+    f.write(key)
   return lib
 
 
@@ -135,9 +141,10 @@ def main() -> None:
   ap.add_argument("--jobs", type=int, default=None)
   ap.add_argument("--save-temps", action="store_true")
   ap.add_argument("--variant", nargs="+", metavar=("TAG", "DEF"), help="build variants/libffpa_attn_hip_TAG.so with -D defs")
+  ap.add_argument("--dims", type=lambda s: [int(x) for x in s.split(",")], default=None, help="variant: only recompile these head dims")
   args = ap.parse_args()
   if args.variant:
-    print(build_variant(args.variant[0], [d if d.startswith("-D") else "-D" + d for d in args.variant[1:]], jobs=args.jobs))
+    print(build_variant(args.variant[0], [d if d.startswith("-D") else "-D" + d for d in args.variant[1:]], jobs=args.jobs, head_dims=args.dims))
     return
   print(build(force=args.force, jobs=args.jobs, save_temps=args.save_temps))
 

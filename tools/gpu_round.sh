@@ -68,6 +68,36 @@ ab)
   timeout 600 python tools/gpu_ab.py $AB_ARGS > gpurun_out/ab.log 2>&1; echo "ab exit $?"; cat gpurun_out/ab.log ;;
 ab2)
   timeout 600 python tools/gpu_ab.py $AB2_ARGS > gpurun_out/ab2.log 2>&1; echo "ab2 exit $?"; cat gpurun_out/ab2.log ;;
+wprof)
+  # rocprofv3 kernel stats + PMC passes for one bench workload ($PMC_WORKLOAD, default cfg3); counters beyond the SQ sets are
+  # one pass each, short timeouts: a TCC pass hung on this pool in round 1, so those run last
+  W=${PMC_WORKLOAD:-cfg3}; OUT=gpurun_out/wprof_$W; rm -rf $OUT; mkdir -p $OUT
+  BENCH="python $PWD/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-sdpa"
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT -o trace -- python $OLDPWD/bench.py --workload $W --steps 30 --warmup 5 --no-cpu-baseline --no-sdpa) > $OUT/trace.log 2>&1; echo "wprof $W trace exit $?"
+  pass() { n=$1; shift; (cd /tmp && timeout -s KILL ${PASS_TIMEOUT:-120} rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $OLDPWD/$OUT -o $n -- $BENCH) > $OUT/$n.log 2>&1; echo "wprof $W $n exit $?"; }
+  pass sq1 SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS GRBM_GUI_ACTIVE
+  pass sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM SQ_INSTS_VALU
+  pass sq3 SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_ADDR_CONFLICT SQ_WAVE_CYCLES
+  pass fetch FETCH_SIZE
+  pass write WRITE_SIZE
+  pass tcp1 TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum
+  pass ta1 TA_TA_BUSY_sum TA_BUFFER_READ_LDS_WAVEFRONTS_sum
+  pass ta2 TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
+  pass tcp2 TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_GATE_EN1_sum TCP_RFIFO_STALL_CYCLES_sum
+  if [ "${PMC_TCC:-1}" = 1 ]; then
+    PASS_TIMEOUT=75 pass tcc1 TCC_REQ_sum TCC_READ_sum
+    PASS_TIMEOUT=75 pass tcc2 TCC_HIT_sum TCC_MISS_sum
+    PASS_TIMEOUT=75 pass tcc3 TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum
+  fi
+  python tools/pmc_summary.py $OUT $OUT/summary.json "workload $W" > $OUT/summary.log 2>&1; tail -40 $OUT/summary.log ;;
+probe)
+  mkdir -p tools/probes/bin
+  [ -x tools/probes/bin/stream_probe ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probes/stream_probe.hip -o tools/probes/bin/stream_probe
+  timeout 300 tools/probes/bin/stream_probe > gpurun_out/stream_probe.log 2>&1; echo "probe exit $?"; cat gpurun_out/stream_probe.log ;;
+ab3)
+  timeout 600 python tools/gpu_ab.py $AB3_ARGS > gpurun_out/ab3.log 2>&1; echo "ab3 exit $?"; cat gpurun_out/ab3.log ;;
+rocminfo)
+  (rocminfo | grep -E "Name:|Compute Unit|Max Clock|gfx" | head -40; rocm-smi --showclocks 2>/dev/null | head -30; rocprofv3 -L 2>/dev/null | grep -c "Name") > gpurun_out/rocminfo.log 2>&1 ;;
 esac
 done
 ls -la gpurun_out | head -30

@@ -1,24 +1,44 @@
 """Summarise rocprofv3 --pmc passes of bench.py into the JSON committed under profiles/ (developer tool).
 
-Usage: python tools/pmc_summary.py <dir with *counter_collection.csv> <out.json> [note]
+Usage: python tools/pmc_summary.py <dir with *counter_collection.csv> <out.json> [note] [--kernel SUBSTR]
 
-Per counter: mean over the ffpa_fwd_split_d_kernel dispatches of every pass found.  Derived values follow
-/opt/skills/guides/MI355X_MICROARCH.md: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles,
-SQ_VALU_MFMA_BUSY_CYCLES counts cycles (32 per 32x32x16 MFMA), GRBM_GUI_ACTIVE is summed over the 8 XCDs,
-FETCH_SIZE is KiB and reads half of a wide coalesced stream on gfx950 (corrected x2 here).
+Per counter: mean over the dispatches of the dominant kernel (default: ffpa_fwd_split_d_kernel) of every pass found.
+Derived values follow /opt/skills/guides/MI355X_MICROARCH.md: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count
+quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES counts cycles (32 per 32x32x16 MFMA), GRBM_GUI_ACTIVE is summed over the 8 XCDs,
+FETCH_SIZE is KiB and reads half of a wide coalesced stream on gfx950 (corrected x2 here).  The workload's algorithmic
+bytes / FLOPs and the kernel's L2->LDS operand stream are taken from the bench line in
+<dir>/*.log when one is found, so that request counters can be read as bytes per request.
 """
-import collections, csv, glob, json, os, sys
+import collections, csv, glob, json, os, re, sys
+
+
+def bench_line(src):
+  for path in sorted(glob.glob(os.path.join(src, "*.log"))):
+    for line in open(path, errors="replace"):
+      line = line.strip()
+      if line.startswith("{") and '"roofline"' in line:
+        try:
+          return json.loads(line)
+        except ValueError:
+          pass
+  return None
 
 
 def main():
-  src, out = sys.argv[1], sys.argv[2]
-  note = sys.argv[3] if len(sys.argv) > 3 else ""
+  argv = sys.argv[1:]
+  kernel = "ffpa_fwd_split_d_kernel"
+  if "--kernel" in argv:
+    i = argv.index("--kernel")
+    kernel = argv[i + 1]
+    del argv[i:i + 2]
+  src, out = argv[0], argv[1]
+  note = argv[2] if len(argv) > 2 else ""
   vals = collections.defaultdict(list)
   durs, grbm_durs = [], []
   for path in sorted(glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True)):
     seen = set()
     for r in csv.DictReader(open(path)):
-      if "ffpa_fwd_split_d_kernel" not in r["Kernel_Name"]:
+      if kernel not in r["Kernel_Name"]:
         continue
       vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
       dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
@@ -28,11 +48,12 @@ def main():
         seen.add(r["Dispatch_Id"])
         durs.append(dur)
   res = {
-      "source": "rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sdpa "
-                "(one pass per counter group, tools/gpu_round.sh stages pmcsq + pmcfetch), MI355X. " + note,
+      "source": "rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --workload W --steps 3 --warmup 1 --no-cpu-baseline --no-sdpa "
+                "(one pass per counter group, tools/gpu_round.sh stage wprof), MI355X. " + note,
       "units": "SQ_WAVE_CYCLES/SQ_WAIT_*/SQ_ACTIVE_INST_* are quad-cycles; SQ_VALU_MFMA_BUSY_CYCLES are cycles (=32 x N_mfma); "
-               "GRBM_GUI_ACTIVE is summed over 8 XCDs; FETCH_SIZE in KiB and reads 1/2 of a wide coalesced stream on gfx950 "
-               "(MI355X_MICROARCH.md, HBM section)",
+               "GRBM_GUI_ACTIVE is summed over 8 XCDs; FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE reads 1/2 of a wide coalesced stream on gfx950 "
+               "(MI355X_MICROARCH.md, HBM section); *_sum counters are summed over all instances of the block",
+      "kernel": kernel,
   }
   for k, v in sorted(vals.items()):
     res[k] = {"per_dispatch_mean": sum(v) / len(v), "dispatches": len(v)}
@@ -42,11 +63,19 @@ def main():
     w = m("SQ_WAVE_CYCLES")
     if m("SQ_VALU_MFMA_BUSY_CYCLES"):
       d["mfma_busy_fraction_of_simd_cycles"] = m("SQ_VALU_MFMA_BUSY_CYCLES") / (4 * w)
-    for k, name in (("SQ_WAIT_ANY", "wait_any_frac"), ("SQ_WAIT_INST_ANY", "wait_inst_any_frac"), ("SQ_ACTIVE_INST_ANY", "active_inst_any_frac")):
-      if m(k):
+    for k, name in (("SQ_WAIT_ANY", "wait_any_frac"), ("SQ_WAIT_INST_ANY", "wait_inst_any_frac"), ("SQ_ACTIVE_INST_ANY", "active_inst_any_frac"),
+                    ("SQ_WAIT_INST_LDS", "wait_inst_lds_frac"), ("SQ_ACTIVE_INST_LDS", "active_inst_lds_frac"),
+                    ("SQ_ACTIVE_INST_VMEM", "active_inst_vmem_frac"), ("SQ_ACTIVE_INST_VALU", "active_inst_valu_frac")):
+      if m(k) is not None:
         d[name] = m(k) / w
+    if m("SQ_INST_LEVEL_VMEM") is not None:
+      d["vmem_instructions_in_flight_per_wave_mean"] = m("SQ_INST_LEVEL_VMEM") / w
+    if m("SQ_INST_LEVEL_LDS") is not None:
+      d["lds_instructions_in_flight_per_wave_mean"] = m("SQ_INST_LEVEL_LDS") / w
   if m("SQ_LDS_BANK_CONFLICT") is not None:
     d["lds_bank_conflict_cycles"] = m("SQ_LDS_BANK_CONFLICT")
+  if m("SQ_LDS_IDX_ACTIVE") and m("SQ_BUSY_CYCLES"):
+    d["lds_idx_active_over_sq_busy_cycles"] = m("SQ_LDS_IDX_ACTIVE") / m("SQ_BUSY_CYCLES")
   if m("GRBM_GUI_ACTIVE"):
     d["cycles_per_xcd"] = m("GRBM_GUI_ACTIVE") / 8
     if grbm_durs:  # clock of the pass that carried GRBM_GUI_ACTIVE (profiled passes clock lower than plain runs)
@@ -54,9 +83,28 @@ def main():
   if m("FETCH_SIZE"):
     d["fetch_size_KiB"] = m("FETCH_SIZE")
     d["hbm_read_bytes_corrected_x2"] = m("FETCH_SIZE") * 1024 * 2
-    if m("WRITE_SIZE"):
-      d["hbm_write_bytes"] = m("WRITE_SIZE") * 1024  # KiB; uncalibrated on gfx950 per the guide
-    d["algorithmic_bytes_Q+K+V+O+LSE"] = 4 * 32 * 8192 * 512 * 2 + 32 * 8192 * 4
+  if m("WRITE_SIZE"):
+    d["hbm_write_bytes"] = m("WRITE_SIZE") * 1024  # KiB; uncalibrated on gfx950 per the guide
+  if m("TCC_HIT_sum") is not None and m("TCC_MISS_sum") is not None and m("TCC_HIT_sum") + m("TCC_MISS_sum") > 0:
+    d["l2_hit_rate"] = m("TCC_HIT_sum") / (m("TCC_HIT_sum") + m("TCC_MISS_sum"))
+  line = bench_line(src)
+  if line:
+    wl = line.get("config", {}).get("workload", "")
+    d["workload"] = wl
+    g = re.search(r"B=(\d+) Hq=(\d+) Hkv=(\d+) Nq=(\d+) Nkv=(\d+) D=(\d+)", wl)
+    if g:
+      B, Hq, Hkv, Nq, Nkv, D = (int(x) for x in g.groups())
+      d["algorithmic_bytes_Q+K+V+O+LSE"] = 2 * D * (2 * B * Hq * Nq + 2 * B * Hkv * Nkv) + 4 * B * Hq * Nq
+      br = 128 if D <= 512 else 64
+      stream = B * Hq * ((Nq + br - 1) // br) * 2 * Nkv * D * 2 + B * Hq * Nq * D * 2
+      d["l2_to_lds_operand_stream_bytes"] = stream  # every row tile streams K and V once (+ Q once)
+      if d.get("cycles_per_xcd"):
+        d["operand_stream_bytes_per_clk_per_cu"] = stream / 256 / d["cycles_per_xcd"]
+      for k in ("TCP_TCC_READ_REQ_sum", "TCC_REQ_sum", "TCC_READ_sum", "TA_BUFFER_READ_LDS_WAVEFRONTS_sum"):
+        if m(k):
+          d["operand_stream_bytes_per_" + k] = stream / m(k)
+      if d["kernel_ms_mean_under_pmc"]:
+        d["operand_stream_TBps_under_pmc"] = stream / (d["kernel_ms_mean_under_pmc"] * 1e-3) / 1e12
   res["derived"] = d
   json.dump(res, open(out, "w"), indent=1)
   print(json.dumps(d, indent=1))

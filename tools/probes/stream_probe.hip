@@ -1,0 +1,235 @@
+// Probe (developer tool): what does one gfx950 CU sustain when a one-wave-per-SIMD workgroup mixes the three
+// instruction streams of the attention kernel's KV-tile loop —
+//   * v_mfma_f32_32x32x16_bf16 (16 rotating accumulators = 256 registers, like O^T),
+//   * one ds_read_b128 fragment read per MFMA (the A operand),
+//   * 1 KiB LDS-DMA pieces (buffer_load_dwordx4 ... lds) streaming an L2-resident K/V image into LDS,
+// with and without the per-tile drain + workgroup barrier?  It answers, with numbers a third party can rerun:
+//   (1) the sustained bf16 MFMA rate on random vs zero operands (clock x busy: the DVFS / power ceiling),
+//   (2) the L2 -> LDS delivery ceiling of LDS-DMA per CU as a function of the bytes in flight and of the number of waves,
+//   (3) what a DMA piece costs a wave that is also issuing MFMAs (the "issue bubble"), at the D = 512 mix
+//       (32 pieces per 128 MFMAs) and the D = 1024 mix (32 pieces per 64 MFMAs).
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probes/stream_probe.hip -o tools/probes/bin/stream_probe
+//   tools/probes/bin/stream_probe            (prints one PROBE line per configuration)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <vector>
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+#define LDSAS __attribute__((address_space(3)))
+
+#define CHECK(x)                                                                      \
+  do {                                                                                \
+    hipError_t e_ = (x);                                                              \
+    if (e_ != hipSuccess) {                                                           \
+      fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      exit(1);                                                                        \
+    }                                                                                 \
+  } while (0)
+
+struct Args {
+  const char* src;       // stream image, `region` bytes per XCD slice
+  uint32_t region;       // bytes of the image one XCD's workgroups walk (wraps)
+  int tiles;             // loop iterations
+  const uint32_t* bsrc;  // 64 x 4 dwords: the B operand (random or zero bf16)
+  float* sink;
+  unsigned long long* ticks;  // per wave: s_memtime delta
+};
+
+__device__ __forceinline__ void lds_dma(u32x4 rsrc, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+// NM MFMAs per tile; NDMA 1 KiB pieces per wave per tile, spread evenly over the MFMAs; NREAD: one ds_read_b128 per
+// MFMA feeding its A operand; MODE 0: per tile drain (vmcnt(0)) + s_barrier (the kernel's structure, one tile in flight),
+// MODE 1: no barrier, wait until only the youngest tile's pieces are in flight (vmcnt(NDMA)), MODE 2: never wait
+// inside the loop (vmcnt saturates at 63: the deepest queue the hardware keeps).
+template <int NM, int NDMA, int NREAD, int MODE, bool MFMA_ON>
+__global__ __launch_bounds__(MFMA_ON ? 256 : 1024) void probe(const Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwave = blockDim.x >> 6;
+  const int xcd = blockIdx.x & 7;
+  // every workgroup of an XCD walks the same image in lockstep (like row tiles of one head sharing K/V through L2)
+  const char* base = a.src + (size_t)xcd * a.region;
+  const uint64_t ba = (uint64_t)base;
+  const u32x4 rsrc = {(uint32_t)ba, (uint32_t)(ba >> 32) & 0xffffu, a.region, 0x00020000u};
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(LDSAS char*)smem;
+  const uint32_t per_tile = (uint32_t)(nwave * (NDMA > 0 ? NDMA : 1) * 1024);  // bytes of the image per tile
+  const uint32_t lds_ring = 128u * 1024u;
+  // the fragment-read region: first 64 KiB of LDS, lane-linear (conflict-free b128)
+  for (int i = threadIdx.x; i < 16384; i += blockDim.x) ((LDSAS uint32_t*)smem)[i] = 0x3f803f80u ^ (uint32_t)(i * 2654435761u >> 12 & 0x00ff00ffu);
+  __syncthreads();
+  const u32x4 braw = *(const u32x4*)(a.bsrc + lane * 4);
+  const bf16x8 bfrag = __builtin_bit_cast(bf16x8, braw);
+  f32x16 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = (f32x16)(0.f);
+  const uint32_t voff = (uint32_t)lane * 16u;
+  uint32_t soff = (uint32_t)wave * (uint32_t)(NDMA > 0 ? NDMA : 1) * 1024u;
+  // fragment reads run PF MFMAs ahead of their consumer through a ring of 8 registers sets (the kernel's software pipeline)
+  constexpr int PF = 6;
+  static_assert(NM % 8 == 0, "ring indices must be static across tiles");
+  bf16x8 fr[8];
+  auto frag_read = [&](int n) -> bf16x8 {
+    const u32x4 raw = *(LDSAS const u32x4*)(smem + ((n * 1024) & 0xffff) + lane * 16);
+    return __builtin_bit_cast(bf16x8, raw);
+  };
+#pragma unroll
+  for (int i = 0; i < 8; ++i) fr[i] = bfrag;
+  if constexpr (NREAD > 0) {
+#pragma unroll
+    for (int n = 0; n < PF; ++n) fr[n] = frag_read(n);
+  }
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int t = 0; t < a.tiles; ++t) {
+    constexpr int STEP = NDMA > 0 ? (NM / NDMA > 0 ? NM / NDMA : 1) : 1;
+#pragma unroll
+    for (int n = 0; n < NM; ++n) {
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NREAD > 0) fr[(n + PF) & 7] = frag_read((n + PF) % NM);
+      if constexpr (NDMA > 0) {
+        if (n % STEP == 0 && n / STEP < NDMA) {
+          const int piece = n / STEP;
+          // destination: this wave's slot in a ring over LDS (the fragment reads only need *some* data there)
+          const uint32_t dst = lds0 + (uint32_t)(((wave * NDMA + piece) * 1024) & (lds_ring - 1));
+          lds_dma(rsrc, dst, voff, soff + (uint32_t)piece * 1024u);
+        }
+      }
+      if constexpr (MFMA_ON) acc[n & 15] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[n & 7], bfrag, acc[n & 15], 0, 0, 0);
+      else if constexpr (NREAD > 0) asm volatile("" ::"v"(fr[n & 7]));
+    }
+    if constexpr (NM == 0 && NDMA > 0) {}
+    __builtin_amdgcn_sched_barrier(0);
+    soff += per_tile;
+    if (soff + per_tile > a.region) soff = (uint32_t)wave * (uint32_t)(NDMA > 0 ? NDMA : 1) * 1024u;
+    if constexpr (MODE == 0) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __builtin_amdgcn_s_barrier();
+    } else if constexpr (MODE == 1 && NDMA > 0) {
+      constexpr int W = NDMA > 63 ? 63 : NDMA;
+      __builtin_amdgcn_s_waitcnt(0x0F70 | (W & 15) | ((W >> 4) << 14));
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][7];
+  if (s == 12345.678f) a.sink[0] = s;
+  if (lane == 0) a.ticks[blockIdx.x * nwave + wave] = t1 - t0;
+}
+
+static double g_clock_hint = 0;
+
+template <int NM, int NDMA, int NREAD, int MODE, bool MFMA_ON>
+static void run(const char* name, Args a, int threads, const uint32_t* brand, const uint32_t* bzero, bool zero_ops, int tiles) {
+  auto k = probe<NM, NDMA, NREAD, MODE, MFMA_ON>;
+  const int lds = 144 * 1024;
+  CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  a.tiles = tiles;
+  a.bsrc = zero_ops ? bzero : brand;
+  const int grid = 256;
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, 0, a);  // warm-up (also warms L2 / MALL)
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0));
+  const int reps = 3;
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, 0, a);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  const int nw = threads / 64;
+  std::vector<unsigned long long> ticks(grid * nw);
+  CHECK(hipMemcpy(ticks.data(), a.ticks, ticks.size() * 8, hipMemcpyDeviceToHost));
+  unsigned long long tmax = 0;
+  double tsum = 0;
+  for (auto t : ticks) {
+    tmax = t > tmax ? t : tmax;
+    tsum += (double)t;
+  }
+  const double tavg = tsum / ticks.size();
+  // __builtin_readcyclecounter = s_memtime: a constant-rate counter (100 MHz on gfx950); report it and derive nothing from it
+  const double mfma_per_simd = (double)NM * tiles * (nw / 4.0);
+  const double flops = MFMA_ON ? mfma_per_simd * 4 * 256 * 32768.0 : 0;
+  const double bytes_cu = (double)NDMA * 1024.0 * nw * tiles;
+  printf("PROBE %-34s waves/CU %2d ops=%s tiles %5d | %8.3f ms | MFMA %7.1f TFLOP/s (%5.1f%% of 2500) | LDS-DMA %6.2f TB/s chip = %6.1f GB/s/CU"
+         " | ns per tile %7.1f | memtime ticks avg %.0f max %llu\n",
+         name, nw, zero_ops ? "zero  " : "random", tiles, ms, flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 2.5e15 * 100.0,
+         bytes_cu * 256 / (ms * 1e-3) / 1e12, bytes_cu / (ms * 1e-3) / 1e9, ms * 1e6 / tiles, tavg, tmax);
+  fflush(stdout);
+  (void)g_clock_hint;
+}
+
+int main(int argc, char** argv) {
+  const uint32_t region = 32u << 20;  // K + V of one head at D = 1024, N = 8192: what an XCD's 32 workgroups stream together
+  char* src;
+  CHECK(hipMalloc(&src, (size_t)region * 8));
+  {
+    std::vector<uint16_t> h((size_t)region * 8 / 2);
+    uint32_t s = 12345u;
+    for (auto& x : h) {
+      s = s * 1664525u + 1013904223u;
+      // random bf16 in roughly N(0,1) range: sign + exponent 0x3f/0x3e/0x40 + random mantissa
+      x = (uint16_t)(((s >> 31) << 15) | ((0x3e80 + ((s >> 20) & 0x1ff))));
+    }
+    CHECK(hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  }
+  uint32_t *brand, *bzero;
+  CHECK(hipMalloc(&brand, 1024));
+  CHECK(hipMalloc(&bzero, 1024));
+  {
+    std::vector<uint32_t> h(256);
+    uint32_t s = 777u;
+    for (auto& x : h) {
+      s = s * 1664525u + 1013904223u;
+      const uint32_t lo = ((s >> 31) << 15) | (0x3e80 + ((s >> 20) & 0x1ff));
+      s = s * 1664525u + 1013904223u;
+      const uint32_t hi = ((s >> 31) << 15) | (0x3e80 + ((s >> 20) & 0x1ff));
+      x = lo | (hi << 16);
+    }
+    CHECK(hipMemcpy(brand, h.data(), 1024, hipMemcpyHostToDevice));
+    CHECK(hipMemset(bzero, 0, 1024));
+  }
+  Args a{};
+  a.src = src;
+  a.region = region;
+  CHECK(hipMalloc(&a.sink, 64));
+  CHECK(hipMalloc(&a.ticks, 256 * 16 * 8));
+  const int T = argc > 1 ? atoi(argv[1]) : 4096;
+
+  // (1) bare MFMA stream: the sustained-clock x issue ceiling, random vs zero operands
+  run<64, 0, 0, 2, true>("mfma_only", a, 256, brand, bzero, false, T * 2);
+  run<64, 0, 0, 2, true>("mfma_only", a, 256, brand, bzero, true, T * 2);
+  // (1b) + one conflict-free ds_read_b128 per MFMA (A operand from LDS)
+  run<64, 0, 1, 2, true>("mfma+ldsread", a, 256, brand, bzero, false, T * 2);
+  // (2) LDS-DMA alone: delivery ceiling vs queue depth and waves per CU
+  run<32, 32, 0, 0, false>("dma_only drain+barrier/tile", a, 256, brand, bzero, false, T);
+  run<32, 32, 0, 1, false>("dma_only 32..64 in flight", a, 256, brand, bzero, false, T);
+  run<32, 32, 0, 2, false>("dma_only queue saturated", a, 256, brand, bzero, false, T);
+  run<32, 32, 0, 2, false>("dma_only queue saturated", a, 512, brand, bzero, false, T / 2);
+  run<32, 32, 0, 2, false>("dma_only queue saturated", a, 1024, brand, bzero, false, T / 4);
+  run<16, 16, 0, 1, false>("dma_only 16..32 in flight", a, 256, brand, bzero, false, T * 2);
+  // (2b) fragment reads alone and DMA + fragment reads (LDS port sharing), no MFMA
+  run<64, 0, 1, 2, false>("ldsread_only", a, 256, brand, bzero, false, T * 2);
+  run<64, 32, 1, 1, false>("dma32+ldsread64", a, 256, brand, bzero, false, T);
+  // (3) the kernel's mixes.  D = 1024 tile: 64 MFMAs + 32 pieces per wave; D = 512 tile: 128 MFMAs + 32 pieces
+  run<64, 32, 0, 1, true>("D1024mix mfma64+dma32", a, 256, brand, bzero, false, T);
+  run<64, 32, 1, 1, true>("D1024mix +ldsread", a, 256, brand, bzero, false, T);
+  run<64, 32, 1, 0, true>("D1024mix +ldsread +barrier", a, 256, brand, bzero, false, T);
+  run<64, 16, 1, 1, true>("half the DMA: mfma64+dma16+read", a, 256, brand, bzero, false, T);
+  run<128, 32, 0, 1, true>("D512mix mfma128+dma32", a, 256, brand, bzero, false, T / 2);
+  run<128, 32, 1, 1, true>("D512mix +ldsread", a, 256, brand, bzero, false, T / 2);
+  run<128, 32, 1, 0, true>("D512mix +ldsread +barrier", a, 256, brand, bzero, false, T / 2);
+  return 0;
+}
