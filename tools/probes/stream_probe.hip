@@ -49,7 +49,9 @@ __device__ __forceinline__ void lds_dma(u32x4 rsrc, uint32_t lds_addr, uint32_t 
 // MFMA feeding its A operand; MODE 0: per tile drain (vmcnt(0)) + s_barrier (the kernel's structure, one tile in flight),
 // MODE 1: no barrier, wait until only the youngest tile's pieces are in flight (vmcnt(NDMA)), MODE 2: never wait
 // inside the loop (vmcnt saturates at 63: the deepest queue the hardware keeps).
-template <int NM, int NDMA, int NREAD, int MODE, bool MFMA_ON>
+// SWZ: per-lane source offset of a piece: 0 = lane-linear, 1 = 16-byte slots XOR-permuted inside 256-byte groups (the kernel's K image),
+// 2 = 64-byte quarters permuted inside 256-byte groups (the kernel's V image)
+template <int NM, int NDMA, int NREAD, int MODE, bool MFMA_ON, int SWZ = 0>
 __global__ __launch_bounds__(MFMA_ON ? 256 : 1024) void probe(const Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -99,7 +101,8 @@ __global__ __launch_bounds__(MFMA_ON ? 256 : 1024) void probe(const Args a) {
           const int piece = n / STEP;
           // destination: this wave's slot in a ring over LDS (the fragment reads only need *some* data there)
           const uint32_t dst = lds0 + (uint32_t)(((wave * NDMA + piece) * 1024) & (lds_ring - 1));
-          lds_dma(rsrc, dst, voff, soff + (uint32_t)piece * 1024u);
+          const uint32_t vo = SWZ == 1 ? (uint32_t)((lane ^ (piece & 15)) << 4) : SWZ == 2 ? (uint32_t)((lane ^ ((piece & 3) << 2)) << 4) : voff;
+          lds_dma(rsrc, dst, vo, soff + (uint32_t)piece * 1024u);
         }
       }
       if constexpr (MFMA_ON) acc[n & 15] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[n & 7], bfrag, acc[n & 15], 0, 0, 0);
@@ -128,9 +131,9 @@ __global__ __launch_bounds__(MFMA_ON ? 256 : 1024) void probe(const Args a) {
 
 static double g_clock_hint = 0;
 
-template <int NM, int NDMA, int NREAD, int MODE, bool MFMA_ON>
+template <int NM, int NDMA, int NREAD, int MODE, bool MFMA_ON, int SWZ = 0>
 static void run(const char* name, Args a, int threads, const uint32_t* brand, const uint32_t* bzero, bool zero_ops, int tiles) {
-  auto k = probe<NM, NDMA, NREAD, MODE, MFMA_ON>;
+  auto k = probe<NM, NDMA, NREAD, MODE, MFMA_ON, SWZ>;
   const int lds = 144 * 1024;
   CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   a.tiles = tiles;
@@ -231,5 +234,10 @@ int main(int argc, char** argv) {
   run<128, 32, 0, 1, true>("D512mix mfma128+dma32", a, 256, brand, bzero, false, T / 2);
   run<128, 32, 1, 1, true>("D512mix +ldsread", a, 256, brand, bzero, false, T / 2);
   run<128, 32, 1, 0, true>("D512mix +ldsread +barrier", a, 256, brand, bzero, false, T / 2);
+  // (4) does the bank-conflict swizzle of the SOURCE offsets (lanes of a piece no longer ascend through memory) cost delivery rate?
+  run<32, 32, 0, 1, false, 1>("dma_only, 16-B slot swizzle (K)", a, 256, brand, bzero, false, T);
+  run<32, 32, 0, 1, false, 2>("dma_only, 64-B quarter swizzle (V)", a, 256, brand, bzero, false, T);
+  run<64, 32, 1, 1, true, 1>("D1024mix +ldsread, K swizzle", a, 256, brand, bzero, false, T);
+  run<64, 32, 1, 1, true, 2>("D1024mix +ldsread, V swizzle", a, 256, brand, bzero, false, T);
   return 0;
 }
