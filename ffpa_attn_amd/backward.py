@@ -119,7 +119,28 @@ def _chunked_recompute_backward(grad_out, q, k, v, o, lse, causal, scale, attn_b
   return dq.to(q.dtype), _reduce_groups(dk, k, group), _reduce_groups(dv, v, group), dbias
 
 
-_aten_ok: dict = {}
+# (dtype, head_dim) -> False once the aten op has said it cannot serve that head dim / dtype at all.  Only such
+# capability refusals are remembered; a failure that may be specific to one call (bias layout, alignment, out of
+# memory) falls back for that call only and aten is tried again next time.
+_aten_unsupported: dict = {}
+_CAPABILITY_MARKERS = ("head_dim", "head dim", "headdim", "not supported", "unsupported", "no available kernel", "not implemented", "no kernel")
+
+
+def _is_capability_error(exc: Exception) -> bool:
+  if isinstance(exc, torch.OutOfMemoryError):
+    return False
+  msg = str(exc).lower()
+  if "out of memory" in msg:
+    return False
+  return isinstance(exc, NotImplementedError) or any(m in msg for m in _CAPABILITY_MARKERS)
+
+
+def _additive_bias(attn_bias, dtype):
+  """The additive form of a boolean mask (0 / -inf in ``dtype``, what the reference builds for every call,
+  functional.py:891-898): only the backward implementations need it."""
+  if attn_bias is not None and attn_bias.dtype in (torch.bool, torch.uint8):
+    return torch.zeros_like(attn_bias, dtype=dtype).masked_fill_(attn_bias == 0, float("-inf"))
+  return attn_bias
 
 
 def attention_backward(grad_out, q, k, v, o, lse, *, causal: bool, scale: float, attn_bias=None,
@@ -127,18 +148,21 @@ def attention_backward(grad_out, q, k, v, o, lse, *, causal: bool, scale: float,
   """``(dq, dk, dv, d_attn_bias)`` for the forward ``o, lse = ffpa(q, k, v)``.  ``force`` = ``"aten"`` /
   ``"recompute"`` pins one implementation (tests); otherwise aten first, recompute if it refuses."""
   key = (q.dtype, q.size(-1))
+  attn_bias = _additive_bias(attn_bias, q.dtype)
   if dropout is not None:
     # the fused aten backward would regenerate a DIFFERENT mask on ROCm: rebuild the kernel's own (philox.py)
     return _chunked_recompute_backward(grad_out, q, k, v, o, lse, causal, scale, attn_bias, want_bias_grad, dropout=dropout)
-  if force != "recompute" and _aten_ok.get(key, True):
+  if force != "recompute" and not _aten_unsupported.get(key, False):
     try:
-      out = _aten_efficient_backward(grad_out, q, k, v, o, lse, causal, scale, attn_bias, want_bias_grad)
-      _aten_ok[key] = True
-      return out
+      return _aten_efficient_backward(grad_out, q, k, v, o, lse, causal, scale, attn_bias, want_bias_grad)
     except (RuntimeError, NotImplementedError) as e:
       if force == "aten":
         raise
-      _aten_ok[key] = False
-      warning_once(f"ffpa_attn_func: aten efficient-attention backward unavailable for D={q.size(-1)} "
-                   f"({str(e).splitlines()[0][:120]}); using the chunked recompute backward")
+      if isinstance(e, torch.OutOfMemoryError) or "out of memory" in str(e).lower():
+        raise  # the recompute path needs more memory, not less
+      if _is_capability_error(e):
+        _aten_unsupported[key] = True
+      warning_once(f"ffpa_attn_func: aten efficient-attention backward refused D={q.size(-1)} "
+                   f"({str(e).splitlines()[0][:120]}); using the chunked recompute backward"
+                   + (" from now on" if _aten_unsupported.get(key) else " for this call"))
   return _chunked_recompute_backward(grad_out, q, k, v, o, lse, causal, scale, attn_bias, want_bias_grad)

@@ -7,7 +7,7 @@ object per head dim (compiled in parallel) + the C-ABI object, linked into a
 shared library that stays next to the sources (it travels to the GPU box with the
 repo snapshot; a JIT cache would not).
 
-Usage:  python -m ffpa_attn_amd.build [--force] [--jobs N] [--save-temps]
+Usage:  python -m ffpa_attn_amd.build [--force] [--jobs N] [--no-test-lib]
 """
 
 from __future__ import annotations
@@ -26,10 +26,11 @@ INCLUDE = os.path.join(REPO, "include")
 OBJ_DIR = os.path.join(CSRC, "build")
 LIB_NAME = "libffpa_attn_hip.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
+TEST_LIB_PATH = os.path.join(HERE, "libffpa_attn_hip_test.so")
 
 HEAD_DIMS = [64 * i for i in range(1, 17)]
-# head dims that also get the test-only "safe path" kernel (register staging +
-# scalar V gather) used to bisect LDS-DMA / transpose-read problems on hardware.
+# head dims whose test-only "safe path" twin kernel (register staging + scalar V gather, used to bisect
+# LDS-DMA / transpose-read problems on hardware) is built into libffpa_attn_hip_test.so — never into the product library.
 SAFE_HEAD_DIMS = {64, 128, 320, 512, 640, 1024}
 
 ARCH = "gfx950"
@@ -64,36 +65,88 @@ def _run(cmd: list[str], cwd: str | None = None) -> None:
     raise RuntimeError("command failed: " + " ".join(cmd) + "\n" + proc.stdout + proc.stderr)
 
 
-def build(force: bool = False, jobs: int | None = None, save_temps: bool = False, verbose: bool = True) -> str:
-  """Compile every kernel for gfx950 and link ``libffpa_attn_hip.so``; returns its path."""
+def _check_isa(verbose: bool) -> None:
+  """The S^T MFMAs and the LDS-DMA are inline asm (no compiler hazard padding, M0 written behind the compiler's
+  back): prove on the ISA just generated that no VALU write lands in an MFMA operand's hazard window and that
+  nothing outside the DMA asm touches M0 (tools/check_mfma_hazards.py).  A violation fails the build."""
+  import importlib.util
+
+  path = os.path.join(REPO, "tools", "check_mfma_hazards.py")
+  if not os.path.exists(path):  # an installed copy without the developer tools
+    return
+  spec = importlib.util.spec_from_file_location("check_mfma_hazards", path)
+  chk = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(chk)
+  import contextlib, io
+
+  old_argv, sys.argv = sys.argv, ["check_mfma_hazards"]
+  buf = io.StringIO()
+  try:
+    with contextlib.redirect_stdout(buf):
+      rc = chk.main()
+  finally:
+    sys.argv = old_argv
+  if verbose or rc != 0:
+    print(buf.getvalue(), end="", flush=True)
+  if rc != 0:
+    raise RuntimeError("ISA check failed: an inline-asm MFMA operand is written inside its hazard window, or M0 is written outside the DMA asm")
+
+
+def build(force: bool = False, jobs: int | None = None, save_temps: bool = True, verbose: bool = True, test_lib: bool = True) -> str:
+  """Compile every kernel for gfx950, link ``libffpa_attn_hip.so`` (product kernels only) and — with ``test_lib`` —
+  ``libffpa_attn_hip_test.so`` (the same library plus the register-staged SAFE twins behind FFPA_FLAG_DEBUG_SAFE_PATH,
+  used by the GPU tests to bisect the LDS-DMA / transpose-read data path); returns the product library's path.
+  The generated ISA is kept (``-save-temps``) and checked for the hazards the inline asm hides from the compiler."""
   newest = _sources_mtime()
-  if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
+  have = os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest
+  have_test = not test_lib or (os.path.exists(TEST_LIB_PATH) and os.path.getmtime(TEST_LIB_PATH) >= newest)
+  if not force and have and have_test:
     return LIB_PATH
   hipcc = _hipcc()
   os.makedirs(OBJ_DIR, exist_ok=True)
   jobs = jobs or max(1, (os.cpu_count() or 4))
   tasks: list[tuple[str, list[str], str | None]] = []
   objs: list[str] = []
+  test_objs: list[str] = []
   extra = ["-save-temps"] if save_temps else []  # temps land in the compile's cwd (one dir per TU)
+
+  def stale(obj: str) -> bool:
+    return force or not os.path.exists(obj) or os.path.getmtime(obj) < newest
+
   for d in HEAD_DIMS:
     obj = os.path.join(OBJ_DIR, f"ffpa_fwd_d{d}.o")
     objs.append(obj)
-    if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
-      defs = [f"-DFFPA_INST_D={d}"] + (["-DFFPA_INST_SAFE=1"] if d in SAFE_HEAD_DIMS else [])
+    if stale(obj):
       tmp = os.path.join(OBJ_DIR, f"temps_d{d}")
       os.makedirs(tmp, exist_ok=True)
-      tasks.append((obj, [hipcc, *CXXFLAGS, *extra, *defs, "-c", os.path.join(CSRC, "ffpa_fwd_inst.hip"), "-o", obj], tmp))
+      tasks.append((obj, [hipcc, *CXXFLAGS, *extra, f"-DFFPA_INST_D={d}", "-c", os.path.join(CSRC, "ffpa_fwd_inst.hip"), "-o", obj], tmp))
+    if test_lib and d in SAFE_HEAD_DIMS:
+      tobj = os.path.join(OBJ_DIR, f"ffpa_fwd_d{d}_test.o")
+      test_objs.append(tobj)
+      if stale(tobj):
+        tasks.append((tobj, [hipcc, *CXXFLAGS, f"-DFFPA_INST_D={d}", "-DFFPA_INST_SAFE=1", "-c", os.path.join(CSRC, "ffpa_fwd_inst.hip"), "-o", tobj], None))
+    elif test_lib:
+      test_objs.append(obj)
   capi = os.path.join(OBJ_DIR, "ffpa_capi.o")
   objs.append(capi)
-  if force or not os.path.exists(capi) or os.path.getmtime(capi) < newest:
+  if stale(capi):
     tasks.append((capi, [hipcc, *CXXFLAGS, "-c", os.path.join(CSRC, "ffpa_capi.hip"), "-o", capi], None))
+  if test_lib:
+    tcapi = os.path.join(OBJ_DIR, "ffpa_capi_test.o")
+    test_objs.append(tcapi)
+    if stale(tcapi):
+      tasks.append((tcapi, [hipcc, *CXXFLAGS, "-DFFPA_INST_SAFE=1", "-c", os.path.join(CSRC, "ffpa_capi.hip"), "-o", tcapi], None))
   if verbose:
     print(f"[ffpa_attn_amd.build] compiling {len(tasks)} objects for {ARCH} with {jobs} jobs", flush=True)
   with ThreadPoolExecutor(max_workers=jobs) as pool:
     list(pool.map(lambda t: _run(t[1], cwd=t[2]), tasks))
+  if save_temps:
+    _check_isa(verbose)
   _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH, *objs, "-Wl,-rpath,/opt/rocm/lib"])
+  if test_lib:
+    _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", TEST_LIB_PATH, *test_objs, "-Wl,-rpath,/opt/rocm/lib"])
   if verbose:
-    print(f"[ffpa_attn_amd.build] linked {LIB_PATH}", flush=True)
+    print(f"[ffpa_attn_amd.build] linked {LIB_PATH}" + (f" and {TEST_LIB_PATH}" if test_lib else ""), flush=True)
   return LIB_PATH
 
 
@@ -139,14 +192,15 @@ def main() -> None:
   ap = argparse.ArgumentParser(description=__doc__)
   ap.add_argument("--force", action="store_true")
   ap.add_argument("--jobs", type=int, default=None)
-  ap.add_argument("--save-temps", action="store_true")
+  ap.add_argument("--save-temps", action="store_true", help="(default now: the generated ISA is always kept and checked)")
+  ap.add_argument("--no-test-lib", action="store_true", help="skip libffpa_attn_hip_test.so (the SAFE twin kernels the GPU tests use)")
   ap.add_argument("--variant", nargs="+", metavar=("TAG", "DEF"), help="build variants/libffpa_attn_hip_TAG.so with -D defs")
   ap.add_argument("--dims", type=lambda s: [int(x) for x in s.split(",")], default=None, help="variant: only recompile these head dims")
   args = ap.parse_args()
   if args.variant:
     print(build_variant(args.variant[0], [d if d.startswith("-D") else "-D" + d for d in args.variant[1:]], jobs=args.jobs, head_dims=args.dims))
     return
-  print(build(force=args.force, jobs=args.jobs, save_temps=args.save_temps))
+  print(build(force=args.force, jobs=args.jobs, test_lib=not args.no_test_lib))
 
 
 if __name__ == "__main__":

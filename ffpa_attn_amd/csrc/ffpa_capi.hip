@@ -3,13 +3,15 @@
 // Host-side argument validation mirrors what the reference checks in its launcher
 // (csrc/cuffpa/launch.cuh:79-129: shapes, bias layout; ffpa_api.cc:193-197: dtype)
 // but reports through status codes instead of TORCH_CHECK, allocates nothing and
-// keeps no global mutable state (the reference's process-global backend hint,
+// keeps no global mutable state beyond write-once per-device caches (the reference's process-global backend hint,
 // csrc/cuffpa/backend.h:16-27, has no equivalent here: every choice is per call).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+
+#include <atomic>
 
 #include "ffpa_attn.h"
 #include "ffpa_fwd_kernel.h"
@@ -54,16 +56,43 @@ struct Plan {
   size_t ws_bytes;
 };
 
+// Per-device facts, looked up once per device and process (write-once caches: the only state the library keeps;
+// std::atomic so that concurrent first calls from several host threads are race-free).
+constexpr int kMaxDevices = 64;
+std::atomic<int> g_cu_count[kMaxDevices];  // 0 = not looked up yet
+std::atomic<int> g_arch_ok[kMaxDevices];   // 0 = not looked up yet, 1 = gfx950, 2 = something else
+
 int device_cu_count() {
-  static int cached[64] = {};
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-  if (cached[dev] == 0) {
-    int n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
+  int n = g_cu_count[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cached[dev] = n;
+    g_cu_count[dev].store(n, std::memory_order_relaxed);
   }
-  return cached[dev];
+  return n;
+}
+
+// FFPA_OK iff the current device is a gfx950 (the only target of the embedded code objects)
+int check_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(FFPA_ERR_NO_DEVICE, "no current HIP device");
+  }
+  int ok = (dev >= 0 && dev < kMaxDevices) ? g_arch_ok[dev].load(std::memory_order_relaxed) : 0;
+  if (ok == 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(FFPA_ERR_NO_DEVICE, "hipGetDeviceProperties(%d) failed", dev);
+    }
+    ok = strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 2;
+    if (dev >= 0 && dev < kMaxDevices) g_arch_ok[dev].store(ok, std::memory_order_relaxed);
+    if (ok == 2) return fail(FFPA_ERR_NO_DEVICE, "device %d is %s: this library holds gfx950 (MI355X) kernels only", dev, prop.gcnArchName);
+  }
+  if (ok == 2) return fail(FFPA_ERR_NO_DEVICE, "device %d is not a gfx950 (MI355X)", dev);
+  return FFPA_OK;
 }
 
 Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
@@ -168,7 +197,7 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   if ((p->bias == nullptr) != (p->bias_dtype == FFPA_BIAS_NONE))
     return fail(FFPA_ERR_BAD_DTYPE, "bias pointer and bias_dtype disagree (ptr %s, dtype %d)",
                 p->bias ? "set" : "NULL", p->bias_dtype);
-  if (p->bias_dtype < FFPA_BIAS_NONE || p->bias_dtype > FFPA_BIAS_FP32)
+  if (p->bias_dtype < FFPA_BIAS_NONE || p->bias_dtype > FFPA_BIAS_BOOL8)
     return fail(FFPA_ERR_BAD_DTYPE, "unknown bias_dtype %d", p->bias_dtype);
   for (int i = 0; i < 4; ++i)
     if (p->bias && p->bias_stride[i] < 0) return fail(FFPA_ERR_BAD_STRIDE, "bias stride[%d] is negative", i);
@@ -186,6 +215,7 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
     return fail(FFPA_ERR_BAD_STRIDE, "kv_bounds strides must be >= 0");
   if (p->workspace != nullptr && !aligned16(p->workspace))
     return fail(FFPA_ERR_MISALIGNED, "workspace must be 16-byte aligned");
+  if ((rc = check_device()) != FFPA_OK) return rc;
   const Plan pl = make_plan(p, de);
   const int lds = pl.lds;
   const int64_t nqt = pl.nqt;
@@ -229,8 +259,8 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   if (p->bias != nullptr && p->bias_stride[3] == 1) {
     // vector bias loads (16 consecutive keys per lane): W elements per load need W-element aligned base and
     // batch / head / row strides.  16-byte loads when possible (W = 8 for 16-bit, 4 for fp32), else 8-byte.
-    const int esz = p->bias_dtype == FFPA_BIAS_FP32 ? 4 : 2;
-    for (int w : {16 / esz, 4}) {
+    const int esz = p->bias_dtype == FFPA_BIAS_FP32 ? 4 : p->bias_dtype == FFPA_BIAS_BOOL8 ? 1 : 2;
+    for (int w : {16 / esz, esz == 1 ? 16 : 4}) {  // boolean masks: 16-byte loads or byte loads
       bool ok = (reinterpret_cast<uintptr_t>(p->bias) % (size_t)(w * esz)) == 0;
       for (int i = 0; i < 3; ++i) ok = ok && (p->bias_stride[i] % w == 0);
       if (ok) {
@@ -279,7 +309,7 @@ size_t ffpa_attn_fwd_workspace_bytes(const ffpa_fwd_params* params) {
 int ffpa_attn_mask_kv_bounds(const void* bias, int bias_dtype, const int64_t bias_stride[4], int bb, int hb, int nq,
                              int nkv, int32_t* out, void* stream) {
   if (bias == nullptr || out == nullptr || bias_stride == nullptr) return fail(FFPA_ERR_NULL_POINTER, "bias / out / strides are NULL");
-  if (bias_dtype < FFPA_BIAS_FP16 || bias_dtype > FFPA_BIAS_FP32) return fail(FFPA_ERR_BAD_DTYPE, "unknown bias_dtype %d", bias_dtype);
+  if (bias_dtype < FFPA_BIAS_FP16 || bias_dtype > FFPA_BIAS_BOOL8) return fail(FFPA_ERR_BAD_DTYPE, "unknown bias_dtype %d", bias_dtype);
   if (bb <= 0 || hb <= 0 || nq <= 0 || nkv <= 0) return fail(FFPA_ERR_BAD_SHAPE, "non-positive mask dimension");
   for (int i = 0; i < 4; ++i)
     if (bias_stride[i] < 0) return fail(FFPA_ERR_BAD_STRIDE, "bias stride[%d] is negative", i);
@@ -294,16 +324,18 @@ int ffpa_attn_mask_kv_bounds(const void* bias, int bias_dtype, const int64_t bia
   const int64_t grid = (int64_t)bb * hb * m.nblk;
   if (grid > 0x7fffffffLL) return fail(FFPA_ERR_BAD_SHAPE, "mask of %lld row blocks is too large", (long long)grid);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int w = bias_dtype == FFPA_BIAS_FP32 ? 4 : 8;  // elements per 16-byte load
+  const int w = bias_dtype == FFPA_BIAS_FP32 ? 4 : bias_dtype == FFPA_BIAS_BOOL8 ? 16 : 8;  // elements per 16-byte load
   const bool vec = bias_stride[3] == 1 && nkv % w == 0 && reinterpret_cast<uintptr_t>(bias) % 16 == 0 &&
                    bias_stride[0] % w == 0 && bias_stride[1] % w == 0 && bias_stride[2] % w == 0;
   const dim3 g((unsigned)grid), blk(256);
   if (vec) {
     if (bias_dtype == FFPA_BIAS_FP32) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_vec_kernel<float>, g, blk, 0, st, m);
+    else if (bias_dtype == FFPA_BIAS_BOOL8) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_vec_kernel<uint8_t>, g, blk, 0, st, m);
     else if (bias_dtype == FFPA_BIAS_BF16) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_vec_kernel<__bf16>, g, blk, 0, st, m);
     else hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_vec_kernel<_Float16>, g, blk, 0, st, m);
   } else {
     if (bias_dtype == FFPA_BIAS_FP32) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_kernel<float>, g, blk, 0, st, m);
+    else if (bias_dtype == FFPA_BIAS_BOOL8) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_kernel<uint8_t>, g, blk, 0, st, m);
     else if (bias_dtype == FFPA_BIAS_BF16) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_kernel<__bf16>, g, blk, 0, st, m);
     else hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_kernel<_Float16>, g, blk, 0, st, m);
   }
@@ -334,7 +366,11 @@ int ffpa_attn_query(int what) {
     case FFPA_QUERY_HEAD_DIM_MULTIPLE: return 64;
     case FFPA_QUERY_FP16_AVAILABLE: return 1;
     case FFPA_QUERY_DROPOUT_AVAILABLE: return 1;
-    case FFPA_QUERY_DEBUG_KERNELS: return 1;
+#ifdef FFPA_INST_SAFE
+    case FFPA_QUERY_DEBUG_KERNELS: return 1;  // the test-only twin library
+#else
+    case FFPA_QUERY_DEBUG_KERNELS: return 0;
+#endif
     default: return -1;
   }
 }

@@ -2,6 +2,8 @@
 // -DFFPA_INST_D=<D>); keeps hipcc invocations small and parallel.  The reference
 // generates one TU per (dtype, acc, headdim, stage) from env.py:455-521; here the
 // only axis is the head dim (bf16 + fp16 in the same TU).
+#include <atomic>
+
 #include "ffpa_fwd_kernel.h"
 #include "ffpa_launch.h"
 
@@ -16,15 +18,15 @@ static int launch_one(const FwdArgs& a, hipStream_t stream) {
   constexpr int BC = (ND == 1) ? ((D <= FFPA_BC128_MAX_D) ? 128 : 64) : 32;
   constexpr int LDS = 2 * BC * D * 2 + (ND > 1 ? 4 * 4096 : 0);
   auto kern = ffpa_fwd_split_d_kernel<T, D, ND, SAFE, DROP>;
-  static bool attr_done[64] = {};
+  static std::atomic<bool> attr_done[64];  // write-once per device (setting the attribute twice is harmless)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return -1;
-  if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+  if (dev < 0 || dev >= 64 || !attr_done[dev].load(std::memory_order_acquire)) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
       (void)hipGetLastError();
       return -2;
     }
-    attr_done[dev] = true;
+    if (dev >= 0 && dev < 64) attr_done[dev].store(true, std::memory_order_release);
   }
   const unsigned grid = (unsigned)a.B * (unsigned)a.Hq * (unsigned)a.nqt * (unsigned)a.nsplit;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, stream, a);

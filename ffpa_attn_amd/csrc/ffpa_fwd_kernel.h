@@ -157,7 +157,7 @@ struct FwdArgs {
   int B, Hq, Hkv, Nq, Nkv;
   int group;          // Hq / Hkv
   int nqt;            // row tiles per (batch, head)
-  int bias_dtype;     // 0 none, 1 fp16, 2 bf16, 3 fp32
+  int bias_dtype;     // 0 none, 1 fp16, 2 bf16, 3 fp32 (additive), 4 bool8 (byte != 0 <=> key visible, else -inf)
   int causal;
   int causal_offset;  // visible iff key <= row + causal_offset
   float scale_log2;   // softmax_scale * log2(e)
@@ -175,7 +175,7 @@ struct FwdArgs {
   // optional [first, end) visible-key bounds per block of 32 query rows (see ffpa_fwd_params.kv_bounds)
   const int* kv_bounds;
   int64_t s_bounds[2];  // element strides: batch, head (0 = broadcast)
-  int bias_vec;  // W in {0, 4, 8}: bias key stride is 1 and base / strides are W-element aligned -> W-wide loads
+  int bias_vec;  // W in {0, 4, 8, 16}: bias key stride is 1 and base / strides are W-element aligned -> W-wide loads (16: bool8 masks)
   // dropout (prefill.cuh:398-546): keep iff u > p, u from Philox4x32-10 at the logical element offset
   float dropout_p;          // 0 = off
   float keep_scale;         // 1 / (1 - p)
@@ -449,6 +449,25 @@ __device__ __forceinline__ void add_bias_block_vec(float (&x)[16], const void* b
   for (int i = 0; i < 16 / W; ++i)
 #pragma unroll
     for (int t = 0; t < W; ++t) x[W * i + t] += (float)raw[i][t] * 1.4426950408889634f;
+}
+
+// Boolean mask (FFPA_BIAS_BOOL8: one byte per score, non-zero = visible): what the reference's host turns into an additive
+// 0 / -inf tensor in q.dtype before the launch (functional.py:891-898) is applied here straight from the caller's bytes —
+// x += 0 or x = -inf are the same scores, without the mask-sized temporary.  16 consecutive keys per lane and key block.
+__device__ __forceinline__ void apply_bool_block(float (&x)[16], const void* mask, int64_t row_off, int64_t stride_key, int key_base, int nkv) {
+  const uint8_t* mp = (const uint8_t*)mask + row_off;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int key = key_base + r;
+    key = key < nkv ? key : nkv - 1;
+    if (mp[key * stride_key] == 0) x[r] = -INFINITY;
+  }
+}
+__device__ __forceinline__ void apply_bool_block_vec(float (&x)[16], const void* mask, int64_t row_off, int key_base) {
+  const u32x4 raw = *(const u32x4*)((const uint8_t*)mask + row_off + key_base);
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if (((raw[r >> 2] >> (8 * (r & 3))) & 0xffu) == 0u) x[r] = -INFINITY;
 }
 
 // DROP selects the dropout-capable build of the kernel: kept out of the default instantiation because its
@@ -751,7 +770,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
     // the K(j+1) burst, so that their latency overlaps both; consumed in the score-modifier section below.
     constexpr bool kBiasEarly = FFPA_BIAS_EARLY != 0 && !SAFE && ND > 1;  // measured: -10 % at D = 1024; D <= 512 has no registers to spare (+2 %)
     u32x4 braw[kBiasEarly ? 2 * NKB : 1];
-    const bool bias_early = kBiasEarly && a.bias_vec == 8 && k0 + BC <= a.Nkv;
+    const bool bias_early = kBiasEarly && a.bias_vec == 8 && a.bias_dtype != 4 && k0 + BC <= a.Nkv;
     if constexpr (kBiasEarly) {
       if (bias_early) {
         const char* bp = (const char*)a.bias + 2 * (b * a.sbias[0] + hq * a.sbias[1] + (int64_t)qrow_c * a.sbias[2] + k0 + 16 * h);
@@ -893,6 +912,11 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
         const int kbase = k0 + kb * 32 + 16 * h;
+        if (a.bias_dtype == 4) {
+          if (a.bias_vec == 16 && k0 + BC <= a.Nkv) apply_bool_block_vec(x[kb], a.bias, brow, kbase);
+          else apply_bool_block(x[kb], a.bias, brow, a.sbias[3], kbase, a.Nkv);
+          continue;
+        }
         if (a.bias_vec && k0 + BC <= a.Nkv) {  // full tile, unit key stride, rows aligned to the vector width
           if (a.bias_dtype == 3) add_bias_block_vec<float, 4>(x[kb], a.bias, brow, kbase);
           else if (a.bias_vec == 8) {
@@ -1162,6 +1186,9 @@ template <>
 __device__ __forceinline__ bool mask_elem_visible<__bf16>(__bf16 x) { return __builtin_bit_cast(uint16_t, x) != (uint16_t)0xff80u; }
 template <>
 __device__ __forceinline__ bool mask_elem_visible<_Float16>(_Float16 x) { return __builtin_bit_cast(uint16_t, x) != (uint16_t)0xfc00u; }
+
+template <>
+__device__ __forceinline__ bool mask_elem_visible<uint8_t>(uint8_t x) { return x != 0; }
 
 struct MaskBoundsArgs {
   const void* bias;

@@ -163,8 +163,8 @@ class FFPAAttnMeta:
     return self
 
   def normalize_attn_mask(self, query, key, attn_mask):
-    """SDPA ``attn_mask`` -> compact 4-D additive bias (functional.py:851-911): bool masks become
-    0 / -inf in ``query.dtype``; 2-D / 3-D masks become broadcasting 4-D views."""
+    """SDPA ``attn_mask`` -> compact 4-D bias / mask (functional.py:851-911): validated like the reference; 2-D / 3-D
+    masks become broadcasting 4-D views; bool masks stay bool (the kernel applies them)."""
     if attn_mask is None:
       return None
     if attn_mask.device != query.device:
@@ -188,10 +188,10 @@ class FFPAAttnMeta:
       raise ValueError(f"ffpa_attn_func: attn_mask batch dimension must be 1 or {B}, got {attn_mask.size(0)}")
     if attn_mask.dim() == 4 and attn_mask.size(1) not in (1, Hq):
       raise ValueError(f"ffpa_attn_func: 4-D attn_mask head dimension must be 1 or {Hq}, got {attn_mask.size(1)}")
-    if attn_mask.dtype == torch.bool:
-      bias = torch.zeros_like(attn_mask, dtype=query.dtype).masked_fill_(~attn_mask, float("-inf"))
-    else:
-      bias = attn_mask
+    # Boolean masks reach the kernel as they are (FFPA_BIAS_BOOL8: one byte per score, False = -inf).  The reference
+    # materialises a 0 / -inf tensor in query.dtype here (functional.py:891-898) — two extra kernels and a mask-sized
+    # allocation per call; the scores are the same.  backward.py builds the additive form only if a gradient needs it.
+    bias = attn_mask
     if bias.dim() == 2:
       bias = bias.view(1, 1, bias.size(0), bias.size(1))
     elif bias.dim() == 3:

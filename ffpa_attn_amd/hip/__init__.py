@@ -29,8 +29,9 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_PKG, "libffpa_attn_hip.so")
+TEST_LIB_PATH = os.path.join(_PKG, "libffpa_attn_hip_test.so")  # product kernels + the register-staged SAFE twins (tests only)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # enum ffpa_status (include/ffpa_attn.h)
 _STATUS_EXC = {
@@ -49,7 +50,8 @@ _STATUS_EXC = {
 FLAG_DEBUG_SAFE_PATH = 0x1
 FLAG_NO_XCD_REMAP = 0x2
 
-_BIAS_DTYPE = {torch.float16: 1, torch.bfloat16: 2, torch.float32: 3}
+# enum ffpa_bias_dtype: additive fp16 / bf16 / fp32, or a boolean mask read as bytes (non-zero = visible)
+_BIAS_DTYPE = {torch.float16: 1, torch.bfloat16: 2, torch.float32: 3, torch.bool: 4, torch.uint8: 4}
 _DTYPE = {torch.bfloat16: 0, torch.float16: 1}
 
 
@@ -96,6 +98,7 @@ class FfpaFwdParams(ctypes.Structure):
 
 
 _lib = None
+_debug_lib = None
 _lib_lock = threading.Lock()
 
 EXPORTS = (
@@ -153,6 +156,16 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     return lib
 
 
+def load_debug_library() -> ctypes.CDLL:
+  """The test-only twin of the library (``libffpa_attn_hip_test.so``: the same kernels plus the register-staged
+  SAFE variants behind ``FLAG_DEBUG_SAFE_PATH``).  The product library does not carry them
+  (``ffpa_attn_query(FFPA_QUERY_DEBUG_KERNELS) == 0``)."""
+  global _debug_lib
+  if _debug_lib is None:
+    _debug_lib = load_library(TEST_LIB_PATH)
+  return _debug_lib
+
+
 def library_available() -> bool:
   return os.path.exists(LIB_PATH)
 
@@ -184,7 +197,7 @@ def _dense_rows(t: torch.Tensor) -> torch.Tensor:
 
 
 def mask_kv_bounds(attn_bias: torch.Tensor, nq: int, nkv: int) -> torch.Tensor:
-  """Visible-key bounds of an additive mask for the kernel's tile clipping: int32 ``[Bb, Hb, ceil(Nq/32), 2]`` holding,
+  """Visible-key bounds of an additive (-inf = hidden) or boolean (False = hidden) mask for the kernel's tile clipping: int32 ``[Bb, Hb, ceil(Nq/32), 2]`` holding,
   per block of 32 query rows, ``[first, end)`` such that every key outside is -inf for every row of the block
   (``{Nkv, 0}`` for a block without any visible key).  On the GPU: one fused pass of the library over the mask
   (``ffpa_attn_mask_kv_bounds``); elsewhere (tests) the same thing in torch ops."""
@@ -200,7 +213,7 @@ def mask_kv_bounds(attn_bias: torch.Tensor, nq: int, nkv: int) -> torch.Tensor:
     if rc != 0:
       raise _STATUS_EXC.get(rc, RuntimeError)(lib.ffpa_attn_last_error().decode())
     return out
-  vis = ~torch.isneginf(attn_bias)                                     # [Bb, Hb, Nq|1, Nkv|1]
+  vis = attn_bias.ne(0) if attn_bias.dtype in (torch.bool, torch.uint8) else ~torch.isneginf(attn_bias)  # [Bb, Hb, Nq|1, Nkv|1]
   col_any = vis.expand(bb, hb, nq, nkv)
   pad = nblk * 32 - nq
   if pad:
@@ -263,9 +276,24 @@ def forward(
     raise NotImplementedError(
       f"ffpa_attn::_fwd_hip has no implementation for device '{q.device.type}' (the HIP kernel needs a GPU tensor)"
     )
-  lib = load_library()
+  lib = load_debug_library() if (flags & FLAG_DEBUG_SAFE_PATH) else load_library()
   if q.dtype not in _DTYPE or k.dtype != q.dtype or v.dtype != q.dtype:
     raise TypeError(f"ffpa_attn::_fwd_hip only supports fp16/bf16 q/k/v of one dtype, got {q.dtype}, {k.dtype}, {v.dtype}")
+  # The kernel takes raw pointers: everything its buffer descriptors assume is checked here, as the reference's
+  # launcher does with TORCH_CHECK (csrc/cuffpa/launch.cuh:79-129) — the public API validates earlier, but the
+  # registered op can be called directly.
+  if q.dim() != 4 or k.dim() != 4 or v.dim() != 4:
+    raise ValueError("ffpa_attn::_fwd_hip: q/k/v must be 4-D [B, H, N, D] tensors")
+  if k.shape != v.shape:
+    raise ValueError(f"ffpa_attn::_fwd_hip: key and value must have the same shape, got {tuple(k.shape)} and {tuple(v.shape)}")
+  if k.size(0) != q.size(0) or k.size(3) != q.size(3):
+    raise ValueError(f"ffpa_attn::_fwd_hip: q {tuple(q.shape)} and k/v {tuple(k.shape)} must share batch size and head dim")
+  if k.size(1) == 0 or q.size(1) % k.size(1) != 0:
+    raise ValueError(f"ffpa_attn::_fwd_hip: query num_heads ({q.size(1)}) must be a multiple of key/value num_heads ({k.size(1)})")
+  if k.device != q.device or v.device != q.device:
+    raise ValueError(f"ffpa_attn::_fwd_hip: q/k/v must be on one device, got {q.device}, {k.device}, {v.device}")
+  if attn_bias is not None and attn_bias.numel() > 0 and attn_bias.device != q.device:
+    raise ValueError(f"ffpa_attn::_fwd_hip: attn_bias must be on q's device, got {attn_bias.device} and {q.device}")
   B, Hq, Nq, D = q.shape
   _, Hkv, Nkv, _ = k.shape
   out_shape = (B, Hq, Nq)
@@ -301,7 +329,7 @@ def forward(
     if attn_bias.dim() != 4:
       raise ValueError("attn_bias must be 4-D [B|1, Hq|1, Nq|1, Nkv|1]")
     if attn_bias.dtype not in _BIAS_DTYPE:
-      raise TypeError(f"attn_bias dtype must be fp16/bf16/fp32, got {attn_bias.dtype}")
+      raise TypeError(f"attn_bias dtype must be fp16/bf16/fp32 (additive) or bool (mask), got {attn_bias.dtype}")
     full = (B, Hq, Nq, Nkv)
     strides = []
     for dim in range(4):
@@ -358,7 +386,7 @@ def forward(
     o = o.view(*out_shape, Dp)
     lse = lse.view(out_shape) if lse is not None else None
   if Dp != D:
-    o = o[..., :D]
+    o = o[..., :D].contiguous()  # the op's contract (and its fake impl): a dense [B, Hq, Nq, D]
   return o, lse
 
 

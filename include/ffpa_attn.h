@@ -11,7 +11,8 @@
  *
  * Every entry point is extern "C", takes plain pointers / sizes / strides and
  * a hipStream_t passed as void*.  No torch types, no allocation, no device
- * synchronisation, no global mutable state: the caller owns every buffer and
+ * synchronisation, no global mutable state beyond write-once per-device caches (CU count, arch check,
+ * kernel attributes; std::atomic): the caller owns every buffer and
  * picks the stream.  Each function cites the reference interface it replaces.
  */
 #ifndef FFPA_ATTN_H_
@@ -24,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FFPA_ATTN_ABI_VERSION 2
+#define FFPA_ATTN_ABI_VERSION 3
 
 /* status codes (0 == success).  The Python host maps them onto the exception
  * classes the reference raises (TORCH_CHECK -> RuntimeError,
@@ -39,19 +40,23 @@ enum ffpa_status {
   FFPA_ERR_MISALIGNED = 6,        /* base pointer not 16-byte aligned                   */
   FFPA_ERR_UNSUPPORTED = 7,       /* feature not built (e.g. dropout)                   */
   FFPA_ERR_LAUNCH = 8,            /* hipGetLastError() after the launch                 */
-  FFPA_ERR_NO_DEVICE = 9,         /* current device is not gfx950                       */
+  FFPA_ERR_NO_DEVICE = 9,         /* no current device, or it is not a gfx950           */
   FFPA_ERR_BAD_ABI = 10           /* struct_size / abi_version mismatch                 */
 };
 
 enum ffpa_dtype { FFPA_DTYPE_BF16 = 0, FFPA_DTYPE_FP16 = 1 };
 
 /* attn_bias element type.  Same codes as the reference's native launcher
- * (csrc/cuffpa/native/launch.cuh:279-281): 0 none, 1 fp16, 2 bf16, 3 fp32. */
+ * (csrc/cuffpa/native/launch.cuh:279-281): 0 none, 1 fp16, 2 bf16, 3 fp32 — plus 4: a boolean mask, one byte per
+ * score, non-zero = the key is visible, zero = score -inf.  The reference's host materialises that as a 0 / -inf
+ * tensor in q's dtype before every launch (src/ffpa_attn/functional.py:891-898); here the kernel reads the caller's
+ * bytes (torch.bool storage) directly: same scores, no mask-sized temporary, 1 byte per element of mask traffic. */
 enum ffpa_bias_dtype {
   FFPA_BIAS_NONE = 0,
   FFPA_BIAS_FP16 = 1,
   FFPA_BIAS_BF16 = 2,
-  FFPA_BIAS_FP32 = 3
+  FFPA_BIAS_FP32 = 3,
+  FFPA_BIAS_BOOL8 = 4
 };
 
 /* ffpa_fwd_params.flags */
@@ -65,11 +70,11 @@ enum ffpa_bias_dtype {
  *
  *   q  [B, Hq,  Nq,  D]     k, v [B, Hkv, Nkv, D]     o [B, Hq, Nq, D]
  *   lse  [B, Hq, Nq] fp32 contiguous, natural log, may be NULL (cuda/__init__.py:102-112)
- *   bias [B|1, Hq|1, Nq|1, Nkv|1] additive, stride 0 on broadcast dims
- *        (native/launch.cuh:277-290); NULL <=> bias_dtype == FFPA_BIAS_NONE.
+ *   bias [B|1, Hq|1, Nq|1, Nkv|1] additive (fp16 / bf16 / fp32) or boolean (FFPA_BIAS_BOOL8), stride 0 on
+ *        broadcast dims (native/launch.cuh:277-290); NULL <=> bias_dtype == FFPA_BIAS_NONE.
  *
  * Score = scale * q.k + bias ; masked iff (causal && key > row + causal_offset)
- * or key >= Nkv.  causal_offset = Nkv - Nq reproduces the reference's
+ * or key >= Nkv or (boolean mask && mask byte == 0).  causal_offset = Nkv - Nq reproduces the reference's
  * tail-aligned causal mask (split_d.cuh:222-228); 0 reproduces PyTorch SDPA's
  * top-left alignment (SURVEY.md §8 "config-4 semantic trap").
  */
@@ -161,7 +166,8 @@ size_t ffpa_attn_fwd_workspace_bytes(const ffpa_fwd_params* params);
 int ffpa_attn_fwd_plan(const ffpa_fwd_params* params, int out[4]);
 
 /*
- * Visible-key bounds of an additive mask, in the layout ffpa_fwd_params.kv_bounds expects: one fused pass over
+ * Visible-key bounds of an additive (-inf = hidden) or boolean (0 = hidden) mask, in the layout
+ * ffpa_fwd_params.kv_bounds expects: one fused pass over
  * `bias` ([bb, hb, nq|1, nkv|1] with element strides bias_stride, 0 = broadcast; enum ffpa_bias_dtype) writes
  * out[bb][hb][ceil(nq / 32)][2] (int32, contiguous) on `stream`.  Returns an ffpa_status.
  */
@@ -178,7 +184,8 @@ enum ffpa_query {
   FFPA_QUERY_HEAD_DIM_MULTIPLE = 4, /* 64: other D are zero-padded by the host */
   FFPA_QUERY_FP16_AVAILABLE = 5,
   FFPA_QUERY_DROPOUT_AVAILABLE = 6,
-  FFPA_QUERY_DEBUG_KERNELS = 7    /* 1 if FFPA_FLAG_DEBUG_SAFE_PATH kernels are built */
+  FFPA_QUERY_DEBUG_KERNELS = 7    /* 1 if FFPA_FLAG_DEBUG_SAFE_PATH kernels are built: only in the test-only twin library
+                                     libffpa_attn_hip_test.so, never in the product library */
 };
 int ffpa_attn_query(int what);
 

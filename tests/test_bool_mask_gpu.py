@@ -1,0 +1,184 @@
+"""Boolean masks on the kernel's own path (FFPA_BIAS_BOOL8) and the boundary hygiene of C-ABI v3 (`pytest -m gpu`).
+
+The reference turns every boolean ``attn_mask`` into a 0 / -inf tensor in q's dtype on the host before the launch
+(src/ffpa_attn/functional.py:891-898) and adds it as a bias (native/prefill.cuh:556-658).  Here the kernel reads the
+caller's bytes: ``score + 0`` / ``score + (-inf)`` and ``keep score`` / ``-inf`` are the same numbers, so every result
+must be BIT-identical to the additive form — that is what these tests pin, next to SDPA and the oracle.
+"""
+
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_fwd_gpu import _check_vs_oracle, _close, _f32, _rand, _within_north_star, hip  # noqa: F401  (fixture + helpers)
+
+pytestmark = pytest.mark.gpu
+
+
+def _additive(mask, dtype):
+  return torch.zeros(mask.shape, dtype=dtype, device=mask.device).masked_fill(~mask, float("-inf"))
+
+
+def _same_bits(a, b):
+  return torch.equal(torch.nan_to_num(a.float(), nan=7.0), torch.nan_to_num(b.float(), nan=7.0))
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 600), (2, 1, 1, 600), (1, 4, 1, 600), (1, 1, 520, 600), (2, 4, 520, 600), (2, 1, 520, 1),
+                                   (1, 4, 520, 600)])
+@pytest.mark.parametrize("D", [320, 512, 1024])
+def test_bool_mask_is_bit_identical_to_its_additive_form(hip, shape, D):
+  B, H, Nq, Nkv = 2, 4, 520, 600  # Nkv = 600: the last tile is ragged (byte loads), 600 % 16 != 0 rows are unaligned
+  q, k, v = _rand((B, H, Nq, D), seed=51), _rand((B, H, Nkv, D), seed=52), _rand((B, H, Nkv, D), seed=53)
+  g = torch.Generator(device="cuda").manual_seed(sum(shape) * 7 + D)
+  mask = torch.rand(shape, device="cuda", generator=g) > 0.25
+  mask[..., 0] = True
+  ob, lb = hip.forward(q, k, v, mask, False, D ** -0.5, kv_bounds=False)
+  oa, la = hip.forward(q, k, v, _additive(mask, q.dtype), False, D ** -0.5, kv_bounds=False)
+  assert torch.equal(ob, oa) and torch.equal(lb, la), f"{shape} D={D}"
+  _close(ob, F.scaled_dot_product_attention(q, k, v, attn_mask=mask), q.dtype, f"sdpa {shape}")
+  if D == 320:
+    _check_vs_oracle(ob, lb, q, k, v, bias=_f32(_additive(mask, torch.float32)), name=f"bool {shape}")
+
+
+def test_bool_mask_vector_and_byte_paths_tails_and_nan_rows(hip):
+  """16-byte mask loads need unit key stride and 16-byte aligned rows; everything else walks bytes.  Fully masked rows
+  give NaN (SDPA semantics), a row whose first tiles are hidden stays finite."""
+  D = 512
+  for Nq, Nkv in ((513, 1024), (513, 1000), (130, 777)):  # aligned rows / ragged last tile / unaligned rows
+    q, k, v = _rand((1, 2, Nq, D), seed=61), _rand((1, 2, Nkv, D), seed=62), _rand((1, 2, Nkv, D), seed=63)
+    mask = torch.rand(1, 2, Nq, Nkv, device="cuda") > 0.3
+    mask[0, 0, 5, :] = False
+    mask[0, :, 9, :128] = False
+    mask[0, 1, 100, 1:] = False
+    mask[0, 1, 100, 0] = True
+    ob, lb = hip.forward(q, k, v, mask, False, D ** -0.5, kv_bounds=False)
+    oa, la = hip.forward(q, k, v, _additive(mask, q.dtype), False, D ** -0.5, kv_bounds=False)
+    assert _same_bits(ob, oa) and _same_bits(lb, la), (Nq, Nkv)
+    assert torch.isnan(ob[0, 0, 5]).all() and torch.isfinite(ob[:, :, 9]).all()
+    assert torch.equal(ob[0, 1, 100], v[0, 1, 0])
+    # a strided view (key stride 2) and a uint8 mask take the byte path / the same enum
+    wide = torch.zeros(1, 2, Nq, 2 * Nkv, dtype=torch.bool, device="cuda")
+    wide[..., ::2] = mask
+    os_, _ = hip.forward(q, k, v, wide[..., ::2], False, D ** -0.5, kv_bounds=False)
+    ou, _ = hip.forward(q, k, v, mask.to(torch.uint8), False, D ** -0.5, kv_bounds=False)
+    assert _same_bits(os_, oa) and _same_bits(ou, oa)
+
+
+def test_bool_mask_bounds_match_the_additive_scan_and_clip_the_same_tiles(hip):
+  B, Hq, Hkv, Nq, Nkv, D = 2, 4, 2, 700, 1500, 512
+  q, k, v = _rand((B, Hq, Nq, D), seed=501), _rand((B, Hkv, Nkv, D), seed=502), _rand((B, Hkv, Nkv, D), seed=503)
+  rows, cols = torch.arange(Nq, device="cuda")[:, None], torch.arange(Nkv, device="cuda")[None, :]
+  masks = {
+      "causal": cols <= rows + (Nkv - Nq),
+      "window": (cols <= rows + 400) & (cols >= rows + 100),
+      "padding": (cols < 900).expand(Nq, Nkv),
+      "holes": ((cols <= rows + 300) & (rows >= 64)),
+  }
+  for name, m in masks.items():
+    m4 = m.view(1, 1, Nq, Nkv).contiguous()
+    bb = hip.mask_kv_bounds(m4, Nq, Nkv)
+    ba = hip.mask_kv_bounds(_additive(m4, q.dtype), Nq, Nkv)
+    assert torch.equal(bb, ba), name
+    o_all, l_all = hip.forward(q, k, v, m4, False, D ** -0.5, kv_bounds=False)
+    o_clip, l_clip = hip.forward(q, k, v, m4, False, D ** -0.5, kv_bounds=True)
+    assert _same_bits(o_all, o_clip) and _same_bits(l_all, l_clip), name
+  # the unaligned / strided scan kernel
+  odd = (cols <= rows + 300)[:, :1499].contiguous().view(1, 1, Nq, 1499)
+  assert torch.equal(hip.mask_kv_bounds(odd, Nq, 1499), hip.mask_kv_bounds(_additive(odd, q.dtype), Nq, 1499))
+
+
+def test_public_api_bool_mask_allocates_nothing_mask_sized(hip):
+  """ffpa_attn_func(attn_mask=<bool>) hands the mask's own bytes to the kernel: no 0 / -inf temporary (the reference
+  allocates 2 B per mask element per call).  Peak memory during the call stays below the mask's own size."""
+  from ffpa_attn_amd import ffpa_attn_func
+
+  B, H, N, D = 1, 4, 8192, 512  # 256 row tiles: a full launch (no KV-split scratch); O + LSE = 32 MiB
+  q, k, v = _rand((B, H, N, D), seed=71), _rand((B, H, N, D), seed=72), _rand((B, H, N, D), seed=73)
+  mask = torch.ones(N, N, dtype=torch.bool, device="cuda").tril()  # 64 MiB; its additive bf16 form would be 128 MiB
+  ffpa_attn_func(q, k, v, attn_mask=mask)  # warm-up (workspace caches, library load)
+  torch.cuda.synchronize()
+  torch.cuda.reset_peak_memory_stats()
+  base = torch.cuda.memory_allocated()
+  out = ffpa_attn_func(q, k, v, attn_mask=mask)
+  torch.cuda.synchronize()
+  extra = torch.cuda.max_memory_allocated() - base
+  assert extra < mask.numel(), f"{extra} bytes allocated during the call, the mask itself is {mask.numel()}"
+  ref = F.scaled_dot_product_attention(q, k, v, is_causal=True)
+  _within_north_star(out, ref)
+
+
+def test_baseline_config_4_through_the_public_api(hip):
+  """BASELINE configs[3] as specified: B=2 Hq=32/Hkv=8 Nq=8192 Nkv=2048 D=320, GQA cross-attention with a causal mask —
+  `ffpa_attn_func(attn_mask=tril, enable_gqa=True)` at full size (bool mask -> kernel bytes + automatic tile clipping),
+  against SDPA's own top-left `is_causal` and against the op-level causal_offset=0 form."""
+  from ffpa_attn_amd import ffpa_attn_func
+
+  torch.manual_seed(0)
+  q = torch.randn(2, 32, 8192, 320, dtype=torch.bfloat16, device="cuda")
+  k = torch.randn(2, 8, 2048, 320, dtype=torch.bfloat16, device="cuda")
+  v = torch.randn(2, 8, 2048, 320, dtype=torch.bfloat16, device="cuda")
+  mask = torch.ones(8192, 2048, dtype=torch.bool, device="cuda").tril()
+  out = ffpa_attn_func(q, k, v, attn_mask=mask, enable_gqa=True)
+  ref = F.scaled_dot_product_attention(q, k, v, is_causal=True, enable_gqa=True)
+  _within_north_star(out, ref)
+  o0, _ = hip.forward(q, k, v, None, True, 320 ** -0.5, causal_offset=0)
+  assert (out.float() - o0.float()).abs().max().item() <= 4e-3
+  # the additive form of the same mask gives the same bits
+  oa = ffpa_attn_func(q, k, v, attn_mask=_additive(mask, q.dtype), enable_gqa=True)
+  assert torch.equal(out, oa)
+
+
+def test_backward_through_a_bool_mask(hip):
+  from ffpa_attn_amd import ffpa_attn_func
+
+  B, H, N, D = 1, 2, 640, 320
+  mask = torch.rand(1, 1, N, N, device="cuda") > 0.2
+  mask[..., 0] = True
+  qs = [_rand((B, H, N, D), seed=s).requires_grad_(True) for s in (81, 82, 83)]
+  rs = [t.detach().clone().requires_grad_(True) for t in qs]
+  go = _rand((B, H, N, D), seed=84)
+  ffpa_attn_func(*qs, attn_mask=mask).backward(go)
+  s = (rs[0].float() @ rs[1].float().transpose(-1, -2)) * D ** -0.5
+  (torch.softmax(s.masked_fill(~mask, float("-inf")), -1) @ rs[2].float()).to(go.dtype).backward(go)
+  for a, b, n in zip(qs, rs, "qkv"):
+    assert (a.grad.float() - b.grad.float()).abs().max().item() <= 3e-2 * max(1.0, b.grad.float().abs().max().item()), n
+
+
+# ----------------------------------------------------------------------------- boundary hygiene (C-ABI v3)
+def test_debug_kernels_live_only_in_the_test_library(hip):
+  prod, dbg = hip.load_library(), hip.load_debug_library()
+  assert prod.ffpa_attn_query(7) == 0 and dbg.ffpa_attn_query(7) == 1
+  # FFPA_FLAG_DEBUG_SAFE_PATH against the product library: a clean status, not a launch
+  q, k, v = _rand((1, 1, 64, 512)), _rand((1, 1, 64, 512), seed=1), _rand((1, 1, 64, 512), seed=2)
+  o = torch.empty_like(q)
+  p = hip.FfpaFwdParams()
+  p.struct_size, p.abi_version = ctypes.sizeof(hip.FfpaFwdParams), hip.ABI_VERSION
+  p.q, p.k, p.v, p.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
+  p.batch, p.heads_q, p.heads_kv, p.seqlen_q, p.seqlen_kv, p.head_dim = 1, 1, 1, 64, 64, 512
+  for name, t in (("q_stride", q), ("k_stride", k), ("v_stride", v), ("o_stride", o)):
+    getattr(p, name)[:] = list(t.stride()[:3])
+  p.softmax_scale, p.rescale_threshold, p.flags = 0.05, -1.0, hip.FLAG_DEBUG_SAFE_PATH
+  rc = prod.ffpa_attn_fwd(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+  assert rc == 7, prod.ffpa_attn_last_error()  # FFPA_ERR_UNSUPPORTED
+  assert dbg.ffpa_attn_fwd(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+  torch.cuda.synchronize()
+
+
+def test_direct_op_calls_are_validated_before_pointers_reach_the_kernel(hip):
+  q, k, v = _rand((1, 4, 64, 512)), _rand((1, 2, 640, 512), seed=1), _rand((1, 2, 640, 512), seed=2)
+  with pytest.raises(ValueError, match="same shape"):
+    hip.forward(q, k, v[:, :, :600], None, False, 0.05)
+  with pytest.raises(ValueError, match="batch size and head dim"):
+    hip.forward(q, k[..., :256], v[..., :256], None, False, 0.05)
+  with pytest.raises(ValueError, match="multiple of key/value num_heads"):
+    hip.forward(q[:, :3], k, v, None, False, 0.05)
+  with pytest.raises(ValueError, match="batch size and head dim"):
+    hip.forward(q, k.expand(2, -1, -1, -1), v.expand(2, -1, -1, -1), None, False, 0.05)
+  with pytest.raises(ValueError, match="on q's device"):
+    hip.forward(q, k, v, torch.zeros(1, 1, 64, 640), False, 0.05)
+  # the op's real and fake implementations agree on layout for a padded head dim
+  qq, kk, vv = _rand((1, 2, 520, 264)), _rand((1, 2, 520, 264), seed=1), _rand((1, 2, 520, 264), seed=2)
+  o, _ = hip.forward(qq, kk, vv, None, False, 264 ** -0.5)
+  assert o.is_contiguous() and o.shape == qq.shape

@@ -70,10 +70,12 @@ def test_mask_normalisation_shapes():
   q = torch.empty(2, 4, 600, 320, dtype=torch.bfloat16)
   k = torch.empty(2, 4, 700, 320, dtype=torch.bfloat16)
   m = FFPAAttnMeta.from_kwargs()
-  b = m.normalize_attn_mask(q, k, torch.ones(600, 700, dtype=torch.bool))
-  assert b.shape == (1, 1, 600, 700) and b.dtype == torch.bfloat16 and float(b.max()) == 0.0
+  # boolean masks keep their bytes (the kernel reads them: FFPA_BIAS_BOOL8) — no 0 / -inf temporary
+  mask = torch.ones(600, 700, dtype=torch.bool)
+  b = m.normalize_attn_mask(q, k, mask)
+  assert b.shape == (1, 1, 600, 700) and b.dtype == torch.bool and b.data_ptr() == mask.data_ptr()
   b = m.normalize_attn_mask(q, k, torch.zeros(2, 1, 700, dtype=torch.bool))
-  assert b.shape == (2, 1, 1, 700) and torch.isinf(b).all()
+  assert b.shape == (2, 1, 1, 700) and not b.any()
   b = m.normalize_attn_mask(q, k, torch.zeros(2, 4, 1, 700))
   assert b.dtype == torch.float32 and b.shape == (2, 4, 1, 700)
 
@@ -86,6 +88,7 @@ def test_mask_kv_bounds_per_32_row_block():
   m[40:70] = False
   bias = torch.zeros(1, 1, Nq, Nkv).masked_fill(~m, float("-inf"))
   assert mask_kv_bounds(bias, Nq, Nkv)[0, 0].tolist() == [[0, 82], [0, 90], [0, 146], [0, 150]]
+  assert torch.equal(mask_kv_bounds(m.view(1, 1, Nq, Nkv), Nq, Nkv), mask_kv_bounds(bias, Nq, Nkv))  # bool masks: False = hidden
   win = torch.ones(64, 512, dtype=torch.bool).tril(diagonal=200).triu(diagonal=150)       # sliding window
   b = mask_kv_bounds(torch.zeros(2, 1, 64, 512).masked_fill(~win, float("-inf")), 64, 512)
   assert b.shape == (2, 1, 2, 2) and b.dtype == torch.int32
