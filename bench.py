@@ -1,24 +1,32 @@
-"""bench.py — the reference's headline benchmark on MI355X.
+"""bench.py — the reference's headline benchmark (and its whole forward case matrix) on MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py                                  # BASELINE metric: cfg2 = B1 H32 N8192 D512 bf16, 1 GPU
+    python bench.py --workload cfg3 | cfg4_mask | cfg4_offset0 | cross | gqa | attn_mask | dropout | non_aligned | decode | ...
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N [--workload cfg5] [--gather]
 
-Metric (BASELINE.json): attention forward TFLOPS + max-abs-err vs SDPA, bf16 B=1 H=32 N=8192 D=512.
-One "step" = one pass of the hot path (ffpa_attn_func -> ffpa_attn::_fwd_hip -> C-ABI -> HIP kernel)
-over one synthetic batch already resident in HBM.  FLOPs = 4*B*Hq*D*valid_pairs, the reference's own
-model (src/ffpa_attn/cli/_flops.py:37-53); inputs are seed-0 randn, q then k then v
-(src/ffpa_attn/cli/_runner_fwd.py:344-347).
+One "step" = one pass of the hot path (ffpa_attn_func -> ffpa_attn::_fwd_hip -> C-ABI -> HIP kernel) over one
+synthetic batch already resident in HBM.  FLOPs = 4*B*Hq*D*valid_pairs, the reference's own model
+(src/ffpa_attn/cli/_flops.py:37-53); inputs are seed-0 randn, q then k then v (cli/_runner_fwd.py:344-347).
+The workloads are BASELINE.json's configs plus the reference bench's cases at its defaults (H=32, N=8192, D=512:
+self / cross 1024xN / decode / gqa H/4 / causal / attn-mask [1,1,1,Nkv]*0.25 / dropout 0.1 / non-aligned N-1 with
+H/4 heads; cli/_runner_fwd.py:599-672).
 
-N > 1: the path is embarrassingly parallel over (batch, kv-head) (ffpa_attn_amd/sharding.py), so every
-rank owns one BASELINE-shaped batch element (config 5 is B=8 over 8 GPUs): weak scaling, no data-path
-collective; `--gather` adds the RCCL all_gather of O that a caller wanting the full tensor on every
-rank would pay.  Timing: barrier + synchronize on both sides of exactly K steps, max over ranks.
+N > 1: the path is embarrassingly parallel over (batch, kv-head) units (ffpa_attn_amd/sharding.py) and every rank's
+block is BORN sharded (per-unit seeds, nothing replicated), no data-path collective:
+  * default workloads: every rank owns one workload-shaped batch element -> "scaling": "weak" (8 x cfg2 is config 5);
+  * --workload cfg5: the fixed global problem B=8 H=32 N=8192 D=512 (256 units) is split over the ranks ->
+    "scaling": "strong"; per-rank TFLOPS are listed next to the aggregate;
+  * --gather adds the one RCCL all_gather_into_tensor of O a caller wanting the full tensor on every rank would pay.
+Timing: barrier + synchronize on both sides of exactly K steps, max over ranks.
 
-Rank 0 prints ONE JSON line.  `roofline` is the dominant (only) kernel against the dense bf16 MFMA
-peak, with the kernel's average launch duration measured by HIP events on the launch stream;
-`cpu_baseline` is the reference's CPU path for this op (PyTorch CPU SDPA — the reference has no CPU
-kernel, ffpa_attn_interface.py:165-176) timed on this box's host cores on a bounded sample.
+Rank 0 prints ONE JSON line.  `roofline` is the dominant kernel against the dense bf16 MFMA peak (HBM peak for the
+decode workload), its average launch duration measured by HIP events on the launch stream; `roofline.traffic` is the
+HBM bytes per launch from the committed rocprofv3 PMC pass of the same command (`traffic_source` names the file; null
+when no such pass is committed) — a profile artefact, not a measurement of this very run.  `cpu_baseline` is the
+reference's CPU path for this op (PyTorch CPU SDPA — the reference has no CPU kernel, ffpa_attn_interface.py:165-176)
+timed on this box's host cores on a bounded sample.  `ref_protocol` repeats the reference bench's own timing protocol
+(2 warm-ups, 10 iterations, perf_counter + synchronize: cli/_runner_fwd.py:84-103).
 """
 
 from __future__ import annotations
@@ -39,50 +47,116 @@ from ffpa_attn_amd import ffpa_attn_func  # noqa: E402
 from ffpa_attn_amd.flops import attention_fwd_flops  # noqa: E402
 
 # Dense bf16 MFMA peak of one MI355X, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters":
-# 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz ~= 2.5 PFLOP/s (measured 2495 TF with 32x32x16).
+# 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz ~= 2.5 PFLOP/s (measured 2470-2495 TF with 32x32x16 on zero operands).
 MFMA_BF16_PEAK_TFLOPS = 2500.0
+HBM_PEAK_GBPS = 8000.0  # same guide: 8 TB/s spec (about 6.3 TB/s achievable)
+
+BASELINE_METRIC = "attention fwd TFLOPS + max-abs-err vs SDPA, bf16 B=1 H=32 N=8192 D=512"
+
+
+def _w(B, Hq, Hkv, Nq, Nkv, D, **kw):
+  d = dict(B=B, Hq=Hq, Hkv=Hkv, Nq=Nq, Nkv=Nkv, D=D, causal=False, mask=None, dropout=0.0, via="api", bound="mfma", note="")
+  d.update(kw)
+  return d
+
 
 WORKLOADS = {
-  # name: (B, Hq, Hkv, Nq, Nkv, D, causal)
-  "cfg2": (1, 32, 32, 8192, 8192, 512, False),   # BASELINE configs[1] — the headline shape
-  "cfg3": (1, 32, 32, 8192, 8192, 1024, False),  # configs[2]
-  "cfg2_causal": (1, 32, 32, 8192, 8192, 512, True),
-  "cfg4": (2, 32, 8, 8192, 2048, 320, False),    # configs[3] without the mask (see tests for parity)
+  # BASELINE.json configs
+  "cfg2": _w(1, 32, 32, 8192, 8192, 512, note="BASELINE configs[1], the headline shape"),
+  "cfg3": _w(1, 32, 32, 8192, 8192, 1024, note="BASELINE configs[2], max head dim"),
+  "cfg4_mask": _w(2, 32, 8, 8192, 2048, 320, mask="tril_bool", note="BASELINE configs[3] as specified: GQA cross-attention + causal mask, "
+                  "ffpa_attn_func(attn_mask=tril(ones(Nq,Nkv,bool)), enable_gqa=True); FLOPs count the visible pairs"),
+  "cfg4_offset0": _w(2, 32, 8, 8192, 2048, 320, causal=True, via="op_offset0", note="configs[3] through the op's structured top-left causal mask "
+                     "(causal_offset=0 = SDPA's is_causal for Nq > Nkv)"),
+  "cfg4_nomask": _w(2, 32, 8, 8192, 2048, 320, note="configs[3] shape without the mask (dense FLOPs)"),
+  "cfg5": _w(8, 32, 32, 8192, 8192, 512, note="BASELINE configs[4]: the global B=8 problem split over the ranks (strong scaling)"),
+  # the reference bench's case matrix at its defaults (cli/_runner_fwd.py:599-672)
+  "cfg2_causal": _w(1, 32, 32, 8192, 8192, 512, causal=True, note="reference bench case 'causal'"),
+  "cross": _w(1, 32, 32, 1024, 8192, 512, note="reference bench case 'cross-attn' (Nq = 1024)"),
+  "gqa": _w(1, 32, 8, 8192, 8192, 512, note="reference bench case 'gqa' (Hkv = H/4)"),
+  "attn_mask": _w(1, 32, 32, 8192, 8192, 512, mask="key_bias", note="reference bench case 'attn-mask': additive [1,1,1,Nkv] randn*0.25 (cli/_runner_fwd.py:75-81)"),
+  "dropout": _w(1, 32, 32, 8192, 8192, 512, dropout=0.1, note="reference bench case 'dropout' (p = 0.1, in-kernel Philox)"),
+  "non_aligned": _w(1, 8, 8, 8191, 8191, 512, note="reference bench case 'non-aligned' (N-1, H/4 heads)"),
+  "decode": _w(1, 32, 32, 1, 8192, 512, bound="hbm", note="reference bench case 'decode-attn' (Nq = 1: split-KV kernel + LSE merge; HBM-bound)"),
 }
 
 
+def metric_name(name: str, w: dict) -> str:
+  if name == "cfg2":
+    return BASELINE_METRIC
+  heads = f"H={w['Hq']}" if w["Hq"] == w["Hkv"] else f"Hq={w['Hq']}/Hkv={w['Hkv']}"
+  seq = f"N={w['Nq']}" if w["Nq"] == w["Nkv"] else f"Nq={w['Nq']} Nkv={w['Nkv']}"
+  tags = [t for t in ("causal" if w["causal"] else "", {"tril_bool": "bool causal mask", "key_bias": "additive key bias"}.get(w["mask"], ""),
+                      f"dropout {w['dropout']}" if w["dropout"] else "") if t]
+  return f"attention fwd TFLOPS + max-abs-err vs SDPA, bf16 B={w['B']} {heads} {seq} D={w['D']}" + (" " + " + ".join(tags) if tags else "") + f" [{name}]"
+
+
+def valid_pairs_flops(w: dict, B: int) -> int:
+  causal = w["causal"] or w["mask"] == "tril_bool"
+  if w["via"] == "op_offset0" or w["mask"] == "tril_bool":  # top-left alignment: key <= row
+    pairs = sum(min(w["Nkv"], r + 1) for r in range(w["Nq"]))
+    return 4 * B * w["Hq"] * w["D"] * pairs
+  return attention_fwd_flops(B, w["Hq"], w["Nq"], w["Nkv"], w["D"], causal)
+
+
+def algorithmic_bytes(w: dict, B: int) -> int:
+  return 2 * w["D"] * (2 * B * w["Hq"] * w["Nq"] + 2 * B * w["Hkv"] * w["Nkv"]) + 4 * B * w["Hq"] * w["Nq"]
+
+
+def make_mask(w: dict, dtype, device, seed: int = 0):
+  if w["mask"] == "tril_bool":
+    return torch.ones(w["Nq"], w["Nkv"], dtype=torch.bool, device=device).tril()
+  if w["mask"] == "key_bias":
+    torch.manual_seed(seed + 1)
+    return torch.randn(1, 1, 1, w["Nkv"], dtype=dtype, device=device) * 0.25
+  return None
+
+
 def measured_traffic(workload: str):
-  """HBM bytes per launch from the committed rocprofv3 PMC pass of THIS command (profiles/): bench.py
-  cannot profile itself, so it reports the figure measured with `rocprofv3 --pmc FETCH_SIZE` (x2: gfx950
-  counts 128-B requests at 64 B, MI355X_MICROARCH.md §HBM) + `--pmc WRITE_SIZE`, or null if absent."""
-  path = os.path.join(ROOT, "profiles", "r01_bench_cfg2_pmc.json")
-  if workload != "cfg2" or not os.path.exists(path):
-    return None
-  try:
-    d = json.load(open(path))["derived"]
-    return int(d["hbm_read_bytes_corrected_x2"] + d.get("hbm_write_bytes", 0))
-  except (KeyError, ValueError):
-    return None
+  """(bytes, source): HBM bytes per launch from the committed rocprofv3 PMC pass of this workload's bench command
+  (`rocprofv3 --pmc FETCH_SIZE` x2 — gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md §HBM — plus
+  `--pmc WRITE_SIZE`; tools/gpu_round.sh stage wprof, summarised by tools/pmc_summary.py).  bench.py cannot profile
+  itself, so this is a profile artefact named by `traffic_source`, or (None, None) when none is committed."""
+  for rnd in ("r02", "r01"):
+    path = os.path.join(ROOT, "profiles", f"{rnd}_bench_{workload}_pmc.json")
+    if os.path.exists(path):
+      try:
+        d = json.load(open(path))["derived"]
+        return int(d["hbm_read_bytes_corrected_x2"] + d.get("hbm_write_bytes", 0)), os.path.relpath(path, ROOT)
+      except (KeyError, ValueError):
+        pass
+  return None, None
 
 
-def cpu_baseline(seconds_budget: float = 20.0) -> dict:
-  """The reference's CPU path (torch CPU SDPA) on a bounded sample of the same workload: H=4 of the
-  32 heads of B=1 N=8192 D=512 bf16, warm-up 1 + best of 3."""
+def cpu_baseline(w: dict, seconds_budget: float = 20.0) -> dict:
+  """The reference's CPU path (torch CPU SDPA) on a bounded sample of the same workload: at most 4 query heads (and
+  the matching KV heads) of one batch element, warm-up 1 + best of 3."""
   cores = os.cpu_count() or 1
   torch.set_num_threads(cores)
-  H = 4
+  g = w["Hq"] // w["Hkv"]
+  Hq = min(4, w["Hq"]) if g == 1 else g  # keep whole GQA groups
+  Hkv = max(1, Hq // g)
+  Nq, Nkv, D = w["Nq"], w["Nkv"], w["D"]
   torch.manual_seed(0)
-  q = torch.randn(1, H, 8192, 512, dtype=torch.bfloat16)
-  k = torch.randn(1, H, 8192, 512, dtype=torch.bfloat16)
-  v = torch.randn(1, H, 8192, 512, dtype=torch.bfloat16)
-  flops = attention_fwd_flops(1, H, 8192, 8192, 512)
+  q = torch.randn(1, Hq, Nq, D, dtype=torch.bfloat16)
+  k = torch.randn(1, Hkv, Nkv, D, dtype=torch.bfloat16)
+  v = torch.randn(1, Hkv, Nkv, D, dtype=torch.bfloat16)
+  kw = dict(enable_gqa=Hq != Hkv)
+  if w["mask"] == "tril_bool" or w["via"] == "op_offset0":
+    kw["is_causal"] = True  # top-left, what the mask / causal_offset=0 express
+  elif w["causal"]:
+    kw["is_causal"] = True
+  elif w["mask"] == "key_bias":
+    kw["attn_mask"] = make_mask(w, torch.bfloat16, "cpu")
+  sample = dict(w, Hq=Hq, Hkv=Hkv)
+  flops = valid_pairs_flops(sample, 1)
   t_begin = time.perf_counter()
-  torch._C._nn.scaled_dot_product_attention(q, k, v)  # warm-up
+  torch._C._nn.scaled_dot_product_attention(q, k, v, **kw)  # warm-up
   best = float("inf")
   reps = 0
   while reps < 3 and time.perf_counter() - t_begin < seconds_budget:
     t0 = time.perf_counter()
-    torch._C._nn.scaled_dot_product_attention(q, k, v)
+    torch._C._nn.scaled_dot_product_attention(q, k, v, **kw)
     best = min(best, time.perf_counter() - t0)
     reps += 1
   out = {
@@ -90,23 +164,76 @@ def cpu_baseline(seconds_budget: float = 20.0) -> dict:
     "unit": "TFLOPS",
     "cores": torch.get_num_threads(),
     "kind": "reference",
-    "sample": f"torch CPU SDPA (the reference's CPU path: ffpa_attn_func falls back to it) on B=1 H={H} N=8192 "
-              f"D=512 bf16, best of {reps} after 1 warm-up, {best * 1e3:.1f} ms per pass",
+    "sample": f"torch CPU SDPA (the reference's CPU path: ffpa_attn_func falls back to it) on B=1 Hq={Hq} Hkv={Hkv} Nq={Nq} Nkv={Nkv} "
+              f"D={D} bf16{' causal' if 'is_causal' in kw else ''}{' + key bias' if 'attn_mask' in kw else ''}, best of {reps} after 1 warm-up, "
+              f"{best * 1e3:.1f} ms per pass",
   }
-  try:  # the oracle (scalar C restatement of the kernel's recurrence), for scale: one thread, 64 rows of one head
+  try:  # the oracle (scalar C restatement of the kernel's recurrence), for scale: one thread, <= 64 rows of one head
     from oracle import ffpa_oracle as fo
-    rows = 64
+    rows = min(64, Nq)
     qb, dname = fo.torch_to_bits(q[:, :1, :rows].contiguous())
     kb, _ = fo.torch_to_bits(k[:, :1].contiguous())
     vb, _ = fo.torch_to_bits(v[:, :1].contiguous())
     t0 = time.perf_counter()
-    fo.oracle_forward(qb, kb, vb, dname, scale=512 ** -0.5)
+    fo.oracle_forward(qb, kb, vb, dname, scale=D ** -0.5)
     dt = time.perf_counter() - t0
-    out["oracle_port"] = {"value": round(attention_fwd_flops(1, 1, rows, 8192, 512) / dt / 1e12, 6), "unit": "TFLOPS", "cores": 1,
-                          "kind": "port", "sample": f"oracle/ffpa_oracle.c on {rows} rows x 8192 keys of one head, D=512, {dt * 1e3:.0f} ms"}
+    out["oracle_port"] = {"value": round(attention_fwd_flops(1, 1, rows, Nkv, D) / dt / 1e12, 6), "unit": "TFLOPS", "cores": 1,
+                          "kind": "port", "sample": f"oracle/ffpa_oracle.c on {rows} rows x {Nkv} keys of one head, D={D}, {dt * 1e3:.0f} ms"}
   except Exception as exc:  # the oracle is test infrastructure: its absence must not break the bench line
     out["oracle_port"] = {"error": str(exc)[:120]}
   return out
+
+
+def accuracy(w: dict, q, k, v, mask, scale: float) -> dict:
+  """max / mean |O - O_sdpa| on the whole tensors (fp32 promote, cli/_runner_fwd.py:178-200), max |LSE - LSE_ref| with
+  LSE_ref = fp32 logsumexp of the scores of the first and last head of batch 0, and the same-device SDPA timing."""
+  from ffpa_attn_amd import hip
+
+  res = {}
+  gqa = w["Hq"] != w["Hkv"]
+  top_left = w["mask"] == "tril_bool" or w["via"] == "op_offset0"
+  sdpa_kw = dict(enable_gqa=gqa)
+  if top_left or w["causal"]:
+    sdpa_kw["is_causal"] = True
+  elif mask is not None:
+    sdpa_kw["attn_mask"] = mask
+  bias = None if (w["via"] == "op_offset0") else mask
+  o, lse = hip.ffpa_attn_forward_hip(q, k, v, bias if bias is None or bias.dim() == 4 else bias.view(1, 1, *bias.shape), causal=bool(w["causal"]),
+                                     softmax_scale=scale, causal_offset=0 if w["via"] == "op_offset0" else None)
+  ref = torch.nn.functional.scaled_dot_product_attention(q, k, v, **sdpa_kw)
+  d = (o.float() - ref.float()).abs()
+  res["max_abs_err_vs_sdpa"] = round(d.max().item(), 6)
+  res["mean_abs_err_vs_sdpa"] = round(d.mean().item(), 8)
+  lse_err = 0.0
+  g = w["Hq"] // w["Hkv"]
+  rows = torch.arange(w["Nq"], device=q.device)[:, None]
+  cols = torch.arange(w["Nkv"], device=q.device)[None, :]
+  for h in sorted({0, w["Hq"] - 1}):
+    s = (q[0, h].float() @ k[0, h // g].float().T) * scale
+    if top_left:
+      s = s.masked_fill(cols > rows, float("-inf"))
+    elif w["causal"]:
+      s = s.masked_fill(cols > rows + (w["Nkv"] - w["Nq"]), float("-inf"))
+    elif mask is not None:
+      s = s + mask.float().reshape(-1, w["Nkv"])  # the bench's additive masks are key biases: [1, Nkv] broadcasts over the rows
+    lse_err = max(lse_err, (lse[0, h] - torch.logsumexp(s, -1)).abs().max().item())
+    del s
+  res["max_abs_lse_err"] = round(lse_err, 7)
+  res["lse_ref"] = "fp32 logsumexp(scale*QK^T [+mask]) of heads {0, Hq-1} of batch 0"
+  flops = valid_pairs_flops(w, w["B"])
+  for _ in range(2):
+    torch.nn.functional.scaled_dot_product_attention(q, k, v, **sdpa_kw)
+  torch.cuda.synchronize()
+  reps = 5
+  t1 = time.perf_counter()
+  for _ in range(reps):
+    torch.nn.functional.scaled_dot_product_attention(q, k, v, **sdpa_kw)
+  torch.cuda.synchronize()
+  sdpa_s = (time.perf_counter() - t1) / reps
+  res["sdpa_gpu_tflops"] = round(flops / sdpa_s / 1e12, 2)
+  res["sdpa_gpu_ms"] = round(sdpa_s * 1e3, 4)
+  res["sdpa_call"] = "F.scaled_dot_product_attention(" + ", ".join(f"{a}={'<mask>' if a == 'attn_mask' else b}" for a, b in sdpa_kw.items()) + ")"
+  return res
 
 
 def main() -> None:
@@ -117,7 +244,8 @@ def main() -> None:
   ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
   ap.add_argument("--gather", action="store_true", help="include an RCCL all_gather of O in the timed step (N > 1)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
-  ap.add_argument("--no-sdpa", action="store_true", help="skip the SDPA-on-GPU comparison")
+  ap.add_argument("--no-sdpa", action="store_true", help="skip the SDPA-on-GPU accuracy / speed comparison")
+  ap.add_argument("--no-ref-protocol", action="store_true", help="skip the reference bench's own timing protocol (2 warm-ups + 10 iterations)")
   args = ap.parse_args()
 
   world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -134,23 +262,51 @@ def main() -> None:
     dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
   assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-  B, Hq, Hkv, Nq, Nkv, D, causal = WORKLOADS[args.workload]
-  torch.manual_seed(0 + rank)  # every rank owns its own batch element(s): weak scaling
-  q = torch.randn(B, Hq, Nq, D, dtype=torch.bfloat16, device=dev)
-  k = torch.randn(B, Hkv, Nkv, D, dtype=torch.bfloat16, device=dev)
-  v = torch.randn(B, Hkv, Nkv, D, dtype=torch.bfloat16, device=dev)
-  gqa = Hq != Hkv
-  flops_per_rank = attention_fwd_flops(B, Hq, Nq, Nkv, D, causal)
+  from ffpa_attn_amd import hip, sharding
 
-  gathered = None
-  if args.gather and world > 1:
-    gathered = torch.empty((world * B, Hq, Nq, D), dtype=torch.bfloat16, device=dev)
+  hip.load_library()  # fail loudly when the HIP extension is missing
+  name = args.workload
+  w = WORKLOADS[name]
+  B, Hq, Hkv, Nq, Nkv, D = (w[x] for x in ("B", "Hq", "Hkv", "Nq", "Nkv", "D"))
+  scale = D ** -0.5
+  strong = name == "cfg5"
+  sharded = world > 1 or strong
+  grp = Hq // Hkv
+  mask = make_mask(w, torch.bfloat16, dev)
 
-  def step():
-    o = ffpa_attn_func(q, k, v, is_causal=causal, enable_gqa=gqa)
-    if gathered is not None:
-      dist.all_gather_into_tensor(gathered, o)
-    return o
+  if sharded:
+    # born-sharded: this rank's contiguous block of (batch, kv-head) units of the global problem, per-unit seeds
+    global_B = B if strong else B * world
+    n_units = global_B * Hkv
+    u0, u1 = sharding.partition_units(n_units, world, rank)
+    q, k, v = sharding.synthetic_unit_block(u0, u1, grp, Nq, Nkv, D, device=dev, seed=0)
+    local_units = u1 - u0
+    flops_local = valid_pairs_flops(w, 1) // Hkv * local_units  # FLOPs are uniform over the units
+    flops_global = valid_pairs_flops(w, global_B)
+    gathered = torch.empty((n_units, grp, Nq, D), dtype=torch.bfloat16, device=dev) if (args.gather and world > 1) else None
+    api_kw = dict(is_causal=w["causal"], dropout_p=w["dropout"])
+    if mask is not None:
+      api_kw["attn_mask"] = mask
+
+    def step():
+      o = sharding.attend_units(q, k, v, **api_kw)
+      if gathered is not None:
+        sharding.gather_units(o, n_units, out=gathered)
+      return o
+  else:
+    global_B = B
+    torch.manual_seed(0)
+    q = torch.randn(B, Hq, Nq, D, dtype=torch.bfloat16, device=dev)
+    k = torch.randn(B, Hkv, Nkv, D, dtype=torch.bfloat16, device=dev)
+    v = torch.randn(B, Hkv, Nkv, D, dtype=torch.bfloat16, device=dev)
+    flops_local = flops_global = valid_pairs_flops(w, B)
+    gathered = None
+    if w["via"] == "op_offset0":
+      def step():
+        return hip.ffpa_attn_forward_hip(q, k, v, None, causal=True, softmax_scale=scale, causal_offset=0)[0]
+    else:
+      def step():
+        return ffpa_attn_func(q, k, v, attn_mask=mask, dropout_p=w["dropout"], is_causal=w["causal"], enable_gqa=Hq != Hkv)
 
   for _ in range(args.warmup):
     step()
@@ -168,23 +324,42 @@ def main() -> None:
     out = step()
     ends[i].record()
   torch.cuda.synchronize()
+  local_elapsed = time.perf_counter() - t0
   if dist is not None:
     dist.barrier()
   elapsed = time.perf_counter() - t0
+  per_rank_tflops = None
   if dist is not None:
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    mine = torch.tensor([flops_local * args.steps / local_elapsed / 1e12], dtype=torch.float64, device=dev)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    per_rank_tflops = [round(float(x.item()), 2) for x in every]
   kernel_ms = sorted(s.elapsed_time(e) for s, e in zip(starts, ends))
   kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
 
-  total_flops = flops_per_rank * world * args.steps
-  value = total_flops / elapsed / 1e12
+  value = flops_global * args.steps / elapsed / 1e12
 
   if rank == 0:
-    achieved = flops_per_rank / (kernel_ms_avg * 1e-3) / 1e12
+    traffic, traffic_src = measured_traffic(name) if world == 1 else (None, None)
+    if w["bound"] == "hbm":
+      bytes_launch = algorithmic_bytes(w, global_B)
+      achieved = bytes_launch / (kernel_ms_avg * 1e-3) / 1e9
+      roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+              "traffic": traffic, "traffic_source": traffic_src, "kernel": "ffpa_fwd_split_d_kernel<.,.,4> + ffpa_fwd_merge_kernel",
+              "kernel_ms_avg": round(kernel_ms_avg, 4), "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 4), "bytes_per_launch": bytes_launch}
+    else:
+      achieved = flops_local / (kernel_ms_avg * 1e-3) / 1e12
+      roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+              "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+              "kernel": "ffpa_fwd_split_d_kernel", "kernel_ms_avg": round(kernel_ms_avg, 4),
+              "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 4), "flops_per_launch": flops_local,
+              "algorithmic_bytes_per_launch": algorithmic_bytes(w, max(1, (u1 - u0) // Hkv) if sharded else B)}
+    shape = f"B={global_B} Hq={Hq} Hkv={Hkv} Nq={Nq} Nkv={Nkv} D={D}"
     line = {
-      "metric": "attention fwd TFLOPS + max-abs-err vs SDPA, bf16 B=1 H=32 N=8192 D=512",
+      "metric": metric_name(name, w),
       "value": round(value, 2),
       "unit": "TFLOPS",
       "n_gpus": world,
@@ -192,54 +367,50 @@ def main() -> None:
       "warmup": args.warmup,
       "ms_per_step": round(elapsed / args.steps * 1e3, 4),
       "higher_is_better": True,
-      "scaling": "weak",
+      "scaling": "strong" if strong else "weak",
       "vs_baseline": None,  # BASELINE.md holds no published MI355X number for this metric
       "dtype": "bf16",
       "data": "synthetic",
       "config": {
-        "workload": f"{args.workload}: B={B} Hq={Hq} Hkv={Hkv} Nq={Nq} Nkv={Nkv} D={D} bf16 "
-                    f"{'causal ' if causal else ''}attention forward per GPU (BASELINE configs[1] shape)"
-                    if args.workload == "cfg2" else
-                    f"{args.workload}: B={B} Hq={Hq} Hkv={Hkv} Nq={Nq} Nkv={Nkv} D={D} bf16 "
-                    f"{'causal ' if causal else ''}attention forward per GPU",
-        "global_batch": B * world,
+        "workload": f"{name}: {shape} bf16 attention forward" + (f" ({w['note']})" if w["note"] else ""),
+        "global_batch": global_B,
         "seq_len": Nq,
-        "parallelism": f"(batch,head)-sharded x{world}, no data-path collective" + (" + all_gather(O)" if gathered is not None else ""),
+        "parallelism": (f"(batch,kv-head) units born sharded x{world}: {Hkv * global_B} units, {Hkv * global_B / world:g} per rank, no data-path collective"
+                        if sharded else "single GPU") + (" + all_gather_into_tensor(O)" if gathered is not None else ""),
         "flops_model": "4*B*Hq*D*valid_pairs",
+        "step": "hip.ffpa_attn_forward_hip(causal=True, causal_offset=0)" if w["via"] == "op_offset0" else
+                ("sharding.attend_units -> ffpa_attn_func" if sharded else "ffpa_attn_func"),
       },
-      "roofline": {
-        "bound": "mfma",
-        "achieved": round(achieved, 2),
-        "peak": MFMA_BF16_PEAK_TFLOPS,
-        "unit": "TFLOP/s",
-        "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
-        "traffic": measured_traffic(args.workload),
-        "kernel": "ffpa_fwd_split_d_kernel",
-        "kernel_ms_avg": round(kernel_ms_avg, 4),
-        "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 4),
-        "flops_per_launch": flops_per_rank,
-      },
+      "roofline": roof,
     }
-    if world == 1 and not args.no_sdpa:
-      # accuracy + the same-device SDPA number the 1.5x target is relative to
+    if per_rank_tflops is not None:
+      line["per_rank_tflops_kernel_path"] = per_rank_tflops
+      line["frac_of_mfma_peak_aggregate"] = round(value / (MFMA_BF16_PEAK_TFLOPS * world), 4)
+    if world == 1 and not sharded and not args.no_ref_protocol:
+      # the reference bench's protocol: 2 warm-ups, 10 iterations, perf_counter around a synchronize (cli/_runner_fwd.py:84-103)
+      for _ in range(2):
+        step()
+      torch.cuda.synchronize()
+      t1 = time.perf_counter()
+      for _ in range(10):
+        step()
+      torch.cuda.synchronize()
+      ref_ms = (time.perf_counter() - t1) * 1e3 / 10
+      line["ref_protocol"] = {"ms": round(ref_ms, 4), "tflops": round(flops_global / ref_ms / 1e9, 2), "warmup": 2, "iters": 10,
+                              "timer": "perf_counter + cuda.synchronize (cli/_runner_fwd.py:84-103)"}
+    if world == 1 and not sharded and not args.no_sdpa and w["dropout"] == 0.0:
       try:
-        ref = torch.nn.functional.scaled_dot_product_attention(q, k, v, is_causal=causal, enable_gqa=gqa)
-        line["max_abs_err_vs_sdpa"] = round((out.float() - ref.float()).abs().max().item(), 6)
-        for _ in range(2):
-          torch.nn.functional.scaled_dot_product_attention(q, k, v, is_causal=causal, enable_gqa=gqa)
-        torch.cuda.synchronize()
-        reps = 5
-        t1 = time.perf_counter()
-        for _ in range(reps):
-          torch.nn.functional.scaled_dot_product_attention(q, k, v, is_causal=causal, enable_gqa=gqa)
-        torch.cuda.synchronize()
-        sdpa_s = (time.perf_counter() - t1) / reps
-        line["sdpa_gpu_tflops"] = round(flops_per_rank / sdpa_s / 1e12, 2)
-        line["speedup_vs_sdpa_gpu"] = round((flops_per_rank / (elapsed / args.steps)) / (flops_per_rank / sdpa_s), 3)
+        acc = accuracy(w, q, k, v, mask, scale)
+        line.update(acc)
+        line["speedup_vs_sdpa_gpu"] = round(acc["sdpa_gpu_ms"] / (elapsed / args.steps * 1e3), 3)
       except Exception as e:  # noqa: BLE001 - the comparison is informative, the metric above is not
         line["sdpa_error"] = str(e)[:200]
+    elif w["dropout"] > 0.0:
+      line["accuracy_note"] = ("dropout: PyTorch-ROCm's fused SDPA draws another Philox stream, so outputs are not comparable element-wise "
+                               "(the reference skips its dropout-parity test on ROCm, tests/test_ffpa_fwd.py:339-342); the mask is pinned "
+                               "bit-for-bit against the oracle in tests/test_fwd_gpu.py")
     if world == 1 and not args.no_cpu_baseline:
-      line["cpu_baseline"] = cpu_baseline()
+      line["cpu_baseline"] = cpu_baseline(w)
     print(json.dumps(line), flush=True)
 
   if dist is not None:

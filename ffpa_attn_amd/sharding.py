@@ -5,9 +5,18 @@ only multi-GPU code is a Ray task farm for autotuning, src/ffpa_attn/ray/).  The
 embarrassingly parallel over ``(b, hkv)``: output rows of query head ``hq`` depend only on
 ``Q[b, hq]`` and ``K/V[b, hq // group]`` (csrc/cuffpa/native/sm_80/split_d.cuh:135-142).  So the
 MI355X plan is: one process per GPU, each owns a contiguous block of ``B*Hkv`` *units* (a KV head
-together with its ``group`` query heads, so K/V are never duplicated), runs the kernel locally, and
-— only if the caller wants the full tensor on every rank — one ``all_gather`` of O over RCCL/xGMI.
-There is no reduction and no exchange inside the attention itself.
+together with its ``group`` query heads, so K/V are never duplicated), runs the HIP kernel on its
+block, and — only if the caller wants the full tensor on every rank — ONE ``all_gather`` of O over
+RCCL/xGMI, straight into the output tensor.  There is no reduction and no exchange inside the
+attention itself.
+
+Two entries:
+
+* born-sharded (the data-parallel case, what ``bench.py`` measures): every rank holds only its block in
+  unit-major layout ``q [U, group, Nq, D]``, ``k / v [U, 1, Nkv, D]`` — ``local_units`` /
+  ``synthetic_unit_block`` build it, ``attend_units`` runs the kernel, ``gather_units`` is the optional
+  collective;
+* replicated inputs (``sharded_attention``): every rank holds the full tensors and takes views of its block.
 """
 
 from __future__ import annotations
@@ -49,36 +58,92 @@ def shard_units(q, k, v, world_size: int, rank: int):
   return qu[s:e], ku[s:e], vu[s:e]
 
 
+def local_units(n_units: int, group: "dist.ProcessGroup | None" = None) -> tuple[int, int]:
+  """``[start, stop)`` of the calling rank's units (the whole range without an initialised process group)."""
+  if dist.is_available() and dist.is_initialized():
+    return partition_units(n_units, dist.get_world_size(group), dist.get_rank(group))
+  return 0, n_units
+
+
+def synthetic_unit_block(start: int, stop: int, group_size: int, nq: int, nkv: int, head_dim: int, *, dtype=torch.bfloat16,
+                         device="cuda", seed: int = 0):
+  """Born-sharded synthetic inputs: units ``[start, stop)`` of a global problem, each unit drawn from its own
+  generator (seed, unit index) — q, then k, then v, N(0,1) like the reference's bench inputs
+  (src/ffpa_attn/cli/_runner_fwd.py:344-347).  The values of a unit do not depend on how the units are spread over
+  ranks, so any partition of the same global problem computes the same numbers; nothing is replicated."""
+  n = stop - start
+  q = torch.empty((n, group_size, nq, head_dim), dtype=dtype, device=device)
+  k = torch.empty((n, 1, nkv, head_dim), dtype=dtype, device=device)
+  v = torch.empty((n, 1, nkv, head_dim), dtype=dtype, device=device)
+  gen = torch.Generator(device=device)
+  for i in range(n):
+    gen.manual_seed((int(seed) << 32) + start + i)
+    q[i].normal_(generator=gen)
+    k[i].normal_(generator=gen)
+    v[i].normal_(generator=gen)
+  return q, k, v
+
+
+def attend_units(qu: torch.Tensor, ku: torch.Tensor, vu: torch.Tensor, **kwargs) -> torch.Tensor:
+  """The local step: this rank's block through ``ffpa_attn_func`` (HIP kernel; dim 0 = units as the batch axis,
+  dim 1 = the unit's query heads against its single KV head)."""
+  from .interface import ffpa_attn_func
+
+  if qu.size(0) == 0:
+    return qu.new_empty(qu.shape)
+  return ffpa_attn_func(qu, ku, vu, enable_gqa=qu.size(1) != ku.size(1), **kwargs)
+
+
+def gather_units(o_local: torch.Tensor, n_units: int, group: "dist.ProcessGroup | None" = None,
+                 out: torch.Tensor | None = None) -> torch.Tensor:
+  """All ranks' blocks -> ``[n_units, group, Nq, D]`` on every rank with ONE ``all_gather_into_tensor``.
+  When the units divide evenly (config 5: 256 units over 1 / 2 / 4 / 8 GPUs) the collective writes straight
+  into the result — no padding, no concatenation; otherwise blocks are padded to the largest and compacted
+  in place afterwards (the only copy, of the tail blocks)."""
+  world = dist.get_world_size(group)
+  g, nq, d = o_local.shape[1:]
+  per = -(-n_units // world)
+  if n_units % world == 0:
+    if out is None:
+      out = o_local.new_empty((n_units, g, nq, d))
+    dist.all_gather_into_tensor(out, o_local.contiguous(), group=group)
+    return out
+  buf = o_local.new_empty((per, g, nq, d))
+  buf[: o_local.size(0)] = o_local
+  padded = o_local.new_empty((world * per, g, nq, d))
+  dist.all_gather_into_tensor(padded, buf, group=group)
+  for r in range(1, world):  # block r sits at r * per, belongs at start(r) <= r * per: move down, in rank order
+    s, e = partition_units(n_units, world, r)
+    if s != r * per:
+      padded[s:e] = padded[r * per : r * per + (e - s)].clone()
+  res = padded[:n_units]
+  if out is not None:
+    out.copy_(res)
+    return out
+  return res
+
+
 def sharded_attention(
   q: torch.Tensor,
   k: torch.Tensor,
   v: torch.Tensor,
-  attn_fn: Callable[[torch.Tensor, torch.Tensor, torch.Tensor], torch.Tensor],
+  attn_fn: Callable[[torch.Tensor, torch.Tensor, torch.Tensor], torch.Tensor] | None = None,
   *,
   group: "dist.ProcessGroup | None" = None,
   gather: bool = True,
 ) -> torch.Tensor:
-  """Every rank holds the full ``q, k, v``; each computes its block of units with ``attn_fn`` (which
-  sees ``[U, group, Nq, D]`` / ``[U, 1, Nkv, D]`` and must treat dim 1 as GQA heads) and, with
-  ``gather=True``, the blocks are all-gathered into the full ``[B, Hq, Nq, D]`` output.
-  """
+  """Replicated-input entry: every rank holds the full ``q, k, v``; each computes its block of units with
+  ``attn_fn`` (default: ``attend_units``, the HIP kernel; it sees ``[U, group, Nq, D]`` / ``[U, 1, Nkv, D]``
+  and must treat dim 1 as GQA heads) and, with ``gather=True``, the blocks are all-gathered into the full
+  ``[B, Hq, Nq, D]`` output.  ``gather=False`` returns the local block."""
   world = dist.get_world_size(group)
   rank = dist.get_rank(group)
   B, Hq, Nq, D = q.shape
   Hkv = k.size(1)
   g = Hq // Hkv
   ql, kl, vl = shard_units(q, k, v, world, rank)
-  o_local = attn_fn(ql, kl, vl) if ql.size(0) > 0 else ql.new_empty((0, g, Nq, D))
+  fn = attn_fn or attend_units
+  o_local = fn(ql, kl, vl) if ql.size(0) > 0 else ql.new_empty((0, g, Nq, D))
   if not gather:
     return o_local
-  n_units = B * Hkv
-  per = -(-n_units // world)  # pad every block to the largest so one all_gather_into_tensor suffices
-  buf = o_local.new_zeros((per, g, Nq, D))
-  buf[: o_local.size(0)] = o_local
-  out = o_local.new_empty((world * per, g, Nq, D))
-  dist.all_gather_into_tensor(out, buf, group=group)
-  pieces = []
-  for r in range(world):
-    s, e = partition_units(n_units, world, r)
-    pieces.append(out[r * per : r * per + (e - s)])
-  return torch.cat(pieces, dim=0).reshape(B, Hq, Nq, D)
+  return gather_units(o_local, B * Hkv, group).reshape(B, Hq, Nq, D)

@@ -61,6 +61,33 @@ def _worker(rank, world, port, B, Hq, Hkv, ret):
   dist.destroy_process_group()
 
 
+def _born_worker(rank, world, port, n_units, g, ret):
+  """The born-sharded path bench.py measures: per-unit seeded blocks, local attention, one all_gather."""
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  from ffpa_attn_amd import sharding as sh
+
+  s, e = sh.local_units(n_units)
+  q, k, v = sh.synthetic_unit_block(s, e, g, 24, 40, 64, dtype=torch.float32, device="cpu", seed=3)
+  o_local = torch.nn.functional.scaled_dot_product_attention(q, k, v, enable_gqa=True)  # stand-in for the HIP kernel
+  full = sh.gather_units(o_local, n_units)
+  # the same global problem generated in one piece: a unit's values do not depend on the partition
+  qa, ka, va = sh.synthetic_unit_block(0, n_units, g, 24, 40, 64, dtype=torch.float32, device="cpu", seed=3)
+  ref = torch.nn.functional.scaled_dot_product_attention(qa, ka, va, enable_gqa=True)
+  ret[rank] = (bool(torch.equal(full, ref)), (s, e), bool(torch.equal(q, qa[s:e])))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_two_rank_gloo_born_sharded_blocks_and_gather():
+  for n_units, g in ((8, 2), (5, 1)):  # even: the collective writes straight into the result; uneven: padded + compacted
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_born_worker, args=(2, port, n_units, g, ret), nprocs=2, join=True)
+    assert ret[0][0] and ret[1][0] and ret[0][2] and ret[1][2]
+    assert ret[0][1][0] == 0 and ret[0][1][1] == ret[1][1][0] and ret[1][1][1] == n_units
+
+
 def test_two_rank_gloo_sharded_attention_matches_unsharded():
   for (B, Hq, Hkv) in ((2, 8, 2), (1, 6, 3)):  # even and uneven (3 units over 2 ranks) splits
     port = _free_port()

@@ -1,0 +1,68 @@
+"""The multi-GPU path with the real kernel over RCCL (`pytest -m gpu`).
+
+`ffpa_attn_amd.sharding` born-sharded flow — per-unit seeded blocks -> HIP kernel on the local block -> one
+all_gather_into_tensor of O — as `bench.py --workload cfg5` runs it.  World size 1 always runs (one MI355X: the
+"nccl" backend is RCCL, the collective degenerates to a copy but goes through the same calls); world size 2 runs
+when the box has two GPUs (the driver's 8-GPU node), and must reproduce the one-rank result bit for bit — units are
+independent, so the partition cannot change a single output element.
+"""
+
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+N_UNITS, GROUP, NQ, NKV, D = 8, 4, 640, 1024, 512  # 8 (batch, kv-head) units of 4 query heads each
+
+
+def _free_port():
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    return s.getsockname()[1]
+
+
+def _worker(rank, world, port, ret):
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+  torch.cuda.set_device(rank)
+  dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+  from ffpa_attn_amd import hip
+  from ffpa_attn_amd import sharding as sh
+
+  hip.load_library()  # no fallback: the extension must be there
+  s, e = sh.local_units(N_UNITS)
+  q, k, v = sh.synthetic_unit_block(s, e, GROUP, NQ, NKV, D, device=f"cuda:{rank}", seed=11)
+  o_local = sh.attend_units(q, k, v)
+  full = sh.gather_units(o_local, N_UNITS)
+  torch.cuda.synchronize()
+  ref = torch.nn.functional.scaled_dot_product_attention(q, k, v, enable_gqa=True)
+  err = (o_local.float() - ref.float()).abs().max().item()
+  ret[rank] = (full.cpu(), err, (s, e))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def _run(world):
+  ret = mp.Manager().dict()
+  mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+  return ret
+
+
+def test_one_rank_rccl_born_sharded_flow_with_the_hip_kernel():
+  ret = _run(1)
+  full, err, span = ret[0]
+  assert span == (0, N_UNITS) and full.shape == (N_UNITS, GROUP, NQ, D)
+  assert err <= 1e-2  # the north star's max-abs bound vs SDPA on the same inputs
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (runs on the driver's multi-GPU node)")
+def test_two_ranks_over_rccl_reproduce_the_one_rank_result_bit_for_bit():
+  one = _run(1)[0][0]
+  ret = _run(2)
+  assert ret[0][2] == (0, N_UNITS // 2) and ret[1][2] == (N_UNITS // 2, N_UNITS)
+  assert torch.equal(ret[0][0], one) and torch.equal(ret[1][0], one)
+  assert max(ret[0][1], ret[1][1]) <= 1e-2
