@@ -320,6 +320,9 @@ int ffpa_attn_mask_kv_bounds(const void* bias, int bias_dtype, const int64_t bia
   m.nq = nq;
   m.nkv = nkv;
   m.nblk = (nq + 31) / 32;
+  m.words = (nkv + 31) / 32;
+  if ((size_t)m.words * 4 > 60 * 1024) m.words = 0;  // the neutral-key bitmap must fit LDS (Nkv <= 491520); else no free range
+  const size_t smem = (size_t)m.words * 4;
   m.out = out;
   const int64_t grid = (int64_t)bb * hb * m.nblk;
   if (grid > 0x7fffffffLL) return fail(FFPA_ERR_BAD_SHAPE, "mask of %lld row blocks is too large", (long long)grid);
@@ -329,15 +332,15 @@ int ffpa_attn_mask_kv_bounds(const void* bias, int bias_dtype, const int64_t bia
                    bias_stride[0] % w == 0 && bias_stride[1] % w == 0 && bias_stride[2] % w == 0;
   const dim3 g((unsigned)grid), blk(256);
   if (vec) {
-    if (bias_dtype == FFPA_BIAS_FP32) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_vec_kernel<float>, g, blk, 0, st, m);
-    else if (bias_dtype == FFPA_BIAS_BOOL8) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_vec_kernel<uint8_t>, g, blk, 0, st, m);
-    else if (bias_dtype == FFPA_BIAS_BF16) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_vec_kernel<__bf16>, g, blk, 0, st, m);
-    else hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_vec_kernel<_Float16>, g, blk, 0, st, m);
+    if (bias_dtype == FFPA_BIAS_FP32) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_vec_kernel<float>, g, blk, smem, st, m);
+    else if (bias_dtype == FFPA_BIAS_BOOL8) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_vec_kernel<uint8_t>, g, blk, smem, st, m);
+    else if (bias_dtype == FFPA_BIAS_BF16) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_vec_kernel<__bf16>, g, blk, smem, st, m);
+    else hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_vec_kernel<_Float16>, g, blk, smem, st, m);
   } else {
-    if (bias_dtype == FFPA_BIAS_FP32) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_kernel<float>, g, blk, 0, st, m);
-    else if (bias_dtype == FFPA_BIAS_BOOL8) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_kernel<uint8_t>, g, blk, 0, st, m);
-    else if (bias_dtype == FFPA_BIAS_BF16) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_kernel<__bf16>, g, blk, 0, st, m);
-    else hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_kernel<_Float16>, g, blk, 0, st, m);
+    if (bias_dtype == FFPA_BIAS_FP32) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_kernel<float>, g, blk, smem, st, m);
+    else if (bias_dtype == FFPA_BIAS_BOOL8) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_kernel<uint8_t>, g, blk, smem, st, m);
+    else if (bias_dtype == FFPA_BIAS_BF16) hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_kernel<__bf16>, g, blk, smem, st, m);
+    else hipLaunchKernelGGL(ffpa::ffpa_mask_kv_bounds_kernel<_Float16>, g, blk, smem, st, m);
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(FFPA_ERR_LAUNCH, "mask bounds launch failed: %s", hipGetErrorString(e));

@@ -641,6 +641,10 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
     const int t1 = t0 + a.tiles_per_split;
     nt = nt < t1 ? nt : t1;
   }
+  // keys [free_lo, free_hi): the mask is neutral (adds exactly 0 / every key visible) for EVERY row of this wave's
+  // 32-row block — KV tiles inside that range skip the mask loads altogether (the interior of a causal / sliding-window /
+  // padding mask costs what an unmasked launch costs; only the tiles the mask's edge crosses read it)
+  int free_lo = 0, free_hi = 0;
   if (a.kv_bounds != nullptr) {
     // the caller's mask leaves only keys [first, end) visible to the 32-row blocks of this row tile
     const int* bp = a.kv_bounds + b * a.s_bounds[0] + hq * a.s_bounds[1];
@@ -649,7 +653,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
     for (int blk = 0; blk < BR / 32; ++blk) {
       const int r32 = q0 / 32 + blk;
       if (r32 * 32 < a.Nq) {
-        const int lo = bp[2 * r32], hi = bp[2 * r32 + 1];
+        const int lo = bp[4 * r32], hi = bp[4 * r32 + 1];
         first = first < lo ? first : lo;
         end = end > hi ? end : hi;
       }
@@ -657,6 +661,13 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
     const int tf = first / BC, te = (end + BC - 1) / BC;
     t0 = t0 > tf ? t0 : tf;
     nt = nt < te ? nt : te;
+    const int r32w = q0 / 32 + qb;
+    if (r32w * 32 < a.Nq) {
+      free_lo = __builtin_amdgcn_readfirstlane(bp[4 * r32w + 2]);
+      free_hi = __builtin_amdgcn_readfirstlane(bp[4 * r32w + 3]);
+    } else {
+      free_hi = 0x7fffffff;  // a row block past the last query row: nothing it computes is stored
+    }
   }
 
   // ---- Q fragments: B operand of S^T = K.Q^T.  lane (row l31, half h) holds
@@ -770,7 +781,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
     // the K(j+1) burst, so that their latency overlaps both; consumed in the score-modifier section below.
     constexpr bool kBiasEarly = FFPA_BIAS_EARLY != 0 && !SAFE && ND > 1;  // measured: -10 % at D = 1024; D <= 512 has no registers to spare (+2 %)
     u32x4 braw[kBiasEarly ? 2 * NKB : 1];
-    const bool bias_early = kBiasEarly && a.bias_vec == 8 && a.bias_dtype != 4 && k0 + BC <= a.Nkv;
+    const bool mask_free = k0 >= free_lo && k0 + BC <= free_hi;  // wave-uniform: this tile lies in the mask's neutral interior
+    const bool bias_early = kBiasEarly && a.bias_vec == 8 && a.bias_dtype != 4 && k0 + BC <= a.Nkv && !mask_free;
     if constexpr (kBiasEarly) {
       if (bias_early) {
         const char* bp = (const char*)a.bias + 2 * (b * a.sbias[0] + hq * a.sbias[1] + (int64_t)qrow_c * a.sbias[2] + k0 + 16 * h);
@@ -907,7 +919,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
             for (int e = 0; e < 8; ++e) x[kb][8 * w + e] += (float)t[e] * 1.4426950408889634f;
           }
         }
-    } else if (a.bias_dtype != 0) {
+    } else if (a.bias_dtype != 0 && !mask_free) {
       const int64_t brow = b * a.sbias[0] + hq * a.sbias[1] + (int64_t)qrow_c * a.sbias[2];
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
@@ -1175,9 +1187,12 @@ __global__ __launch_bounds__(64) void ffpa_fwd_merge_kernel(const FwdArgs a, int
   if (a.lse != nullptr && lane == 0 && blockIdx.y == 0) a.lse[row] = (mx == -INFINITY) ? -INFINITY : mx + __logf(wsum);
 }
 
-// Visible-key bounds of an additive mask (ffpa_fwd_params.kv_bounds): one workgroup per (batch, head, block of 32
-// query rows) scans its 32 x Nkv slab once (coalesced along the keys) and writes {first, end} of the keys that are
-// not -inf for at least one row of the block ({Nkv, 0} when there is none).  HBM-bound, 2-4 bytes per mask element.
+// Visible-key bounds of a mask (ffpa_fwd_params.kv_bounds): one workgroup per (batch, head, block of 32 query rows) scans
+// its 32 x Nkv slab once (coalesced along the keys) and writes four ints:
+//   {first, end}            the keys that are visible (not -inf / not False) for at least one row of the block ({Nkv, 0}: none)
+//   {free_first, free_end}  the first run of keys for which the mask is NEUTRAL (adds exactly 0 / True) for every row of the block
+//                           ({0, 0}: none) — the tiles inside it need no mask at all.
+// HBM-bound, 1-4 bytes per mask element.  The per-key "neutral for all 32 rows" flags go through an LDS bitmap (Nkv bits).
 template <typename BT>
 __device__ __forceinline__ bool mask_elem_visible(BT x);
 template <>
@@ -1186,20 +1201,106 @@ template <>
 __device__ __forceinline__ bool mask_elem_visible<__bf16>(__bf16 x) { return __builtin_bit_cast(uint16_t, x) != (uint16_t)0xff80u; }
 template <>
 __device__ __forceinline__ bool mask_elem_visible<_Float16>(_Float16 x) { return __builtin_bit_cast(uint16_t, x) != (uint16_t)0xfc00u; }
-
 template <>
 __device__ __forceinline__ bool mask_elem_visible<uint8_t>(uint8_t x) { return x != 0; }
+
+template <typename BT>
+__device__ __forceinline__ bool mask_elem_neutral(BT x);  // +0.0 / -0.0 for additive masks, True for boolean ones
+template <>
+__device__ __forceinline__ bool mask_elem_neutral<float>(float x) { return (__builtin_bit_cast(uint32_t, x) & 0x7fffffffu) == 0u; }
+template <>
+__device__ __forceinline__ bool mask_elem_neutral<__bf16>(__bf16 x) { return (__builtin_bit_cast(uint16_t, x) & 0x7fffu) == 0u; }
+template <>
+__device__ __forceinline__ bool mask_elem_neutral<_Float16>(_Float16 x) { return (__builtin_bit_cast(uint16_t, x) & 0x7fffu) == 0u; }
+template <>
+__device__ __forceinline__ bool mask_elem_neutral<uint8_t>(uint8_t x) { return x != 0; }
 
 struct MaskBoundsArgs {
   const void* bias;
   int64_t sb[4];  // element strides: batch, head, row, key (0 = broadcast)
   int hb, nq, nkv, nblk;
-  int* out;       // [bb, hb, nblk, 2]
+  int words;      // LDS bitmap words = ceil(nkv / 32), 0 = bitmap does not fit (no neutral range is reported)
+  int* out;       // [bb, hb, nblk, 4]
 };
+
+// Shared tail of both scan kernels: reduce {first, end} over the workgroup, find the first run of set bits in the
+// neutral-key bitmap, write the four results.
+__device__ __forceinline__ void mask_bounds_finish(const MaskBoundsArgs& m, FFPA_LDS uint32_t* bits, int first, int end) {
+  __shared__ int red[4][4];
+  const int tid = threadIdx.x, wv = tid >> 6;
+  auto wave_min = [](int x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const int y = __shfl_xor(x, o);
+      x = x < y ? x : y;
+    }
+    return x;
+  };
+  auto wave_max = [](int x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const int y = __shfl_xor(x, o);
+      x = x > y ? x : y;
+    }
+    return x;
+  };
+  first = wave_min(first);
+  end = wave_max(end);
+  __syncthreads();  // the bitmap is complete
+  // first neutral key
+  int ff = m.nkv;
+  for (int w = tid; w < m.words; w += 256) {
+    const uint32_t x = bits[w];
+    if (x != 0u) {
+      const int c = w * 32 + __builtin_ctz(x);
+      ff = ff < c ? ff : c;
+    }
+  }
+  ff = wave_min(ff);
+  if ((tid & 63) == 0) {
+    red[0][wv] = first;
+    red[1][wv] = end;
+    red[2][wv] = ff;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    first = first < red[0][w] ? first : red[0][w];
+    end = end > red[1][w] ? end : red[1][w];
+    ff = ff < red[2][w] ? ff : red[2][w];
+  }
+  // first key at or after ff that is not neutral
+  int fe = m.nkv;
+  for (int w = (ff >> 5) + tid; w < m.words; w += 256) {
+    uint32_t x = ~bits[w];
+    if (w == (ff >> 5)) x &= ~0u << (ff & 31);
+    if (x != 0u) {
+      const int c = w * 32 + __builtin_ctz(x);
+      fe = fe < c ? fe : c;
+    }
+  }
+  fe = wave_min(fe);
+  if ((tid & 63) == 0) red[3][wv] = fe;
+  __syncthreads();
+  if (tid == 0) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) fe = fe < red[3][w] ? fe : red[3][w];
+    fe = fe < m.nkv ? fe : m.nkv;
+    const bool none = m.words == 0 || ff >= m.nkv;
+    int* o = m.out + 4 * (int64_t)blockIdx.x;
+    o[0] = first;
+    o[1] = end;
+    o[2] = none ? 0 : ff;
+    o[3] = none ? 0 : fe;
+  }
+}
 
 template <typename BT>
 __global__ __launch_bounds__(256) void ffpa_mask_kv_bounds_kernel(const MaskBoundsArgs m) {
-  __shared__ int red[2][4];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  FFPA_LDS uint32_t* bits = (FFPA_LDS uint32_t*)smem;
+  for (int w = threadIdx.x; w < m.words; w += 256) bits[w] = 0u;
+  __syncthreads();
   const int blk = blockIdx.x % m.nblk;
   const int bh = blockIdx.x / m.nblk;
   const int h = bh % m.hb, b = bh / m.hb;
@@ -1222,44 +1323,34 @@ __global__ __launch_bounds__(256) void ffpa_mask_kv_bounds_kernel(const MaskBoun
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int c = c0 + 256 * u;
-      bool vis = false;
+      bool vis = false, neutral = true;
 #pragma unroll
-      for (int r = 0; r < 32; ++r) vis = vis || mask_elem_visible<BT>(x[u][r]);
-      if (vis && c < m.nkv) {
-        first = first < c ? first : c;
-        end = end > c + 1 ? end : c + 1;
+      for (int r = 0; r < 32; ++r) {
+        vis = vis || mask_elem_visible<BT>(x[u][r]);
+        neutral = neutral && mask_elem_neutral<BT>(x[u][r]);
+      }
+      if (c < m.nkv) {
+        if (vis) {
+          first = first < c ? first : c;
+          end = end > c + 1 ? end : c + 1;
+        }
+        if (neutral && m.words) __hip_atomic_fetch_or(&bits[c >> 5], 1u << (c & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const int f2 = __shfl_xor(first, o), e2 = __shfl_xor(end, o);
-    first = first < f2 ? first : f2;
-    end = end > e2 ? end : e2;
-  }
-  if ((threadIdx.x & 63) == 0) {
-    red[0][threadIdx.x >> 6] = first;
-    red[1][threadIdx.x >> 6] = end;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int w = 1; w < 4; ++w) {
-      first = first < red[0][w] ? first : red[0][w];
-      end = end > red[1][w] ? end : red[1][w];
-    }
-    m.out[2 * (int64_t)blockIdx.x] = first;
-    m.out[2 * (int64_t)blockIdx.x + 1] = end;
-  }
+  mask_bounds_finish(m, bits, first, end);
 }
 
-// 16-byte variant (unit key stride, 16-byte aligned rows, Nkv a multiple of the vector width): each lane owns W = 8
-// (16-bit) or 4 (fp32) consecutive keys, so a wave reads 1 KiB of a row per load instead of 128 B.
+// 16-byte variant (unit key stride, 16-byte aligned rows, Nkv a multiple of the vector width): each lane owns W = 16
+// (bytes), 8 (16-bit) or 4 (fp32) consecutive keys, so a wave reads 1 KiB of a row per load instead of 64-256 B.
 template <typename BT>
 __global__ __launch_bounds__(256) void ffpa_mask_kv_bounds_vec_kernel(const MaskBoundsArgs m) {
   constexpr int W = 16 / (int)sizeof(BT);
   typedef __attribute__((ext_vector_type(W))) BT bvec;
-  __shared__ int red[2][4];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  FFPA_LDS uint32_t* bits = (FFPA_LDS uint32_t*)smem;
+  for (int w = threadIdx.x; w < m.words; w += 256) bits[w] = 0u;
+  __syncthreads();
   const int blk = blockIdx.x % m.nblk;
   const int bh = blockIdx.x / m.nblk;
   const int h = bh % m.hb, b = bh / m.hb;
@@ -1274,37 +1365,24 @@ __global__ __launch_bounds__(256) void ffpa_mask_kv_bounds_vec_kernel(const Mask
       const int rr = r0 + r < r1 ? r0 + r : r1 - 1;
       x[r] = *(const bvec*)(base + (int64_t)rr * m.sb[2] + c);
     }
+    uint32_t nbits = 0u;  // W <= 16 consecutive keys: they sit inside one bitmap word (c is a multiple of W, W divides 32)
 #pragma unroll
     for (int e = 0; e < W; ++e) {
-      bool vis = false;
+      bool vis = false, neutral = true;
 #pragma unroll
-      for (int r = 0; r < 32; ++r) vis = vis || mask_elem_visible<BT>(x[r][e]);
+      for (int r = 0; r < 32; ++r) {
+        vis = vis || mask_elem_visible<BT>(x[r][e]);
+        neutral = neutral && mask_elem_neutral<BT>(x[r][e]);
+      }
       if (vis) {
         first = first < c + e ? first : c + e;
         end = end > c + e + 1 ? end : c + e + 1;
       }
+      if (neutral) nbits |= 1u << e;
     }
+    if (nbits != 0u && m.words) __hip_atomic_fetch_or(&bits[c >> 5], nbits << (c & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const int f2 = __shfl_xor(first, o), e2 = __shfl_xor(end, o);
-    first = first < f2 ? first : f2;
-    end = end > e2 ? end : e2;
-  }
-  if ((threadIdx.x & 63) == 0) {
-    red[0][threadIdx.x >> 6] = first;
-    red[1][threadIdx.x >> 6] = end;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int w = 1; w < 4; ++w) {
-      first = first < red[0][w] ? first : red[0][w];
-      end = end > red[1][w] ? end : red[1][w];
-    }
-    m.out[2 * (int64_t)blockIdx.x] = first;
-    m.out[2 * (int64_t)blockIdx.x + 1] = end;
-  }
+  mask_bounds_finish(m, bits, first, end);
 }
 
 }  // namespace ffpa

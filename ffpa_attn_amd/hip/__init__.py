@@ -197,15 +197,17 @@ def _dense_rows(t: torch.Tensor) -> torch.Tensor:
 
 
 def mask_kv_bounds(attn_bias: torch.Tensor, nq: int, nkv: int) -> torch.Tensor:
-  """Visible-key bounds of an additive (-inf = hidden) or boolean (False = hidden) mask for the kernel's tile clipping: int32 ``[Bb, Hb, ceil(Nq/32), 2]`` holding,
-  per block of 32 query rows, ``[first, end)`` such that every key outside is -inf for every row of the block
-  (``{Nkv, 0}`` for a block without any visible key).  On the GPU: one fused pass of the library over the mask
+  """Key ranges of an additive (-inf = hidden, 0 = neutral) or boolean (False = hidden) mask for the kernel's tile clipping:
+  int32 ``[Bb, Hb, ceil(Nq/32), 4]`` holding, per block of 32 query rows, ``[first, end)`` such that every key outside is
+  hidden for every row of the block (``{Nkv, 0}`` for a block without any visible key) and ``[free_first, free_end)``, the
+  first run of keys on which the mask does nothing for every row of the block (``{0, 0}``: none) — tiles inside it are
+  computed without reading the mask.  On the GPU: one fused pass of the library over the mask
   (``ffpa_attn_mask_kv_bounds``); elsewhere (tests) the same thing in torch ops."""
   bb, hb = attn_bias.size(0), attn_bias.size(1)
   nblk = (nq + 31) // 32
   if attn_bias.is_cuda and attn_bias.dtype in _BIAS_DTYPE:
     lib = load_library()
-    out = torch.empty((bb, hb, nblk, 2), dtype=torch.int32, device=attn_bias.device)
+    out = torch.empty((bb, hb, nblk, 4), dtype=torch.int32, device=attn_bias.device)
     strides = (ctypes.c_int64 * 4)(*[attn_bias.stride(d) if attn_bias.size(d) > 1 else 0 for d in range(4)])
     with torch.cuda.device(attn_bias.device):
       rc = lib.ffpa_attn_mask_kv_bounds(ctypes.c_void_p(attn_bias.data_ptr()), _BIAS_DTYPE[attn_bias.dtype], strides, bb, hb, nq, nkv,
@@ -213,16 +215,28 @@ def mask_kv_bounds(attn_bias: torch.Tensor, nq: int, nkv: int) -> torch.Tensor:
     if rc != 0:
       raise _STATUS_EXC.get(rc, RuntimeError)(lib.ffpa_attn_last_error().decode())
     return out
-  vis = attn_bias.ne(0) if attn_bias.dtype in (torch.bool, torch.uint8) else ~torch.isneginf(attn_bias)  # [Bb, Hb, Nq|1, Nkv|1]
-  col_any = vis.expand(bb, hb, nq, nkv)
+  is_bool = attn_bias.dtype in (torch.bool, torch.uint8)
+  vis = attn_bias.ne(0) if is_bool else ~torch.isneginf(attn_bias)      # [Bb, Hb, Nq|1, Nkv|1]
+  neutral = attn_bias.ne(0) if is_bool else attn_bias.eq(0)
   pad = nblk * 32 - nq
-  if pad:
-    col_any = torch.nn.functional.pad(col_any, (0, 0, 0, pad))         # padded rows see nothing
-  col_any = col_any.reshape(bb, hb, nblk, 32, nkv).any(dim=3)          # any over the rows of a block: [Bb, Hb, nblk, Nkv]
+
+  def per_block(t, pad_value, reduce):
+    t = t.expand(bb, hb, nq, nkv)
+    if pad:
+      t = torch.nn.functional.pad(t, (0, 0, 0, pad), value=pad_value)  # rows past Nq: see nothing / constrain nothing
+    t = t.reshape(bb, hb, nblk, 32, nkv)
+    return t.any(dim=3) if reduce == "any" else t.all(dim=3)            # [Bb, Hb, nblk, Nkv]
+
+  col_any, col_all = per_block(vis, False, "any"), per_block(neutral, True, "all")
   idx = torch.arange(nkv, device=attn_bias.device, dtype=torch.int32)
   first = torch.where(col_any, idx, torch.full_like(idx, nkv)).amin(dim=-1)
   end = torch.where(col_any, idx + 1, torch.zeros_like(idx)).amax(dim=-1)
-  return torch.stack((first, end), dim=-1).to(torch.int32).contiguous()
+  ff = torch.where(col_all, idx, torch.full_like(idx, nkv)).amin(dim=-1)                           # first neutral key
+  after = (~col_all) & (idx >= ff.unsqueeze(-1))
+  fe = torch.where(after, idx, torch.full_like(idx, nkv)).amin(dim=-1)                              # first non-neutral key after it
+  none = ff >= nkv
+  ff, fe = torch.where(none, torch.zeros_like(ff), ff), torch.where(none, torch.zeros_like(fe), fe)
+  return torch.stack((first, end, ff, fe), dim=-1).to(torch.int32).contiguous()
 
 
 def _want_mask_bounds(attn_bias: torch.Tensor, b: int, hq: int, nq: int, nkv: int) -> bool:
@@ -268,8 +282,9 @@ def forward(
   1 = never) and merges by LSE; the scratch for the partials is allocated here with torch.
   ``plan_out``, if given, receives the launch plan (variant, block_rows, block_keys, splits, packed).
 
-  ``kv_bounds``: visible-key bounds of the mask (``mask_kv_bounds``) — the kernel then skips the KV tiles the mask
-  hides entirely (an explicit causal mask costs what ``is_causal`` costs); ``None`` derives them from ``attn_bias``
+  ``kv_bounds``: key ranges of the mask (``mask_kv_bounds``) — the kernel then skips the KV tiles the mask hides
+  entirely and does not read the mask for the tiles it leaves untouched (an explicit causal mask costs what ``is_causal``
+  costs); ``None`` derives them from ``attn_bias``
   when that is worth a scan of the mask, ``False`` never, ``True`` always, or pass a precomputed tensor.
   """
   if not q.is_cuda:
@@ -346,8 +361,8 @@ def forward(
       kv_bounds = mask_kv_bounds(attn_bias, Nq, Nkv)
     if isinstance(kv_bounds, torch.Tensor):
       nblk = (Nq + 31) // 32
-      if kv_bounds.dtype != torch.int32 or kv_bounds.dim() != 4 or kv_bounds.shape[2:] != (nblk, 2) or not kv_bounds.is_contiguous():
-        raise ValueError(f"kv_bounds must be a contiguous int32 [B|1, Hq|1, {nblk}, 2] tensor")
+      if kv_bounds.dtype != torch.int32 or kv_bounds.dim() != 4 or kv_bounds.shape[2:] != (nblk, 4) or not kv_bounds.is_contiguous():
+        raise ValueError(f"kv_bounds must be a contiguous int32 [B|1, Hq|1, {nblk}, 4] tensor (mask_kv_bounds)")
       if kv_bounds.size(0) not in (1, B) or kv_bounds.size(1) not in (1, Hq) or kv_bounds.device != q.device:
         raise ValueError("kv_bounds batch / head dims must be 1 or match q, on q's device")
       p.kv_bounds = kv_bounds.data_ptr()

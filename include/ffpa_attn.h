@@ -134,13 +134,18 @@ typedef struct ffpa_fwd_params {
    * 0 = rows are plain query rows. */
   int32_t causal_row_mod;
 
-  /* Optional visible-key bounds derived from the mask by the caller (NULL = none): for every block of 32
-   * query rows, [first, end) such that EVERY key outside it is masked (bias == -inf) for EVERY row of the
-   * block.  int32 pairs, shape [Bb, Hb, ceil(Nq / 32), 2] with element strides kv_bounds_stride = {batch, head}
-   * (0 = broadcast); an empty block is {Nkv, 0}.  The kernel clips its KV-tile loop to the union of its
-   * blocks' ranges: results are unchanged (the skipped tiles contribute exp(-inf) = 0), an explicit causal /
-   * sliding-window / padding mask just stops costing the tiles it masks out entirely.  The reference has no
-   * counterpart (it always walks every tile: native/sm_80/split_d.cuh:222-228 clips for is_causal only). */
+  /* Optional key ranges derived from the mask by the caller (NULL = none), four int32 per block of 32 query rows:
+   *   {first, end}            EVERY key outside [first, end) is masked (bias == -inf / mask == False) for EVERY row of the
+   *                           block; an empty block is {Nkv, 0};
+   *   {free_first, free_end}  for EVERY key inside [free_first, free_end) the mask is neutral (bias == 0 / mask == True) for
+   *                           EVERY row of the block; {0, 0} = no such claim.
+   * Shape [Bb, Hb, ceil(Nq / 32), 4] with element strides kv_bounds_stride = {batch, head} (0 = broadcast);
+   * ffpa_attn_mask_kv_bounds() computes it.  The kernel clips its KV-tile loop to the union of its blocks' [first, end) and
+   * does not read the mask for tiles inside a block's free range: results are unchanged (the skipped tiles contribute
+   * exp(-inf) = 0, the skipped mask reads would have added 0); an explicit causal / sliding-window / padding mask stops
+   * costing the tiles it hides AND the tiles it leaves fully visible — only the tiles its edge crosses pay for it.  The
+   * reference has no counterpart (it walks every tile and adds the bias everywhere: native/sm_80/split_d.cuh:222-228 clips
+   * for is_causal only). */
   const int32_t* kv_bounds;
   int64_t kv_bounds_stride[2];
 } ffpa_fwd_params;
@@ -169,7 +174,8 @@ int ffpa_attn_fwd_plan(const ffpa_fwd_params* params, int out[4]);
  * Visible-key bounds of an additive (-inf = hidden) or boolean (0 = hidden) mask, in the layout
  * ffpa_fwd_params.kv_bounds expects: one fused pass over
  * `bias` ([bb, hb, nq|1, nkv|1] with element strides bias_stride, 0 = broadcast; enum ffpa_bias_dtype) writes
- * out[bb][hb][ceil(nq / 32)][2] (int32, contiguous) on `stream`.  Returns an ffpa_status.
+ * out[bb][hb][ceil(nq / 32)][4] = {first, end, free_first, free_end} (int32, contiguous) on `stream`.  Returns an
+ * ffpa_status.
  */
 int ffpa_attn_mask_kv_bounds(const void* bias, int bias_dtype, const int64_t bias_stride[4], int bb, int hb,
                              int nq, int nkv, int32_t* out, void* stream);

@@ -89,6 +89,50 @@ def test_bool_mask_bounds_match_the_additive_scan_and_clip_the_same_tiles(hip):
   assert torch.equal(hip.mask_kv_bounds(odd, Nq, 1499), hip.mask_kv_bounds(_additive(odd, q.dtype), Nq, 1499))
 
 
+@pytest.mark.parametrize("dtype", [torch.bool, torch.bfloat16, torch.float16, torch.float32])
+def test_scan_kernel_ranges_equal_the_torch_reference(hip, dtype):
+  """ffpa_attn_mask_kv_bounds (both the 16-byte and the element-wise kernels) against the same ranges computed with
+  torch ops on the CPU: {first, end} of the keys any row of a 32-row block sees, {free_first, free_end} of the first run
+  of keys on which the mask does nothing for all of them."""
+  g = torch.Generator(device="cuda").manual_seed(5)
+  for (bb, hb, nq, nkv) in ((1, 1, 700, 1536), (2, 3, 130, 1000), (1, 2, 64, 777), (1, 1, 1, 2048)):
+    rows, cols = torch.arange(nq, device="cuda")[:, None], torch.arange(nkv, device="cuda")[None, :]
+    keep = ((cols <= rows + nkv // 2) & (cols + 300 >= rows)).expand(bb, hb, nq, nkv).clone()
+    keep &= torch.rand(bb, hb, 1, nkv, device="cuda", generator=g) > 0.02   # a few keys hidden everywhere: runs get cut
+    if dtype == torch.bool:
+      m = keep
+    else:
+      m = torch.zeros(bb, hb, nq, nkv, dtype=dtype, device="cuda").masked_fill(~keep, float("-inf"))
+      m[:, :, :, nkv // 3] = 0.25  # a finite, non-neutral bias column: visible but not free
+    want = hip.mask_kv_bounds(m.cpu(), nq, nkv)
+    assert torch.equal(hip.mask_kv_bounds(m, nq, nkv).cpu(), want), (dtype, bb, hb, nq, nkv)
+    wide = torch.zeros(bb, hb, nq, 2 * nkv, dtype=m.dtype, device="cuda")
+    wide[..., ::2] = m
+    assert torch.equal(hip.mask_kv_bounds(wide[..., ::2], nq, nkv).cpu(), want), ("strided", dtype)
+
+
+def test_tiles_in_the_free_range_skip_the_mask_without_changing_a_bit(hip):
+  """Results with the ranges (tile clipping + no mask reads in the neutral interior) == results walking and masking every
+  tile, for boolean and additive masks, D <= 512 and split-D kernels; a forged free range over masked keys must show."""
+  for D in (320, 512, 1024):
+    B, Hq, Hkv, Nq, Nkv = 1, 4, 2, 900, 2048
+    q, k, v = _rand((B, Hq, Nq, D), seed=701), _rand((B, Hkv, Nkv, D), seed=702), _rand((B, Hkv, Nkv, D), seed=703)
+    rows, cols = torch.arange(Nq, device="cuda")[:, None], torch.arange(Nkv, device="cuda")[None, :]
+    for name, keep in (("causal", cols <= rows + 600), ("window", (cols <= rows + 700) & (cols + 200 >= rows)), ("padding", (cols < 1500).expand(Nq, Nkv))):
+      for m in (keep.view(1, 1, Nq, Nkv).contiguous(), _additive(keep.view(1, 1, Nq, Nkv), q.dtype)):
+        o_all, l_all = hip.forward(q, k, v, m, False, D ** -0.5, kv_bounds=False)
+        bounds = hip.mask_kv_bounds(m, Nq, Nkv)
+        assert int((bounds[..., 3] - bounds[..., 2]).max()) >= 512, name  # there IS an interior to skip
+        o_rng, l_rng = hip.forward(q, k, v, m, False, D ** -0.5, kv_bounds=bounds)
+        assert _same_bits(o_all, o_rng) and _same_bits(l_all, l_rng), (D, name, m.dtype)
+    # the kernel really trusts the range: claim everything is free -> the mask is ignored -> equals the unmasked result
+    forged = bounds.clone()
+    forged[..., 0], forged[..., 1], forged[..., 2], forged[..., 3] = 0, Nkv, 0, Nkv
+    o_forged, _ = hip.forward(q, k, v, m, False, D ** -0.5, kv_bounds=forged)
+    o_plain, _ = hip.forward(q, k, v, None, False, D ** -0.5)
+    assert torch.equal(o_forged, o_plain)
+
+
 def test_public_api_bool_mask_allocates_nothing_mask_sized(hip):
   """ffpa_attn_func(attn_mask=<bool>) hands the mask's own bytes to the kernel: no 0 / -inf temporary (the reference
   allocates 2 B per mask element per call).  Peak memory during the call stays below the mask's own size."""

@@ -577,7 +577,7 @@ def test_mask_derived_tile_clipping_changes_nothing_but_the_time(hip, D):
   mbh[..., 0] = True
   bias = torch.zeros(B, Hq, Nq, Nkv, dtype=q.dtype, device="cuda").masked_fill(~mbh, float("-inf"))
   bounds = hip.mask_kv_bounds(bias, Nq, Nkv)
-  assert bounds.shape == (B, Hq, (Nq + 31) // 32, 2) and int(bounds[..., 1].max()) <= 1000
+  assert bounds.shape == (B, Hq, (Nq + 31) // 32, 4) and int(bounds[..., 1].max()) <= 1000
   o_all, _ = hip.forward(q, k, v, bias, False, scale, kv_bounds=False)
   o_clip, _ = hip.forward(q, k, v, bias, False, scale, kv_bounds=bounds)
   assert torch.equal(o_all, o_clip)

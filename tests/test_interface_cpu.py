@@ -87,13 +87,19 @@ def test_mask_kv_bounds_per_32_row_block():
   m = torch.ones(Nq, Nkv, dtype=torch.bool).tril(diagonal=50)
   m[40:70] = False
   bias = torch.zeros(1, 1, Nq, Nkv).masked_fill(~m, float("-inf"))
-  assert mask_kv_bounds(bias, Nq, Nkv)[0, 0].tolist() == [[0, 82], [0, 90], [0, 146], [0, 150]]
+  assert mask_kv_bounds(bias, Nq, Nkv)[0, 0, :, :2].tolist() == [[0, 82], [0, 90], [0, 146], [0, 150]]
   assert torch.equal(mask_kv_bounds(m.view(1, 1, Nq, Nkv), Nq, Nkv), mask_kv_bounds(bias, Nq, Nkv))  # bool masks: False = hidden
+  # neutral interior: keys every row of the block sees unmasked.  block 0 = rows 0..31 (tril +50): keys 0..50; block 1 holds the
+  # all-hidden rows 40..63 -> nothing; block 2 (rows 64..95, rows 64..69 hidden) -> nothing; block 3 = rows 96..99: keys 0..146
+  assert mask_kv_bounds(bias, Nq, Nkv)[0, 0, :, 2:].tolist() == [[0, 51], [0, 0], [0, 0], [0, 147]]
   win = torch.ones(64, 512, dtype=torch.bool).tril(diagonal=200).triu(diagonal=150)       # sliding window
   b = mask_kv_bounds(torch.zeros(2, 1, 64, 512).masked_fill(~win, float("-inf")), 64, 512)
-  assert b.shape == (2, 1, 2, 2) and b.dtype == torch.int32
-  assert b[1, 0].tolist() == [[150, 232], [182, 264]]
-  none = mask_kv_bounds(torch.full((1, 1, 32, 64), float("-inf")), 32, 64)                # nothing visible: empty range
-  assert none[0, 0].tolist() == [[64, 0]]
+  assert b.shape == (2, 1, 2, 4) and b.dtype == torch.int32
+  assert b[1, 0, :, :2].tolist() == [[150, 232], [182, 264]]
+  assert b[1, 0, :, 2:].tolist() == [[181, 201], [213, 233]]                               # keys r+150..r+200 for all of r0..r0+31
+  none = mask_kv_bounds(torch.full((1, 1, 32, 64), float("-inf")), 32, 64)                # nothing visible: empty ranges
+  assert none[0, 0].tolist() == [[64, 0, 0, 0]]
   pad = mask_kv_bounds(torch.zeros(1, 1, 1, 100).index_fill_(3, torch.arange(60, 100), float("-inf")), 40, 100)   # key padding
-  assert pad[0, 0].tolist() == [[0, 60], [0, 60]]
+  assert pad[0, 0].tolist() == [[0, 60, 0, 60], [0, 60, 0, 60]]
+  alibi = mask_kv_bounds(-torch.arange(64.0).view(1, 1, 1, 64).expand(1, 1, 32, 64) * 0.5, 32, 64)  # a real bias: only key 0 adds 0
+  assert alibi[0, 0].tolist() == [[0, 64, 0, 1]]
