@@ -120,6 +120,23 @@ def test_small_cases_vs_oracle_and_sdpa_fixtures(hip, small_cases):
     np.testing.assert_allclose(_f32(lse), c["lse_f64"], atol=3e-4, rtol=3e-5, err_msg=c["name"])
 
 
+def test_kernel_matches_the_executed_reference_triton_kernel(hip):
+  """fp16 outputs of the reference's own Triton forward (tests/golden/make_triton_golden.py, run under TRITON_INTERPRET=1
+  in the authoring container) vs the HIP kernel on the re-created inputs: tails, tail-aligned causal + GQA, additive
+  biases with -inf entries, D = 320 / 512 / 1024."""
+  from test_oracle import _triton_cases
+
+  for case, (q, k, v, bias), o_ref_bits, lse_ref in _triton_cases():
+    name, D, causal = case[0], case[6], case[7]
+    qt, kt, vt = (torch.from_numpy(a).cuda() for a in (q, k, v))
+    bt = None if bias is None else torch.from_numpy(bias).cuda()
+    o, lse = hip.forward(qt, kt, vt, bt, causal, D ** -0.5)
+    want = torch.from_numpy(o_ref_bits.view(np.float16).copy()).cuda().float()
+    d = (o.float() - want).abs()
+    assert d.max().item() <= 1e-3 and d.mean().item() <= 5e-5, (name, d.max().item(), d.mean().item())
+    assert (lse.cpu() - torch.from_numpy(lse_ref)).abs().max().item() <= 2e-5, name
+
+
 # ----------------------------------------------------------------------------- fast path == safe path
 @pytest.mark.parametrize("D", [64, 128, 320, 512, 640, 1024])
 def test_dma_and_transpose_read_path_is_bit_identical_to_register_staged_twin(hip, D):
