@@ -44,9 +44,16 @@ const DimEntry kDims[] = {
 #undef FFPA_ROW
 };
 
+// Head dims are instantiated in multiples of 64; any multiple of 8 up to 1024 runs on the next instantiation with the
+// columns past the caller's head dim read as zeros and never stored (the reference pads to its compiled multiples on
+// the host, csrc/cuffpa/ffpa_api.cc:123-161).
+int kernel_head_dim(int d) { return (d + 63) / 64 * 64; }
+
 const DimEntry* find_dim(int d) {
+  if (d <= 0 || d % 8 != 0) return nullptr;
+  const int dk = kernel_head_dim(d);
   for (const DimEntry& e : kDims)
-    if (e.d == d) return &e;
+    if (e.d == dk) return &e;
   return nullptr;
 }
 
@@ -119,7 +126,7 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
     if (want > ffpa::kMergeMaxSplits) want = ffpa::kMergeMaxSplits;  // the merge kernel keeps the split weights in LDS
     if (p->num_splits > 1 && want > p->num_splits) want = p->num_splits;
     if (want < 1) want = 1;
-    const size_t per_split = (size_t)p->batch * p->heads_q * p->seqlen_q * ((size_t)p->head_dim + 1) * sizeof(float);
+    const size_t per_split = (size_t)p->batch * p->heads_q * p->seqlen_q * ((size_t)kernel_head_dim(p->head_dim) + 1) * sizeof(float);
     if (p->workspace == nullptr) want = 1;
     else if ((uint64_t)want * per_split > p->workspace_bytes) want = (int64_t)(p->workspace_bytes / per_split);
     if (want < 1) want = 1;
@@ -129,7 +136,7 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
   if (pl.tiles_per_split < 1) pl.tiles_per_split = 1;
   pl.splits = (pl.nt + pl.tiles_per_split - 1) / pl.tiles_per_split;
   if (pl.splits < 1) pl.splits = 1;
-  pl.ws_bytes = pl.splits > 1 ? (size_t)pl.splits * p->batch * p->heads_q * p->seqlen_q * ((size_t)p->head_dim + 1) * sizeof(float) : 0;
+  pl.ws_bytes = pl.splits > 1 ? (size_t)pl.splits * p->batch * p->heads_q * p->seqlen_q * ((size_t)kernel_head_dim(p->head_dim) + 1) * sizeof(float) : 0;
   return pl;
 }
 
@@ -144,7 +151,7 @@ int check_basic(const ffpa_fwd_params* p, const DimEntry** de_out) {
                 p->heads_kv, p->seqlen_q, p->seqlen_kv);
   const DimEntry* de = find_dim(p->head_dim);
   if (de == nullptr)
-    return fail(FFPA_ERR_BAD_HEADDIM, "headdim not support! D=%d (built: multiples of 64 in [64, 1024])", p->head_dim);
+    return fail(FFPA_ERR_BAD_HEADDIM, "headdim not support! D=%d (supported: multiples of 8 in [8, 1024])", p->head_dim);
   *de_out = de;
   return FFPA_OK;
 }
@@ -180,7 +187,7 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
     return fail(FFPA_ERR_BAD_SHAPE, "num_heads: Hq=%d is not a multiple of Hkv=%d", p->heads_q, p->heads_kv);
   const DimEntry* de = find_dim(p->head_dim);
   if (de == nullptr)
-    return fail(FFPA_ERR_BAD_HEADDIM, "headdim not support! D=%d (built: multiples of 64 in [64, 1024])", p->head_dim);
+    return fail(FFPA_ERR_BAD_HEADDIM, "headdim not support! D=%d (supported: multiples of 8 in [8, 1024])", p->head_dim);
   if (!aligned16(p->q) || !aligned16(p->k) || !aligned16(p->v) || !aligned16(p->o))
     return fail(FFPA_ERR_MISALIGNED, "q/k/v/o base pointers must be 16-byte aligned");
   int rc;
@@ -242,6 +249,7 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   a.Hkv = p->heads_kv;
   a.Nq = p->seqlen_q;
   a.Nkv = p->seqlen_kv;
+  a.d_valid = p->head_dim;
   a.group = p->heads_q / p->heads_kv;
   a.nqt = (int)nqt;
   a.bias_dtype = p->bias_dtype;
@@ -275,16 +283,16 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   a.philox_offset = p->philox_offset;
   if (pl.splits > 1) {
     a.ws_o = static_cast<float*>(p->workspace);
-    a.ws_lse = a.ws_o + (size_t)pl.splits * p->batch * p->heads_q * p->seqlen_q * p->head_dim;
+    a.ws_lse = a.ws_o + (size_t)pl.splits * p->batch * p->heads_q * p->seqlen_q * kernel_head_dim(p->head_dim);
   }
 
   int st = de->launch(p->dtype, safe, pl.variant, a, static_cast<hipStream_t>(stream));
   if (st == 0 && pl.splits > 1) {
     const unsigned rows = (unsigned)((int64_t)p->batch * p->heads_q * p->seqlen_q);
     if (p->dtype == FFPA_DTYPE_BF16)
-      hipLaunchKernelGGL(ffpa::ffpa_fwd_merge_kernel<__bf16>, dim3(rows, (unsigned)(p->head_dim + 255) / 256), dim3(64), 0, static_cast<hipStream_t>(stream), a, p->head_dim);
+      hipLaunchKernelGGL(ffpa::ffpa_fwd_merge_kernel<__bf16>, dim3(rows, (unsigned)(p->head_dim + 255) / 256), dim3(64), 0, static_cast<hipStream_t>(stream), a, kernel_head_dim(p->head_dim));
     else
-      hipLaunchKernelGGL(ffpa::ffpa_fwd_merge_kernel<_Float16>, dim3(rows, (unsigned)(p->head_dim + 255) / 256), dim3(64), 0, static_cast<hipStream_t>(stream), a, p->head_dim);
+      hipLaunchKernelGGL(ffpa::ffpa_fwd_merge_kernel<_Float16>, dim3(rows, (unsigned)(p->head_dim + 255) / 256), dim3(64), 0, static_cast<hipStream_t>(stream), a, kernel_head_dim(p->head_dim));
     st = (int)hipGetLastError();
   }
   if (st == -3) return fail(FFPA_ERR_UNSUPPORTED, "debug safe-path kernel is not built for D=%d / this dtype", p->head_dim);
@@ -364,9 +372,9 @@ int ffpa_attn_query(int what) {
   switch (what) {
     case FFPA_QUERY_ABI_VERSION: return FFPA_ATTN_ABI_VERSION;
     case FFPA_QUERY_FWD_AVAILABLE: return 1;
-    case FFPA_QUERY_MIN_HEAD_DIM: return 64;
+    case FFPA_QUERY_MIN_HEAD_DIM: return 8;
     case FFPA_QUERY_MAX_HEAD_DIM: return 1024;
-    case FFPA_QUERY_HEAD_DIM_MULTIPLE: return 64;
+    case FFPA_QUERY_HEAD_DIM_MULTIPLE: return 8;
     case FFPA_QUERY_FP16_AVAILABLE: return 1;
     case FFPA_QUERY_DROPOUT_AVAILABLE: return 1;
 #ifdef FFPA_INST_SAFE

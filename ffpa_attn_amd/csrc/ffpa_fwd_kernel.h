@@ -155,6 +155,7 @@ struct FwdArgs {
   int64_t sq[3], sk[3], sv[3], so[3];  // element strides: batch, head, row
   int64_t sbias[4];                    // element strides: batch, head, row, key
   int B, Hq, Hkv, Nq, Nkv;
+  int d_valid;        // the caller's head dim (a multiple of 8, <= the kernel's D): columns [d_valid, D) read as zeros and are never stored
   int group;          // Hq / Hkv
   int nqt;            // row tiles per (batch, head)
   int bias_dtype;     // 0 none, 1 fp16, 2 bf16, 3 fp32 (additive), 4 bool8 (byte != 0 <=> key visible, else -inf)
@@ -318,8 +319,8 @@ struct TileSrc {
   const char* base;
   int rows;
 };
-template <int BC, int RB>
-__device__ __forceinline__ TileSrc tile_src(const void* slice, uint32_t row_bytes, int key0, int nkv) {
+template <int BC>
+__device__ __forceinline__ TileSrc tile_src(const void* slice, uint32_t row_bytes, int key0, int nkv, uint32_t RB) {
   // min / max only: a select here is lowered to VALU by hipcc and the descriptor then lands in VGPRs
   const int kc = key0 < nkv ? key0 : nkv;
   int rows = nkv - kc;
@@ -336,9 +337,15 @@ __device__ __forceinline__ TileSrc tile_src(const void* slice, uint32_t row_byte
 // (the rest reads as zeros).  Each wave moves TILE/4 bytes as 1 KiB LDS-DMA pieces: lane l of piece p lands at
 // lds_tile + p*1024 + l*16 (the hardware's lane-linear rule), so the swizzle goes on the per-lane SOURCE
 // offset.  SAFE = the register-staged twin used by the tests.
+// kDmaOob: a per-lane offset no tile reaches (tile spans are < 2 GiB and 32-bit offset sums cannot wrap): the range check
+// zero-fills that lane.  Used for the K columns at and past the caller's head dim when it is not a multiple of 64 (`slots_valid`
+// 16-byte slots per row hold data).  V would not need it — a column of V only ever reaches the same column of O^T, and
+// columns past the head dim are not stored — so the hoisted / row-uniform V offsets are left alone (what they fetch there
+// is in range: the descriptor ends with the last valid row's last valid byte); the per-piece form masks both.
+constexpr uint32_t kDmaOob = 0x80000000u;
 template <typename T, int D, int BC, bool IS_V, bool SAFE>
 __device__ __forceinline__ void stage_piece(u32x4 rsrc, const char* __restrict__ base, uint32_t row_bytes, int rows,
-                                            FFPA_LDS char* lds_tile, int wave, int lane, int i) {
+                                            FFPA_LDS char* lds_tile, int wave, int lane, int i, int slots_valid) {
   constexpr int SPR = D / 8;  // 16-byte slots per row
   constexpr int PPW = BC * D * 2 / 4096;
   const int p = wave * PPW + i;
@@ -351,6 +358,7 @@ __device__ __forceinline__ void stage_piece(u32x4 rsrc, const char* __restrict__
     const int sw = IS_V ? v_slot_swizzle<D>(key) : k_slot_swizzle<D>(key);
     voff = (uint32_t)((lane ^ sw) << 4);
     soff = (uint32_t)key * row_bytes + (uint32_t)(p % RPP) * 1024u;
+    if ((p % RPP) * 64 + (lane ^ sw) >= slots_valid) voff = kDmaOob;
   } else {
     const int g = p * 64 + lane;
     key = g / SPR;
@@ -358,12 +366,13 @@ __device__ __forceinline__ void stage_piece(u32x4 rsrc, const char* __restrict__
     const int src_slot = slot ^ (IS_V ? v_slot_swizzle<D>(key) : k_slot_swizzle<D>(key));
     voff = (uint32_t)key * row_bytes + (uint32_t)(src_slot << 4);
     soff = 0;
+    if (src_slot >= slots_valid) voff = kDmaOob;
   }
   if constexpr (!SAFE) {
     lds_dma_16(rsrc, (uint32_t)(uintptr_t)(lds_tile + p * 1024), voff, soff);
   } else {
     u32x4 x = {0u, 0u, 0u, 0u};
-    if (key < rows) x = *(const u32x4*)(base + (size_t)voff + (size_t)soff);
+    if (key < rows && voff != kDmaOob) x = *(const u32x4*)(base + (size_t)voff + (size_t)soff);
     *(FFPA_LDS u32x4*)(lds_tile + p * 1024 + lane * 16) = x;
   }
 }
@@ -562,6 +571,10 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   const uint32_t k_row_bytes = (uint32_t)a.sk[2] * 2u;
   const uint32_t v_row_bytes = (uint32_t)a.sv[2] * 2u;
 
+  // the caller's head dim when it is not a multiple of 64 (else == D): bytes / 16-byte slots of a row that hold data
+  const uint32_t rb_valid = (uint32_t)a.d_valid * 2u;
+  const int slots_valid = a.d_valid >> 3;
+
   // ---- DMA issue helpers (piece i of this wave for the tile starting at key0)
   uint32_t krel[kHoist ? BC * D * 2 / 4096 : 1], vrel[kHoist ? BC * D * 2 / 4096 : 1];
   if constexpr (kHoist) {
@@ -572,6 +585,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
       const int key = g / SPRh;
       const int slot = g - key * SPRh;
       krel[i] = (uint32_t)key * k_row_bytes + (uint32_t)((slot ^ k_slot_swizzle<D>(key)) << 4);
+      if ((slot ^ k_slot_swizzle<D>(key)) >= slots_valid) krel[i] = kDmaOob;  // K columns past the head dim read as zeros
       vrel[i] = (uint32_t)key * v_row_bytes + (uint32_t)((slot ^ v_slot_swizzle<D>(key)) << 4);
     }
   }
@@ -582,6 +596,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) {
       kvo[bb] = (uint32_t)((lane ^ (4 * wave + bb)) << 4);
+      if (RPP == 1 && (lane ^ (4 * wave + bb)) >= slots_valid) kvo[bb] = kDmaOob;  // (two-piece rows: masked per piece below)
       vvo[bb] = (uint32_t)((lane ^ (4 * bb)) << 4);
     }
 #pragma unroll
@@ -597,26 +612,31 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   // descriptor zero-fills rows past the last key.
   auto issue_k = [&](auto ic, int key0, int dlane) {
     constexpr int i = decltype(ic)::value;
-    const TileSrc ts = tile_src<BC, RB>(Kg, k_row_bytes, key0, a.Nkv);
+    const TileSrc ts = tile_src<BC>(Kg, k_row_bytes, key0, a.Nkv, rb_valid);
     if constexpr (kRowDma) {
       constexpr int jk = i / RPP, half = i % RPP;
-      lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(ts.rsrc, k_lds, kvo[jk & 3], kro[jk]);
+      uint32_t kv = kvo[jk & 3];
+      if constexpr (RPP > 1 && half == RPP - 1) {
+        // the row's last piece: lanes whose 16-byte slot lies at or past the caller's head dim fetch zeros
+        if (half * 64 + (dlane ^ (4 * wave + (jk & 3))) >= slots_valid) kv = kDmaOob;
+      }
+      lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(ts.rsrc, k_lds, kv, kro[jk]);
     } else if constexpr (kHoist) {
       lds_dma_16(ts.rsrc, (uint32_t)(uintptr_t)(Kt + (wave * PPW + i) * 1024), krel[i], 0u);
     } else {
-      stage_piece<T, D, BC, false, SAFE>(ts.rsrc, ts.base, k_row_bytes, ts.rows, Kt, wave, dlane, i);
+      stage_piece<T, D, BC, false, SAFE>(ts.rsrc, ts.base, k_row_bytes, ts.rows, Kt, wave, dlane, i, slots_valid);
     }
   };
   auto issue_v = [&](auto ic, int key0, int dlane) {
     constexpr int i = decltype(ic)::value;
-    const TileSrc ts = tile_src<BC, RB>(Vg, v_row_bytes, key0, a.Nkv);
+    const TileSrc ts = tile_src<BC>(Vg, v_row_bytes, key0, a.Nkv, rb_valid);
     if constexpr (kRowDma) {
       constexpr int jk = i / RPP, half = i % RPP;
       lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(ts.rsrc, v_lds, vvo[jk & 3], vro[jk]);
     } else if constexpr (kHoist) {
       lds_dma_16(ts.rsrc, (uint32_t)(uintptr_t)(Vt + (wave * PPW + i) * 1024), vrel[i], 0u);
     } else {
-      stage_piece<T, D, BC, true, SAFE>(ts.rsrc, ts.base, v_row_bytes, ts.rows, Vt, wave, dlane, i);
+      stage_piece<T, D, BC, true, SAFE>(ts.rsrc, ts.base, v_row_bytes, ts.rows, Vt, wave, dlane, i, slots_valid);
     }
   };
   auto issue_k_tile = [&](int key0) {
@@ -676,7 +696,11 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   {
     const T* qp = (const T*)a.q + b * a.sq[0] + hq * a.sq[1] + (int64_t)qrow_c * a.sq[2] + dh * DW + h * 8;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) qf[s] = *(const v8*)(qp + s * 16);
+    for (int s = 0; s < KS; ++s) {
+      // columns at and past the caller's head dim are zeros (and are not read: the last row may end the allocation)
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      qf[s] = (dh * DW + s * 16 + h * 8 < a.d_valid) ? *(const v8*)(qp + s * 16) : __builtin_bit_cast(v8, z);
+    }
   }
 
   f32x16 oacc[NDB];
@@ -1114,7 +1138,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
             run[w] = sw[0];
             run[2 + w] = sw[1];
           }
-          *(u32x4*)(op + db * 32 + pr * 16) = run;
+          if (dh * DW + db * 32 + pr * 16 + 8 * h < a.d_valid) *(u32x4*)(op + db * 32 + pr * 16) = run;
         }
       if (a.lse != nullptr && h == 0 && dh == 0) {
         // natural-log LSE = ln(l) + m*ln2 (prefill.cuh:1063-1073)
@@ -1152,7 +1176,7 @@ __global__ __launch_bounds__(64) void ffpa_fwd_merge_kernel(const FwdArgs a, int
   __syncthreads();
   const float inv = 1.f / wsum;  // every share empty -> 0 * inf = NaN, like an unsplit fully masked row
   const int d = blockIdx.y * 256 + lane * 4;
-  if (d < D) {
+  if (d < a.d_valid) {  // D = the kernel's (64-multiple) head dim = the partials' row length; only the caller's columns are stored
     const float* src = a.ws_o + row * D + d;
     const int64_t sstride = rows * D;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};

@@ -181,8 +181,9 @@ def tile_config(head_dim: int) -> dict:
 
 
 def padded_head_dim(d: int) -> int:
-  """Head dims are built in multiples of 64; others are zero-padded like the reference
-  pads to its compiled multiples (csrc/cuffpa/ffpa_api.cc:123-161)."""
+  """The head dim of the kernel instantiation that serves ``d``: kernels are built per multiple of 64; a head dim in
+  between (any multiple of 8) runs on the next one with the missing columns read as zeros and never stored — in the
+  kernel, without padded copies (the reference pads on the host, csrc/cuffpa/ffpa_api.cc:123-161)."""
   return ((d + 63) // 64) * 64
 
 
@@ -314,7 +315,7 @@ def forward(
   out_shape = (B, Hq, Nq)
   if causal_offset is None:
     causal_offset = Nkv - Nq
-  Dp = padded_head_dim(D)
+  Dp = (D + 7) // 8 * 8  # rows must be whole 16-byte slots: only a head dim that is not a multiple of 8 is padded (copies)
   if Dp != D:
     pad = (0, Dp - D)
     q, k, v = (torch.nn.functional.pad(t, pad) for t in (q, k, v))

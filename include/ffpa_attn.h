@@ -94,7 +94,7 @@ typedef struct ffpa_fwd_params {
   int32_t heads_kv;    /* Hkv */
   int32_t seqlen_q;    /* Nq  */
   int32_t seqlen_kv;   /* Nkv */
-  int32_t head_dim;    /* D   */
+  int32_t head_dim;    /* D: any multiple of 8 in [8, 1024] */
 
   int64_t q_stride[3];    /* elements: batch, head, row */
   int64_t k_stride[3];
@@ -185,9 +185,10 @@ int ffpa_attn_mask_kv_bounds(const void* bias, int bias_dtype, const int64_t bia
 enum ffpa_query {
   FFPA_QUERY_ABI_VERSION = 0,
   FFPA_QUERY_FWD_AVAILABLE = 1,   /* 1 if the gfx950 kernels are in this build */
-  FFPA_QUERY_MIN_HEAD_DIM = 2,    /* 64   */
+  FFPA_QUERY_MIN_HEAD_DIM = 2,    /* 8    */
   FFPA_QUERY_MAX_HEAD_DIM = 3,    /* 1024 */
-  FFPA_QUERY_HEAD_DIM_MULTIPLE = 4, /* 64: other D are zero-padded by the host */
+  FFPA_QUERY_HEAD_DIM_MULTIPLE = 4, /* 8: kernels are built per multiple of 64; a head dim in between runs on the next one with
+                                       the missing columns read as zeros in-kernel (no padded copies) */
   FFPA_QUERY_FP16_AVAILABLE = 5,
   FFPA_QUERY_DROPOUT_AVAILABLE = 6,
   FFPA_QUERY_DEBUG_KERNELS = 7    /* 1 if FFPA_FLAG_DEBUG_SAFE_PATH kernels are built: only in the test-only twin library

@@ -165,6 +165,33 @@ def test_every_head_dim(hip, D):
   _check_vs_oracle(o, lse, q, k, v, block_keys=bc, name=f"D{D}")
 
 
+@pytest.mark.parametrize("D", [8, 72, 200, 264, 328, 456, 504, 520, 648, 968, 1000, 1016, 1001])
+def test_head_dims_between_the_built_multiples_of_64_run_in_kernel(hip, D):
+  """A head dim that is a multiple of 8 runs on the next 64-multiple instantiation with its missing columns read as zeros
+  (Q guard, K range-check zero-fill) and never stored — no padded copies of q / k / v.  Adding exact zeros to the QK^T sums
+  and leaving O's extra columns out cannot change a bit: the result must EQUAL the host-padded run (the reference's way,
+  csrc/cuffpa/ffpa_api.cc:123-161), for the prefill tiles, causal, a ragged last tile, the short-query split-KV path and
+  dropout (per-piece DMA form).  The tensors are allocated exactly (the last row ends the allocation).  D = 1001: not a
+  multiple of 8 — padded to 1008 by the host, then the same path."""
+  Dk = hip.padded_head_dim(D)
+  for (B, Hq, Hkv, Nq, Nkv, causal, drop) in ((1, 2, 1, 130, 257, False, 0.0), (1, 2, 2, 200, 333, True, 0.0), (2, 4, 2, 3, 1500, False, 0.0),
+                                              (1, 2, 2, 96, 160, False, 0.25)):
+    q, k, v = _rand((B, Hq, Nq, D), seed=D), _rand((B, Hkv, Nkv, D), seed=D + 1), _rand((B, Hkv, Nkv, D), seed=D + 2)
+    kw = dict(dropout_p=drop, philox_seed=1234, philox_offset=8) if drop else {}
+    o, lse = hip.forward(q, k, v, None, causal, D ** -0.5, **kw)
+    assert o.shape == q.shape and o.is_contiguous()
+    qp, kp, vp = (F.pad(t, (0, Dk - D)) for t in (q, k, v))
+    op, lsep = hip.forward(qp, kp, vp, None, causal, D ** -0.5, **kw)
+    assert torch.equal(o, op[..., :D]) and torch.equal(lse, lsep), (D, Nq, Nkv, causal, drop)
+    if not drop:
+      _check_vs_oracle(o, lse, q, k, v, causal=causal, block_keys=hip.tile_config(Dk)["block_keys"], name=f"D{D} {Nq}x{Nkv}")
+  if D >= 264:
+    from ffpa_attn_amd import ffpa_attn_func
+
+    q, k, v = _rand((1, 4, 640, D), seed=3), _rand((1, 4, 640, D), seed=4), _rand((1, 4, 640, D), seed=5)
+    _close(ffpa_attn_func(q, k, v), F.scaled_dot_product_attention(q, k, v), q.dtype, f"api D{D}")
+
+
 @pytest.mark.parametrize("Nq,Nkv", [(1, 1), (1, 4096), (7, 513), (15, 64), (127, 129), (128, 128), (129, 65), (513, 1000),
                                    (1000, 31), (640, 2049), (64, 63), (65, 32), (33, 33)])
 @pytest.mark.parametrize("D", [320, 512, 768])
