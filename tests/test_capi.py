@@ -65,7 +65,7 @@ def test_ctypes_mirror_matches_the_c_header(tmp_path):
 def test_queries(lib):
   assert lib.ffpa_attn_query(0) == hip.ABI_VERSION
   assert lib.ffpa_attn_query(1) == 1
-  assert (lib.ffpa_attn_query(2), lib.ffpa_attn_query(3), lib.ffpa_attn_query(4)) == (64, 1024, 64)
+  assert (lib.ffpa_attn_query(2), lib.ffpa_attn_query(3), lib.ffpa_attn_query(4)) == (8, 1024, 8)  # min / max head dim, multiple
   assert lib.ffpa_attn_query(5) == 1 and lib.ffpa_attn_query(6) == 1
   assert lib.ffpa_attn_query(99) == -1
   assert lib.ffpa_attn_version().startswith(b"ffpa-attn-amd")
