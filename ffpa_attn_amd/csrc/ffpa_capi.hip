@@ -252,6 +252,7 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   a.d_valid = p->head_dim;
   a.group = p->heads_q / p->heads_kv;
   a.nqt = (int)nqt;
+  a.total_wg = (int)grid;
   a.bias_dtype = p->bias_dtype;
   a.causal = p->causal ? 1 : 0;
   a.causal_offset = p->causal_offset;

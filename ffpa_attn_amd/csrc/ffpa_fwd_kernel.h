@@ -102,6 +102,9 @@
 #ifndef FFPA_V_PRE
 #define FFPA_V_PRE 0  // this many V(j) pieces go out behind the first fragment reads of the QK^T loop (their LDS latency is dead time anyway)
 #endif
+#ifndef FFPA_PERSISTENT
+#define FFPA_PERSISTENT 0  // 1: a workgroup walks several (batch, head, row tile) ids when the host launches fewer workgroups than ids
+#endif
 #ifndef FFPA_V_EARLY
 #define FFPA_V_EARLY 1  // issue the first PV fragment reads right after barrier A (latency hides under softmax)
 #endif
@@ -155,6 +158,7 @@ struct FwdArgs {
   int64_t sq[3], sk[3], sv[3], so[3];  // element strides: batch, head, row
   int64_t sbias[4];                    // element strides: batch, head, row, key
   int B, Hq, Hkv, Nq, Nkv;
+  int total_wg;       // B * Hq * nqt * nsplit: the (batch, head, row tile, split) ids of the launch (== gridDim.x unless persistent)
   int d_valid;        // the caller's head dim (a multiple of 8, <= the kernel's D): columns [d_valid, D) read as zeros and are never stored
   int group;          // Hq / Hkv
   int nqt;            // row tiles per (batch, head)
@@ -483,7 +487,7 @@ __device__ __forceinline__ void apply_bool_block_vec(float (&x)[16], const void*
 // Philox temporaries push hipcc into spilling Q fragments inside the QK^T loop (and every reload drains the
 // DMA queue); dropout launches pay that, plain launches do not.
 template <typename T, int D, int ND, bool SAFE, bool DROP = false>
-__global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) {
+__global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_in) {
   using E = Elem<T>;
   using v8 = typename E::v8;
   using v4 = typename E::v4;
@@ -543,6 +547,42 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   // ---- workgroup -> (batch, head, row tile).  Block b runs on XCD b % 8; give every
   // XCD a contiguous range of virtual ids so that the row tiles of one head (which
   // stream the same K/V) are co-resident on one XCD and hit in its L2.
+#if FFPA_PERSISTENT
+  // Persistent form: the host launches G <= total workgroups (G a multiple of 8); the G / 8 workgroups of an XCD walk that
+  // XCD's id range in rounds of G / 8 consecutive ids (the row tiles that stream the same K/V stay co-resident), odd rounds
+  // in reverse order so that causal launches (ids sorted longest first) hand every workgroup the same amount of work.
+  // The next id's Q fragments and first K tile are requested right behind this id's O stores: the store drain, the
+  // workgroup teardown / launch gap and part of the fetch latency overlap.  The kernel arguments are re-read through a
+  // laundered pointer every round: nothing derived from them may be hoisted out of (and kept live across) the outer loop
+  // — that is what made two earlier persistent attempts lose to scalar-register pressure.
+  for (int round = 0;; ++round) {
+  typedef const __attribute__((address_space(4))) FwdArgs CArgs;
+  auto kargs = (CArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kargs));
+  CArgs& a = *kargs;
+  int vid = blockIdx.x;
+  {
+    const int G = gridDim.x, total = a.total_wg;
+    if (G == total) {
+      if (round > 0) break;
+      if (!(a.flags & kFlagNoXcdRemap)) {
+        const int xcd = vid & 7, idx = vid >> 3, per = total >> 3, rem = total & 7;
+        vid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
+      }
+    } else {
+      const int xcd = vid & 7, idx = vid >> 3, wgs = G >> 3;  // workgroups per XCD
+      const int per = total >> 3, rem = total & 7;
+      const int start = xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per;
+      const int cnt = per + (xcd < rem ? 1 : 0);
+      if (round * wgs >= cnt) break;
+      const int in_round = (round & 1) ? wgs - 1 - idx : idx;
+      const int id = round * wgs + in_round;
+      if (id >= cnt) continue;
+      vid = start + id;
+    }
+  }
+#else
+  const FwdArgs& a = a_in;
   int vid = blockIdx.x;
   if (!(a.flags & kFlagNoXcdRemap)) {
     const int total = gridDim.x;
@@ -552,6 +592,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
     const int rem = total & 7;
     vid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
   }
+#endif
   const int split = vid % a.nsplit;
   vid /= a.nsplit;
   const int bh = vid / a.nqt;
@@ -1146,6 +1187,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
       }
     }
   }
+#if FFPA_PERSISTENT
+  }  // persistent rounds
+#endif
 }
 
 // Merge the split-KV partials of one launch (the reference's decode stage 2,
