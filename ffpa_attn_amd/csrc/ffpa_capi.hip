@@ -278,6 +278,17 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
       }
     }
   }
+  // A key bias (no row axis, unit key stride, 16-byte aligned rows, 16- or 32-bit) is cached in LDS once per workgroup when the
+  // head dim's tiles leave room for a whole number of tiles' worth of it (ffpa_fwd_kernel.h: FwdArgs.bias_lds)
+  if (p->bias != nullptr && pl.variant == 0 && pl.splits == 1 && p->seqlen_q > 1 && p->bias_stride[2] == 0 && p->bias_stride[3] == 1 &&
+      p->bias_dtype >= FFPA_BIAS_FP16 && p->bias_dtype <= FFPA_BIAS_FP32 && !(p->flags & FFPA_FLAG_NO_BIAS_LDS) && !safe) {
+    const int esz = p->bias_dtype == FFPA_BIAS_FP32 ? 4 : 2;
+    const int64_t row_bytes = (int64_t)p->seqlen_kv * esz;
+    const int64_t bytes = (int64_t)pl.nt * pl.bc * esz;
+    const bool ok = reinterpret_cast<uintptr_t>(p->bias) % 16 == 0 && row_bytes % 16 == 0 && (p->bias_stride[0] * esz) % 16 == 0 &&
+                    (p->bias_stride[1] * esz) % 16 == 0 && pl.lds + bytes <= 160 * 1024;
+    if (ok) a.bias_lds = (int)bytes;
+  }
   a.dropout_p = p->dropout_p;
   a.keep_scale = p->dropout_p > 0.f ? 1.f / (1.f - p->dropout_p) : 1.f;
   a.philox_seed = p->philox_seed;

@@ -16,13 +16,15 @@ namespace ffpa {
 template <typename T, int D, int ND, bool SAFE, bool DROP = false>
 static int launch_one(const FwdArgs& a, hipStream_t stream) {
   constexpr int BC = (ND == 1) ? ((D <= FFPA_BC128_MAX_D) ? 128 : 64) : 32;
-  constexpr int LDS = 2 * BC * D * 2 + (ND > 1 ? 4 * 4096 : 0);
+  constexpr int LDS_BASE = 2 * BC * D * 2 + (ND > 1 ? 4 * 4096 : 0);
+  const int LDS = LDS_BASE + (a.bias_lds > 0 ? a.bias_lds : 0);  // + the key-bias row cache, sized by the C-ABI layer (<= 160 KiB in total)
+  constexpr int kMaxLds = 160 * 1024;
   auto kern = ffpa_fwd_split_d_kernel<T, D, ND, SAFE, DROP>;
   static std::atomic<bool> attr_done[64];  // write-once per device (setting the attribute twice is harmless)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return -1;
   if (dev < 0 || dev >= 64 || !attr_done[dev].load(std::memory_order_acquire)) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess) {
       (void)hipGetLastError();
       return -2;
     }

@@ -180,6 +180,8 @@ struct FwdArgs {
   // optional [first, end) visible-key bounds per block of 32 query rows (see ffpa_fwd_params.kv_bounds)
   const int* kv_bounds;
   int64_t s_bounds[2];  // element strides: batch, head (0 = broadcast)
+  int bias_lds;  // > 0: the bias is a key bias (no row axis): its [Nkv] row of this (batch, head) is copied to LDS once per workgroup
+                 //      (this many bytes, a whole number of tiles) and the tiles read it from there instead of from global memory
   int bias_vec;  // W in {0, 4, 8, 16}: bias key stride is 1 and base / strides are W-element aligned -> W-wide loads (16: bool8 masks)
   // dropout (prefill.cuh:398-546): keep iff u > p, u from Philox4x32-10 at the logical element offset
   float dropout_p;          // 0 = off
@@ -535,6 +537,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
   FFPA_LDS char* const Kt = (FFPA_LDS char*)smem;
   FFPA_LDS char* const Vt = Kt + TILE;
   FFPA_LDS char* const Xb = Kt + 2 * TILE;  // ND == 2: partial-S exchange, 4 KiB per wave
+  FFPA_LDS char* const Bl = Kt + 2 * TILE + (ND > 1 ? 4 * 4096 : 0);  // key-bias row cache (FwdArgs.bias_lds bytes, when enabled)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -783,6 +786,19 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
     }
   }
 
+  if (a.bias_lds > 0 && nt > t0) {
+    // key bias [.., .., 1, Nkv]: every row of the workgroup adds the same Nkv values — fetch them once (a few KiB) instead of
+    // 2-4 latency-exposed global loads per lane and key block in every tile; bytes past Nkv are zeros (those keys get the
+    // tail mask).  Made visible by the barrier below.
+    const int esz = a.bias_dtype == 3 ? 4 : 2;
+    const char* src = (const char*)a.bias + (int64_t)esz * (b * a.sbias[0] + hq * a.sbias[1]);
+    const int valid = a.Nkv * esz;
+    for (int i = tid * 16; i < a.bias_lds; i += 256 * 16) {
+      u32x4 w = {0u, 0u, 0u, 0u};
+      if (i < valid) w = *(const u32x4*)(src + i);
+      *(FFPA_LDS u32x4*)(Bl + i) = w;
+    }
+  }
   if (nt > t0) {
     issue_k_tile(t0 * BC);
     dma_wait_all();
@@ -847,7 +863,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
     constexpr bool kBiasEarly = FFPA_BIAS_EARLY != 0 && !SAFE && ND > 1;  // measured: -10 % at D = 1024; D <= 512 has no registers to spare (+2 %)
     u32x4 braw[kBiasEarly ? 2 * NKB : 1];
     const bool mask_free = k0 >= free_lo && k0 + BC <= free_hi;  // wave-uniform: this tile lies in the mask's neutral interior
-    const bool bias_early = kBiasEarly && a.bias_vec == 8 && a.bias_dtype != 4 && k0 + BC <= a.Nkv && !mask_free;
+    const bool bias_early = kBiasEarly && a.bias_vec == 8 && a.bias_dtype != 4 && a.bias_lds == 0 && k0 + BC <= a.Nkv && !mask_free;
     if constexpr (kBiasEarly) {
       if (bias_early) {
         const char* bp = (const char*)a.bias + 2 * (b * a.sbias[0] + hq * a.sbias[1] + (int64_t)qrow_c * a.sbias[2] + k0 + 16 * h);
@@ -984,6 +1000,38 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
             for (int e = 0; e < 8; ++e) x[kb][8 * w + e] += (float)t[e] * 1.4426950408889634f;
           }
         }
+    } else if (a.bias_lds > 0 && !mask_free) {
+      // key bias from the LDS row cache: every lane of a half reads the same 16 keys (LDS broadcast)
+      typedef __attribute__((ext_vector_type(8))) __bf16 b8;
+      typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const int key = k0 + kb * 32 + 16 * h;
+        if (a.bias_dtype == 3) {
+          FFPA_LDS const char* bp = Bl + key * 4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const f32x4 t = *(FFPA_LDS const f32x4*)(bp + 16 * i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[kb][4 * i + e] += t[e] * 1.4426950408889634f;
+          }
+        } else {
+          FFPA_LDS const char* bp = Bl + key * 2;
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {
+            const u32x4 raw = *(FFPA_LDS const u32x4*)(bp + 16 * w);
+            if (a.bias_dtype == 2) {
+              const b8 t = __builtin_bit_cast(b8, raw);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x[kb][8 * w + e] += (float)t[e] * 1.4426950408889634f;
+            } else {
+              const h8 t = __builtin_bit_cast(h8, raw);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x[kb][8 * w + e] += (float)t[e] * 1.4426950408889634f;
+            }
+          }
+        }
+      }
     } else if (a.bias_dtype != 0 && !mask_free) {
       const int64_t brow = b * a.sbias[0] + hq * a.sbias[1] + (int64_t)qrow_c * a.sbias[2];
 #pragma unroll

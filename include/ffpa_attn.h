@@ -62,6 +62,8 @@ enum ffpa_bias_dtype {
 /* ffpa_fwd_params.flags */
 #define FFPA_FLAG_DEBUG_SAFE_PATH 0x1u /* test-only: register-staged K/V + scalar V gather  */
 #define FFPA_FLAG_NO_XCD_REMAP    0x2u /* bench-only: dispatch-order block mapping          */
+#define FFPA_FLAG_NO_PERSISTENT   0x4u /* bench-only (builds with FFPA_PERSISTENT): one workgroup per id */
+#define FFPA_FLAG_NO_BIAS_LDS     0x8u /* bench-only: read a key bias from global memory in every tile   */
 
 /*
  * One forward call.  Layout contract (replaces the dense-[B,H,N,D] assumption of

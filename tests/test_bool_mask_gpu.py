@@ -226,3 +226,24 @@ def test_direct_op_calls_are_validated_before_pointers_reach_the_kernel(hip):
   qq, kk, vv = _rand((1, 2, 520, 264)), _rand((1, 2, 520, 264), seed=1), _rand((1, 2, 520, 264), seed=2)
   o, _ = hip.forward(qq, kk, vv, None, False, 264 ** -0.5)
   assert o.is_contiguous() and o.shape == qq.shape
+
+
+@pytest.mark.parametrize("D", [384, 512, 1024])
+@pytest.mark.parametrize("bdtype", [torch.bfloat16, torch.float32])
+def test_key_bias_row_cache_in_lds_is_bit_identical_to_the_global_reads(hip, D, bdtype):
+  """A bias without a row axis ([B|1, H|1, 1, Nkv]: key padding as an additive mask, per-head key biases, the reference
+  bench's 'attn-mask' case) is copied to LDS once per workgroup and read from there in every tile — same numbers as the
+  per-tile global loads (FFPA_FLAG_NO_BIAS_LDS), also with a ragged last tile, -inf entries and GQA."""
+  B, Hq, Hkv, Nq = 2, 4, 2, 300
+  for Nkv, shape in ((1024, (1, 1, 1, 1024)), (1000, (2, 4, 1, 1000)), (2048, (1, 4, 1, 2048)), (1001, (1, 1, 1, 1001))):
+    q, k, v = _rand((B, Hq, Nq, D), seed=D), _rand((B, Hkv, Nkv, D), seed=D + 1), _rand((B, Hkv, Nkv, D), seed=D + 2)
+    g = torch.Generator(device="cuda").manual_seed(Nkv)
+    bias = (torch.randn(shape, device="cuda", generator=g) * 0.5).to(bdtype)
+    bias[..., 5::7] = float("-inf")
+    o1, l1 = hip.forward(q, k, v, bias, False, D ** -0.5)
+    o0, l0 = hip.forward(q, k, v, bias, False, D ** -0.5, flags=hip.FLAG_NO_BIAS_LDS)
+    assert torch.equal(o1, o0) and torch.equal(l1, l0), (D, Nkv, shape)
+    if bdtype == torch.bfloat16:
+      _close(o1, F.scaled_dot_product_attention(q, k, v, attn_mask=bias, enable_gqa=True), q.dtype, f"sdpa {shape}")
+    if D == 512 and Nkv == 1000:
+      _check_vs_oracle(o1, l1, q, k, v, bias=_f32(bias.float()), name="key bias")
