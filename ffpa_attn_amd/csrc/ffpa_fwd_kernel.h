@@ -81,9 +81,6 @@
 #ifndef FFPA_K_PRE
 #define FFPA_K_PRE 8  // interleaved mode: this many K(j+1) pieces are issued right after QK^T (they stream under
 #endif                //   the softmax); V(j) is then awaited with a counted vmcnt just before PV.  0 = one barrier A
-#ifndef FFPA_QK_SPLIT_ACC
-#define FFPA_QK_SPLIT_ACC 0  // one-key-block tiles (ND > 1): accumulate even / odd contraction steps of S^T in two registers sets and add them
-#endif                       //   at the end, so that consecutive MFMAs never chain on one accumulator
 #ifndef FFPA_K_PRE_SPREAD
 #define FFPA_K_PRE_SPREAD 0  // ND == 1; 1: the FFPA_K_PRE pieces go out in four groups between the softmax stages instead of as one burst behind barrier A1
 #endif
@@ -92,15 +89,6 @@
 #endif
 #ifndef FFPA_K_PRE_SPREAD_ND2
 #define FFPA_K_PRE_SPREAD_ND2 1  // split-D kernels: all of K(j+1) goes out between the softmax stages, none between the PV MFMAs (D = 1024: +7 %)
-#endif
-#ifndef FFPA_MERGE_A
-#define FFPA_MERGE_A 0  // (needs FFPA_K_PRE_SPREAD with FFPA_K_PRE = all pieces) two barriers per tile: V(j) is issued in the first part of the QK^T loop
-#endif                  //   (one piece per FFPA_V_STEP MFMAs) and awaited at barrier A1; there is no barrier A2
-#ifndef FFPA_V_STEP
-#define FFPA_V_STEP 1
-#endif
-#ifndef FFPA_V_PRE
-#define FFPA_V_PRE 0  // this many V(j) pieces go out behind the first fragment reads of the QK^T loop (their LDS latency is dead time anyway)
 #endif
 #ifndef FFPA_PERSISTENT
 #define FFPA_PERSISTENT 0  // 1: a workgroup walks several (batch, head, row tile) ids when the host launches fewer workgroups than ids
@@ -530,8 +518,6 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
   constexpr int kPre = !(kInterleave && kPreReq > 0) ? 0
                        : kSpreadReq              ? ((kPreReq < PPW ? kPreReq : PPW) / 4) * 4
                                                  : (kPreReq <= PPW ? kPreReq : 0);
-  constexpr bool kMergeA = FFPA_MERGE_A != 0 && kSpreadReq && kPre == PPW && kPre > 0 && !(FFPA_ABL & 1);
-  constexpr int kVStep = kMergeA ? FFPA_V_STEP : kStep;  // MFMAs between two V(j) pieces in the QK^T loop
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   FFPA_LDS char* const Kt = (FFPA_LDS char*)smem;
@@ -815,8 +801,6 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
     f32x16 sacc[NKB];
     {
       constexpr int N1 = KS * NKB;
-      constexpr bool kSplitAcc = FFPA_QK_SPLIT_ACC != 0 && NKB == 1 && KS >= 2 && !SAFE;
-      f32x16 sodd;
       v8 kf[N1];
       auto k_frag = [&](int n) -> v8 {
         const int s = FFPA_QK_ORDER ? n % KS : n / NKB, kb = FFPA_QK_ORDER ? n / KS : n % NKB;
@@ -827,34 +811,22 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int n = 0; n < PF1 && n < N1; ++n) kf[n] = k_frag(n);
-      constexpr int kVPre = (kInterleave && !(FFPA_ABL & 1) && ND == 2) ? FFPA_V_PRE : 0;
-      if constexpr (kVPre > 0) {
-        static_for<kVPre>([&](auto ic) { issue_v(ic, k0, dlane); });
-        __builtin_amdgcn_sched_barrier(0);
-      }
       static_for<N1>([&](auto ic) {
         constexpr int n = decltype(ic)::value;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (n + PF1 < N1) kf[n + PF1] = k_frag(n + PF1);
-        if constexpr (kInterleave && !(FFPA_ABL & 1) && n % kVStep == 0 && n / kVStep + kVPre < PPW) {
+        if constexpr (kInterleave && !(FFPA_ABL & 1) && n % kStep == 0 && n / kStep < PPW) {
           // V(j) streams in under this tile's QK^T (the V buffer is free since barrier B of tile j-1)
-          issue_v(std::integral_constant<int, n / kVStep + kVPre>{}, k0, dlane);
+          issue_v(std::integral_constant<int, n / kStep>{}, k0, dlane);
         }
         constexpr int s = FFPA_QK_ORDER ? n % KS : n / NKB, kb = FFPA_QK_ORDER ? n / KS : n % NKB;
         if constexpr ((FFPA_ABL & (128 | 256)) != 0) { if constexpr (s == 0) sacc[kb] = (f32x16)(0.f); }
-        else if constexpr (kSplitAcc && (s & 1)) {
-          if constexpr (s == 1) E::template mfma_v_first<kPad>(sodd, kf[n], qf[s]);
-          else E::template mfma_v_acc<kPad>(sodd, kf[n], qf[s]);
-        }
         else if constexpr (s == 0) E::template mfma_v_first<kPad>(sacc[kb], kf[n], qf[s]);
         else E::template mfma_v_acc<kPad>(sacc[kb], kf[n], qf[s]);
       });
       // MFMA result -> VALU reader wait states (invisible to the compiler inside asm)
       if constexpr (NKB == 2) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sacc[0]), "+v"(sacc[1]));
-      else if constexpr (kSplitAcc) {
-        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sacc[0]), "+v"(sodd));
-        sacc[0] += sodd;
-      } else asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sacc[0]));
+      else asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sacc[0]));
       __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -901,7 +873,6 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
     if constexpr (kPre > 0) {
       // split form: A1 only frees the K buffer, so the first K(j+1) pieces stream under the softmax;
       // V(j) (issued before them) is awaited by count right before the PV loop (barrier A2 below).
-      if constexpr (kMergeA && !(FFPA_ABL & 16)) dma_wait_all();  // V(j) has landed (its pieces went out early in the QK^T loop)
       if constexpr (!(FFPA_ABL & 4)) __syncthreads();
       if constexpr (!(FFPA_ABL & 1) && !kPreSpread) {
         const int plane = opaque_lane(lane);
@@ -1150,7 +1121,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
     {
       const int dlane = opaque_lane(lane);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (kPre > 0 && !kMergeA) {
+      if constexpr (kPre > 0) {
         // barrier A2: V(j) has landed on every wave (all but the kPre younger K pieces have retired)
         if constexpr (!(FFPA_ABL & 16)) dma_wait_except<kPre>();
         if constexpr (!(FFPA_ABL & 4)) __syncthreads();
