@@ -289,6 +289,19 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
                     (p->bias_stride[1] * esz) % 16 == 0 && pl.lds + bytes <= 160 * 1024;
     if (ok) a.bias_lds = (int)bytes;
   }
+  // A 16-bit bias with a real row axis is staged through LDS by LDS-DMA one KV step ahead (4 waves x [32 rows x keys-per-tile])
+  // where the head dim's tiles leave room for it (D >= 384); a.bias_lds then carries the extra LDS bytes
+  if (p->bias != nullptr && pl.variant == 0 && pl.splits == 1 && p->bias_stride[2] != 0 && p->bias_stride[3] == 1 &&
+      (p->bias_dtype == FFPA_BIAS_FP16 || p->bias_dtype == FFPA_BIAS_BF16) && !(p->flags & FFPA_FLAG_NO_BIAS_LDS) && !safe && pl.bc <= 64 &&
+      !(p->dropout_p > 0.f)) {
+    const int64_t bytes = 4LL * 32 * pl.bc * 2;
+    bool ok = reinterpret_cast<uintptr_t>(p->bias) % 16 == 0 && pl.lds + bytes <= 160 * 1024 && p->bias_stride[2] < (1LL << 24);
+    for (int i = 0; i < 3; ++i) ok = ok && (p->bias_stride[i] * 2) % 16 == 0;
+    if (ok) {
+      a.bias_tile = 1;
+      a.bias_lds = -(int)bytes;  // negative: LDS bytes reserved for the tile staging (no key-bias row cache)
+    }
+  }
   a.dropout_p = p->dropout_p;
   a.keep_scale = p->dropout_p > 0.f ? 1.f / (1.f - p->dropout_p) : 1.f;
   a.philox_seed = p->philox_seed;

@@ -168,8 +168,10 @@ struct FwdArgs {
   // optional [first, end) visible-key bounds per block of 32 query rows (see ffpa_fwd_params.kv_bounds)
   const int* kv_bounds;
   int64_t s_bounds[2];  // element strides: batch, head (0 = broadcast)
-  int bias_lds;  // > 0: the bias is a key bias (no row axis): its [Nkv] row of this (batch, head) is copied to LDS once per workgroup
+  int bias_lds;  // < 0: -bytes of LDS reserved for bias_tile staging.  > 0: the bias is a key bias (no row axis): its [Nkv] row of this (batch, head) is copied to LDS once per workgroup
                  //      (this many bytes, a whole number of tiles) and the tiles read it from there instead of from global memory
+  int bias_tile; // 1: a 16-bit bias with a real row axis is staged through LDS: every wave LDS-DMAs the [32 rows x BC keys] tile of
+                 //    the NEXT step into a private area while the PV MFMAs run, and reads it there when it is needed
   int bias_vec;  // W in {0, 4, 8, 16}: bias key stride is 1 and base / strides are W-element aligned -> W-wide loads (16: bool8 masks)
   // dropout (prefill.cuh:398-546): keep iff u > p, u from Philox4x32-10 at the logical element offset
   float dropout_p;          // 0 = off
@@ -476,7 +478,12 @@ __device__ __forceinline__ void apply_bool_block_vec(float (&x)[16], const void*
 // DROP selects the dropout-capable build of the kernel: kept out of the default instantiation because its
 // Philox temporaries push hipcc into spilling Q fragments inside the QK^T loop (and every reload drains the
 // DMA queue); dropout launches pay that, plain launches do not.
-template <typename T, int D, int ND, bool SAFE, bool DROP = false>
+// BTILE selects the build that stages 16-bit bias tiles through LDS (FwdArgs.bias_tile): its own instantiation for the same
+// reason as DROP — inside the default kernel its descriptor arithmetic costs the hot loops scalar registers they do not have.
+// MASK = false is the build for calls without any attn_bias / mask ranges (is_causal and ragged tails are structural and stay):
+// with every bias path compiled out the prefill kernels lose the scalar registers and the per-tile branch chain those paths
+// cost them — + 1.5 ... 4 % (D = 512: 1215 vs 1187 TFLOPS, D = 320: 1170 vs 1131, N = 2048: + 4 %, measured A/B).
+template <typename T, int D, int ND, bool SAFE, bool DROP = false, bool BTILE = false, bool MASK = true>
 __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_in) {
   using E = Elem<T>;
   using v8 = typename E::v8;
@@ -605,6 +612,37 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
   const uint32_t rb_valid = (uint32_t)a.d_valid * 2u;
   const int slots_valid = a.d_valid >> 3;
 
+  // ---- bias tiles through LDS (FwdArgs.bias_tile): the wave's private [32 rows][BC keys] 16-bit image, row stride BC * 2 bytes,
+  // 16-byte slot s of row r stored at slot s ^ g(r) (source-side swizzle, like K / V) so that the 16-lane groups of the
+  // ds_read_b128 that fetch one slot of 16 different rows are conflict-free.  Filled by BC / 16 pieces of 1 KiB.
+  constexpr bool kBiasTile = BTILE && MASK && ND <= 2 && !SAFE && BC <= 64;
+  constexpr int kBtSlots = BC / 8;              // 16-byte slots per bias row
+  constexpr int kBtRowsPerPiece = 64 / kBtSlots;  // rows one 1 KiB piece covers
+  constexpr int kBtPieces = 32 / kBtRowsPerPiece;
+  FFPA_LDS char* const Bt = Bl + wave * (32 * BC * 2);
+  auto bias_swz = [](int row) { return BC == 64 ? (row >> 1) & 7 : (row >> 2) & 3; };
+  uint32_t bvo[kBiasTile ? (BC == 64 ? 2 : 1) : 1];  // per-lane source offsets (piece parity: the swizzle of BC = 64 depends on it)
+  if constexpr (kBiasTile) {
+    const uint32_t rs = (uint32_t)a.sbias[2] * 2u;
+    const int r = lane / kBtSlots, sl = lane % kBtSlots;
+    bvo[0] = (uint32_t)r * rs + (uint32_t)((sl ^ bias_swz(r)) << 4);
+    if constexpr (BC == 64) bvo[1] = (uint32_t)r * rs + (uint32_t)((sl ^ bias_swz(kBtRowsPerPiece + r)) << 4);
+  }
+  // piece i of the bias tile of KV step key0 for this wave's rows (issued one step ahead, awaited by barrier B's drain)
+  auto issue_bias = [&](auto ic, int key0) {
+    if constexpr (kBiasTile) {
+      constexpr int i = decltype(ic)::value;
+      const uint32_t rs = (uint32_t)a.sbias[2] * 2u;
+      const int64_t plane = 2 * (b * a.sbias[0] + hq * a.sbias[1]);
+      const int64_t first = (int64_t)wq0 * rs + 2 * (int64_t)key0;                           // this wave's first row, first key of the step
+      const int64_t plane_bytes = (int64_t)(a.Nq - 1) * rs + 2 * (int64_t)a.Nkv;             // rows past Nq / the plane's end read as zeros
+      int64_t left = plane_bytes - first;
+      left = left < 0 ? 0 : (left > 0x7fffffff ? 0x7fffffff : left);
+      const u32x4 rsrc = make_rsrc((const char*)a.bias + plane + first, (uint32_t)left);
+      lds_dma_16(rsrc, (uint32_t)(uintptr_t)(Bt + i * 1024), bvo[BC == 64 ? (i & 1) : 0], (uint32_t)(i * kBtRowsPerPiece) * rs);
+    }
+  };
+
   // ---- DMA issue helpers (piece i of this wave for the tile starting at key0)
   uint32_t krel[kHoist ? BC * D * 2 / 4096 : 1], vrel[kHoist ? BC * D * 2 / 4096 : 1];
   if constexpr (kHoist) {
@@ -695,7 +733,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
   // 32-row block — KV tiles inside that range skip the mask loads altogether (the interior of a causal / sliding-window /
   // padding mask costs what an unmasked launch costs; only the tiles the mask's edge crosses read it)
   int free_lo = 0, free_hi = 0;
-  if (a.kv_bounds != nullptr) {
+  if (MASK && a.kv_bounds != nullptr) {
     // the caller's mask leaves only keys [first, end) visible to the 32-row blocks of this row tile
     const int* bp = a.kv_bounds + b * a.s_bounds[0] + hq * a.s_bounds[1];
     int first = 0x7fffffff, end = 0;
@@ -772,7 +810,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
     }
   }
 
-  if (a.bias_lds > 0 && nt > t0) {
+  if (MASK && a.bias_lds > 0 && nt > t0) {
     // key bias [.., .., 1, Nkv]: every row of the workgroup adds the same Nkv values — fetch them once (a few KiB) instead of
     // 2-4 latency-exposed global loads per lane and key block in every tile; bytes past Nkv are zeros (those keys get the
     // tail mask).  Made visible by the barrier below.
@@ -787,6 +825,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
   }
   if (nt > t0) {
     issue_k_tile(t0 * BC);
+    if constexpr (kBiasTile) {
+      static_for<kBtPieces>([&](auto ic) { issue_bias(ic, t0 * BC); });
+    }
     dma_wait_all();
     __syncthreads();  // K(t0) landed and visible
     if constexpr (!kInterleave) issue_v_tile(t0 * BC);
@@ -835,7 +876,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
     constexpr bool kBiasEarly = FFPA_BIAS_EARLY != 0 && !SAFE && ND > 1;  // measured: -10 % at D = 1024; D <= 512 has no registers to spare (+2 %)
     u32x4 braw[kBiasEarly ? 2 * NKB : 1];
     const bool mask_free = k0 >= free_lo && k0 + BC <= free_hi;  // wave-uniform: this tile lies in the mask's neutral interior
-    const bool bias_early = kBiasEarly && a.bias_vec == 8 && a.bias_dtype != 4 && a.bias_lds == 0 && k0 + BC <= a.Nkv && !mask_free;
+    const bool bias_early = MASK && kBiasEarly && a.bias_vec == 8 && a.bias_dtype != 4 && a.bias_lds == 0 && a.bias_tile == 0 && k0 + BC <= a.Nkv && !mask_free;
     if constexpr (kBiasEarly) {
       if (bias_early) {
         const char* bp = (const char*)a.bias + 2 * (b * a.sbias[0] + hq * a.sbias[1] + (int64_t)qrow_c * a.sbias[2] + k0 + 16 * h);
@@ -967,6 +1008,28 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
             for (int e = 0; e < 8; ++e) x[kb][8 * w + e] += (float)t[e] * 1.4426950408889634f;
           } else {
             const h8 t = __builtin_bit_cast(h8, braw[2 * kb + w]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[kb][8 * w + e] += (float)t[e] * 1.4426950408889634f;
+          }
+        }
+    } else if (!MASK) {
+    } else if (kBiasTile && !mask_free) {
+      // bias tile staged by this wave during the previous step's PV loop (drained at barrier B)
+      typedef __attribute__((ext_vector_type(8))) __bf16 b8;
+      typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+      FFPA_LDS const char* brow_lds = Bt + l31 * (BC * 2);
+      const int g = bias_swz(l31);
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const u32x4 raw = *(FFPA_LDS const u32x4*)(brow_lds + (((kb * 4 + 2 * h + w) ^ g) << 4));
+          if (a.bias_dtype == 2) {
+            const b8 t = __builtin_bit_cast(b8, raw);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[kb][8 * w + e] += (float)t[e] * 1.4426950408889634f;
+          } else {
+            const h8 t = __builtin_bit_cast(h8, raw);
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[kb][8 * w + e] += (float)t[e] * 1.4426950408889634f;
           }
@@ -1139,6 +1202,14 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
           // last tile that is an empty tile (every lane out of range: zeros, no memory traffic): cheaper
           // than a branch per piece, and barrier B still drains it before the workgroup can exit.
           issue_k(std::integral_constant<int, n / kStep + kPre>{}, k0 + BC, dlane);
+        }
+        if constexpr (kBiasTile && kInterleave && !(FFPA_ABL & 1)) {
+          // the bias tile of step j+1 (this wave's rows only, into its private area: no other wave reads or writes it, so the
+          // wave's own queue drain at barrier B is all the synchronisation it needs); slots the K pieces leave free
+          constexpr int kBStep = kStep >= 2 ? kStep : 2;
+          if constexpr (n % kBStep == kBStep / 2 && n / kBStep < kBtPieces) {
+            issue_bias(std::integral_constant<int, n / kBStep>{}, k0 + BC);
+          }
         }
         constexpr int db = FFPA_PV_ORDER ? n % NDB : n / NKS, ks = FFPA_PV_ORDER ? n / NDB : n % NKS;
         if constexpr (!(FFPA_ABL & (128 | 512))) oacc[db] = E::mfma(vf[n], pf[ks], oacc[db]);
