@@ -82,8 +82,8 @@
 #define FFPA_K_PRE 8  // interleaved mode: this many K(j+1) pieces are issued right after QK^T (they stream under
 #endif                //   the softmax); V(j) is then awaited with a counted vmcnt just before PV.  0 = one barrier A
 #ifndef FFPA_K_PRE_SPREAD
-#define FFPA_K_PRE_SPREAD 0  // ND == 1; 1: the FFPA_K_PRE pieces go out in four groups between the softmax stages instead of as one burst behind barrier A1
-#endif
+#define FFPA_K_PRE_SPREAD 1  // ND == 1; 1: the FFPA_K_PRE pieces go out in four groups between the softmax stages instead of as one burst behind
+#endif                       //   barrier A1 (+0.2 ... 1.4 % on every head dim 128 ... 512; re-measured on the bias-free build)
 #ifndef FFPA_K_PRE_ND2
 #define FFPA_K_PRE_ND2 64  // split-D kernels: as FFPA_K_PRE; with FFPA_K_PRE_SPREAD_ND2 it is clamped to the tile's pieces (a multiple of 4)
 #endif
