@@ -388,8 +388,11 @@ __device__ __forceinline__ void philox4x32_10(unsigned long long seed, unsigned 
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
   for (int round = 0; round < 10; ++round) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a v_mul_hi_u32 + v_mul_lo_u32 pair: 32-bit integer
+    // multiplies run at a quarter of the VALU rate and are what dropout costs
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     c0 = hi1 ^ c1 ^ k0;
     c2 = hi0 ^ c3 ^ k1;
     c1 = lo1;
@@ -406,12 +409,20 @@ __device__ __forceinline__ void philox4x32_10(unsigned long long seed, unsigned 
 // keep-scale (1/(1-p) or 0) for the 4 consecutive elements e0 .. e0+3 of one score row
 __device__ __forceinline__ void dropout_keep4(unsigned long long seed, unsigned long long e0, float p, float keep_scale,
                                               float (&keep)[4]) {
-  uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t blk[4];
   const unsigned a = (unsigned)(e0 & 3ull);
   philox4x32_10(seed, e0 >> 2, blk);
+  if (__builtin_amdgcn_ballot_w64(a != 0) == 0ull) {
+    // every lane's group is one whole Philox block (philox_offset and Nkv multiples of 4: the usual case): no second block,
+    // no word selection
 #pragma unroll
-  for (int i = 0; i < 4; ++i) w[i] = blk[i];
+    for (int t = 0; t < 4; ++t) {
+      const float u = ((float)blk[t] + 1.0f) * 2.3283064365386963e-10f;  // (0, 1]  (prefill.cuh:437-440)
+      keep[t] = (u > p) ? keep_scale : 0.f;
+    }
+    return;
+  }
+  uint32_t w[8] = {blk[0], blk[1], blk[2], blk[3], 0, 0, 0, 0};
   if (a != 0) {  // the group straddles two Philox blocks
     philox4x32_10(seed, (e0 >> 2) + 1, blk);
 #pragma unroll
