@@ -17,7 +17,8 @@ block is BORN sharded (per-unit seeds, nothing replicated), no data-path collect
   * default workloads: every rank owns one workload-shaped batch element -> "scaling": "weak" (8 x cfg2 is config 5);
   * --workload cfg5: the fixed global problem B=8 H=32 N=8192 D=512 (256 units) is split over the ranks ->
     "scaling": "strong"; per-rank TFLOPS are listed next to the aggregate;
-  * --gather adds the one RCCL all_gather_into_tensor of O a caller wanting the full tensor on every rank would pay.
+  * --gather adds the RCCL all_gather of O a caller wanting the full tensor on every rank would pay, in --gather-chunks pieces
+    that overlap with the compute of the next piece (sharding.attend_and_gather_units).
 Timing: barrier + synchronize on both sides of exactly K steps, max over ranks.
 
 Rank 0 prints ONE JSON line.  `roofline` is the dominant kernel against the dense bf16 MFMA peak (HBM peak for the
@@ -250,6 +251,7 @@ def main() -> None:
   ap.add_argument("--warmup", type=int, default=5)
   ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
   ap.add_argument("--gather", action="store_true", help="include an RCCL all_gather of O in the timed step (N > 1)")
+  ap.add_argument("--gather-chunks", type=int, default=4, help="--gather: pieces the local block is attended / gathered in (overlap)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-sdpa", action="store_true", help="skip the SDPA-on-GPU accuracy / speed comparison")
   ap.add_argument("--no-ref-protocol", action="store_true", help="skip the reference bench's own timing protocol (2 warm-ups + 10 iterations)")
@@ -296,10 +298,9 @@ def main() -> None:
       api_kw["attn_mask"] = mask
 
     def step():
-      o = sharding.attend_units(q, k, v, **api_kw)
-      if gathered is not None:
-        sharding.gather_units(o, n_units, out=gathered)
-      return o
+      if gathered is not None:  # the block in pieces, each piece all-gathered (RCCL's stream) while the next one computes
+        return sharding.attend_and_gather_units(q, k, v, n_units, chunks=args.gather_chunks, out=gathered, **api_kw)
+      return sharding.attend_units(q, k, v, **api_kw)
   else:
     global_B = B
     torch.manual_seed(0)
@@ -383,7 +384,7 @@ def main() -> None:
         "global_batch": global_B,
         "seq_len": Nq,
         "parallelism": (f"(batch,kv-head) units born sharded x{world}: {Hkv * global_B} units, {Hkv * global_B / world:g} per rank, no data-path collective"
-                        if sharded else "single GPU") + (" + all_gather_into_tensor(O)" if gathered is not None else ""),
+                        if sharded else "single GPU") + (f" + all_gather(O) in {args.gather_chunks} pieces overlapped with compute" if gathered is not None else ""),
         "flops_model": "4*B*Hq*D*valid_pairs",
         "step": "hip.ffpa_attn_forward_hip(causal=True, causal_offset=0)" if w["via"] == "op_offset0" else
                 ("sharding.attend_units -> ffpa_attn_func" if sharded else "ffpa_attn_func"),

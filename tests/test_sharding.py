@@ -74,7 +74,17 @@ def _born_worker(rank, world, port, n_units, g, ret):
   # the same global problem generated in one piece: a unit's values do not depend on the partition
   qa, ka, va = sh.synthetic_unit_block(0, n_units, g, 24, 40, 64, dtype=torch.float32, device="cpu", seed=3)
   ref = torch.nn.functional.scaled_dot_product_attention(qa, ka, va, enable_gqa=True)
-  ret[rank] = (bool(torch.equal(full, ref)), (s, e), bool(torch.equal(q, qa[s:e])))
+  ok = bool(torch.equal(full, ref))
+  if n_units % world == 0:  # the overlapped form: pieces of the block gathered while the next piece computes
+    import ffpa_attn_amd.sharding as shm
+    real = shm.attend_units
+    shm.attend_units = lambda a, b, c, **kw: torch.nn.functional.scaled_dot_product_attention(a, b, c, enable_gqa=True)
+    try:
+      for chunks in (1, 2, 3):
+        ok = ok and bool(torch.equal(sh.attend_and_gather_units(q, k, v, n_units, chunks=chunks), ref))
+    finally:
+      shm.attend_units = real
+  ret[rank] = (ok, (s, e), bool(torch.equal(q, qa[s:e])))
   dist.barrier()
   dist.destroy_process_group()
 

@@ -38,7 +38,9 @@ def _worker(rank, world, port, ret):
   q, k, v = sh.synthetic_unit_block(s, e, GROUP, NQ, NKV, D, device=f"cuda:{rank}", seed=11)
   o_local = sh.attend_units(q, k, v)
   full = sh.gather_units(o_local, N_UNITS)
+  overlapped = sh.attend_and_gather_units(q, k, v, N_UNITS, chunks=2)  # pieces gathered on RCCL's stream while the next computes
   torch.cuda.synchronize()
+  assert torch.equal(overlapped, full)
   ref = torch.nn.functional.scaled_dot_product_attention(q, k, v, enable_gqa=True)
   err = (o_local.float() - ref.float()).abs().max().item()
   ret[rank] = (full.cpu(), err, (s, e))
