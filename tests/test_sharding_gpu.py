@@ -39,8 +39,12 @@ def _worker(rank, world, port, ret):
   o_local = sh.attend_units(q, k, v)
   full = sh.gather_units(o_local, N_UNITS)
   overlapped = sh.attend_and_gather_units(q, k, v, N_UNITS, chunks=2)  # pieces gathered on RCCL's stream while the next computes
+  whole = sh.attend_and_gather_units(q, k, v, N_UNITS, chunks=1)
   torch.cuda.synchronize()
-  assert torch.equal(overlapped, full)
+  assert torch.equal(whole, full)
+  # a piece of this small problem under-fills the chip, so its launch splits the KV axis (fp32 partials + LSE merge): same
+  # values to rounding, not to the bit
+  assert (overlapped.float() - full.float()).abs().max().item() <= 2e-3
   ref = torch.nn.functional.scaled_dot_product_attention(q, k, v, enable_gqa=True)
   err = (o_local.float() - ref.float()).abs().max().item()
   ret[rank] = (full.cpu(), err, (s, e))
