@@ -696,8 +696,11 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
       constexpr int jk = i / RPP, half = i % RPP;
       uint32_t kv = kvo[jk & 3];
       if constexpr (RPP > 1 && half == RPP - 1) {
-        // the row's last piece: lanes whose 16-byte slot lies at or past the caller's head dim fetch zeros
-        if (half * 64 + (dlane ^ (4 * wave + (jk & 3))) >= slots_valid) kv = kDmaOob;
+        // the row's last piece: lanes whose 16-byte slot lies at or past the caller's head dim fetch zeros (a wave-uniform
+        // branch: launches whose head dim is the kernel's own skip the per-lane test)
+        if (a.d_valid != D) {
+          if (half * 64 + (dlane ^ (4 * wave + (jk & 3))) >= slots_valid) kv = kDmaOob;
+        }
       }
       lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(ts.rsrc, k_lds, kv, kro[jk]);
     } else if constexpr (kHoist) {
