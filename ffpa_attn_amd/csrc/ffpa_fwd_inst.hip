@@ -13,13 +13,13 @@
 
 namespace ffpa {
 
-template <typename T, int D, int ND, bool SAFE, bool DROP = false, bool BTILE = false, bool MASK = true>
+template <typename T, int D, int ND, bool SAFE, bool DROP = false, bool BTILE = false, int MK = 1>
 static int launch_one(const FwdArgs& a, hipStream_t stream) {
   constexpr int BC = (ND == 1) ? ((D <= FFPA_BC128_MAX_D) ? 128 : 64) : 32;
   constexpr int LDS_BASE = 2 * BC * D * 2 + (ND > 1 ? 4 * 4096 : 0);
   const int LDS = LDS_BASE + (a.bias_lds > 0 ? a.bias_lds : -a.bias_lds);  // + the key-bias row cache or the bias-tile staging area, sized by the C-ABI layer (<= 160 KiB in total)
   constexpr int kMaxLds = 160 * 1024;
-  auto kern = ffpa_fwd_split_d_kernel<T, D, ND, SAFE, DROP, BTILE, MASK>;
+  auto kern = ffpa_fwd_split_d_kernel<T, D, ND, SAFE, DROP, BTILE, MK>;
   static std::atomic<bool> attr_done[64];  // write-once per device (setting the attribute twice is harmless)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return -1;
@@ -87,8 +87,13 @@ int FFPA_CAT(launch_fwd_d, FFPA_INST_D)(int dtype, int safe, int variant, const 
     }
   }
   if (a.bias_dtype == 0 && a.kv_bounds == nullptr) {  // no attn_bias, no mask ranges: the build without any bias path
-    if (dtype == 0) return launch_one<__bf16, D, ND, false, false, false, false>(a, stream);
-    if (dtype == 1) return launch_one<_Float16, D, ND, false, false, false, false>(a, stream);
+    if (dtype == 0) return launch_one<__bf16, D, ND, false, false, false, 0>(a, stream);
+    if (dtype == 1) return launch_one<_Float16, D, ND, false, false, false, 0>(a, stream);
+    return -4;
+  }
+  if (a.bias_dtype == 4) {  // boolean mask (+ ranges): the build that carries only that path
+    if (dtype == 0) return launch_one<__bf16, D, ND, false, false, false, 2>(a, stream);
+    if (dtype == 1) return launch_one<_Float16, D, ND, false, false, false, 2>(a, stream);
     return -4;
   }
   if (dtype == 0) return launch_one<__bf16, D, ND, false>(a, stream);

@@ -491,11 +491,15 @@ __device__ __forceinline__ void apply_bool_block_vec(float (&x)[16], const void*
 // DMA queue); dropout launches pay that, plain launches do not.
 // BTILE selects the build that stages 16-bit bias tiles through LDS (FwdArgs.bias_tile): its own instantiation for the same
 // reason as DROP — inside the default kernel its descriptor arithmetic costs the hot loops scalar registers they do not have.
-// MASK = false is the build for calls without any attn_bias / mask ranges (is_causal and ragged tails are structural and stay):
-// with every bias path compiled out the prefill kernels lose the scalar registers and the per-tile branch chain those paths
-// cost them — + 1.5 ... 4 % (D = 512: 1215 vs 1187 TFLOPS, D = 320: 1170 vs 1131, N = 2048: + 4 %, measured A/B).
-template <typename T, int D, int ND, bool SAFE, bool DROP = false, bool BTILE = false, bool MASK = true>
+// MK (mask kind) selects which bias / mask paths a build carries: 0 = none — the build for calls without any attn_bias / mask
+// ranges (is_causal and ragged tails are structural and stay): with every bias path compiled out the prefill kernels lose the
+// scalar registers and the per-tile branch chain those paths cost them, + 1.5 ... 4 % (D = 512: 1215 vs 1187 TFLOPS,
+// D = 320: 1170 vs 1131, N = 2048: + 4 %, measured A/B); 2 = boolean masks only (bytes + mask ranges; what
+// ffpa_attn_func(attn_mask=<bool>) launches: config 4 as specified); 1 = every path.
+template <typename T, int D, int ND, bool SAFE, bool DROP = false, bool BTILE = false, int MK = 1>
 __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_in) {
+  constexpr bool MASK = MK != 0;
+  constexpr bool kBoolOnly = MK == 2;
   using E = Elem<T>;
   using v8 = typename E::v8;
   using v4 = typename E::v4;
@@ -824,7 +828,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
     }
   }
 
-  if (MASK && a.bias_lds > 0 && nt > t0) {
+  if (MASK && !kBoolOnly && a.bias_lds > 0 && nt > t0) {
     // key bias [.., .., 1, Nkv]: every row of the workgroup adds the same Nkv values — fetch them once (a few KiB) instead of
     // 2-4 latency-exposed global loads per lane and key block in every tile; bytes past Nkv are zeros (those keys get the
     // tail mask).  Made visible by the barrier below.
@@ -890,7 +894,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
     constexpr bool kBiasEarly = FFPA_BIAS_EARLY != 0 && !SAFE && ND > 1;  // measured: -10 % at D = 1024; D <= 512 has no registers to spare (+2 %)
     u32x4 braw[kBiasEarly ? 2 * NKB : 1];
     const bool mask_free = k0 >= free_lo && k0 + BC <= free_hi;  // wave-uniform: this tile lies in the mask's neutral interior
-    const bool bias_early = MASK && kBiasEarly && a.bias_vec == 8 && a.bias_dtype != 4 && a.bias_lds == 0 && a.bias_tile == 0 && k0 + BC <= a.Nkv && !mask_free;
+    const bool bias_early = MASK && !kBoolOnly && kBiasEarly && a.bias_vec == 8 && a.bias_dtype != 4 && a.bias_lds == 0 && a.bias_tile == 0 && k0 + BC <= a.Nkv && !mask_free;
     if constexpr (kBiasEarly) {
       if (bias_early) {
         const char* bp = (const char*)a.bias + 2 * (b * a.sbias[0] + hq * a.sbias[1] + (int64_t)qrow_c * a.sbias[2] + k0 + 16 * h);
@@ -1027,6 +1031,16 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
           }
         }
     } else if (!MASK) {
+    } else if (kBoolOnly) {
+      if (!mask_free) {
+        const int64_t brow = b * a.sbias[0] + hq * a.sbias[1] + (int64_t)qrow_c * a.sbias[2];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+          const int kbase = k0 + kb * 32 + 16 * h;
+          if (a.bias_vec == 16 && k0 + BC <= a.Nkv) apply_bool_block_vec(x[kb], a.bias, brow, kbase);
+          else apply_bool_block(x[kb], a.bias, brow, a.sbias[3], kbase, a.Nkv);
+        }
+      }
     } else if (kBiasTile && !mask_free) {
       // bias tile staged by this wave during the previous step's PV loop (drained at barrier B)
       typedef __attribute__((ext_vector_type(8))) __bf16 b8;

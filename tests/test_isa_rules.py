@@ -34,11 +34,12 @@ def test_headline_kernel_has_no_spill_code_inside_its_mfma_loops(capsys, monkeyp
   headline workload launches has none between the two loops either."""
   monkeypatch.setattr(sys, "argv", ["isa_stats", "512"])
   _tool("isa_stats").main()
-  # template flags after "<D> <ND>": SAFE, DROP, BTILE, MASK.  The three non-dropout builds of the prefill kernel: without any
-  # bias path (what the headline workload launches), with every bias / mask path, with bias tiles staged through LDS.
+  # template flags after "<D> <ND>": SAFE, DROP, BTILE, mask kind.  The four non-dropout builds of the prefill kernel: without
+  # any bias path (mask kind 0: what the headline workload launches), boolean masks only (2), every bias / mask path (1), and
+  # bias tiles staged through LDS (BTILE).
   lines = [l for l in capsys.readouterr().out.splitlines() if "bf16  512 1 b0 b0" in l]
-  assert len(lines) == 3, lines
+  assert len(lines) == 4, lines
   for l in lines:
     assert "vgpr 256 agpr 256" in l and "inside MFMA loops: scratch 0, lane spills 0" in l, l
-  headline = [l for l in lines if "512 1 b0 b0 b0 b0" in l]
+  headline = [l for l in lines if "512 1 b0 b0 b0 0 " in l]
   assert len(headline) == 1 and "first..last MFMA: scratch ops 0, lane spills 0" in headline[0], headline
