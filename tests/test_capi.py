@@ -182,3 +182,21 @@ def test_misaligned_pointer(lib):
   p = _params()
   p.k = p.k + 2
   assert lib.ffpa_attn_fwd(ctypes.byref(p), None) == 6
+
+
+def test_no_gfx950_device_is_a_status_not_a_launch(lib):
+  """Valid parameters on a box without a gfx950 (this CPU container): FFPA_ERR_NO_DEVICE, nothing is launched.  (On an
+  MI355X the same call would launch on the host buffer's address, so the test only runs where there is no GPU.)"""
+  import torch
+
+  if torch.cuda.is_available():
+    pytest.skip("a GPU is present: the call would launch")
+  p = _params()
+  assert lib.ffpa_attn_fwd(ctypes.byref(p), None) == 9
+  assert b"device" in lib.ffpa_attn_last_error()
+  # boolean masks (FFPA_BIAS_BOOL8 = 4) are a known bias dtype; 5 is not
+  buf = p._keepalive
+  q = _params(bias=ctypes.addressof(buf), bias_dtype=4)
+  assert lib.ffpa_attn_fwd(ctypes.byref(q), None) == 9
+  q = _params(bias=ctypes.addressof(buf), bias_dtype=5)
+  assert lib.ffpa_attn_fwd(ctypes.byref(q), None) == 2
