@@ -298,6 +298,9 @@ def main() -> None:
       api_kw["attn_mask"] = mask
 
     def step():
+      if w["via"] == "op_offset0":  # the op's structured top-left causal mask (the public is_causal is tail-aligned and needs Nkv >= Nq)
+        o = hip.ffpa_attn_forward_hip(q, k, v, None, causal=True, softmax_scale=scale, causal_offset=0)[0]
+        return sharding.gather_units(o, n_units, out=gathered) if gathered is not None else o
       if gathered is not None:  # the block in pieces, each piece all-gathered (RCCL's stream) while the next one computes
         return sharding.attend_and_gather_units(q, k, v, n_units, chunks=args.gather_chunks, out=gathered, **api_kw)
       return sharding.attend_units(q, k, v, **api_kw)
