@@ -60,6 +60,7 @@ const DimEntry* find_dim(int d) {
 // Launch plan: which tile variant, and over how many workgroups the KV axis is split.
 struct Plan {
   int variant, br, bc, lds, nqt, nt, splits, tiles_per_split;
+  int btile;  // 1: a 16-bit bias with a row axis goes through LDS tiles (the 64-key-tile build)
   size_t ws_bytes;
 };
 
@@ -131,6 +132,23 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
     else if ((uint64_t)want * per_split > p->workspace_bytes) want = (int64_t)(p->workspace_bytes / per_split);
     if (want < 1) want = 1;
     pl.splits = (int)want;
+  }
+  // A 16-bit bias with a real row axis is staged through LDS by LDS-DMA one KV step ahead (4 waves x [32 rows x 64 keys]); those
+  // launches run the build with 64-key tiles at every head dim (tile config variant 2)
+  if (pl.variant == 0 && pl.splits == 1 && p->bias != nullptr && p->bias_stride[2] != 0 && p->bias_stride[3] == 1 &&
+      (p->bias_dtype == FFPA_BIAS_FP16 || p->bias_dtype == FFPA_BIAS_BF16) && !(p->flags & (FFPA_FLAG_NO_BIAS_LDS | FFPA_FLAG_DEBUG_SAFE_PATH)) &&
+      !(p->dropout_p > 0.f)) {
+    bool ok = reinterpret_cast<uintptr_t>(p->bias) % 16 == 0 && p->bias_stride[2] < (1LL << 24);
+    for (int i = 0; i < 3; ++i) ok = ok && (p->bias_stride[i] * 2) % 16 == 0;
+    int br = 0, bc = 0, lds = 0;
+    de->config(2, &br, &bc, &lds);
+    if (ok && lds + 4 * 32 * bc * 2 <= 160 * 1024) {
+      pl.btile = 1;
+      pl.br = br;
+      pl.bc = bc;
+      pl.lds = lds;
+      pl.nt = (p->seqlen_kv + pl.bc - 1) / pl.bc;
+    }
   }
   pl.tiles_per_split = (pl.nt + pl.splits - 1) / pl.splits;
   if (pl.tiles_per_split < 1) pl.tiles_per_split = 1;
@@ -289,18 +307,9 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
                     (p->bias_stride[1] * esz) % 16 == 0 && pl.lds + bytes <= 160 * 1024;
     if (ok) a.bias_lds = (int)bytes;
   }
-  // A 16-bit bias with a real row axis is staged through LDS by LDS-DMA one KV step ahead (4 waves x [32 rows x keys-per-tile])
-  // where the head dim's tiles leave room for it (D >= 384); a.bias_lds then carries the extra LDS bytes
-  if (p->bias != nullptr && pl.variant == 0 && pl.splits == 1 && p->bias_stride[2] != 0 && p->bias_stride[3] == 1 &&
-      (p->bias_dtype == FFPA_BIAS_FP16 || p->bias_dtype == FFPA_BIAS_BF16) && !(p->flags & FFPA_FLAG_NO_BIAS_LDS) && !safe && pl.bc <= 64 &&
-      !(p->dropout_p > 0.f)) {
-    const int64_t bytes = 4LL * 32 * pl.bc * 2;
-    bool ok = reinterpret_cast<uintptr_t>(p->bias) % 16 == 0 && pl.lds + bytes <= 160 * 1024 && p->bias_stride[2] < (1LL << 24);
-    for (int i = 0; i < 3; ++i) ok = ok && (p->bias_stride[i] * 2) % 16 == 0;
-    if (ok) {
-      a.bias_tile = 1;
-      a.bias_lds = -(int)bytes;  // negative: LDS bytes reserved for the tile staging (no key-bias row cache)
-    }
+  if (pl.btile) {
+    a.bias_tile = 1;
+    a.bias_lds = -(4 * 32 * pl.bc * 2);  // negative: LDS bytes reserved for the tile staging (no key-bias row cache)
   }
   a.dropout_p = p->dropout_p;
   a.keep_scale = p->dropout_p > 0.f ? 1.f / (1.f - p->dropout_p) : 1.f;

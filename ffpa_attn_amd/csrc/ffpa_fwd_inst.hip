@@ -15,7 +15,7 @@ namespace ffpa {
 
 template <typename T, int D, int ND, bool SAFE, bool DROP = false, bool BTILE = false, int MK = 1>
 static int launch_one(const FwdArgs& a, hipStream_t stream) {
-  constexpr int BC = (ND == 1) ? ((D <= FFPA_BC128_MAX_D) ? 128 : 64) : 32;
+  constexpr int BC = (ND == 1) ? ((D <= FFPA_BC128_MAX_D && !BTILE) ? 128 : 64) : 32;
   constexpr int LDS_BASE = 2 * BC * D * 2 + (ND > 1 ? 4 * 4096 : 0);
   const int LDS = LDS_BASE + (a.bias_lds > 0 ? a.bias_lds : -a.bias_lds);  // + the key-bias row cache or the bias-tile staging area, sized by the C-ABI layer (<= 160 KiB in total)
   constexpr int kMaxLds = 160 * 1024;
@@ -78,13 +78,12 @@ int FFPA_CAT(launch_fwd_d, FFPA_INST_D)(int dtype, int safe, int variant, const 
     if (dtype == 1) return launch_one<_Float16, D, ND, false, true>(a, stream);
     return -4;
   }
-  if constexpr ((ND == 1 ? ((D <= FFPA_BC128_MAX_D) ? 128 : 64) : 32) <= 64) {
-    // 16-bit bias with a row axis, staged through LDS one step ahead (head dims whose tiles leave LDS for it)
-    if (a.bias_tile) {
-      if (dtype == 0) return launch_one<__bf16, D, ND, false, false, true>(a, stream);
-      if (dtype == 1) return launch_one<_Float16, D, ND, false, false, true>(a, stream);
-      return -4;
-    }
+  // 16-bit bias with a row axis, staged through LDS one step ahead (the build with 64-key tiles at every head dim, so that the
+  // LDS holds the bias tiles next to K and V; the plan of the C-ABI layer uses tile_config variant 2 for these launches)
+  if (a.bias_tile) {
+    if (dtype == 0) return launch_one<__bf16, D, ND, false, false, true>(a, stream);
+    if (dtype == 1) return launch_one<_Float16, D, ND, false, false, true>(a, stream);
+    return -4;
   }
   if (a.bias_dtype == 0 && a.kv_bounds == nullptr) {  // no attn_bias, no mask ranges: the build without any bias path
     if (dtype == 0) return launch_one<__bf16, D, ND, false, false, false, 0>(a, stream);
@@ -103,8 +102,9 @@ int FFPA_CAT(launch_fwd_d, FFPA_INST_D)(int dtype, int safe, int variant, const 
 
 void FFPA_CAT(tile_config_d, FFPA_INST_D)(int variant, int* br, int* bc, int* lds) {
   constexpr int D = FFPA_INST_D;
+  // variant 0: prefill tiles, 1: short-query tiles, 2: prefill tiles of the bias-tile build (64 keys at every head dim)
   const int ND = variant == 1 ? ((D % 128 == 0) ? 4 : 2) : ((D <= 512) ? 1 : 2);
-  const int BC = (ND == 1) ? ((D <= FFPA_BC128_MAX_D) ? 128 : 64) : 32;
+  const int BC = (ND == 1) ? ((D <= FFPA_BC128_MAX_D && variant != 2) ? 128 : 64) : 32;
   *br = 32 * (4 / ND);
   *bc = BC;
   *lds = 2 * BC * D * 2 + (ND > 1 ? 4 * 4096 : 0);

@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
   constexpr int KS = DW / 16;      // QK contraction steps per wave
   // keys per tile: 128 for small head dims (fewer barriers / phase fills per key), 64 up to D = 512, 32 when D
   // is split over waves (ND == 4, short-query launches: small tiles, 2 workgroups / CU)
-  constexpr int BC = (ND == 1) ? ((D <= FFPA_BC128_MAX_D) ? 128 : 64) : 32;
+  constexpr int BC = (ND == 1) ? ((D <= FFPA_BC128_MAX_D && !BTILE) ? 128 : 64) : 32;  // (bias-tile builds: 64 keys, the LDS must hold the bias tiles too)
   constexpr int NKB = BC / 32;     // 32-key S^T blocks per tile
   constexpr int NKS = BC / 16;     // PV contraction steps per tile
   constexpr int NQB = 4 / ND;      // 32-row blocks per workgroup
@@ -1242,6 +1242,13 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
         constexpr int db = FFPA_PV_ORDER ? n % NDB : n / NKS, ks = FFPA_PV_ORDER ? n / NDB : n % NKS;
         if constexpr (!(FFPA_ABL & (128 | 512))) oacc[db] = E::mfma(vf[n], pf[ks], oacc[db]);
       });
+      if constexpr (kBiasTile && kInterleave && !(FFPA_ABL & 1)) {
+        // (short PV loops — small head dims — do not have a slot for every bias piece: the rest go out here)
+        constexpr int kBStep = kStep >= 2 ? kStep : 2;
+        static_for<kBtPieces>([&](auto ic) {
+          if constexpr (decltype(ic)::value * kBStep + kBStep / 2 >= N2) issue_bias(ic, k0 + BC);
+        });
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
 

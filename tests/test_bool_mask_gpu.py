@@ -35,7 +35,9 @@ def test_bool_mask_is_bit_identical_to_its_additive_form(hip, shape, D):
   mask = torch.rand(shape, device="cuda", generator=g) > 0.25
   mask[..., 0] = True
   ob, lb = hip.forward(q, k, v, mask, False, D ** -0.5, kv_bounds=False)
-  oa, la = hip.forward(q, k, v, _additive(mask, q.dtype), False, D ** -0.5, kv_bounds=False)
+  # (FLAG_NO_BIAS_LDS: the additive form takes the same tiles as the boolean one — a 16-bit bias with a row axis would otherwise
+  # run the bias-tile build, whose 64-key tiles at D <= 320 sum in another order)
+  oa, la = hip.forward(q, k, v, _additive(mask, q.dtype), False, D ** -0.5, kv_bounds=False, flags=hip.FLAG_NO_BIAS_LDS)
   assert torch.equal(ob, oa) and torch.equal(lb, la), f"{shape} D={D}"
   _close(ob, F.scaled_dot_product_attention(q, k, v, attn_mask=mask), q.dtype, f"sdpa {shape}")
   if D == 320:
@@ -54,7 +56,7 @@ def test_bool_mask_vector_and_byte_paths_tails_and_nan_rows(hip):
     mask[0, 1, 100, 1:] = False
     mask[0, 1, 100, 0] = True
     ob, lb = hip.forward(q, k, v, mask, False, D ** -0.5, kv_bounds=False)
-    oa, la = hip.forward(q, k, v, _additive(mask, q.dtype), False, D ** -0.5, kv_bounds=False)
+    oa, la = hip.forward(q, k, v, _additive(mask, q.dtype), False, D ** -0.5, kv_bounds=False, flags=hip.FLAG_NO_BIAS_LDS)
     assert _same_bits(ob, oa) and _same_bits(lb, la), (Nq, Nkv)
     assert torch.isnan(ob[0, 0, 5]).all() and torch.isfinite(ob[:, :, 9]).all()
     assert torch.equal(ob[0, 1, 100], v[0, 1, 0])
@@ -120,7 +122,7 @@ def test_tiles_in_the_free_range_skip_the_mask_without_changing_a_bit(hip):
     rows, cols = torch.arange(Nq, device="cuda")[:, None], torch.arange(Nkv, device="cuda")[None, :]
     for name, keep in (("causal", cols <= rows + 600), ("window", (cols <= rows + 700) & (cols + 200 >= rows)), ("padding", (cols < 1500).expand(Nq, Nkv))):
       for m in (keep.view(1, 1, Nq, Nkv).contiguous(), _additive(keep.view(1, 1, Nq, Nkv), q.dtype)):
-        o_all, l_all = hip.forward(q, k, v, m, False, D ** -0.5, kv_bounds=False)
+        o_all, l_all = hip.forward(q, k, v, m, False, D ** -0.5, kv_bounds=False)  # (both runs of a mask take the same build)
         bounds = hip.mask_kv_bounds(m, Nq, Nkv)
         assert int((bounds[..., 3] - bounds[..., 2]).max()) >= 512, name  # there IS an interior to skip
         o_rng, l_rng = hip.forward(q, k, v, m, False, D ** -0.5, kv_bounds=bounds)
@@ -169,9 +171,10 @@ def test_baseline_config_4_through_the_public_api(hip):
   _within_north_star(out, ref)
   o0, _ = hip.forward(q, k, v, None, True, 320 ** -0.5, causal_offset=0)
   assert (out.float() - o0.float()).abs().max().item() <= 4e-3
-  # the additive form of the same mask gives the same bits
+  # the additive form of the same mask: the same values (its 64-key bias-tile build sums in another order than the 128-key tiles
+  # of the boolean build, so to rounding, not to the bit)
   oa = ffpa_attn_func(q, k, v, attn_mask=_additive(mask, q.dtype), enable_gqa=True)
-  assert torch.equal(out, oa)
+  assert (out.float() - oa.float()).abs().max().item() <= 8e-3
 
 
 def test_backward_through_a_bool_mask(hip):
@@ -249,9 +252,10 @@ def test_key_bias_row_cache_in_lds_is_bit_identical_to_the_global_reads(hip, D, 
       _check_vs_oracle(o1, l1, q, k, v, bias=_f32(bias.float()), name="key bias")
 
 
-@pytest.mark.parametrize("D", [384, 512, 640, 1024])
+@pytest.mark.parametrize("D", [64, 128, 256, 320, 384, 512, 640, 1024])
 def test_bias_tiles_staged_through_lds_are_bit_identical_to_the_global_reads(hip, D):
-  """A 16-bit bias WITH a row axis is LDS-DMA'd one KV step ahead into a private area per wave (D >= 384) and read there —
+  """A 16-bit bias WITH a row axis is LDS-DMA'd one KV step ahead into a private area per wave (the build with 64-key tiles at
+  every head dim) and read there —
   same numbers as the per-tile global loads (FFPA_FLAG_NO_BIAS_LDS): broadcast batch / head dims, ragged rows and keys, -inf
   entries and fully hidden rows, causal on top, GQA, fp16."""
   B, Hq, Hkv = 2, 4, 2
@@ -264,7 +268,12 @@ def test_bias_tiles_staged_through_lds_are_bit_identical_to_the_global_reads(hip
     bias[:, :, 7, :] = float("-inf")  # a fully hidden row -> NaN
     o1, l1 = hip.forward(q, k, v, bias, causal, D ** -0.5, kv_bounds=False)
     o0, l0 = hip.forward(q, k, v, bias, causal, D ** -0.5, kv_bounds=False, flags=hip.FLAG_NO_BIAS_LDS)
-    assert _same_bits(o1, o0) and _same_bits(l1, l0), (D, Nq, Nkv, shape)
+    if D > 320:  # same 64-key tiles in both builds: the same bits
+      assert _same_bits(o1, o0) and _same_bits(l1, l0), (D, Nq, Nkv, shape)
+    else:        # D <= 320: the global-read build uses 128-key tiles, another summation order
+      keep = [r for r in range(Nq) if r != 7]
+      _close(o1[:, :, keep], o0[:, :, keep], dt, f"tiles {D} {shape}")
+      assert (l1[:, :, keep] - l0[:, :, keep]).abs().max().item() <= 2e-5
     assert torch.isnan(o1[:, :, 7]).all()
     if not causal:  # (PyTorch-ROCm's fused SDPA does not return NaN for the fully hidden row: compare the others)
       ref = F.scaled_dot_product_attention(q, k, v, attn_mask=bias, enable_gqa=True)
@@ -272,7 +281,7 @@ def test_bias_tiles_staged_through_lds_are_bit_identical_to_the_global_reads(hip
       _close(o1[:, :, keep], ref[:, :, keep], dt, f"sdpa {shape}")
     # with the mask ranges on top (tiles skipped / mask reads skipped): still the same bits
     o2, l2 = hip.forward(q, k, v, bias, causal, D ** -0.5, kv_bounds=True)
-    assert _same_bits(o2, o0) and _same_bits(l2, l0)
+    assert _same_bits(o2, o1) and _same_bits(l2, l1)
   if D == 512:
     q, k, v = _rand((1, 2, 260, D), seed=1), _rand((1, 2, 700, D), seed=2), _rand((1, 2, 700, D), seed=3)
     bias = _rand((1, 2, 260, 704), seed=4)[..., :700]  # row stride 704 elements, 700 keys

@@ -3,7 +3,7 @@ import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ffpa_attn_amd import hip
 from ffpa_attn_amd.flops import attention_fwd_flops
-for D, hb in ((512, 1), (512, 32), (1024, 1), (448, 1)):
+for D, hb in ((512, 1), (512, 32), (1024, 1), (448, 1), (320, 1), (256, 1), (128, 1)):
   torch.manual_seed(0)
   N = 8192
   q, k, v = (torch.randn(1, 32, N, D, dtype=torch.bfloat16, device="cuda") for _ in range(3))
