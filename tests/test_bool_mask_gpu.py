@@ -287,3 +287,23 @@ def test_bias_tiles_staged_through_lds_are_bit_identical_to_the_global_reads(hip
     bias = _rand((1, 2, 260, 704), seed=4)[..., :700]  # row stride 704 elements, 700 keys
     o1, l1 = hip.forward(q, k, v, bias, False, D ** -0.5)
     _check_vs_oracle(o1, l1, q, k, v, bias=_f32(bias.float()), name="bias tile, strided rows")
+
+
+def test_bool_and_key_bias_masks_on_the_short_query_path(hip):
+  """Nq <= 32 launches (split-KV tiles + LSE merge) with a boolean mask and with a key bias: the same bits as the additive /
+  global-read forms, padding-style masks per batch element included."""
+  D = 512
+  for (B, Hq, Hkv, Nq, Nkv) in ((2, 8, 2, 1, 4096), (1, 4, 4, 7, 3000), (3, 4, 2, 20, 1500)):
+    q, k, v = _rand((B, Hq, Nq, D), seed=Nq), _rand((B, Hkv, Nkv, D), seed=Nq + 1), _rand((B, Hkv, Nkv, D), seed=Nq + 2)
+    lens = torch.tensor([Nkv - 17 * i for i in range(B)], device="cuda")
+    keep = (torch.arange(Nkv, device="cuda")[None, :] < lens[:, None]).view(B, 1, 1, Nkv)  # key padding per batch element
+    ob, lb = hip.forward(q, k, v, keep, False, D ** -0.5)
+    oa, la = hip.forward(q, k, v, _additive(keep, q.dtype), False, D ** -0.5, flags=hip.FLAG_NO_BIAS_LDS)
+    assert _same_bits(ob, oa) and _same_bits(lb, la), (Nq, Nkv)
+    ref = F.scaled_dot_product_attention(q, k, v, attn_mask=keep, enable_gqa=True)
+    _close(ob, ref, q.dtype, f"short-query bool {Nq}x{Nkv}")
+    full = (torch.rand(B, Hq, Nq, Nkv, device="cuda") > 0.3)
+    full[..., 0] = True
+    ob2, _ = hip.forward(q, k, v, full, False, D ** -0.5)
+    oa2, _ = hip.forward(q, k, v, _additive(full, q.dtype), False, D ** -0.5, flags=hip.FLAG_NO_BIAS_LDS)
+    assert _same_bits(ob2, oa2)
