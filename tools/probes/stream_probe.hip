@@ -51,8 +51,8 @@ __device__ __forceinline__ void lds_dma(u32x4 rsrc, uint32_t lds_addr, uint32_t 
 // inside the loop (vmcnt saturates at 63: the deepest queue the hardware keeps).
 // SWZ: per-lane source offset of a piece: 0 = lane-linear, 1 = 16-byte slots XOR-permuted inside 256-byte groups (the kernel's K image),
 // 2 = 64-byte quarters permuted inside 256-byte groups (the kernel's V image)
-template <int NM, int NDMA, int NREAD, int MODE, bool MFMA_ON, int SWZ = 0>
-__global__ __launch_bounds__(MFMA_ON ? 256 : 1024) void probe(const Args a) {
+template <int NM, int NDMA, int NREAD, int MODE, bool MFMA_ON, int SWZ = 0, int NACC = 16>
+__global__ __launch_bounds__(MFMA_ON ? (NACC == 16 ? 256 : 512) : 1024) void probe(const Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -70,9 +70,9 @@ __global__ __launch_bounds__(MFMA_ON ? 256 : 1024) void probe(const Args a) {
   __syncthreads();
   const u32x4 braw = *(const u32x4*)(a.bsrc + lane * 4);
   const bf16x8 bfrag = __builtin_bit_cast(bf16x8, braw);
-  f32x16 acc[16];
+  f32x16 acc[NACC];  // 16 = a one-wave-per-SIMD kernel's 256 accumulator registers; 8 = two waves per SIMD
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = (f32x16)(0.f);
+  for (int i = 0; i < NACC; ++i) acc[i] = (f32x16)(0.f);
   const uint32_t voff = (uint32_t)lane * 16u;
   uint32_t soff = (uint32_t)wave * (uint32_t)(NDMA > 0 ? NDMA : 1) * 1024u;
   // fragment reads run PF MFMAs ahead of their consumer through a ring of 8 registers sets (the kernel's software pipeline)
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(MFMA_ON ? 256 : 1024) void probe(const Args a) {
           lds_dma(rsrc, dst, vo, soff + (uint32_t)piece * 1024u);
         }
       }
-      if constexpr (MFMA_ON) acc[n & 15] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[n & 7], bfrag, acc[n & 15], 0, 0, 0);
+      if constexpr (MFMA_ON) acc[n % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[n & 7], bfrag, acc[n % NACC], 0, 0, 0);
       else if constexpr (NREAD > 0) asm volatile("" ::"v"(fr[n & 7]));
     }
     if constexpr (NM == 0 && NDMA > 0) {}
@@ -124,16 +124,16 @@ __global__ __launch_bounds__(MFMA_ON ? 256 : 1024) void probe(const Args a) {
   const unsigned long long t1 = __builtin_readcyclecounter();
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][7];
+  for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][7];
   if (s == 12345.678f) a.sink[0] = s;
   if (lane == 0) a.ticks[blockIdx.x * nwave + wave] = t1 - t0;
 }
 
 static double g_clock_hint = 0;
 
-template <int NM, int NDMA, int NREAD, int MODE, bool MFMA_ON, int SWZ = 0>
+template <int NM, int NDMA, int NREAD, int MODE, bool MFMA_ON, int SWZ = 0, int NACC = 16>
 static void run(const char* name, Args a, int threads, const uint32_t* brand, const uint32_t* bzero, bool zero_ops, int tiles) {
-  auto k = probe<NM, NDMA, NREAD, MODE, MFMA_ON, SWZ>;
+  auto k = probe<NM, NDMA, NREAD, MODE, MFMA_ON, SWZ, NACC>;
   const int lds = 144 * 1024;
   CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   a.tiles = tiles;
@@ -239,5 +239,12 @@ int main(int argc, char** argv) {
   run<32, 32, 0, 1, false, 2>("dma_only, 64-B quarter swizzle (V)", a, 256, brand, bzero, false, T);
   run<64, 32, 1, 1, true, 1>("D1024mix +ldsread, K swizzle", a, 256, brand, bzero, false, T);
   run<64, 32, 1, 1, true, 2>("D1024mix +ldsread, V swizzle", a, 256, brand, bzero, false, T);
+  // (5) would TWO waves per SIMD (8 per CU, 256 registers each: 128 accumulators) hide the in-order stalls?  Same work per CU and
+  // tile as the D = 512 / D = 1024 mixes, split over 8 waves (half the MFMAs, pieces and reads per wave)
+  run<64, 0, 0, 2, true, 0, 8>("8 waves: mfma_only", a, 512, brand, bzero, false, T * 2);
+  run<64, 16, 1, 1, true, 0, 8>("8 waves: D512mix (64 mfma + 16 dma + reads)/wave", a, 512, brand, bzero, false, T / 2 * 2);
+  run<64, 16, 1, 0, true, 0, 8>("8 waves: D512mix +barrier", a, 512, brand, bzero, false, T / 2 * 2);
+  run<32, 16, 1, 1, true, 0, 8>("8 waves: D1024mix (32 mfma + 16 dma + reads)/wave", a, 512, brand, bzero, false, T * 2);
+  run<32, 16, 1, 0, true, 0, 8>("8 waves: D1024mix +barrier", a, 512, brand, bzero, false, T * 2);
   return 0;
 }
