@@ -129,6 +129,121 @@ __global__ __launch_bounds__(MFMA_ON ? (NACC == 16 ? 256 : 512) : 1024) void pro
   if (lane == 0) a.ticks[blockIdx.x * nwave + wave] = t1 - t0;
 }
 
+// bare v_mfma_f32_16x16x32_bf16 stream (64 rotating 4-register accumulators = the same 256 registers): does the other bf16
+// shape sustain a different clock / rate on random operands?
+typedef __attribute__((ext_vector_type(4))) float f32x4p;
+__global__ __launch_bounds__(256) void probe_mfma16(const Args a) {
+  const int lane = threadIdx.x & 63;
+  const u32x4 braw = *(const u32x4*)(a.bsrc + lane * 4);
+  const bf16x8 bfrag = __builtin_bit_cast(bf16x8, braw);
+  f32x4p acc[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) acc[i] = (f32x4p)(0.f);
+  for (int t = 0; t < a.tiles; ++t) {
+#pragma unroll
+    for (int n = 0; n < 128; ++n) {
+      __builtin_amdgcn_sched_barrier(0);
+      acc[n & 63] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag, bfrag, acc[n & 63], 0, 0, 0);
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 64; ++i) s += acc[i][0];
+  if (s == 12345.678f) a.sink[0] = s;
+}
+
+// The kernel's instruction mix rebuilt on the 16x16x32 shape: one ds_read_b128 A fragment feeds TWO MFMAs (the two 16-row halves
+// of a wave's 32 query rows are its B operands), so LDS bytes per FLOP equal the 32x32x16 mix; NM16 MFMAs of 16 K FLOP, NDMA
+// pieces and NM16 / 2 fragment reads per wave and tile.
+template <int NM16, int NDMA, int MODE>
+__global__ __launch_bounds__(256) void probe_mix16(const Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xcd = blockIdx.x & 7;
+  const char* base = a.src + (size_t)xcd * a.region;
+  const uint64_t ba = (uint64_t)base;
+  const u32x4 rsrc = {(uint32_t)ba, (uint32_t)(ba >> 32) & 0xffffu, a.region, 0x00020000u};
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(LDSAS char*)smem;
+  for (int i = threadIdx.x; i < 16384; i += blockDim.x) ((LDSAS uint32_t*)smem)[i] = 0x3f803f80u ^ (uint32_t)(i * 2654435761u >> 12 & 0x00ff00ffu);
+  __syncthreads();
+  const u32x4 braw = *(const u32x4*)(a.bsrc + lane * 4);
+  const u32x4 braw2 = *(const u32x4*)(a.bsrc + ((lane + 7) & 63) * 4);
+  const bf16x8 b0 = __builtin_bit_cast(bf16x8, braw), b1 = __builtin_bit_cast(bf16x8, braw2);
+  f32x4p acc[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) acc[i] = (f32x4p)(0.f);
+  const uint32_t voff = (uint32_t)lane * 16u;
+  uint32_t soff = (uint32_t)wave * (uint32_t)(NDMA > 0 ? NDMA : 1) * 1024u;
+  const uint32_t per_tile = 4u * (uint32_t)(NDMA > 0 ? NDMA : 1) * 1024u;
+  constexpr int PF = 3;  // fragments ahead (each feeds two MFMAs)
+  constexpr int NF = NM16 / 2;
+  bf16x8 fr[4];
+  auto frag_read = [&](int f) -> bf16x8 {
+    const u32x4 raw = *(LDSAS const u32x4*)(smem + ((f * 1024) & 0xffff) + lane * 16);
+    return __builtin_bit_cast(bf16x8, raw);
+  };
+#pragma unroll
+  for (int f = 0; f < PF; ++f) fr[f] = frag_read(f);
+  for (int t = 0; t < a.tiles; ++t) {
+    constexpr int STEP = NDMA > 0 ? NF / NDMA : 1;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      __builtin_amdgcn_sched_barrier(0);
+      fr[(f + PF) & 3] = frag_read((f + PF) % NF);
+      if constexpr (NDMA > 0) {
+        if (f % STEP == 0 && f / STEP < NDMA) {
+          const int piece = f / STEP;
+          lds_dma(rsrc, lds0 + (uint32_t)(((wave * NDMA + piece) * 1024) & (128u * 1024u - 1)), voff, soff + (uint32_t)piece * 1024u);
+        }
+      }
+      acc[(2 * f) & 63] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[f & 3], b0, acc[(2 * f) & 63], 0, 0, 0);
+      acc[(2 * f + 1) & 63] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[f & 3], b1, acc[(2 * f + 1) & 63], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    soff += per_tile;
+    if (soff + per_tile > a.region) soff = (uint32_t)wave * (uint32_t)(NDMA > 0 ? NDMA : 1) * 1024u;
+    if constexpr (MODE == 0) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __builtin_amdgcn_s_barrier();
+    } else if constexpr (NDMA > 0) {
+      constexpr int W = NDMA > 63 ? 63 : NDMA;
+      __builtin_amdgcn_s_waitcnt(0x0F70 | (W & 15) | ((W >> 4) << 14));
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 64; ++i) s += acc[i][0];
+  if (s == 12345.678f) a.sink[0] = s;
+}
+
+template <int NM16, int NDMA, int MODE>
+static void run16(const char* name, Args a, const uint32_t* brand, int tiles) {
+  auto k = probe_mix16<NM16, NDMA, MODE>;
+  const int lds = 144 * 1024;
+  CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  a.tiles = tiles;
+  a.bsrc = brand;
+  hipLaunchKernelGGL(k, dim3(256), dim3(256), lds, 0, a);
+  CHECK(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  CHECK(hipEventRecord(e0));
+  for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(k, dim3(256), dim3(256), lds, 0, a);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= 3;
+  const double flops = (double)NM16 * tiles * 4 * 256 * 16384.0;
+  const double bytes_cu = (double)NDMA * 1024.0 * 4 * tiles;
+  printf("PROBE %-34s waves/CU  4 ops=random tiles %5d | %8.3f ms | MFMA %7.1f TFLOP/s (%5.1f%% of 2500) | LDS-DMA %6.2f TB/s chip\n", name, tiles, ms,
+         flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 2.5e15 * 100.0, bytes_cu * 256 / (ms * 1e-3) / 1e12);
+  fflush(stdout);
+}
+
 static double g_clock_hint = 0;
 
 template <int NM, int NDMA, int NREAD, int MODE, bool MFMA_ON, int SWZ = 0, int NACC = 16>
@@ -239,6 +354,34 @@ int main(int argc, char** argv) {
   run<32, 32, 0, 1, false, 2>("dma_only, 64-B quarter swizzle (V)", a, 256, brand, bzero, false, T);
   run<64, 32, 1, 1, true, 1>("D1024mix +ldsread, K swizzle", a, 256, brand, bzero, false, T);
   run<64, 32, 1, 1, true, 2>("D1024mix +ldsread, V swizzle", a, 256, brand, bzero, false, T);
+  {  // (1c) the 16x16x32 shape: 128 MFMAs of 16 K FLOP per "tile" = the FLOPs of 64 32x32x16 MFMAs
+    for (int zero = 0; zero < 2; ++zero) {
+      Args b = a;
+      b.tiles = T * 2;
+      b.bsrc = zero ? bzero : brand;
+      hipLaunchKernelGGL(probe_mfma16, dim3(256), dim3(256), 0, 0, b);
+      CHECK(hipDeviceSynchronize());
+      hipEvent_t e0, e1;
+      CHECK(hipEventCreate(&e0));
+      CHECK(hipEventCreate(&e1));
+      CHECK(hipEventRecord(e0));
+      for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(probe_mfma16, dim3(256), dim3(256), 0, 0, b);
+      CHECK(hipEventRecord(e1));
+      CHECK(hipEventSynchronize(e1));
+      float ms = 0;
+      CHECK(hipEventElapsedTime(&ms, e0, e1));
+      ms /= 3;
+      const double flops = 128.0 * b.tiles * 4 * 256 * 16384.0;
+      printf("PROBE %-34s waves/CU  4 ops=%s tiles %5d | %8.3f ms | MFMA %7.1f TFLOP/s (%5.1f%% of 2500)\n", "mfma_only 16x16x32", zero ? "zero  " : "random", b.tiles, ms,
+             flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 2.5e15 * 100.0);
+    }
+  }
+  // (1d) the kernel's mixes on the 16x16x32 shape (A fragment shared by two MFMAs)
+  run16<256, 0, 1>("16x16x32: mfma + shared-A reads", a, brand, T);
+  run16<256, 32, 1>("16x16x32: D512mix (256 mfma16+32 dma)", a, brand, T / 2);
+  run16<256, 32, 0>("16x16x32: D512mix +barrier", a, brand, T / 2);
+  run16<128, 32, 1>("16x16x32: D1024mix (128 mfma16+32 dma)", a, brand, T);
+  run16<128, 32, 0>("16x16x32: D1024mix +barrier", a, brand, T);
   // (5) would TWO waves per SIMD (8 per CU, 256 registers each: 128 accumulators) hide the in-order stalls?  Same work per CU and
   // tile as the D = 512 / D = 1024 mixes, split over 8 waves (half the MFMAs, pieces and reads per wave)
   run<64, 0, 0, 2, true, 0, 8>("8 waves: mfma_only", a, 512, brand, bzero, false, T * 2);
