@@ -5,6 +5,7 @@
 #include <atomic>
 
 #include "ffpa_fwd_kernel.h"
+#include "ffpa_fwd_m16_kernel.h"
 #include "ffpa_launch.h"
 
 #ifndef FFPA_INST_D
@@ -41,6 +42,25 @@ static int launch_one(const FwdArgs& a, hipStream_t stream) {
   }
 #endif
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, stream, a);
+  return (int)hipGetLastError();
+}
+
+// The unmasked prefill kernel on the 16x16x32 MFMA shape (ffpa_fwd_m16_kernel.h): same tiles (128 rows x 64 keys), same plan.
+template <typename T, int D>
+static int launch_m16(const FwdArgs& a, hipStream_t stream) {
+  constexpr int LDS = 2 * 64 * D * 2;
+  auto kern = ffpa_fwd_m16_kernel<T, D>;
+  static std::atomic<bool> attr_done[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  if (dev < 0 || dev >= 64 || !attr_done[dev].load(std::memory_order_acquire)) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      (void)hipGetLastError();
+      return -2;
+    }
+    if (dev >= 0 && dev < 64) attr_done[dev].store(true, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)a.total_wg), dim3(256), LDS, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -86,6 +106,13 @@ int FFPA_CAT(launch_fwd_d, FFPA_INST_D)(int dtype, int safe, int variant, const 
     return -4;
   }
   if (a.bias_dtype == 0 && a.kv_bounds == nullptr) {  // no attn_bias, no mask ranges: the build without any bias path
+    if constexpr (ND == 1 && (D * 2) % 1024 == 0) {
+      if (!(a.flags & 0x10u) && a.d_valid == D) {  // (FFPA_FLAG_NO_M16 keeps the 32x32x16 build: A/B runs, tests)
+        if (dtype == 0) return launch_m16<__bf16, D>(a, stream);
+        if (dtype == 1) return launch_m16<_Float16, D>(a, stream);
+        return -4;
+      }
+    }
     if (dtype == 0) return launch_one<__bf16, D, ND, false, false, false, 0>(a, stream);
     if (dtype == 1) return launch_one<_Float16, D, ND, false, false, false, 0>(a, stream);
     return -4;

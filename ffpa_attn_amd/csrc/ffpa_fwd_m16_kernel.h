@@ -1,0 +1,447 @@
+// ffpa_fwd_m16_kernel.h — the unmasked prefill kernel rebuilt on the 16x16x32 MFMA shape.
+//
+// Same algorithm, same pipeline (LDS-DMA K / V tiles, barriers A1 / A2 / B, lazy-rescale online softmax in the log2 domain)
+// and same numbers-per-row order as ffpa_fwd_split_d_kernel<.., ND = 1, .., MK = 0> (ffpa_fwd_kernel.h, which follows the
+// reference's split_d_fwd_sm80: csrc/cuffpa/native/sm_80/split_d.cuh:96-777); only the mapping of the two products onto the
+// matrix core differs.  Why a second mapping: v_mfma_f32_16x16x32 sustains a 14 - 21 % higher power-capped rate than
+// v_mfma_f32_32x32x16 on random operands, and the D = 512 instruction mix built on it has a 9 % higher ceiling
+// (tools/probes/stream_probe.hip, profiles/r02_stream_probe.txt).
+//
+// Mapping (one wave = 32 query rows as two 16-row halves rh, all of D; 4 waves = 128 rows; 64 keys per tile):
+//   * S^T = K.Q^T per 16-key block kb and row half rh: A = K[16 keys][32 d] (one ds_read_b128 per lane: key lane % 16, d chunk
+//     lane / 16), B = Q^T (resident fragments: row 16 rh + lane % 16, d chunk lane / 16).  One K fragment feeds BOTH row
+//     halves, so LDS bytes per FLOP equal the 32x32x16 kernel's.  C layout: lane (n = lane % 16, c = lane / 16) holds keys
+//     16 kb + 4 c + r (r < 4) of rows n and 16 + n.
+//   * O^T += V^T.P^T per 16-column block db, 32-key step ks and row half: B = P^T straight from the S^T registers (contraction
+//     slot 8 c + e <-> key 32 ks + 16 (e / 4) + 4 c + e % 4 — exactly what the lane holds), A = V^T by two
+//     ds_read_b64_tr_b16 per lane (keys 32 ks + 4 c + .. and + 16), shared by both row halves.  O^T = 64 f32x4 tiles = the
+//     256 AGPRs.
+//   * a query row lives in 4 lanes (c = 0 .. 3): row max / row sum take two cross-lane steps (lane ^ 16, lane ^ 32).
+//   * epilogue: a lane owns 4 consecutive columns of two rows; lanes c and c ^ 1 trade one group (v_permlane16_swap) so that
+//     each stores whole 16-byte runs of ONE row.
+// Built for head dims whose tile rows are whole 1 KiB DMA pieces (D = 512); launched for calls without attn_bias, mask ranges
+// or dropout and with head_dim == D.
+#pragma once
+
+#include "ffpa_fwd_kernel.h"
+
+#ifndef FFPA_M16_PF1
+#define FFPA_M16_PF1 6  // K fragments requested ahead of their (two) MFMAs
+#endif
+#ifndef FFPA_M16_PF2
+#define FFPA_M16_PF2 4  // V^T fragments (two transpose reads each) requested ahead
+#endif
+#ifndef FFPA_M16_K_PRE
+#define FFPA_M16_K_PRE 8  // K(j+1) pieces issued between the softmax stages (a multiple of 4); the rest go out between the PV MFMAs
+#endif
+
+#ifndef FFPA_M16_X
+#define FFPA_M16_X 0
+#endif
+
+namespace ffpa {
+
+template <typename T>
+struct Mfma16;
+template <>
+struct Mfma16<__bf16> {
+  typedef Elem<__bf16>::v8 v8;
+  static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ void first(f32x4& d, v8 a, v8 b) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b)); }
+  static __device__ __forceinline__ void acc(f32x4& d, v8 a, v8 b) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b)); }
+  static __device__ __forceinline__ void acc_a(f32x4& d, v8 a, v8 b) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b)); }
+};
+template <>
+struct Mfma16<_Float16> {
+  typedef Elem<_Float16>::v8 v8;
+  static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ void first(f32x4& d, v8 a, v8 b) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b)); }
+  static __device__ __forceinline__ void acc(f32x4& d, v8 a, v8 b) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b)); }
+  static __device__ __forceinline__ void acc_a(f32x4& d, v8 a, v8 b) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b)); }
+};
+
+// max / sum over the 4 lanes (lane % 16 fixed) that share a query row
+__device__ __forceinline__ float row4_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16));
+  return fmaxf(v, __shfl_xor(v, 32));
+}
+__device__ __forceinline__ float row4_sum(float v) {
+  v += __shfl_xor(v, 16);
+  return v + __shfl_xor(v, 32);
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
+  using E = Elem<T>;
+  using M = Mfma16<T>;
+  using v8 = typename E::v8;
+  using v4 = typename E::v4;
+  static_assert((D * 2) % 1024 == 0 && D <= 512, "tile rows must be whole 1 KiB pieces; O^T must fit the AGPRs");
+  constexpr int BC = 64, BR = 128;
+  constexpr int KS = D / 32;    // QK contraction steps
+  constexpr int NKB = BC / 16;  // 16-key S^T blocks per tile
+  constexpr int NKS = BC / 32;  // PV contraction steps per tile
+  constexpr int NDB = D / 16;   // 16-column O^T blocks
+  constexpr int RB = D * 2;
+  constexpr int TILE = BC * RB;
+  constexpr int PPW = BC * D * 2 / 4096;  // 1 KiB DMA pieces per wave per tile
+  constexpr int RPP = RB / 1024;          // pieces per row
+  constexpr int KPW = BC / 4;             // keys staged per wave per tile
+  constexpr int PF1 = FFPA_M16_PF1, PF2 = FFPA_M16_PF2;
+  constexpr int kPre = ((FFPA_M16_K_PRE < PPW ? FFPA_M16_K_PRE : PPW) / 4) * 4;
+  constexpr int N1 = KS * NKB;   // K fragments per tile
+  constexpr int N2 = NDB * NKS;  // V^T fragments per tile
+  constexpr int kStep1 = N1 / PPW;           // one V piece every this many K fragments
+  constexpr int kStep2 = N2 / PPW;           // one K piece every this many V^T fragments
+  static_assert(kStep1 >= 1 && kStep2 >= 1, "DMA pieces must fit the MFMA loops");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  FFPA_LDS char* const Kt = (FFPA_LDS char*)smem;
+  FFPA_LDS char* const Vt = Kt + TILE;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15;
+  const int c = lane >> 4;
+
+  // workgroup -> (batch, head, row tile, split): as ffpa_fwd_split_d_kernel (all row tiles of a head on one XCD)
+  int vid = blockIdx.x;
+  if (!(a.flags & kFlagNoXcdRemap)) {
+    const int total = gridDim.x;
+    const int xcd = vid & 7, idx = vid >> 3, per = total >> 3, rem = total & 7;
+    vid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
+  }
+  const int split = vid % a.nsplit;
+  vid /= a.nsplit;
+  const int bh = vid / a.nqt;
+  int qt = vid - bh * a.nqt;
+  if (a.causal) qt = a.nqt - 1 - qt;
+  const int b = bh / a.Hq;
+  const int hq = bh - b * a.Hq;
+  const int hkv = hq / a.group;
+  const int q0 = qt * BR;
+  const int wq0 = q0 + wave * 32;
+  int qrow[2], qrow_c[2];
+#pragma unroll
+  for (int rh = 0; rh < 2; ++rh) {
+    qrow[rh] = wq0 + 16 * rh + n16;
+    qrow_c[rh] = qrow[rh] < a.Nq ? qrow[rh] : a.Nq - 1;
+  }
+
+  const T* __restrict__ Kg = (const T*)a.k + b * a.sk[0] + hkv * a.sk[1];
+  const T* __restrict__ Vg = (const T*)a.v + b * a.sv[0] + hkv * a.sv[1];
+  const uint32_t k_row_bytes = (uint32_t)a.sk[2] * 2u;
+  const uint32_t v_row_bytes = (uint32_t)a.sv[2] * 2u;
+
+  // ---- LDS-DMA: wave w stages keys 16 a + 4 w + b4 (a < BC/16, b4 < 4), one row = RPP pieces, lane l -> 16-byte slot l of
+  // the piece; the bank swizzles go on the per-lane SOURCE slot: K slot ^ (key % 16), V slot ^ 2 (key % 8).
+  uint32_t kvo[4], vvo[4];
+  uint32_t kro[KPW], vro[KPW];
+#pragma unroll
+  for (int bb = 0; bb < 4; ++bb) {
+    kvo[bb] = (uint32_t)((lane ^ (4 * wave + bb)) << 4);
+    vvo[bb] = (uint32_t)((lane ^ (((4 * wave + bb) & 7) << 1)) << 4);
+  }
+#pragma unroll
+  for (int jk = 0; jk < KPW; ++jk) {
+    const uint32_t key = (uint32_t)(16 * (jk >> 2) + 4 * wave + (jk & 3));
+    kro[jk] = key * k_row_bytes;
+    vro[jk] = key * v_row_bytes;
+  }
+  const uint32_t k_lds = (uint32_t)(uintptr_t)Kt + (uint32_t)(4 * wave * RB);
+  const uint32_t v_lds = (uint32_t)(uintptr_t)Vt + (uint32_t)(4 * wave * RB);
+  auto issue_k = [&](auto ic, int key0) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int jk = i / RPP, half = i % RPP;
+    const TileSrc ts = tile_src<BC>(Kg, k_row_bytes, key0, a.Nkv, RB);
+    lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(ts.rsrc, k_lds, kvo[jk & 3], kro[jk]);
+  };
+  auto issue_v = [&](auto ic, int key0) {
+    constexpr int i = decltype(ic)::value;
+    constexpr int jk = i / RPP, half = i % RPP;
+    const TileSrc ts = tile_src<BC>(Vg, v_row_bytes, key0, a.Nkv, RB);
+    lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(ts.rsrc, v_lds, vvo[jk & 3], vro[jk]);
+  };
+
+  // ---- KV tile range
+  int nt = (a.Nkv + BC - 1) / BC;
+  if (a.causal) {
+    const int last_row = a.causal_row_mod ? a.causal_row_mod - 1 : q0 + BR - 1;
+    const int64_t last = (int64_t)last_row + a.causal_offset;
+    const int ntc = last < 0 ? 0 : (int)(last / BC) + 1;
+    nt = nt < ntc ? nt : ntc;
+  }
+  const int t0 = split * a.tiles_per_split;
+  {
+    const int t1 = t0 + a.tiles_per_split;
+    nt = nt < t1 ? nt : t1;
+  }
+
+  // ---- Q fragments (B operand of S^T): lane (n, c) holds Q[row 16 rh + n][32 s + 8 c .. + 8]
+  v8 qf[KS][2];
+#pragma unroll
+  for (int rh = 0; rh < 2; ++rh) {
+    const T* qp = (const T*)a.q + b * a.sq[0] + hq * a.sq[1] + (int64_t)qrow_c[rh] * a.sq[2] + c * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[s][rh] = *(const v8*)(qp + s * 32);
+  }
+
+  f32x4 oacc[NDB][2];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i) {
+    oacc[i][0] = (f32x4)(0.f);
+    oacc[i][1] = (f32x4)(0.f);
+  }
+  float m_run[2] = {-INFINITY, -INFINITY};  // running row max (log2 domain), the same value in the row's 4 lanes
+  float l_run[2] = {0.f, 0.f};              // this lane's share of the row sum
+
+  // ---- per-lane fragment addresses
+  // K fragment of step s = 4 q + i, key block kb: kaddr[i] + 256 q + kb * 16 * RB  (slot (4 s + c) ^ (key % 16): the XOR stays
+  // inside the low 4 slot bits)
+  FFPA_LDS const char* kaddr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) kaddr[i] = Kt + n16 * RB + (((4 * i + c) ^ n16) << 4);
+  // V^T fragment of column block db = 8 q + i, key step ks: lane L = lane % 16 of group c reads key 4 c + L / 4 (+ 16 for the second
+  // read), 4 columns 16 db + 4 (L % 4) ..: vaddr[i] + 256 q + (32 ks + {0, 16}) * RB
+  FFPA_LDS const char* vaddr[8];
+  {
+    const int vkey = 4 * c + (n16 >> 2);
+    const int sw = (vkey & 7) << 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vaddr[i] = Vt + vkey * RB + (((2 * i + ((n16 & 3) >> 1)) ^ sw) << 4) + 8 * (n16 & 1);
+  }
+
+  if (nt > t0) {
+    static_for<PPW>([&](auto ic) { issue_k(ic, t0 * BC); });
+    dma_wait_all();
+    __syncthreads();
+  }
+
+  for (int j = t0; j < nt; ++j) {
+    const int k0 = j * BC;
+
+    // ================= S^T = K.Q^T =================
+    f32x4 sacc[NKB][2];
+    {
+      v8 kf[N1];
+      auto k_frag = [&](int n) -> v8 {
+        const int s = n / NKB, kb = n % NKB;
+        return *(FFPA_LDS const v8*)(kaddr[s & 3] + (s >> 2) * 256 + kb * 16 * RB);
+      };
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int n = 0; n < PF1 && n < N1; ++n) kf[n] = k_frag(n);
+      static_for<N1>([&](auto ic) {
+        constexpr int n = decltype(ic)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (n + PF1 < N1) kf[n + PF1] = k_frag(n + PF1);
+        if constexpr (n % kStep1 == 0 && n / kStep1 < PPW) issue_v(std::integral_constant<int, n / kStep1>{}, k0);
+        constexpr int s = n / NKB, kb = n % NKB;
+        if constexpr (s == 0) {
+          M::first(sacc[kb][0], kf[n], qf[s][0]);
+          M::first(sacc[kb][1], kf[n], qf[s][1]);
+        } else {
+          M::acc(sacc[kb][0], kf[n], qf[s][0]);
+          M::acc(sacc[kb][1], kf[n], qf[s][1]);
+        }
+      });
+      // MFMA result -> VALU reader wait states (invisible to the compiler inside asm)
+      asm volatile("s_nop 15\n\ts_nop 3"
+                   : "+v"(sacc[0][0]), "+v"(sacc[0][1]), "+v"(sacc[1][0]), "+v"(sacc[1][1]), "+v"(sacc[2][0]), "+v"(sacc[2][1]), "+v"(sacc[3][0]),
+                     "+v"(sacc[3][1]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    static_assert(NKB == 4, "the wait-state statement above names 8 accumulators");
+
+    auto pre_k_group = [&](auto gc) __attribute__((always_inline)) {
+      constexpr int g = decltype(gc)::value;
+      if constexpr (kPre >= 4) {
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<kPre / 4>([&](auto ic) { issue_k(std::integral_constant<int, g * (kPre / 4) + decltype(ic)::value>{}, k0 + BC); });
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+
+    // barrier A1: every wave is done reading K(j)
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    pre_k_group(std::integral_constant<int, 0>{});
+
+    // x[kb][rh][r] = score(row 16 rh + n, key k0 + 16 kb + 4 c + r)
+    float x[NKB][2][4];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[kb][rh][r] = sacc[kb][rh][r] * a.scale_log2;
+    pre_k_group(std::integral_constant<int, 1>{});
+
+    const bool tail = k0 + BC > a.Nkv;
+    const bool diag = a.causal && ((int64_t)k0 + BC - 1 > (int64_t)(a.causal_row_mod ? 0 : wq0) + a.causal_offset);
+    if (tail || diag) {
+#pragma unroll
+      for (int rh = 0; rh < 2; ++rh) {
+        const int crow = a.causal_row_mod ? qrow[rh] % a.causal_row_mod : qrow[rh];
+        const int64_t lim = a.causal ? (int64_t)crow + a.causal_offset : (int64_t)a.Nkv;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = k0 + kb * 16 + 4 * c + r;
+            if (key >= a.Nkv || key > lim) x[kb][rh][r] = -INFINITY;
+          }
+      }
+    }
+
+    // ================= online softmax (prefill.cuh:671-870, log2 domain) =================
+    float tmax[2];
+#pragma unroll
+    for (int rh = 0; rh < 2; ++rh) {
+      float t = x[0][rh][0];
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t = fmaxf(t, x[kb][rh][r]);
+      tmax[rh] = row4_max(t);
+    }
+    pre_k_group(std::integral_constant<int, 2>{});
+    const float m_new0 = fmaxf(m_run[0], tmax[0]), m_new1 = fmaxf(m_run[1], tmax[1]);
+    const bool grow0 = m_new0 > m_run[0] + a.thr, grow1 = m_new1 > m_run[1] + a.thr;
+    if (__any(grow0 || grow1)) {
+      const float alpha0 = grow0 ? __builtin_amdgcn_exp2f(m_run[0] - m_new0) : 1.f;
+      const float alpha1 = grow1 ? __builtin_amdgcn_exp2f(m_run[1] - m_new1) : 1.f;
+      if (j > t0 && !(FFPA_M16_X & 1)) {
+        // rare path: O^T lives in AGPRs; scale in place through one temporary VGPR (see ffpa_fwd_kernel.h)
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+          for (int rh = 0; rh < 2; ++rh) {
+            f32x4 t = oacc[i][rh];
+            asm volatile("" : "+a"(t));
+            t *= (rh ? alpha1 : alpha0);
+            asm volatile("" : "+a"(t));
+            oacc[i][rh] = t;
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      }
+      l_run[0] *= alpha0;
+      l_run[1] *= alpha1;
+      m_run[0] = grow0 ? m_new0 : m_run[0];
+      m_run[1] = grow1 ? m_new1 : m_run[1];
+    }
+
+    // P^T fragments: contraction slot 8 c + e of key step ks <-> key 32 ks + 16 (e / 4) + 4 c + e % 4 = x[2 ks + e / 4][rh][e % 4]
+    v8 pf[NKS][2];
+#pragma unroll
+    for (int rh = 0; rh < 2; ++rh) {
+      const float m_use = (m_run[rh] == -INFINITY) ? 0.f : m_run[rh];
+      float psum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(x[kb][rh][r] - m_use);
+          psum += p;  // row sum from the unrounded P (prefill.cuh:755-756)
+          pf[kb >> 1][rh][4 * (kb & 1) + r] = (T)p;
+        }
+      l_run[rh] += psum;
+    }
+    pre_k_group(std::integral_constant<int, 3>{});
+
+    // ================= O^T += V^T.P^T =================
+    {
+      __builtin_amdgcn_sched_barrier(0);
+      // barrier A2: V(j) has landed on every wave (all but the kPre younger K pieces have retired)
+      dma_wait_except<kPre>();
+      __syncthreads();
+      v8 vf[N2];
+      auto v_frag = [&](int n) -> v8 {
+        const int db = n % NDB, ks = n / NDB;
+        FFPA_LDS const char* vp = vaddr[db & 7] + (db >> 3) * 256 + ks * 32 * RB;
+        const v4 lo = E::tr_read(vp);
+        const v4 hi = E::tr_read(vp + 16 * RB);
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      };
+#pragma unroll
+      for (int n = 0; n < PF2 && n < N2; ++n) vf[n] = v_frag(n);
+      static_for<N2>([&](auto ic) {
+        constexpr int n = decltype(ic)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (n + PF2 < N2) vf[n + PF2] = v_frag(n + PF2);
+        if constexpr (n % kStep2 == 0 && n / kStep2 + kPre < PPW) issue_k(std::integral_constant<int, n / kStep2 + kPre>{}, k0 + BC);
+        constexpr int db = n % NDB, ks = n / NDB;
+        M::acc_a(oacc[db][0], vf[n], pf[ks][0]);
+        M::acc_a(oacc[db][1], vf[n], pf[ks][1]);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // barrier B: every wave is done reading V(j); K(j+1) has landed and is visible
+    dma_wait_all();
+    __syncthreads();
+  }
+
+  // ================= epilogue (prefill.cuh:1018-1093) =================
+  asm volatile("s_nop 15\n\ts_nop 3");  // last PV MFMA (inline asm) -> accumulator reads below: wait states the compiler cannot see
+  float l_tot[2], inv[2];
+#pragma unroll
+  for (int rh = 0; rh < 2; ++rh) {
+    l_tot[rh] = row4_sum(l_run[rh]);
+    inv[rh] = __builtin_amdgcn_rcpf(l_tot[rh]);  // fully masked row: 0 * inf = NaN, as SDPA
+  }
+  if (a.nsplit > 1) {
+    // split-KV partial: normalised fp32 O and its LSE (merged by ffpa_fwd_merge_kernel)
+#pragma unroll
+    for (int rh = 0; rh < 2; ++rh) {
+      if (qrow[rh] >= a.Nq) continue;
+      const bool dead = !(l_tot[rh] > 0.f);
+      const int64_t prow = (((int64_t)split * a.B + b) * a.Hq + hq) * a.Nq + qrow[rh];
+      float* wp = a.ws_o + prow * D + 4 * c;
+#pragma unroll
+      for (int db = 0; db < NDB; ++db) {
+        f32x4 w;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w[t] = dead ? 0.f : oacc[db][rh][t] * inv[rh];
+        *(f32x4*)(wp + db * 16) = w;
+      }
+      if (c == 0) a.ws_lse[prow] = dead ? -INFINITY : __logf(l_tot[rh]) + m_run[rh] * 0.6931471805599453f;
+    }
+    return;
+  }
+  {
+    // lanes c (even) and c + 1 trade one 4-column group per block: the even lane ends up with columns 16 db + 4 c .. + 8 of row
+    // n, the odd one with the same columns of row 16 + n (v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows
+    // of the second)
+    const int rsel = c & 1;
+    const int orow = rsel ? qrow[1] : qrow[0];
+    T* op = (T*)a.o + b * a.so[0] + hq * a.so[1] + (int64_t)(orow < a.Nq ? orow : 0) * a.so[2] + 4 * (c & ~1);
+    const bool ok = orow < a.Nq;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+      v4 g0, g1;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        g0[t] = (T)(oacc[db][0][t] * inv[0]);
+        g1[t] = (T)(oacc[db][1][t] * inv[1]);
+      }
+      const u32x2 x0 = __builtin_bit_cast(u32x2, g0), x1 = __builtin_bit_cast(u32x2, g1);
+      u32x4 run;
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(x0[w], x1[w], false, false);
+        run[w] = sw[0];
+        run[2 + w] = sw[1];
+      }
+      if (ok) *(u32x4*)(op + db * 16) = run;
+    }
+    if (a.lse != nullptr && c == 0) {
+#pragma unroll
+      for (int rh = 0; rh < 2; ++rh)
+        if (qrow[rh] < a.Nq) a.lse[((int64_t)b * a.Hq + hq) * a.Nq + qrow[rh]] = __logf(l_tot[rh]) + m_run[rh] * 0.6931471805599453f;
+    }
+  }
+}
+
+}  // namespace ffpa

@@ -50,6 +50,7 @@ _STATUS_EXC = {
 FLAG_DEBUG_SAFE_PATH = 0x1
 FLAG_NO_XCD_REMAP = 0x2
 FLAG_NO_BIAS_LDS = 0x8
+FLAG_NO_M16 = 0x10  # bench-only: unmasked launches stay on the 32x32x16-MFMA build
 
 # enum ffpa_bias_dtype: additive fp16 / bf16 / fp32, or a boolean mask read as bytes (non-zero = visible)
 _BIAS_DTYPE = {torch.float16: 1, torch.bfloat16: 2, torch.float32: 3, torch.bool: 4, torch.uint8: 4}

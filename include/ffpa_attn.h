@@ -64,6 +64,7 @@ enum ffpa_bias_dtype {
 #define FFPA_FLAG_NO_XCD_REMAP    0x2u /* bench-only: dispatch-order block mapping          */
 #define FFPA_FLAG_NO_PERSISTENT   0x4u /* bench-only (builds with FFPA_PERSISTENT): one workgroup per id */
 #define FFPA_FLAG_NO_BIAS_LDS     0x8u /* bench-only: read a key bias from global memory in every tile   */
+#define FFPA_FLAG_NO_M16          0x10u /* bench-only: keep unmasked launches on the 32x32x16-MFMA build    */
 
 /*
  * One forward call.  Layout contract (replaces the dense-[B,H,N,D] assumption of
