@@ -82,6 +82,14 @@ WORKLOADS = {
 }
 
 
+def dominant_kernel(w: dict) -> str:
+  """The kernel the roofline object is about (csrc/ffpa_fwd_inst.hip's dispatch): head dims in (448, 512] without an additive bias or
+  dropout run the 16x16x32-MFMA build, everything else the 32x32x16-MFMA build."""
+  if 448 < w["D"] <= 512 and w["Nq"] > 32 and w["mask"] != "key_bias" and not w["dropout"]:
+    return "ffpa_fwd_m16_kernel"
+  return "ffpa_fwd_split_d_kernel"
+
+
 def metric_name(name: str, w: dict) -> str:
   if name == "cfg2":
     return BASELINE_METRIC
@@ -365,7 +373,7 @@ def main() -> None:
       achieved = flops_local / (kernel_ms_avg * 1e-3) / 1e12
       roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
               "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-              "kernel": "ffpa_fwd_split_d_kernel", "kernel_ms_avg": round(kernel_ms_avg, 4),
+              "kernel": dominant_kernel(w), "kernel_ms_avg": round(kernel_ms_avg, 4),
               "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 4), "flops_per_launch": flops_local,
               "algorithmic_bytes_per_launch": algorithmic_bytes(w, max(1, (u1 - u0) // Hkv) if sharded else B)}
     shape = f"B={global_B} Hq={Hq} Hkv={Hkv} Nq={Nq} Nkv={Nkv} D={D}"

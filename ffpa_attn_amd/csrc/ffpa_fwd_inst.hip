@@ -46,10 +46,10 @@ static int launch_one(const FwdArgs& a, hipStream_t stream) {
 }
 
 // The unmasked prefill kernel on the 16x16x32 MFMA shape (ffpa_fwd_m16_kernel.h): same tiles (128 rows x 64 keys), same plan.
-template <typename T, int D>
+template <typename T, int D, int MK>
 static int launch_m16(const FwdArgs& a, hipStream_t stream) {
   constexpr int LDS = 2 * 64 * D * 2;
-  auto kern = ffpa_fwd_m16_kernel<T, D>;
+  auto kern = ffpa_fwd_m16_kernel<T, D, MK>;
   static std::atomic<bool> attr_done[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return -1;
@@ -107,9 +107,9 @@ int FFPA_CAT(launch_fwd_d, FFPA_INST_D)(int dtype, int safe, int variant, const 
   }
   if (a.bias_dtype == 0 && a.kv_bounds == nullptr) {  // no attn_bias, no mask ranges: the build without any bias path
     if constexpr (ND == 1 && (D * 2) % 1024 == 0) {
-      if (!(a.flags & 0x10u) && a.d_valid == D) {  // (FFPA_FLAG_NO_M16 keeps the 32x32x16 build: A/B runs, tests)
-        if (dtype == 0) return launch_m16<__bf16, D>(a, stream);
-        if (dtype == 1) return launch_m16<_Float16, D>(a, stream);
+      if (!(a.flags & 0x10u)) {  // (FFPA_FLAG_NO_M16 keeps the 32x32x16 build: A/B runs, tests)
+        if (dtype == 0) return launch_m16<__bf16, D, 0>(a, stream);
+        if (dtype == 1) return launch_m16<_Float16, D, 0>(a, stream);
         return -4;
       }
     }
@@ -118,6 +118,13 @@ int FFPA_CAT(launch_fwd_d, FFPA_INST_D)(int dtype, int safe, int variant, const 
     return -4;
   }
   if (a.bias_dtype == 4) {  // boolean mask (+ ranges): the build that carries only that path
+    if constexpr (ND == 1 && (D * 2) % 1024 == 0) {
+      if (!(a.flags & 0x10u)) {
+        if (dtype == 0) return launch_m16<__bf16, D, 2>(a, stream);
+        if (dtype == 1) return launch_m16<_Float16, D, 2>(a, stream);
+        return -4;
+      }
+    }
     if (dtype == 0) return launch_one<__bf16, D, ND, false, false, false, 2>(a, stream);
     if (dtype == 1) return launch_one<_Float16, D, ND, false, false, false, 2>(a, stream);
     return -4;

@@ -20,7 +20,7 @@
 //   * epilogue: a lane owns 4 consecutive columns of two rows; lanes c and c ^ 1 trade one group (v_permlane16_swap) so that
 //     each stores whole 16-byte runs of ONE row.
 // Built for head dims whose tile rows are whole 1 KiB DMA pieces (D = 512); launched for calls without attn_bias, mask ranges
-// or dropout and with head_dim == D.
+// or dropout (any head_dim in (D - 64, D]).
 #pragma once
 
 #include "ffpa_fwd_kernel.h"
@@ -60,18 +60,38 @@ struct Mfma16<_Float16> {
   static __device__ __forceinline__ void acc_a(f32x4& d, v8 a, v8 b) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b)); }
 };
 
-// max / sum over the 4 lanes (lane % 16 fixed) that share a query row
-__device__ __forceinline__ float row4_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16));
-  return fmaxf(v, __shfl_xor(v, 32));
-}
-__device__ __forceinline__ float row4_sum(float v) {
-  v += __shfl_xor(v, 16);
-  return v + __shfl_xor(v, 32);
+// A query row lives in the 4 lanes n, n + 16, n + 32, n + 48, and every lane carries a value for two rows (n and 16 + n).
+// Both 4-lane reductions together in three register swaps (no LDS crossbar): v_permlane32_swap pairs row n's halves in lanes
+// 0 .. 31 and row 16 + n's in lanes 32 .. 63, v_permlane16_swap folds the remaining lane ^ 16 step, and a last
+// v_permlane32_swap hands every lane both results.
+#ifndef FFPA_M16_SWAP_REDUCE
+#define FFPA_M16_SWAP_REDUCE 1
+#endif
+template <bool IS_MAX>
+__device__ __forceinline__ void row4_reduce2(float& t0, float& t1) {
+  auto op = [](float x, float y) { return IS_MAX ? fmaxf(x, y) : x + y; };
+#if FFPA_M16_SWAP_REDUCE
+  const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t0), __float_as_uint(t1), false, false);
+  const float v = op(__uint_as_float(s1[0]), __uint_as_float(s1[1]));
+  const auto s2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float w = op(__uint_as_float(s2[0]), __uint_as_float(s2[1]));
+  const auto s3 = __builtin_amdgcn_permlane32_swap(__float_as_uint(w), __float_as_uint(w), false, false);
+  t0 = __uint_as_float(s3[0]);
+  t1 = __uint_as_float(s3[1]);
+#else
+  t0 = op(t0, __shfl_xor(t0, 16));
+  t0 = op(t0, __shfl_xor(t0, 32));
+  t1 = op(t1, __shfl_xor(t1, 16));
+  t1 = op(t1, __shfl_xor(t1, 32));
+#endif
 }
 
-template <typename T, int D>
+// MK (mask kind, as in ffpa_fwd_split_d_kernel): 0 = the build for calls without attn_bias / mask ranges, 2 = boolean masks
+// (FFPA_BIAS_BOOL8 bytes and / or kv_bounds ranges: what ffpa_attn_func(attn_mask=<bool>) launches).
+template <typename T, int D, int MK = 0>
 __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
+  static_assert(MK == 0 || MK == 2, "additive biases stay on the 32x32x16 build");
+  constexpr bool MASK = MK != 0;
   using E = Elem<T>;
   using M = Mfma16<T>;
   using v8 = typename E::v8;
@@ -136,11 +156,17 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 
   // ---- LDS-DMA: wave w stages keys 16 a + 4 w + b4 (a < BC/16, b4 < 4), one row = RPP pieces, lane l -> 16-byte slot l of
   // the piece; the bank swizzles go on the per-lane SOURCE slot: K slot ^ (key % 16), V slot ^ 2 (key % 8).
+  // A caller's head dim below D (a multiple of 8): K columns at and past it read as zeros (lanes whose source slot lies there get
+  // an out-of-range offset: the descriptor's range check zero-fills them), Q columns are not loaded, O columns are not stored.
+  static_assert(RPP == 1, "the head-dim guard below assumes one piece per row");
+  const uint32_t rb_valid = (uint32_t)a.d_valid * 2u;
+  const int slots_valid = a.d_valid >> 3;
   uint32_t kvo[4], vvo[4];
   uint32_t kro[KPW], vro[KPW];
 #pragma unroll
   for (int bb = 0; bb < 4; ++bb) {
     kvo[bb] = (uint32_t)((lane ^ (4 * wave + bb)) << 4);
+    if ((lane ^ (4 * wave + bb)) >= slots_valid) kvo[bb] = kDmaOob;
     vvo[bb] = (uint32_t)((lane ^ (((4 * wave + bb) & 7) << 1)) << 4);
   }
 #pragma unroll
@@ -154,13 +180,13 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   auto issue_k = [&](auto ic, int key0) {
     constexpr int i = decltype(ic)::value;
     constexpr int jk = i / RPP, half = i % RPP;
-    const TileSrc ts = tile_src<BC>(Kg, k_row_bytes, key0, a.Nkv, RB);
+    const TileSrc ts = tile_src<BC>(Kg, k_row_bytes, key0, a.Nkv, rb_valid);
     lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(ts.rsrc, k_lds, kvo[jk & 3], kro[jk]);
   };
   auto issue_v = [&](auto ic, int key0) {
     constexpr int i = decltype(ic)::value;
     constexpr int jk = i / RPP, half = i % RPP;
-    const TileSrc ts = tile_src<BC>(Vg, v_row_bytes, key0, a.Nkv, RB);
+    const TileSrc ts = tile_src<BC>(Vg, v_row_bytes, key0, a.Nkv, rb_valid);
     lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(ts.rsrc, v_lds, vvo[jk & 3], vro[jk]);
   };
 
@@ -172,10 +198,36 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     const int ntc = last < 0 ? 0 : (int)(last / BC) + 1;
     nt = nt < ntc ? nt : ntc;
   }
-  const int t0 = split * a.tiles_per_split;
+  int t0 = split * a.tiles_per_split;
   {
     const int t1 = t0 + a.tiles_per_split;
     nt = nt < t1 ? nt : t1;
+  }
+  // mask ranges (ffpa_fwd_params.kv_bounds): KV tiles no row of this row tile can see are skipped; keys [free_lo, free_hi) are
+  // visible to EVERY row of this wave's 32-row block — tiles inside that range do not read the mask at all
+  int free_lo = 0, free_hi = 0;
+  if (MASK && a.kv_bounds != nullptr) {
+    const int* bp = a.kv_bounds + b * a.s_bounds[0] + hq * a.s_bounds[1];
+    int first = 0x7fffffff, end = 0;
+#pragma unroll
+    for (int blk = 0; blk < BR / 32; ++blk) {
+      const int r32 = q0 / 32 + blk;
+      if (r32 * 32 < a.Nq) {
+        const int lo = bp[4 * r32], hi = bp[4 * r32 + 1];
+        first = first < lo ? first : lo;
+        end = end > hi ? end : hi;
+      }
+    }
+    const int tf = first / BC, te = (end + BC - 1) / BC;
+    t0 = t0 > tf ? t0 : tf;
+    nt = nt < te ? nt : te;
+    const int r32w = q0 / 32 + wave;
+    if (r32w * 32 < a.Nq) {
+      free_lo = __builtin_amdgcn_readfirstlane(bp[4 * r32w + 2]);
+      free_hi = __builtin_amdgcn_readfirstlane(bp[4 * r32w + 3]);
+    } else {
+      free_hi = 0x7fffffff;  // a row block past the last query row: nothing it computes is stored
+    }
   }
 
   // ---- Q fragments (B operand of S^T): lane (n, c) holds Q[row 16 rh + n][32 s + 8 c .. + 8]
@@ -184,7 +236,10 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   for (int rh = 0; rh < 2; ++rh) {
     const T* qp = (const T*)a.q + b * a.sq[0] + hq * a.sq[1] + (int64_t)qrow_c[rh] * a.sq[2] + c * 8;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) qf[s][rh] = *(const v8*)(qp + s * 32);
+    for (int s = 0; s < KS; ++s) {
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      qf[s][rh] = (s * 32 + c * 8 < a.d_valid) ? *(const v8*)(qp + s * 32) : __builtin_bit_cast(v8, z);
+    }
   }
 
   f32x4 oacc[NDB][2];
@@ -278,6 +333,36 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         for (int r = 0; r < 4; ++r) x[kb][rh][r] = sacc[kb][rh][r] * a.scale_log2;
     pre_k_group(std::integral_constant<int, 1>{});
 
+    if constexpr (MASK) {
+      // boolean mask bytes (non-zero = visible), straight from the caller's tensor; the lane's 4 keys of a block are consecutive
+      const bool mask_free = k0 >= free_lo && k0 + BC <= free_hi;  // wave-uniform
+      if (a.bias_dtype == 4 && !mask_free) {
+        const uint8_t* mp = (const uint8_t*)a.bias + b * a.sbias[0] + hq * a.sbias[1];
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh) {
+          const uint8_t* mr = mp + (int64_t)qrow_c[rh] * a.sbias[2];
+          if (a.bias_vec == 16 && k0 + BC <= a.Nkv) {
+            uint32_t raw[NKB];
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) raw[kb] = *(const uint32_t*)(mr + k0 + kb * 16 + 4 * c);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (((raw[kb] >> (8 * r)) & 0xffu) == 0u) x[kb][rh][r] = -INFINITY;
+          } else {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                int key = k0 + kb * 16 + 4 * c + r;
+                key = key < a.Nkv ? key : a.Nkv - 1;
+                if (mr[key * a.sbias[3]] == 0) x[kb][rh][r] = -INFINITY;
+              }
+          }
+        }
+      }
+    }
     const bool tail = k0 + BC > a.Nkv;
     const bool diag = a.causal && ((int64_t)k0 + BC - 1 > (int64_t)(a.causal_row_mod ? 0 : wq0) + a.causal_offset);
     if (tail || diag) {
@@ -304,8 +389,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) t = fmaxf(t, x[kb][rh][r]);
-      tmax[rh] = row4_max(t);
+      tmax[rh] = t;
     }
+    row4_reduce2<true>(tmax[0], tmax[1]);
     pre_k_group(std::integral_constant<int, 2>{});
     const float m_new0 = fmaxf(m_run[0], tmax[0]), m_new1 = fmaxf(m_run[1], tmax[1]);
     const bool grow0 = m_new0 > m_run[0] + a.thr, grow1 = m_new1 > m_run[1] + a.thr;
@@ -386,11 +472,11 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   // ================= epilogue (prefill.cuh:1018-1093) =================
   asm volatile("s_nop 15\n\ts_nop 3");  // last PV MFMA (inline asm) -> accumulator reads below: wait states the compiler cannot see
   float l_tot[2], inv[2];
+  l_tot[0] = l_run[0];
+  l_tot[1] = l_run[1];
+  row4_reduce2<false>(l_tot[0], l_tot[1]);
 #pragma unroll
-  for (int rh = 0; rh < 2; ++rh) {
-    l_tot[rh] = row4_sum(l_run[rh]);
-    inv[rh] = __builtin_amdgcn_rcpf(l_tot[rh]);  // fully masked row: 0 * inf = NaN, as SDPA
-  }
+  for (int rh = 0; rh < 2; ++rh) inv[rh] = __builtin_amdgcn_rcpf(l_tot[rh]);  // fully masked row: 0 * inf = NaN, as SDPA
   if (a.nsplit > 1) {
     // split-KV partial: normalised fp32 O and its LSE (merged by ffpa_fwd_merge_kernel)
 #pragma unroll
@@ -434,7 +520,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         run[w] = sw[0];
         run[2 + w] = sw[1];
       }
-      if (ok) *(u32x4*)(op + db * 16) = run;
+      if (ok && db * 16 + 4 * (c & ~1) < a.d_valid) *(u32x4*)(op + db * 16) = run;
     }
     if (a.lse != nullptr && c == 0) {
 #pragma unroll

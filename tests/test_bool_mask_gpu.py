@@ -34,7 +34,9 @@ def test_bool_mask_is_bit_identical_to_its_additive_form(hip, shape, D):
   g = torch.Generator(device="cuda").manual_seed(sum(shape) * 7 + D)
   mask = torch.rand(shape, device="cuda", generator=g) > 0.25
   mask[..., 0] = True
-  ob, lb = hip.forward(q, k, v, mask, False, D ** -0.5, kv_bounds=False)
+  # (FLAG_NO_M16: additive biases run the 32x32x16-MFMA build at every head dim; the boolean launch is kept on it for this comparison —
+  # the 16x16x32 build that D = 512 boolean masks normally take sums in another order: tests/test_m16_gpu.py)
+  ob, lb = hip.forward(q, k, v, mask, False, D ** -0.5, kv_bounds=False, flags=hip.FLAG_NO_M16)
   # (FLAG_NO_BIAS_LDS: the additive form takes the same tiles as the boolean one — a 16-bit bias with a row axis would otherwise
   # run the bias-tile build, whose 64-key tiles at D <= 320 sum in another order)
   oa, la = hip.forward(q, k, v, _additive(mask, q.dtype), False, D ** -0.5, kv_bounds=False, flags=hip.FLAG_NO_BIAS_LDS)
@@ -55,7 +57,7 @@ def test_bool_mask_vector_and_byte_paths_tails_and_nan_rows(hip):
     mask[0, :, 9, :128] = False
     mask[0, 1, 100, 1:] = False
     mask[0, 1, 100, 0] = True
-    ob, lb = hip.forward(q, k, v, mask, False, D ** -0.5, kv_bounds=False)
+    ob, lb = hip.forward(q, k, v, mask, False, D ** -0.5, kv_bounds=False, flags=hip.FLAG_NO_M16)  # (both on the 32x32x16 build)
     oa, la = hip.forward(q, k, v, _additive(mask, q.dtype), False, D ** -0.5, kv_bounds=False, flags=hip.FLAG_NO_BIAS_LDS)
     assert _same_bits(ob, oa) and _same_bits(lb, la), (Nq, Nkv)
     assert torch.isnan(ob[0, 0, 5]).all() and torch.isfinite(ob[:, :, 9]).all()
@@ -63,8 +65,8 @@ def test_bool_mask_vector_and_byte_paths_tails_and_nan_rows(hip):
     # a strided view (key stride 2) and a uint8 mask take the byte path / the same enum
     wide = torch.zeros(1, 2, Nq, 2 * Nkv, dtype=torch.bool, device="cuda")
     wide[..., ::2] = mask
-    os_, _ = hip.forward(q, k, v, wide[..., ::2], False, D ** -0.5, kv_bounds=False)
-    ou, _ = hip.forward(q, k, v, mask.to(torch.uint8), False, D ** -0.5, kv_bounds=False)
+    os_, _ = hip.forward(q, k, v, wide[..., ::2], False, D ** -0.5, kv_bounds=False, flags=hip.FLAG_NO_M16)
+    ou, _ = hip.forward(q, k, v, mask.to(torch.uint8), False, D ** -0.5, kv_bounds=False, flags=hip.FLAG_NO_M16)
     assert _same_bits(os_, oa) and _same_bits(ou, oa)
 
 
@@ -130,9 +132,10 @@ def test_tiles_in_the_free_range_skip_the_mask_without_changing_a_bit(hip):
     # the kernel really trusts the range: claim everything is free -> the mask is ignored -> equals the unmasked result
     forged = bounds.clone()
     forged[..., 0], forged[..., 1], forged[..., 2], forged[..., 3] = 0, Nkv, 0, Nkv
-    o_forged, _ = hip.forward(q, k, v, m, False, D ** -0.5, kv_bounds=forged)
-    o_plain, _ = hip.forward(q, k, v, None, False, D ** -0.5)
-    assert torch.equal(o_forged, o_plain)
+    for m, fl in ((m, hip.FLAG_NO_M16), (keep.view(1, 1, Nq, Nkv).contiguous(), 0)):  # additive: 32x32x16 build; boolean: the default build
+      o_forged, _ = hip.forward(q, k, v, m, False, D ** -0.5, kv_bounds=forged)
+      o_plain, _ = hip.forward(q, k, v, None, False, D ** -0.5, flags=fl)
+      assert torch.equal(o_forged, o_plain), (D, m.dtype)
 
 
 def test_public_api_bool_mask_allocates_nothing_mask_sized(hip):

@@ -2,9 +2,9 @@
 
 Usage: python tools/pmc_summary.py <dir with *counter_collection.csv> <out.json> [note] [--kernel SUBSTR]
 
-Per counter: mean over the dispatches of the dominant kernel (default: ffpa_fwd_split_d_kernel) of every pass found.
+Per counter: mean over the dispatches of the dominant kernel (default: the prefill kernels, either MFMA-shape build) of every pass found.
 Derived values follow /opt/skills/guides/MI355X_MICROARCH.md: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count
-quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES counts cycles (32 per 32x32x16 MFMA), GRBM_GUI_ACTIVE is summed over the 8 XCDs,
+quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES counts cycles (32 per 32x32x16 MFMA, 16 per 16x16x32), GRBM_GUI_ACTIVE is summed over the 8 XCDs,
 FETCH_SIZE is KiB and reads half of a wide coalesced stream on gfx950 (corrected x2 here).  The workload's algorithmic
 bytes / FLOPs and the kernel's L2->LDS operand stream are taken from the bench line in
 <dir>/*.log when one is found, so that request counters can be read as bytes per request.
@@ -26,7 +26,7 @@ def bench_line(src):
 
 def main():
   argv = sys.argv[1:]
-  kernel = "ffpa_fwd_split_d_kernel"
+  kernel = r"ffpa_fwd_(split_d|m16)_kernel"  # (regex) the prefill kernels: 32x32x16-MFMA build / 16x16x32-MFMA build
   if "--kernel" in argv:
     i = argv.index("--kernel")
     kernel = argv[i + 1]
@@ -35,11 +35,13 @@ def main():
   note = argv[2] if len(argv) > 2 else ""
   vals = collections.defaultdict(list)
   durs, grbm_durs = [], []
+  names = set()
   for path in sorted(glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True)):
     seen = set()
     for r in csv.DictReader(open(path)):
-      if kernel not in r["Kernel_Name"]:
+      if not re.search(kernel, r["Kernel_Name"]):
         continue
+      names.add(re.sub(r"<.*", "", r["Kernel_Name"]).replace("void ", "").replace("ffpa::", ""))
       vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
       dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
       if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
@@ -53,7 +55,7 @@ def main():
       "units": "SQ_WAVE_CYCLES/SQ_WAIT_*/SQ_ACTIVE_INST_* are quad-cycles; SQ_VALU_MFMA_BUSY_CYCLES are cycles (=32 x N_mfma); "
                "GRBM_GUI_ACTIVE is summed over 8 XCDs; FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE reads 1/2 of a wide coalesced stream on gfx950 "
                "(MI355X_MICROARCH.md, HBM section); *_sum counters are summed over all instances of the block",
-      "kernel": kernel,
+      "kernel": ", ".join(sorted(names)) or kernel,
   }
   for k, v in sorted(vals.items()):
     res[k] = {"per_dispatch_mean": sum(v) / len(v), "dispatches": len(v)}
