@@ -19,12 +19,18 @@
 //   * a query row lives in 4 lanes (c = 0 .. 3): row max / row sum take two cross-lane steps (lane ^ 16, lane ^ 32).
 //   * epilogue: a lane owns 4 consecutive columns of two rows; lanes c and c ^ 1 trade one group (v_permlane16_swap) so that
 //     each stores whole 16-byte runs of ONE row.
-// Built for head dims whose tile rows are whole 1 KiB DMA pieces (D = 512); launched for calls without attn_bias, mask ranges
-// or dropout (any head_dim in (D - 64, D]).
+// Built for every head dim the prefill tiles hold unsplit (D <= 512: 128-key tiles up to D = 320, 64 above, like the 32x32x16
+// build, so that launch plans do not depend on the build); launched for calls without an additive bias or dropout.
 #pragma once
 
 #include "ffpa_fwd_kernel.h"
 
+#ifndef FFPA_M16_MIN_D
+// head dims from here up launch this build (measured A/B against the 32x32x16 build, profiles/r02_m16_ab.txt: + 4 ... 5 % at
+// D = 320 ... 512, even at D = 192 / 256, - 11 % at D = 128 — there the 128-key tiles' S^T / P^T registers and the per-piece DMA
+// offsets leave the compiler spilling scalars inside the loops)
+#define FFPA_M16_MIN_D 320
+#endif
 #ifndef FFPA_M16_PF1
 #define FFPA_M16_PF1 6  // K fragments requested ahead of their (two) MFMAs
 #endif
@@ -88,6 +94,21 @@ __device__ __forceinline__ void row4_reduce2(float& t0, float& t1) {
 
 // MK (mask kind, as in ffpa_fwd_split_d_kernel): 0 = the build for calls without attn_bias / mask ranges, 2 = boolean masks
 // (FFPA_BIAS_BOOL8 bytes and / or kv_bounds ranges: what ffpa_attn_func(attn_mask=<bool>) launches).
+// LDS images of the K / V tiles: row-major [BC][D], 16-byte slot s of row `key` stored at slot s ^ swizzle(key) (applied on the
+// DMA's per-lane source offset).  K fragments are fetched by ds_read_b128 whose 16-lane groups hold 16 different keys and two
+// neighbouring slots; V^T fragments by ds_read_b64_tr_b16 whose 32-lane halves hold 8 keys x 32 bytes.  Row strides that are whole
+// 256-byte bank rows (D % 128 == 0) need the full 4-bit / 3-bit spread, the others (D % 128 == 64: consecutive rows already sit
+// half a bank row apart) one bit less — and their rows only have room for a 3-bit XOR (D / 8 slots, a multiple of 8).
+// tools/sim_lds_layout.py replays both maps and the bank rule on the host (tests/test_lds_layout.py).
+template <int D>
+__device__ __forceinline__ int m16_k_swizzle(int key) {
+  return (D % 128 == 0) ? (key & 15) : ((key >> 1) & 7);
+}
+template <int D>
+__device__ __forceinline__ int m16_v_swizzle(int key) {
+  return (D % 128 == 0) ? ((key & 7) << 1) : (((key >> 1) & 3) << 1);
+}
+
 template <typename T, int D, int MK = 0>
 __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   static_assert(MK == 0 || MK == 2, "additive biases stay on the 32x32x16 build");
@@ -96,8 +117,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   using M = Mfma16<T>;
   using v8 = typename E::v8;
   using v4 = typename E::v4;
-  static_assert((D * 2) % 1024 == 0 && D <= 512, "tile rows must be whole 1 KiB pieces; O^T must fit the AGPRs");
-  constexpr int BC = 64, BR = 128;
+  static_assert(D % 64 == 0 && D <= 512, "O^T (D / 2 registers per lane) must fit the AGPRs");
+  constexpr int BC = (D <= FFPA_BC128_MAX_D) ? 128 : 64, BR = 128;
   constexpr int KS = D / 32;    // QK contraction steps
   constexpr int NKB = BC / 16;  // 16-key S^T blocks per tile
   constexpr int NKS = BC / 32;  // PV contraction steps per tile
@@ -105,15 +126,21 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   constexpr int RB = D * 2;
   constexpr int TILE = BC * RB;
   constexpr int PPW = BC * D * 2 / 4096;  // 1 KiB DMA pieces per wave per tile
-  constexpr int RPP = RB / 1024;          // pieces per row
-  constexpr int KPW = BC / 4;             // keys staged per wave per tile
+  constexpr bool kRowDma = RB % 1024 == 0;   // a tile row is a whole number of pieces (D = 512): wave-uniform rows, scalar addressing
+  constexpr int RPP = kRowDma ? RB / 1024 : 1;  // pieces per row
+  constexpr int KPW = BC / 4;                // keys staged per wave per tile
   constexpr int PF1 = FFPA_M16_PF1, PF2 = FFPA_M16_PF2;
   constexpr int kPre = ((FFPA_M16_K_PRE < PPW ? FFPA_M16_K_PRE : PPW) / 4) * 4;
   constexpr int N1 = KS * NKB;   // K fragments per tile
   constexpr int N2 = NDB * NKS;  // V^T fragments per tile
   constexpr int kStep1 = N1 / PPW;           // one V piece every this many K fragments
   constexpr int kStep2 = N2 / PPW;           // one K piece every this many V^T fragments
-  static_assert(kStep1 >= 1 && kStep2 >= 1, "DMA pieces must fit the MFMA loops");
+  static_assert(kStep1 >= 1 && kStep2 >= 1 && N1 % PPW == 0 && N2 % PPW == 0, "DMA pieces must fit the MFMA loops");
+  constexpr int NH = BC / 64;                       // 64-key halves of a tile (ds_read immediates are 16 bits: one address base per half)
+  constexpr int KV = (D % 128 == 0) ? 4 : 2;        // K fragment address variants: the swizzle reaches slot bits 0 .. 3 / 0 .. 2
+  constexpr int KVB = (D % 128 == 0) ? 256 : 128;   //   and the bytes KV contraction steps advance
+  constexpr int VV = (D % 128 == 0) ? 8 : 4;        // V^T fragment address variants
+  constexpr int VVB = (D % 128 == 0) ? 256 : 128;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   FFPA_LDS char* const Kt = (FFPA_LDS char*)smem;
@@ -154,40 +181,67 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   const uint32_t k_row_bytes = (uint32_t)a.sk[2] * 2u;
   const uint32_t v_row_bytes = (uint32_t)a.sv[2] * 2u;
 
-  // ---- LDS-DMA: wave w stages keys 16 a + 4 w + b4 (a < BC/16, b4 < 4), one row = RPP pieces, lane l -> 16-byte slot l of
-  // the piece; the bank swizzles go on the per-lane SOURCE slot: K slot ^ (key % 16), V slot ^ 2 (key % 8).
-  // A caller's head dim below D (a multiple of 8): K columns at and past it read as zeros (lanes whose source slot lies there get
-  // an out-of-range offset: the descriptor's range check zero-fills them), Q columns are not loaded, O columns are not stored.
+  // ---- LDS-DMA.  A caller's head dim below D (a multiple of 8): K columns at and past it read as zeros (lanes whose source slot
+  // lies there get an out-of-range offset: the descriptor's range check zero-fills them), Q columns are not loaded, O columns are
+  // not stored.  Two addressing forms:
+  //   * rows that are whole pieces (D = 512): wave w stages keys 16 a + 4 w + b4, lane l -> slot l of the row; everything but the
+  //     swizzled lane offset is scalar;
+  //   * other head dims: piece p = wave * PPW + i covers slots [64 p, 64 p + 64) of the row-major image; the per-lane source
+  //     offsets are tile-invariant and live in PPW + PPW registers.
   static_assert(RPP == 1, "the head-dim guard below assumes one piece per row");
   const uint32_t rb_valid = (uint32_t)a.d_valid * 2u;
   const int slots_valid = a.d_valid >> 3;
-  uint32_t kvo[4], vvo[4];
-  uint32_t kro[KPW], vro[KPW];
+  uint32_t kvo[kRowDma ? 4 : 1], vvo[kRowDma ? 4 : 1];
+  uint32_t kro[kRowDma ? KPW : 1], vro[kRowDma ? KPW : 1];
+  uint32_t krel[kRowDma ? 1 : PPW], vrel[kRowDma ? 1 : PPW];
+  uint32_t k_lds = 0, v_lds = 0;
+  if constexpr (kRowDma) {
 #pragma unroll
-  for (int bb = 0; bb < 4; ++bb) {
-    kvo[bb] = (uint32_t)((lane ^ (4 * wave + bb)) << 4);
-    if ((lane ^ (4 * wave + bb)) >= slots_valid) kvo[bb] = kDmaOob;
-    vvo[bb] = (uint32_t)((lane ^ (((4 * wave + bb) & 7) << 1)) << 4);
-  }
+    for (int bb = 0; bb < 4; ++bb) {
+      kvo[bb] = (uint32_t)((lane ^ m16_k_swizzle<D>(4 * wave + bb)) << 4);
+      if ((lane ^ m16_k_swizzle<D>(4 * wave + bb)) >= slots_valid) kvo[bb] = kDmaOob;
+      vvo[bb] = (uint32_t)((lane ^ m16_v_swizzle<D>(4 * wave + bb)) << 4);
+    }
 #pragma unroll
-  for (int jk = 0; jk < KPW; ++jk) {
-    const uint32_t key = (uint32_t)(16 * (jk >> 2) + 4 * wave + (jk & 3));
-    kro[jk] = key * k_row_bytes;
-    vro[jk] = key * v_row_bytes;
+    for (int jk = 0; jk < KPW; ++jk) {
+      const uint32_t key = (uint32_t)(16 * (jk >> 2) + 4 * wave + (jk & 3));
+      kro[jk] = key * k_row_bytes;
+      vro[jk] = key * v_row_bytes;
+    }
+    k_lds = (uint32_t)(uintptr_t)Kt + (uint32_t)(4 * wave * RB);
+    v_lds = (uint32_t)(uintptr_t)Vt + (uint32_t)(4 * wave * RB);
+  } else {
+    constexpr int SPR = D / 8;  // 16-byte slots per row
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int g = (wave * PPW + i) * 64 + lane;
+      const int key = g / SPR;
+      const int slot = g - key * SPR;
+      const int ks = slot ^ m16_k_swizzle<D>(key), vs = slot ^ m16_v_swizzle<D>(key);
+      krel[i] = (uint32_t)key * k_row_bytes + (uint32_t)(ks << 4);
+      if (ks >= slots_valid) krel[i] = kDmaOob;
+      vrel[i] = (uint32_t)key * v_row_bytes + (uint32_t)(vs << 4);
+    }
   }
-  const uint32_t k_lds = (uint32_t)(uintptr_t)Kt + (uint32_t)(4 * wave * RB);
-  const uint32_t v_lds = (uint32_t)(uintptr_t)Vt + (uint32_t)(4 * wave * RB);
   auto issue_k = [&](auto ic, int key0) {
     constexpr int i = decltype(ic)::value;
-    constexpr int jk = i / RPP, half = i % RPP;
     const TileSrc ts = tile_src<BC>(Kg, k_row_bytes, key0, a.Nkv, rb_valid);
-    lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(ts.rsrc, k_lds, kvo[jk & 3], kro[jk]);
+    if constexpr (kRowDma) {
+      constexpr int jk = i / RPP, half = i % RPP;
+      lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(ts.rsrc, k_lds, kvo[jk & 3], kro[jk]);
+    } else {
+      lds_dma_16(ts.rsrc, (uint32_t)(uintptr_t)(Kt + (wave * PPW + i) * 1024), krel[i], 0u);
+    }
   };
   auto issue_v = [&](auto ic, int key0) {
     constexpr int i = decltype(ic)::value;
-    constexpr int jk = i / RPP, half = i % RPP;
     const TileSrc ts = tile_src<BC>(Vg, v_row_bytes, key0, a.Nkv, rb_valid);
-    lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(ts.rsrc, v_lds, vvo[jk & 3], vro[jk]);
+    if constexpr (kRowDma) {
+      constexpr int jk = i / RPP, half = i % RPP;
+      lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(ts.rsrc, v_lds, vvo[jk & 3], vro[jk]);
+    } else {
+      lds_dma_16(ts.rsrc, (uint32_t)(uintptr_t)(Vt + (wave * PPW + i) * 1024), vrel[i], 0u);
+    }
   };
 
   // ---- KV tile range
@@ -251,20 +305,24 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   float m_run[2] = {-INFINITY, -INFINITY};  // running row max (log2 domain), the same value in the row's 4 lanes
   float l_run[2] = {0.f, 0.f};              // this lane's share of the row sum
 
-  // ---- per-lane fragment addresses
-  // K fragment of step s = 4 q + i, key block kb: kaddr[i] + 256 q + kb * 16 * RB  (slot (4 s + c) ^ (key % 16): the XOR stays
-  // inside the low 4 slot bits)
-  FFPA_LDS const char* kaddr[4];
+  // ---- per-lane fragment addresses (one base per 64-key half of the tile; everything else is an immediate)
+  // K fragment of step s = KV q + i, key block kb: kaddr[kb / 4][i] + KVB q + (kb % 4) * 16 * RB: lane (n, c) reads key 16 kb + n,
+  // slot (4 s + c) ^ swizzle(key) (the XOR stays inside the low slot bits the variants enumerate)
+  FFPA_LDS const char* kaddr[NH][KV];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) kaddr[i] = Kt + n16 * RB + (((4 * i + c) ^ n16) << 4);
-  // V^T fragment of column block db = 8 q + i, key step ks: lane L = lane % 16 of group c reads key 4 c + L / 4 (+ 16 for the second
-  // read), 4 columns 16 db + 4 (L % 4) ..: vaddr[i] + 256 q + (32 ks + {0, 16}) * RB
-  FFPA_LDS const char* vaddr[8];
+  for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+    for (int i = 0; i < KV; ++i) kaddr[hf][i] = Kt + (64 * hf + n16) * RB + (((4 * i + c) ^ m16_k_swizzle<D>(n16)) << 4);
+  // V^T fragment of column block db = VV q + i, key step ks: lane L = lane % 16 of group c reads key 32 ks + 4 c + L / 4 (+ 16 for
+  // the second read), 4 columns 16 db + 4 (L % 4) ..: vaddr[ks / 2][i] + VVB q + ((ks % 2) * 32 + {0, 16}) * RB
+  FFPA_LDS const char* vaddr[NH][VV];
   {
     const int vkey = 4 * c + (n16 >> 2);
-    const int sw = (vkey & 7) << 1;
+    const int sw = m16_v_swizzle<D>(vkey);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) vaddr[i] = Vt + vkey * RB + (((2 * i + ((n16 & 3) >> 1)) ^ sw) << 4) + 8 * (n16 & 1);
+    for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+      for (int i = 0; i < VV; ++i) vaddr[hf][i] = Vt + (64 * hf + vkey) * RB + (((2 * i + ((n16 & 3) >> 1)) ^ sw) << 4) + 8 * (n16 & 1);
   }
 
   if (nt > t0) {
@@ -282,7 +340,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       v8 kf[N1];
       auto k_frag = [&](int n) -> v8 {
         const int s = n / NKB, kb = n % NKB;
-        return *(FFPA_LDS const v8*)(kaddr[s & 3] + (s >> 2) * 256 + kb * 16 * RB);
+        return *(FFPA_LDS const v8*)(kaddr[kb / 4][s % KV] + (s / KV) * KVB + (kb % 4) * 16 * RB);
       };
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -302,12 +360,16 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         }
       });
       // MFMA result -> VALU reader wait states (invisible to the compiler inside asm)
+      if constexpr (NKB == 8)
+        asm volatile(""
+                     : "+v"(sacc[4][0]), "+v"(sacc[4][1]), "+v"(sacc[5][0]), "+v"(sacc[5][1]), "+v"(sacc[6][0]), "+v"(sacc[6][1]), "+v"(sacc[7][0]),
+                       "+v"(sacc[7][1]));
       asm volatile("s_nop 15\n\ts_nop 3"
                    : "+v"(sacc[0][0]), "+v"(sacc[0][1]), "+v"(sacc[1][0]), "+v"(sacc[1][1]), "+v"(sacc[2][0]), "+v"(sacc[2][1]), "+v"(sacc[3][0]),
                      "+v"(sacc[3][1]));
       __builtin_amdgcn_sched_barrier(0);
     }
-    static_assert(NKB == 4, "the wait-state statement above names 8 accumulators");
+    static_assert(NKB == 4 || NKB == 8, "the wait-state statements above name 8 / 16 accumulators");
 
     auto pre_k_group = [&](auto gc) __attribute__((always_inline)) {
       constexpr int g = decltype(gc)::value;
@@ -445,7 +507,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       v8 vf[N2];
       auto v_frag = [&](int n) -> v8 {
         const int db = n % NDB, ks = n / NDB;
-        FFPA_LDS const char* vp = vaddr[db & 7] + (db >> 3) * 256 + ks * 32 * RB;
+        FFPA_LDS const char* vp = vaddr[ks / 2][db % VV] + (db / VV) * VVB + (ks % 2) * 32 * RB;
         const v4 lo = E::tr_read(vp);
         const v4 hi = E::tr_read(vp + 16 * RB);
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);

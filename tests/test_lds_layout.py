@@ -19,6 +19,11 @@ def test_fragment_maps_and_bank_conflicts(D):
     assert sim.check(d, nd) == (1, 1)
 
 
+@pytest.mark.parametrize("D", range(64, 513, 64))
+def test_fragment_maps_and_bank_conflicts_of_the_16x16x32_build(D):
+  assert sim.check_m16(D) == (1, 1)
+
+
 def test_key_map_is_a_permutation_that_gives_each_lane_half_16_contiguous_keys():
   assert sorted(sim.pi(a) for a in range(32)) == list(range(32))
   for h in range(2):

@@ -1,6 +1,6 @@
-"""The D = 512 prefill kernel on the 16x16x32 MFMA shape (csrc/ffpa_fwd_m16_kernel.h; `pytest -m gpu`).
+"""The prefill kernel on the 16x16x32 MFMA shape (csrc/ffpa_fwd_m16_kernel.h; `pytest -m gpu`).
 
-Unmasked and boolean-mask launches at head dims in (448, 512] take this build by default; FFPA_FLAG_NO_M16 keeps them on the
+Unmasked and boolean-mask launches at head dims in (256, 512] take this build by default; FFPA_FLAG_NO_M16 keeps them on the
 32x32x16 build (same tiles, same recurrence, another summation order inside the matrix core).  Pinned here: the oracle (the
 reference's recurrence restated on the CPU), the other build within output rounding, exact NaN / -inf patterns, and the
 properties that must hold to the bit inside one build (determinism, head independence, KV splits merge, strided views).
@@ -15,7 +15,8 @@ from test_fwd_gpu import _check_vs_oracle, _close, _f32, _rand, hip  # noqa: F40
 
 pytestmark = pytest.mark.gpu
 
-D = 512
+D = 512  # the headline head dim; DIMS: every 64-multiple this build is launched for (128-key tiles at 320, 64-key tiles above)
+DIMS = [320, 384, 448, 512]
 
 
 def _both(hip, q, k, v, bias, causal, **kw):
@@ -41,14 +42,15 @@ def _same_up_to_rounding(o16, l16, o32, l32, dtype, name):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("D", DIMS)
 @pytest.mark.parametrize("case", [(1, 2, 2, 128, 64, False), (1, 2, 1, 200, 333, False), (2, 4, 2, 384, 384, True), (1, 2, 2, 77, 1000, True),
                                   (1, 1, 1, 640, 1500, False), (1, 4, 4, 33, 65, True), (1, 2, 2, 1, 64, False), (2, 2, 1, 129, 63, False)])
-def test_matches_the_oracle_and_the_other_build(hip, dtype, case):
+def test_matches_the_oracle_and_the_other_build(hip, dtype, D, case):
   B, Hq, Hkv, Nq, Nkv, causal = case
   q, k, v = _rand((B, Hq, Nq, D), dtype, seed=Nq), _rand((B, Hkv, Nkv, D), dtype, seed=Nkv + 1), _rand((B, Hkv, Nkv, D), dtype, seed=Nkv + 2)
   o16, l16, o32, l32 = _both(hip, q, k, v, None, causal, num_splits=1)
   _same_up_to_rounding(o16, l16, o32, l32, dtype, str(case))
-  _check_vs_oracle(o16, l16, q, k, v, causal=causal, block_keys=64, name=f"m16 {case}")
+  _check_vs_oracle(o16, l16, q, k, v, causal=causal, block_keys=hip.tile_config(D)["block_keys"], name=f"m16 D{D} {case}")
 
 
 def test_the_default_launch_is_this_build(hip):
@@ -66,21 +68,23 @@ def test_the_default_launch_is_this_build(hip):
   assert torch.equal(oz, o32)
 
 
-def test_causal_offsets_tails_and_fully_masked_rows(hip):
+@pytest.mark.parametrize("D", [320, 512])
+def test_causal_offsets_tails_and_fully_masked_rows(hip, D):
   Nq, Nkv = 300, 700
   q, k, v = _rand((1, 2, Nq, D), seed=11), _rand((1, 2, Nkv, D), seed=12), _rand((1, 2, Nkv, D), seed=13)
   for off in (0, 400, -40, 650):  # SDPA-style, tail-aligned, rows with no visible key (NaN), almost everything visible
     o16, l16 = hip.forward(q, k, v, None, True, D ** -0.5, causal_offset=off)
     o32, l32 = hip.forward(q, k, v, None, True, D ** -0.5, causal_offset=off, flags=hip.FLAG_NO_M16)
     _same_up_to_rounding(o16, l16, o32, l32, q.dtype, f"offset {off}")
-    _check_vs_oracle(o16, l16, q, k, v, causal=True, causal_offset=off, block_keys=64, name=f"m16 offset {off}")
+    _check_vs_oracle(o16, l16, q, k, v, causal=True, causal_offset=off, block_keys=hip.tile_config(D)["block_keys"], name=f"m16 offset {off}")
   assert torch.isnan(o16).sum().item() == 0
   o, lse = hip.forward(q, k, v, None, True, D ** -0.5, causal_offset=-40)
   assert torch.isnan(o[:, :, :40]).all() and not torch.isnan(o[:, :, 40:]).any()
   assert torch.equal(o[0, :, 40], v[0, :, 0])  # a row that sees exactly one key returns that key's V row
 
 
-def test_boolean_masks_vector_and_byte_paths(hip):
+@pytest.mark.parametrize("D", DIMS)
+def test_boolean_masks_vector_and_byte_paths(hip, D):
   """Mask bytes are read 4 at a time (unit key stride, 16-byte aligned rows, full tile) or one by one; ranges skip tiles and
   mask reads.  Same visible keys as the 32x32x16 build: same NaN rows, outputs equal up to rounding; with and without the
   ranges the SAME bits."""
@@ -149,9 +153,11 @@ def test_underfilled_launch_splits_the_kv_axis_and_merges(hip):
   _check_vs_oracle(o_s, l_s, q, k, v, rows=(0, 64), block_keys=64, name="m16 split")
 
 
-@pytest.mark.parametrize("d", [456, 504])
+@pytest.mark.parametrize("d", [264, 328, 456, 504])
 def test_ragged_head_dims_equal_the_padded_run(hip, d):
-  """Head dims in (448, 512): missing columns read as zeros in-kernel — the same bits as the host-padded run of this build."""
+  """Head dims between the built multiples of 64: missing columns read as zeros in-kernel — the same bits as the host-padded run
+  of this build."""
+  D = hip.padded_head_dim(d)
   for (B, Hq, Hkv, Nq, Nkv, causal) in ((1, 2, 1, 130, 257, False), (1, 2, 2, 200, 333, True)):
     q, k, v = _rand((B, Hq, Nq, d), seed=d), _rand((B, Hkv, Nkv, d), seed=d + 1), _rand((B, Hkv, Nkv, d), seed=d + 2)
     o, lse = hip.forward(q, k, v, None, causal, d ** -0.5)
