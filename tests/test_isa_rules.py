@@ -43,3 +43,21 @@ def test_headline_kernel_has_no_spill_code_inside_its_mfma_loops(capsys, monkeyp
     assert "vgpr 256 agpr 256" in l and "inside MFMA loops: scratch 0, lane spills 0" in l, l
   headline = [l for l in lines if "512 1 b0 b0 b0 0 " in l]
   assert len(headline) == 1 and "first..last MFMA: scratch ops 0, lane spills 0" in headline[0], headline
+
+
+@pytest.mark.skipif(not TEMPS, reason="no --save-temps assembly in csrc/build")
+def test_16x16x32_builds_have_no_spill_code_inside_their_mfma_loops(capsys, monkeypatch):
+  """The builds the headline shape (D = 512, no mask) and config 4 (D = 320, boolean mask) launch: O^T in the AGPRs (D / 2 of
+  them), no scratch at all, no SGPR lane spills inside the MFMA loops (one at D = 320); the headline build has none anywhere between its first and
+  last MFMA."""
+  monkeypatch.setattr(sys, "argv", ["isa_stats", "320", "384", "448", "512"])
+  _tool("isa_stats").main()
+  lines = [l for l in capsys.readouterr().out.splitlines() if " m16 " in l]
+  assert len(lines) == 4 * 4, lines  # {bf16, fp16} x {no mask, boolean mask} per head dim
+  import re
+  for l in lines:
+    hot = int(re.search(r"inside MFMA loops: scratch 0, lane spills (\d+)", l).group(1))
+    # (D = 320, 128-key tiles: hipcc parks ONE scalar in a VGPR lane inside the QK^T loop of the unmasked build)
+    assert "scratch    0 B" in l and hot <= (1 if " 320 " in l else 0), l
+  headline = [l for l in lines if "m16 bf16  512 0 " in l]
+  assert len(headline) == 1 and "vgpr 256 agpr 256" in headline[0] and "first..last MFMA: scratch ops 0, lane spills 0" in headline[0] and "mfma 256" in headline[0], headline
