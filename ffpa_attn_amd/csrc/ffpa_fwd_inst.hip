@@ -48,7 +48,7 @@ static int launch_one(const FwdArgs& a, hipStream_t stream) {
 // The unmasked / boolean-mask prefill kernel on the 16x16x32 MFMA shape (ffpa_fwd_m16_kernel.h): same tiles, same plan.
 template <typename T, int D, int MK>
 static int launch_m16(const FwdArgs& a, hipStream_t stream) {
-  constexpr int LDS = 2 * ((D <= FFPA_BC128_MAX_D) ? 128 : 64) * D * 2;
+  constexpr int LDS = D > 512 ? 2 * 32 * D * 2 + 4 * 4096 : 2 * ((D <= FFPA_BC128_MAX_D) ? 128 : 64) * D * 2;
   auto kern = ffpa_fwd_m16_kernel<T, D, MK>;
   static std::atomic<bool> attr_done[64];
   int dev = 0;
@@ -106,7 +106,7 @@ int FFPA_CAT(launch_fwd_d, FFPA_INST_D)(int dtype, int safe, int variant, const 
     return -4;
   }
   if (a.bias_dtype == 0 && a.kv_bounds == nullptr) {  // no attn_bias, no mask ranges: the build without any bias path
-    if constexpr (ND == 1 && D >= FFPA_M16_MIN_D) {
+    if constexpr (D >= FFPA_M16_MIN_D) {
       if (!(a.flags & 0x10u)) {  // (FFPA_FLAG_NO_M16 keeps the 32x32x16 build: A/B runs, tests)
         if (dtype == 0) return launch_m16<__bf16, D, 0>(a, stream);
         if (dtype == 1) return launch_m16<_Float16, D, 0>(a, stream);
@@ -118,7 +118,7 @@ int FFPA_CAT(launch_fwd_d, FFPA_INST_D)(int dtype, int safe, int variant, const 
     return -4;
   }
   if (a.bias_dtype == 4) {  // boolean mask (+ ranges): the build that carries only that path
-    if constexpr (ND == 1 && D >= FFPA_M16_MIN_D) {
+    if constexpr (D >= FFPA_M16_MIN_D) {
       if (!(a.flags & 0x10u)) {
         if (dtype == 0) return launch_m16<__bf16, D, 2>(a, stream);
         if (dtype == 1) return launch_m16<_Float16, D, 2>(a, stream);

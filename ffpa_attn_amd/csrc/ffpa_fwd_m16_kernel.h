@@ -19,16 +19,17 @@
 //   * a query row lives in 4 lanes (c = 0 .. 3): row max / row sum take two cross-lane steps (lane ^ 16, lane ^ 32).
 //   * epilogue: a lane owns 4 consecutive columns of two rows; lanes c and c ^ 1 trade one group (v_permlane16_swap) so that
 //     each stores whole 16-byte runs of ONE row.
-// Built for every head dim the prefill tiles hold unsplit (D <= 512: 128-key tiles up to D = 320, 64 above, like the 32x32x16
-// build, so that launch plans do not depend on the build); launched for calls without an additive bias or dropout.
+// Built for every head dim with the 32x32x16 build's tiles, so that launch plans do not depend on the build (D <= 512: 128 rows x
+// 128 keys up to D = 320, 64 keys above; D > 512: D split over two waves, 64 rows x 32 keys, partial S^T tiles summed through LDS);
+// launched for calls without an additive bias or dropout.
 #pragma once
 
 #include "ffpa_fwd_kernel.h"
 
 #ifndef FFPA_M16_MIN_D
 // head dims from here up launch this build (measured A/B against the 32x32x16 build, profiles/r02_m16_ab.txt: + 4 ... 5 % at
-// D = 320 ... 512, even at D = 192 / 256, - 11 % at D = 128 — there the 128-key tiles' S^T / P^T registers and the per-piece DMA
-// offsets leave the compiler spilling scalars inside the loops)
+// D = 320 ... 512, + 0.5 ... 2.5 % at D = 576 ... 960, + 5 ... 6 % at D = 1024, even at D = 192 / 256, - 11 % at D = 128 — there the
+// 128-key tiles' S^T / P^T registers and the per-piece DMA offsets leave the compiler spilling scalars inside the loops)
 #define FFPA_M16_MIN_D 320
 #endif
 #ifndef FFPA_M16_PF1
@@ -39,6 +40,9 @@
 #endif
 #ifndef FFPA_M16_K_PRE
 #define FFPA_M16_K_PRE 8  // K(j+1) pieces issued between the softmax stages (a multiple of 4); the rest go out between the PV MFMAs
+#endif
+#ifndef FFPA_M16_K_PRE_ND2
+#define FFPA_M16_K_PRE_ND2 64  // ditto for the split-D tiles (D > 512; clamped to the tile's pieces: all of K(j+1) goes out between the softmax stages)
 #endif
 
 #ifndef FFPA_M16_X
@@ -117,26 +121,34 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   using M = Mfma16<T>;
   using v8 = typename E::v8;
   using v4 = typename E::v4;
-  static_assert(D % 64 == 0 && D <= 512, "O^T (D / 2 registers per lane) must fit the AGPRs");
-  constexpr int BC = (D <= FFPA_BC128_MAX_D) ? 128 : 64, BR = 128;
-  constexpr int KS = D / 32;    // QK contraction steps
+  static_assert(D % 64 == 0 && D <= 1024, "O^T (D / ND / 2 registers per lane) must fit the AGPRs");
+  // D > 512: the head dim is split over two waves (ND = 2, as in ffpa_fwd_split_d_kernel): wave (qb, dh) = (wave / 2, wave % 2) owns rows
+  // 32 qb .. + 32 and columns dh * D/2 .. of both contractions; the two partial S^T tiles of a row block are summed through LDS.
+  constexpr int ND = (D <= 512) ? 1 : 2;
+  constexpr int DW = D / ND;    // columns owned by one wave
+  constexpr int BC = ND == 2 ? 32 : ((D <= FFPA_BC128_MAX_D) ? 128 : 64), BR = 128 / ND;
+  constexpr int KS = DW / 32;   // QK contraction steps per wave
   constexpr int NKB = BC / 16;  // 16-key S^T blocks per tile
   constexpr int NKS = BC / 32;  // PV contraction steps per tile
-  constexpr int NDB = D / 16;   // 16-column O^T blocks
+  constexpr int NDB = DW / 16;  // 16-column O^T blocks per wave
   constexpr int RB = D * 2;
   constexpr int TILE = BC * RB;
   constexpr int PPW = BC * D * 2 / 4096;  // 1 KiB DMA pieces per wave per tile
-  constexpr bool kRowDma = RB % 1024 == 0;   // a tile row is a whole number of pieces (D = 512): wave-uniform rows, scalar addressing
+  // D = 512 with masks: a tile row is one whole piece -> wave-uniform rows, scalar addressing (the per-lane offset tables of the other form
+  // would not fit next to the mask path's registers).  Everything else keeps tile-invariant per-lane offsets in registers: measured equal
+  // or better (D = 512 unmasked: + 0 ... 2 %; D = 1024: 927 vs 776 TFLOPS — the scalar row form loses 16 % there on this build).
+  constexpr bool kRowDma = RB % 1024 == 0 && ND == 1 && MK != 0;
   constexpr int RPP = kRowDma ? RB / 1024 : 1;  // pieces per row
   constexpr int KPW = BC / 4;                // keys staged per wave per tile
   constexpr int PF1 = FFPA_M16_PF1, PF2 = FFPA_M16_PF2;
-  constexpr int kPre = ((FFPA_M16_K_PRE < PPW ? FFPA_M16_K_PRE : PPW) / 4) * 4;
+  constexpr int kPreReq = ND == 2 ? FFPA_M16_K_PRE_ND2 : FFPA_M16_K_PRE;
+  constexpr int kPre = ((kPreReq < PPW ? kPreReq : PPW) / 4) * 4;
   constexpr int N1 = KS * NKB;   // K fragments per tile
   constexpr int N2 = NDB * NKS;  // V^T fragments per tile
   constexpr int kStep1 = N1 / PPW;           // one V piece every this many K fragments
   constexpr int kStep2 = N2 / PPW;           // one K piece every this many V^T fragments
   static_assert(kStep1 >= 1 && kStep2 >= 1 && N1 % PPW == 0 && N2 % PPW == 0, "DMA pieces must fit the MFMA loops");
-  constexpr int NH = BC / 64;                       // 64-key halves of a tile (ds_read immediates are 16 bits: one address base per half)
+  constexpr int NH = BC > 64 ? BC / 64 : 1;         // 64-key halves of a tile (ds_read immediates are 16 bits: one address base per half)
   constexpr int KV = (D % 128 == 0) ? 4 : 2;        // K fragment address variants: the swizzle reaches slot bits 0 .. 3 / 0 .. 2
   constexpr int KVB = (D % 128 == 0) ? 256 : 128;   //   and the bytes KV contraction steps advance
   constexpr int VV = (D % 128 == 0) ? 8 : 4;        // V^T fragment address variants
@@ -145,12 +157,15 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   FFPA_LDS char* const Kt = (FFPA_LDS char*)smem;
   FFPA_LDS char* const Vt = Kt + TILE;
+  FFPA_LDS char* const Xb = Kt + 2 * TILE;  // ND == 2: partial-S exchange, 4 KiB per wave
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n16 = lane & 15;
   const int c = lane >> 4;
+  const int qb = wave / ND;  // row block of this wave
+  const int dh = wave % ND;  // which D / ND slice of the head dim it owns
 
   // workgroup -> (batch, head, row tile, split): as ffpa_fwd_split_d_kernel (all row tiles of a head on one XCD)
   int vid = blockIdx.x;
@@ -168,7 +183,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   const int hq = bh - b * a.Hq;
   const int hkv = hq / a.group;
   const int q0 = qt * BR;
-  const int wq0 = q0 + wave * 32;
+  const int wq0 = q0 + qb * 32;
   int qrow[2], qrow_c[2];
 #pragma unroll
   for (int rh = 0; rh < 2; ++rh) {
@@ -188,7 +203,6 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   //     swizzled lane offset is scalar;
   //   * other head dims: piece p = wave * PPW + i covers slots [64 p, 64 p + 64) of the row-major image; the per-lane source
   //     offsets are tile-invariant and live in PPW + PPW registers.
-  static_assert(RPP == 1, "the head-dim guard below assumes one piece per row");
   const uint32_t rb_valid = (uint32_t)a.d_valid * 2u;
   const int slots_valid = a.d_valid >> 3;
   uint32_t kvo[kRowDma ? 4 : 1], vvo[kRowDma ? 4 : 1];
@@ -199,7 +213,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) {
       kvo[bb] = (uint32_t)((lane ^ m16_k_swizzle<D>(4 * wave + bb)) << 4);
-      if ((lane ^ m16_k_swizzle<D>(4 * wave + bb)) >= slots_valid) kvo[bb] = kDmaOob;
+      if (RPP == 1 && (lane ^ m16_k_swizzle<D>(4 * wave + bb)) >= slots_valid) kvo[bb] = kDmaOob;  // (two-piece rows: masked per piece below)
       vvo[bb] = (uint32_t)((lane ^ m16_v_swizzle<D>(4 * wave + bb)) << 4);
     }
 #pragma unroll
@@ -228,7 +242,15 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     const TileSrc ts = tile_src<BC>(Kg, k_row_bytes, key0, a.Nkv, rb_valid);
     if constexpr (kRowDma) {
       constexpr int jk = i / RPP, half = i % RPP;
-      lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(ts.rsrc, k_lds, kvo[jk & 3], kro[jk]);
+      uint32_t kv = kvo[jk & 3];
+      if constexpr (RPP > 1 && half == RPP - 1) {
+        // the row's last piece: lanes whose slot lies at or past the caller's head dim fetch zeros (a wave-uniform branch: launches
+        // whose head dim is the kernel's own skip the per-lane test)
+        if (a.d_valid != D) {
+          if (half * 64 + (opaque_lane(lane) ^ m16_k_swizzle<D>(4 * wave + (jk & 3))) >= slots_valid) kv = kDmaOob;
+        }
+      }
+      lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(ts.rsrc, k_lds, kv, kro[jk]);
     } else {
       lds_dma_16(ts.rsrc, (uint32_t)(uintptr_t)(Kt + (wave * PPW + i) * 1024), krel[i], 0u);
     }
@@ -275,7 +297,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     const int tf = first / BC, te = (end + BC - 1) / BC;
     t0 = t0 > tf ? t0 : tf;
     nt = nt < te ? nt : te;
-    const int r32w = q0 / 32 + wave;
+    const int r32w = q0 / 32 + qb;
     if (r32w * 32 < a.Nq) {
       free_lo = __builtin_amdgcn_readfirstlane(bp[4 * r32w + 2]);
       free_hi = __builtin_amdgcn_readfirstlane(bp[4 * r32w + 3]);
@@ -288,11 +310,11 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   v8 qf[KS][2];
 #pragma unroll
   for (int rh = 0; rh < 2; ++rh) {
-    const T* qp = (const T*)a.q + b * a.sq[0] + hq * a.sq[1] + (int64_t)qrow_c[rh] * a.sq[2] + c * 8;
+    const T* qp = (const T*)a.q + b * a.sq[0] + hq * a.sq[1] + (int64_t)qrow_c[rh] * a.sq[2] + dh * DW + c * 8;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const u32x4 z = {0u, 0u, 0u, 0u};
-      qf[s][rh] = (s * 32 + c * 8 < a.d_valid) ? *(const v8*)(qp + s * 32) : __builtin_bit_cast(v8, z);
+      qf[s][rh] = (dh * DW + s * 32 + c * 8 < a.d_valid) ? *(const v8*)(qp + s * 32) : __builtin_bit_cast(v8, z);
     }
   }
 
@@ -312,7 +334,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 #pragma unroll
   for (int hf = 0; hf < NH; ++hf)
 #pragma unroll
-    for (int i = 0; i < KV; ++i) kaddr[hf][i] = Kt + (64 * hf + n16) * RB + (((4 * i + c) ^ m16_k_swizzle<D>(n16)) << 4);
+    for (int i = 0; i < KV; ++i) kaddr[hf][i] = Kt + (64 * hf + n16) * RB + (((dh * (DW / 8) + 4 * i + c) ^ m16_k_swizzle<D>(n16)) << 4);
   // V^T fragment of column block db = VV q + i, key step ks: lane L = lane % 16 of group c reads key 32 ks + 4 c + L / 4 (+ 16 for
   // the second read), 4 columns 16 db + 4 (L % 4) ..: vaddr[ks / 2][i] + VVB q + ((ks % 2) * 32 + {0, 16}) * RB
   FFPA_LDS const char* vaddr[NH][VV];
@@ -322,7 +344,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 #pragma unroll
     for (int hf = 0; hf < NH; ++hf)
 #pragma unroll
-      for (int i = 0; i < VV; ++i) vaddr[hf][i] = Vt + (64 * hf + vkey) * RB + (((2 * i + ((n16 & 3) >> 1)) ^ sw) << 4) + 8 * (n16 & 1);
+      for (int i = 0; i < VV; ++i)
+        vaddr[hf][i] = Vt + (64 * hf + vkey) * RB + (((dh * (DW / 8) + 2 * i + ((n16 & 3) >> 1)) ^ sw) << 4) + 8 * (n16 & 1);
   }
 
   if (nt > t0) {
@@ -359,17 +382,17 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
           M::acc(sacc[kb][1], kf[n], qf[s][1]);
         }
       });
-      // MFMA result -> VALU reader wait states (invisible to the compiler inside asm)
+      // MFMA result -> VALU reader wait states (invisible to the compiler inside asm); every accumulator is named so that no read
+      // of one can be scheduled ahead of the statement
       if constexpr (NKB == 8)
         asm volatile(""
                      : "+v"(sacc[4][0]), "+v"(sacc[4][1]), "+v"(sacc[5][0]), "+v"(sacc[5][1]), "+v"(sacc[6][0]), "+v"(sacc[6][1]), "+v"(sacc[7][0]),
                        "+v"(sacc[7][1]));
-      asm volatile("s_nop 15\n\ts_nop 3"
-                   : "+v"(sacc[0][0]), "+v"(sacc[0][1]), "+v"(sacc[1][0]), "+v"(sacc[1][1]), "+v"(sacc[2][0]), "+v"(sacc[2][1]), "+v"(sacc[3][0]),
-                     "+v"(sacc[3][1]));
+      if constexpr (NKB >= 4) asm volatile("" : "+v"(sacc[2][0]), "+v"(sacc[2][1]), "+v"(sacc[3 % NKB][0]), "+v"(sacc[3 % NKB][1]));
+      asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sacc[0][0]), "+v"(sacc[0][1]), "+v"(sacc[1][0]), "+v"(sacc[1][1]));
       __builtin_amdgcn_sched_barrier(0);
     }
-    static_assert(NKB == 4 || NKB == 8, "the wait-state statements above name 8 / 16 accumulators");
+    static_assert(NKB == 2 || NKB == 4 || NKB == 8, "the wait-state statements above name 4 / 8 / 16 accumulators");
 
     auto pre_k_group = [&](auto gc) __attribute__((always_inline)) {
       constexpr int g = decltype(gc)::value;
@@ -380,7 +403,14 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       }
     };
 
-    // barrier A1: every wave is done reading K(j)
+    if constexpr (ND == 2) {  // publish this wave's partial S^T (lane-linear, conflict free)
+      FFPA_LDS char* xw = Xb + wave * 4096 + lane * 16;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh) *(FFPA_LDS f32x4*)(xw + (kb * 2 + rh) * 1024) = sacc[kb][rh];
+    }
+    // barrier A1: every wave is done reading K(j) (ND == 2: and the partial S^T tiles are visible)
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     pre_k_group(std::integral_constant<int, 0>{});
@@ -393,6 +423,18 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       for (int rh = 0; rh < 2; ++rh)
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[kb][rh][r] = sacc[kb][rh][r] * a.scale_log2;
+    if constexpr (ND == 2) {
+      // + the other D-half's partial (a + b == b + a: both waves of a row block see bit-identical scores, so their softmax states agree)
+      FFPA_LDS const char* xr = Xb + (wave ^ 1) * 4096 + lane * 16;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh) {
+          const f32x4 t = *(FFPA_LDS const f32x4*)(xr + (kb * 2 + rh) * 1024);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[kb][rh][r] = (sacc[kb][rh][r] + t[r]) * a.scale_log2;
+        }
+    }
     pre_k_group(std::integral_constant<int, 1>{});
 
     if constexpr (MASK) {
@@ -546,7 +588,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       if (qrow[rh] >= a.Nq) continue;
       const bool dead = !(l_tot[rh] > 0.f);
       const int64_t prow = (((int64_t)split * a.B + b) * a.Hq + hq) * a.Nq + qrow[rh];
-      float* wp = a.ws_o + prow * D + 4 * c;
+      float* wp = a.ws_o + prow * D + dh * DW + 4 * c;
 #pragma unroll
       for (int db = 0; db < NDB; ++db) {
         f32x4 w;
@@ -554,7 +596,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         for (int t = 0; t < 4; ++t) w[t] = dead ? 0.f : oacc[db][rh][t] * inv[rh];
         *(f32x4*)(wp + db * 16) = w;
       }
-      if (c == 0) a.ws_lse[prow] = dead ? -INFINITY : __logf(l_tot[rh]) + m_run[rh] * 0.6931471805599453f;
+      if (c == 0 && dh == 0) a.ws_lse[prow] = dead ? -INFINITY : __logf(l_tot[rh]) + m_run[rh] * 0.6931471805599453f;
     }
     return;
   }
@@ -564,7 +606,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     // of the second)
     const int rsel = c & 1;
     const int orow = rsel ? qrow[1] : qrow[0];
-    T* op = (T*)a.o + b * a.so[0] + hq * a.so[1] + (int64_t)(orow < a.Nq ? orow : 0) * a.so[2] + 4 * (c & ~1);
+    T* op = (T*)a.o + b * a.so[0] + hq * a.so[1] + (int64_t)(orow < a.Nq ? orow : 0) * a.so[2] + dh * DW + 4 * (c & ~1);
     const bool ok = orow < a.Nq;
 #pragma unroll
     for (int db = 0; db < NDB; ++db) {
@@ -582,9 +624,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         run[w] = sw[0];
         run[2 + w] = sw[1];
       }
-      if (ok && db * 16 + 4 * (c & ~1) < a.d_valid) *(u32x4*)(op + db * 16) = run;
+      if (ok && dh * DW + db * 16 + 4 * (c & ~1) < a.d_valid) *(u32x4*)(op + db * 16) = run;
     }
-    if (a.lse != nullptr && c == 0) {
+    if (a.lse != nullptr && c == 0 && dh == 0) {
 #pragma unroll
       for (int rh = 0; rh < 2; ++rh)
         if (qrow[rh] < a.Nq) a.lse[((int64_t)b * a.Hq + hq) * a.Nq + qrow[rh]] = __logf(l_tot[rh]) + m_run[rh] * 0.6931471805599453f;

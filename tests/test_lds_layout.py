@@ -19,7 +19,7 @@ def test_fragment_maps_and_bank_conflicts(D):
     assert sim.check(d, nd) == (1, 1)
 
 
-@pytest.mark.parametrize("D", range(64, 513, 64))
+@pytest.mark.parametrize("D", range(64, 1025, 64))
 def test_fragment_maps_and_bank_conflicts_of_the_16x16x32_build(D):
   assert sim.check_m16(D) == (1, 1)
 

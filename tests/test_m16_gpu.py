@@ -1,6 +1,6 @@
 """The prefill kernel on the 16x16x32 MFMA shape (csrc/ffpa_fwd_m16_kernel.h; `pytest -m gpu`).
 
-Unmasked and boolean-mask launches at head dims in (256, 512] take this build by default; FFPA_FLAG_NO_M16 keeps them on the
+Unmasked and boolean-mask launches at head dims above 256 take this build by default; FFPA_FLAG_NO_M16 keeps them on the
 32x32x16 build (same tiles, same recurrence, another summation order inside the matrix core).  Pinned here: the oracle (the
 reference's recurrence restated on the CPU), the other build within output rounding, exact NaN / -inf patterns, and the
 properties that must hold to the bit inside one build (determinism, head independence, KV splits merge, strided views).
@@ -15,8 +15,8 @@ from test_fwd_gpu import _check_vs_oracle, _close, _f32, _rand, hip  # noqa: F40
 
 pytestmark = pytest.mark.gpu
 
-D = 512  # the headline head dim; DIMS: every 64-multiple this build is launched for (128-key tiles at 320, 64-key tiles above)
-DIMS = [320, 384, 448, 512]
+D = 512  # the headline head dim; DIMS: head dims this build is launched for (128-key tiles at 320, 64-key tiles to 512, split-D tiles above)
+DIMS = [320, 384, 448, 512, 576, 640, 960, 1024]
 
 
 def _both(hip, q, k, v, bias, causal, **kw):
@@ -68,7 +68,7 @@ def test_the_default_launch_is_this_build(hip):
   assert torch.equal(oz, o32)
 
 
-@pytest.mark.parametrize("D", [320, 512])
+@pytest.mark.parametrize("D", [320, 512, 1024])
 def test_causal_offsets_tails_and_fully_masked_rows(hip, D):
   Nq, Nkv = 300, 700
   q, k, v = _rand((1, 2, Nq, D), seed=11), _rand((1, 2, Nkv, D), seed=12), _rand((1, 2, Nkv, D), seed=13)
@@ -153,7 +153,7 @@ def test_underfilled_launch_splits_the_kv_axis_and_merges(hip):
   _check_vs_oracle(o_s, l_s, q, k, v, rows=(0, 64), block_keys=64, name="m16 split")
 
 
-@pytest.mark.parametrize("d", [264, 328, 456, 504])
+@pytest.mark.parametrize("d", [264, 328, 456, 504, 520, 968, 1016])
 def test_ragged_head_dims_equal_the_padded_run(hip, d):
   """Head dims between the built multiples of 64: missing columns read as zeros in-kernel — the same bits as the host-padded run
   of this build."""

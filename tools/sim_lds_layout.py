@@ -126,14 +126,17 @@ def m16_v_sw(D, key):
 
 
 def check_m16(D):
-  """The 16x16x32-MFMA build (csrc/ffpa_fwd_m16_kernel.h), D <= 512:
-    K fragment (lane l, step s, 16-key block kb) = K[16 kb + l % 16][32 s + 8 (l / 16) .. + 8]
-    V^T fragment (lane l, column block db, key step ks, element e) = V[32 ks + 16 (e / 4) + 4 (l / 16) + e % 4][16 db + l % 16]
+  """The 16x16x32-MFMA build (csrc/ffpa_fwd_m16_kernel.h); wave (qb, dh) owns columns dh * DW .. + DW (DW = D for D <= 512, D / 2 above):
+    K fragment (lane l, step s, 16-key block kb) = K[16 kb + l % 16][dh DW + 32 s + 8 (l / 16) .. + 8]
+    V^T fragment (lane l, column block db, key step ks, element e) = V[32 ks + 16 (e / 4) + 4 (l / 16) + e % 4][dh DW + 16 db + l % 16]
   and both instruction groups conflict-free."""
-  BC = 128 if D <= 320 else 64
+  ND = 1 if D <= 512 else 2
+  DW = D // ND
+  BC = 32 if ND == 2 else (128 if D <= 320 else 64)
   RB, SPR = D * 2, D // 8
   PPW = BC * D * 2 // 4096
   row_dma = RB % 1024 == 0
+  RPP = RB // 1024 if row_dma else 1
   imgs = []
   for is_v in (False, True):
     sw = m16_v_sw if is_v else m16_k_sw
@@ -142,11 +145,11 @@ def check_m16(D):
       for i in range(PPW):
         for lane in range(64):
           if row_dma:
-            jk = i  # one piece per row
+            jk, half = divmod(i, RPP)
             key = 16 * (jk >> 2) + 4 * wave + (jk & 3)
-            src = (lane ^ sw(D, 4 * wave + (jk & 3))) << 4
+            src = ((lane ^ sw(D, 4 * wave + (jk & 3))) << 4) + half * 1024
             assert sw(D, key) == sw(D, 4 * wave + (jk & 3))
-            dst = key * RB + lane * 16
+            dst = key * RB + half * 1024 + lane * 16
           else:
             g = (wave * PPW + i) * 64 + lane
             key, slot = divmod(g, SPR)
@@ -162,47 +165,49 @@ def check_m16(D):
   KV, KVB = (4, 256) if D % 128 == 0 else (2, 128)
   VV, VVB = (8, 256) if D % 128 == 0 else (4, 128)
   worst_k = worst_v = 1
-  for kb in range(BC // 16):
-    for s in range(D // 32):
-      addrs = []
-      for lane in range(64):
-        n, c = lane & 15, lane >> 4
-        base = (64 * (kb // 4) + n) * RB + (((4 * (s % KV) + c) ^ m16_k_sw(D, n)) << 4)
-        a = base + (s // KV) * KVB + (kb % 4) * 16 * RB
-        assert (s // KV) * KVB + (kb % 4) * 16 * RB < 65536
-        addrs.append(a)
-        for e in range(8):
-          assert kimg[a + 2 * e] == (16 * kb + n, (32 * s + 8 * c + e) * 2), (D, lane, s, kb, e)
-      for grp in ([0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]):
-        for half in (0, 32):
-          banks = {}
-          for l in grp:
-            banks.setdefault((addrs[l + half] // 16) % 16, set()).add(addrs[l + half])
-          worst_k = max(worst_k, max(len(v) for v in banks.values()))
-  for db in range(D // 16):
-    for ks in range(BC // 32):
-      for second in (0, 1):
-        la = []
+  for dh in range(ND):
+    c0 = dh * (DW // 8)
+    for kb in range(BC // 16):
+      for s in range(DW // 32):
+        addrs = []
         for lane in range(64):
           n, c = lane & 15, lane >> 4
-          vkey = 4 * c + (n >> 2)
-          base = (64 * (ks // 2) + vkey) * RB + (((2 * (db % VV) + ((n & 3) >> 1)) ^ m16_v_sw(D, vkey)) << 4) + 8 * (n & 1)
-          off = (db // VV) * VVB + ((ks % 2) * 32 + 16 * second) * RB
-          assert off < 65536
-          la.append(base + off)
-        for lane in range(64):
-          i, base_lane, c = lane & 15, lane & ~15, lane >> 4
-          for e in range(4):
-            src_lane = base_lane + 4 * e + (i >> 2)
-            got = vimg[la[src_lane] + 2 * (i & 3)]
-            want = (32 * ks + 16 * second + 4 * c + e, (16 * db + i) * 2)
-            assert got == want, (D, lane, db, ks, second, e, got, want)
-        for half in (0, 32):
-          banks = {}
-          for l in range(32):
-            banks.setdefault((la[l + half] // 8) % 32, set()).add(la[l + half])
-          worst_v = max(worst_v, max(len(v) for v in banks.values()))
-  print(f"D={D:5d} 16x16x32 build BC={BC}: K/V fragment maps OK; worst bank conflict: ds_read_b128 {worst_k}-way, tr_b16 {worst_v}-way")
+          base = (64 * (kb // 4) + n) * RB + (((c0 + 4 * (s % KV) + c) ^ m16_k_sw(D, n)) << 4)
+          a = base + (s // KV) * KVB + (kb % 4) * 16 * RB
+          assert (s // KV) * KVB + (kb % 4) * 16 * RB < 65536
+          addrs.append(a)
+          for e in range(8):
+            assert kimg[a + 2 * e] == (16 * kb + n, (dh * DW + 32 * s + 8 * c + e) * 2), (D, lane, s, kb, e)
+        for grp in ([0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]):
+          for half in (0, 32):
+            banks = {}
+            for l in grp:
+              banks.setdefault((addrs[l + half] // 16) % 16, set()).add(addrs[l + half])
+            worst_k = max(worst_k, max(len(v) for v in banks.values()))
+    for db in range(DW // 16):
+      for ks in range(BC // 32):
+        for second in (0, 1):
+          la = []
+          for lane in range(64):
+            n, c = lane & 15, lane >> 4
+            vkey = 4 * c + (n >> 2)
+            base = (64 * (ks // 2) + vkey) * RB + (((c0 + 2 * (db % VV) + ((n & 3) >> 1)) ^ m16_v_sw(D, vkey)) << 4) + 8 * (n & 1)
+            off = (db // VV) * VVB + ((ks % 2) * 32 + 16 * second) * RB
+            assert off < 65536
+            la.append(base + off)
+          for lane in range(64):
+            i, base_lane, c = lane & 15, lane & ~15, lane >> 4
+            for e in range(4):
+              src_lane = base_lane + 4 * e + (i >> 2)
+              got = vimg[la[src_lane] + 2 * (i & 3)]
+              want = (32 * ks + 16 * second + 4 * c + e, (dh * DW + 16 * db + i) * 2)
+              assert got == want, (D, lane, db, ks, second, e, got, want)
+          for half in (0, 32):
+            banks = {}
+            for l in range(32):
+              banks.setdefault((la[l + half] // 8) % 32, set()).add(la[l + half])
+            worst_v = max(worst_v, max(len(v) for v in banks.values()))
+  print(f"D={D:5d} 16x16x32 build ND={ND} BC={BC}: K/V fragment maps OK; worst bank conflict: ds_read_b128 {worst_k}-way, tr_b16 {worst_v}-way")
   return worst_k, worst_v
 
 
@@ -215,5 +220,4 @@ if __name__ == "__main__":
   for D in ([int(x) for x in sys.argv[1:]] or [64, 128, 192, 256, 320, 384, 448, 512, 576, 640, 704, 768, 832, 896, 960, 1024]):
     for d, nd in dict.fromkeys(variants(D)):
       check(d, nd)
-    if D <= 512:
-      check_m16(D)
+    check_m16(D)
