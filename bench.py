@@ -83,9 +83,9 @@ WORKLOADS = {
 
 
 def dominant_kernel(w: dict) -> str:
-  """The kernel the roofline object is about (csrc/ffpa_fwd_inst.hip's dispatch): head dims above 256 without an additive bias or
-  dropout run the 16x16x32-MFMA build, everything else the 32x32x16-MFMA build."""
-  if w["D"] > 256 and w["Nq"] > 32 and w["mask"] != "key_bias" and not w["dropout"]:
+  """The kernel the roofline object is about (csrc/ffpa_fwd_inst.hip's dispatch): head dims above 256 without an additive bias
+  run the 16x16x32-MFMA build, everything else the 32x32x16-MFMA build."""
+  if w["D"] > 256 and w["Nq"] > 32 and w["mask"] != "key_bias":
     return "ffpa_fwd_m16_kernel"
   return "ffpa_fwd_split_d_kernel"
 

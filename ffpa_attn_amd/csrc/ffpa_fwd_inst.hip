@@ -46,10 +46,11 @@ static int launch_one(const FwdArgs& a, hipStream_t stream) {
 }
 
 // The unmasked / boolean-mask prefill kernel on the 16x16x32 MFMA shape (ffpa_fwd_m16_kernel.h): same tiles, same plan.
-template <typename T, int D, int MK>
+template <typename T, int D, int MK, bool DROP = false>
 static int launch_m16(const FwdArgs& a, hipStream_t stream) {
-  constexpr int LDS = D > 512 ? 2 * 32 * D * 2 + 4 * 4096 : 2 * ((D <= FFPA_BC128_MAX_D) ? 128 : 64) * D * 2;
-  auto kern = ffpa_fwd_m16_kernel<T, D, MK>;
+  constexpr int LDS_BASE = D > 512 ? 2 * 32 * D * 2 + 4 * 4096 : 2 * ((D <= FFPA_BC128_MAX_D) ? 128 : 64) * D * 2;
+  const int LDS = LDS_BASE + (a.bias_lds > 0 ? a.bias_lds : 0);  // + the key-bias row cache, sized by the C-ABI layer
+  auto kern = ffpa_fwd_m16_kernel<T, D, MK, DROP>;
   static std::atomic<bool> attr_done[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return -1;
@@ -94,6 +95,13 @@ int FFPA_CAT(launch_fwd_d, FFPA_INST_D)(int dtype, int safe, int variant, const 
   if (safe) return -3;
 #endif
   if (a.dropout_p > 0.f) {
+    if constexpr (D >= FFPA_M16_MIN_D) {
+      if (!(a.flags & 0x10u)) {
+        if (dtype == 0) return launch_m16<__bf16, D, 1, true>(a, stream);
+        if (dtype == 1) return launch_m16<_Float16, D, 1, true>(a, stream);
+        return -4;
+      }
+    }
     if (dtype == 0) return launch_one<__bf16, D, ND, false, true>(a, stream);
     if (dtype == 1) return launch_one<_Float16, D, ND, false, true>(a, stream);
     return -4;
@@ -129,6 +137,8 @@ int FFPA_CAT(launch_fwd_d, FFPA_INST_D)(int dtype, int safe, int variant, const 
     if (dtype == 1) return launch_one<_Float16, D, ND, false, false, false, 2>(a, stream);
     return -4;
   }
+  // (additive biases stay on the 32x32x16 build: its lanes hold 16 consecutive keys per block — two 16-byte bias loads — where the
+  // 16x16x32 layout holds 4 keys of two rows; measured 5 ... 25 % slower there, tools/gpu_bias_m16_ab.py)
   if (dtype == 0) return launch_one<__bf16, D, ND, false>(a, stream);
   if (dtype == 1) return launch_one<_Float16, D, ND, false>(a, stream);
   return -4;

@@ -113,9 +113,16 @@ __device__ __forceinline__ int m16_v_swizzle(int key) {
   return (D % 128 == 0) ? ((key & 7) << 1) : (((key >> 1) & 3) << 1);
 }
 
-template <typename T, int D, int MK = 0>
+// MK (mask kind, as in ffpa_fwd_split_d_kernel): 0 = the build for calls without attn_bias / mask ranges, 2 = boolean masks
+// (FFPA_BIAS_BOOL8 bytes and / or kv_bounds ranges: what ffpa_attn_func(attn_mask=<bool>) launches), 1 = additive biases too (fp16 /
+// bf16 / fp32, any broadcast: key biases from the LDS row cache, everything else straight from global memory).  DROP: the
+// dropout-capable build (Philox4x32-10 at the logical score index, applied to the rounded P: prefill.cuh:398-546), carried by the
+// MK = 1 kernel — the only MK = 1 instantiation that is launched: dropout is + 2 ... 15 % faster on this MFMA shape, additive
+// biases without dropout are 5 ... 25 % slower than on the 32x32x16 build (4 keys of two rows per lane and block instead of 16
+// keys of one row: more, narrower bias loads) and stay there.
+template <typename T, int D, int MK = 0, bool DROP = false>
 __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
-  static_assert(MK == 0 || MK == 2, "additive biases stay on the 32x32x16 build");
+  static_assert(MK >= 0 && MK <= 2 && (!DROP || MK == 1), "mask kinds 0 / 1 / 2; dropout rides on the full build");
   constexpr bool MASK = MK != 0;
   using E = Elem<T>;
   using M = Mfma16<T>;
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   // D = 512 with masks: a tile row is one whole piece -> wave-uniform rows, scalar addressing (the per-lane offset tables of the other form
   // would not fit next to the mask path's registers).  Everything else keeps tile-invariant per-lane offsets in registers: measured equal
   // or better (D = 512 unmasked: + 0 ... 2 %; D = 1024: 927 vs 776 TFLOPS — the scalar row form loses 16 % there on this build).
-  constexpr bool kRowDma = RB % 1024 == 0 && ND == 1 && MK != 0;
+  constexpr bool kRowDma = RB % 1024 == 0 && ND == 1 && MK != 0;  // (MK = 1 / dropout builds included)
   constexpr int RPP = kRowDma ? RB / 1024 : 1;  // pieces per row
   constexpr int KPW = BC / 4;                // keys staged per wave per tile
   constexpr int PF1 = FFPA_M16_PF1, PF2 = FFPA_M16_PF2;
@@ -145,8 +152,14 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   constexpr int kPre = ((kPreReq < PPW ? kPreReq : PPW) / 4) * 4;
   constexpr int N1 = KS * NKB;   // K fragments per tile
   constexpr int N2 = NDB * NKS;  // V^T fragments per tile
-  constexpr int kStep1 = N1 / PPW;           // one V piece every this many K fragments
-  constexpr int kStep2 = N2 / PPW;           // one K piece every this many V^T fragments
+#ifndef FFPA_M16_STEP1_DIV
+#define FFPA_M16_STEP1_DIV 1  // (experiments) > 1: the V pieces go out that much denser, in the front part of the QK^T loop
+#endif
+#ifndef FFPA_M16_STEP2_DIV
+#define FFPA_M16_STEP2_DIV 1
+#endif
+  constexpr int kStep1 = (N1 / PPW) / FFPA_M16_STEP1_DIV > 0 ? (N1 / PPW) / FFPA_M16_STEP1_DIV : 1;  // one V piece every this many K fragments
+  constexpr int kStep2 = (N2 / PPW) / FFPA_M16_STEP2_DIV > 0 ? (N2 / PPW) / FFPA_M16_STEP2_DIV : 1;  // one K piece every this many V^T fragments
   static_assert(kStep1 >= 1 && kStep2 >= 1 && N1 % PPW == 0 && N2 % PPW == 0, "DMA pieces must fit the MFMA loops");
   constexpr int NH = BC > 64 ? BC / 64 : 1;         // 64-key halves of a tile (ds_read immediates are 16 bits: one address base per half)
   constexpr int KV = (D % 128 == 0) ? 4 : 2;        // K fragment address variants: the swizzle reaches slot bits 0 .. 3 / 0 .. 2
@@ -158,6 +171,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   FFPA_LDS char* const Kt = (FFPA_LDS char*)smem;
   FFPA_LDS char* const Vt = Kt + TILE;
   FFPA_LDS char* const Xb = Kt + 2 * TILE;  // ND == 2: partial-S exchange, 4 KiB per wave
+  FFPA_LDS char* const Bl = Kt + 2 * TILE + (ND > 1 ? 4 * 4096 : 0);  // key-bias row cache (FwdArgs.bias_lds bytes, when enabled)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -348,6 +362,18 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         vaddr[hf][i] = Vt + (64 * hf + vkey) * RB + (((dh * (DW / 8) + 2 * i + ((n16 & 3) >> 1)) ^ sw) << 4) + 8 * (n16 & 1);
   }
 
+  if (MK == 1 && a.bias_lds > 0 && nt > t0) {
+    // key bias [.., .., 1, Nkv]: every row of the workgroup adds the same Nkv values — fetched once into LDS (bytes past Nkv are
+    // zeros: those keys get the tail mask); made visible by the barrier below
+    const int esz = a.bias_dtype == 3 ? 4 : 2;
+    const char* src = (const char*)a.bias + (int64_t)esz * (b * a.sbias[0] + hq * a.sbias[1]);
+    const int valid = a.Nkv * esz;
+    for (int i = tid * 16; i < a.bias_lds; i += 256 * 16) {
+      u32x4 w = {0u, 0u, 0u, 0u};
+      if (i < valid) w = *(const u32x4*)(src + i);
+      *(FFPA_LDS u32x4*)(Bl + i) = w;
+    }
+  }
   if (nt > t0) {
     static_for<PPW>([&](auto ic) { issue_k(ic, t0 * BC); });
     dma_wait_all();
@@ -466,6 +492,78 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
           }
         }
       }
+      if constexpr (MK == 1) {
+        typedef __attribute__((ext_vector_type(4))) __bf16 b4;
+        typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+        constexpr float kLog2e = 1.4426950408889634f;
+        if (a.bias_dtype != 0 && a.bias_dtype != 4 && !mask_free) {
+          if (a.bias_lds > 0) {
+            // key bias from the LDS row cache: the lane's 4 keys of a block, the same values for both of its rows
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+              const int key = k0 + kb * 16 + 4 * c;
+              float t[4];
+              if (a.bias_dtype == 3) {
+                const f32x4 w = *(FFPA_LDS const f32x4*)(Bl + key * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[r] = w[r];
+              } else {
+                const u32x2 raw = *(FFPA_LDS const u32x2*)(Bl + key * 2);
+                if (a.bias_dtype == 2) {
+                  const b4 w = __builtin_bit_cast(b4, raw);
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) t[r] = (float)w[r];
+                } else {
+                  const h4 w = __builtin_bit_cast(h4, raw);
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) t[r] = (float)w[r];
+                }
+              }
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                x[kb][0][r] += t[r] * kLog2e;
+                x[kb][1][r] += t[r] * kLog2e;
+              }
+            }
+          } else {
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh) {
+              const int64_t brow = b * a.sbias[0] + hq * a.sbias[1] + (int64_t)qrow_c[rh] * a.sbias[2];
+#pragma unroll
+              for (int kb = 0; kb < NKB; ++kb) {
+                const int kbase = k0 + kb * 16 + 4 * c;
+                if (a.bias_vec && k0 + BC <= a.Nkv) {  // full tile, unit key stride, rows aligned to >= 4 elements
+                  if (a.bias_dtype == 3) {
+                    const f32x4 w = *(const f32x4*)((const float*)a.bias + brow + kbase);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[kb][rh][r] += w[r] * kLog2e;
+                  } else {
+                    const u32x2 raw = *(const u32x2*)((const uint16_t*)a.bias + brow + kbase);
+                    if (a.bias_dtype == 2) {
+                      const b4 w = __builtin_bit_cast(b4, raw);
+#pragma unroll
+                      for (int r = 0; r < 4; ++r) x[kb][rh][r] += (float)w[r] * kLog2e;
+                    } else {
+                      const h4 w = __builtin_bit_cast(h4, raw);
+#pragma unroll
+                      for (int r = 0; r < 4; ++r) x[kb][rh][r] += (float)w[r] * kLog2e;
+                    }
+                  }
+                } else {
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                    int key = kbase + r;
+                    key = key < a.Nkv ? key : a.Nkv - 1;
+                    const int64_t e = brow + key * a.sbias[3];
+                    const float w = a.bias_dtype == 3 ? ((const float*)a.bias)[e] : a.bias_dtype == 2 ? (float)((const __bf16*)a.bias)[e] : (float)((const _Float16*)a.bias)[e];
+                    x[kb][rh][r] += w * kLog2e;
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
     }
     const bool tail = k0 + BC > a.Nkv;
     const bool diag = a.causal && ((int64_t)k0 + BC - 1 > (int64_t)(a.causal_row_mod ? 0 : wq0) + a.causal_offset);
@@ -539,6 +637,26 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       l_run[rh] += psum;
     }
     pre_k_group(std::integral_constant<int, 3>{});
+    if constexpr (DROP) {
+      // applied to the ROUNDED P, after the row sum (LSE is undropped): prefill.cuh:508-546.  The lane's 4 keys of a block are one
+      // Philox group of the row's counter stream (element offset = ((b Hq + hq) Nq + row) Nkv + key).
+#pragma unroll
+      for (int rh = 0; rh < 2; ++rh) {
+        const unsigned long long erow =
+            a.philox_offset + (((unsigned long long)b * a.Hq + hq) * a.Nq + (unsigned long long)qrow_c[rh]) * (unsigned long long)a.Nkv;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+          __builtin_amdgcn_sched_barrier(0);  // one Philox group at a time: bounded register pressure
+          float keep[4];
+          dropout_keep4(a.philox_seed, erow + (unsigned long long)(k0 + kb * 16 + 4 * c), a.dropout_p, a.keep_scale, keep);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float dropped = (float)pf[kb >> 1][rh][4 * (kb & 1) + r] * keep[r];
+            pf[kb >> 1][rh][4 * (kb & 1) + r] = (T)dropped;
+          }
+        }
+      }
+    }
 
     // ================= O^T += V^T.P^T =================
     {

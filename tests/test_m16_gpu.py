@@ -180,3 +180,26 @@ def test_public_api_headline_shape_slice(hip):
   assert (out.float() - ref.float()).abs().max().item() <= 1e-2
   outc = ffpa_attn_func(q, k, v, is_causal=True)
   assert (outc.float() - F.scaled_dot_product_attention(q, k, v, is_causal=True).float()).abs().max().item() <= 1e-2
+
+
+@pytest.mark.parametrize("D", [320, 512, 1024])
+def test_dropout_keeps_the_same_scores_as_the_other_build(hip, D):
+  """Dropout launches take this build too (Philox at the logical score index: the kept set does not depend on the lane layout), with
+  and without a mask or an additive bias riding along — the only launches of its additive-bias code.  Same kept scores as the
+  32x32x16 build: outputs equal up to rounding (one flipped keep decision would move O by ~ p_ij / (1 - p) ~ 1e-1 at these sizes)."""
+  B, Hq, Hkv, Nq, Nkv = 1, 4, 2, 200, 333
+  q, k, v = _rand((B, Hq, Nq, D), seed=81), _rand((B, Hkv, Nkv, D), seed=82), _rand((B, Hkv, Nkv, D), seed=83)
+  g = torch.Generator(device="cuda").manual_seed(5)
+  mask = torch.rand(1, 1, Nq, Nkv, device="cuda", generator=g) > 0.2
+  mask[..., 0] = True
+  cases = {"plain": None, "bool": mask, "f32": torch.randn(1, Hq, Nq, Nkv, device="cuda", generator=g) * 0.5,
+           "key_bias": (torch.randn(1, 1, 1, Nkv, device="cuda", generator=g) * 0.5).to(q.dtype),
+           "bf16_strided": (torch.randn(1, 1, Nq, 2 * Nkv, device="cuda", generator=g) * 0.5).to(q.dtype)[..., ::2]}
+  for name, bias in cases.items():
+    for causal in (False, True):
+      kw = dict(dropout_p=0.3, philox_seed=99, philox_offset=12, kv_bounds=False)
+      o16, l16 = hip.forward(q, k, v, bias, causal, D ** -0.5, **kw)
+      o32, l32 = hip.forward(q, k, v, bias, causal, D ** -0.5, flags=hip.FLAG_NO_M16, **kw)
+      _same_up_to_rounding(o16, l16, o32, l32, q.dtype, f"dropout {name} causal={causal}")
+      o_nodrop, _ = hip.forward(q, k, v, bias, causal, D ** -0.5, kv_bounds=False)
+      assert (o16.float() - o_nodrop.float()).abs().max().item() > 0.02
