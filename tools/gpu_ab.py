@@ -31,6 +31,7 @@ def main():
   ap.add_argument("--hkv", type=int, default=0)
   ap.add_argument("--nkv", type=int, default=0)
   ap.add_argument("--causal", action="store_true")
+  ap.add_argument("--dropout", type=float, default=0.0)
   ap.add_argument("--rounds", type=int, default=5)
   ap.add_argument("--reps", type=int, default=5)
   args = ap.parse_args()
@@ -51,7 +52,7 @@ def main():
 
   def run(lib, flags):
     hip._lib = lib
-    return hip.forward(q, k, v, None, args.causal, D ** -0.5, flags=flags, return_lse=False)[0]
+    return hip.forward(q, k, v, None, args.causal, D ** -0.5, flags=flags, return_lse=False, dropout_p=args.dropout, philox_seed=7)[0]
 
   base = None
   times = {t: [] for t, _, _ in variants}
