@@ -31,6 +31,10 @@
 //     PV(j) with the remaining K(j+1) pieces interleaved -> barrier B.
 //   * blockIdx is remapped so that all row tiles of one (batch, head) run on the same XCD at the same time
 //     and share K/V through that XCD's L2.
+//
+// ffpa_fwd_m16_kernel.h holds a second mapping of the same tiles and pipeline onto the 16x16x32 MFMA shape (it sustains a higher
+// power-capped rate on this chip): unmasked, boolean-mask and dropout launches at head dims >= 320 run there; this file's kernel
+// serves the smaller head dims, additive biases, the short-query / decode tiles and the test-only register-staged twins.
 #pragma once
 
 #include <hip/hip_runtime.h>
