@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void probe_mfma16(const Args a) {
 // The kernel's instruction mix rebuilt on the 16x16x32 shape: one ds_read_b128 A fragment feeds TWO MFMAs (the two 16-row halves
 // of a wave's 32 query rows are its B operands), so LDS bytes per FLOP equal the 32x32x16 mix; NM16 MFMAs of 16 K FLOP, NDMA
 // pieces and NM16 / 2 fragment reads per wave and tile.
-template <int NM16, int NDMA, int MODE>
+template <int NM16, int NDMA, int MODE, int SHARE = 2>
 __global__ __launch_bounds__(256) void probe_mix16(const Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void probe_mix16(const Args a) {
   uint32_t soff = (uint32_t)wave * (uint32_t)(NDMA > 0 ? NDMA : 1) * 1024u;
   const uint32_t per_tile = 4u * (uint32_t)(NDMA > 0 ? NDMA : 1) * 1024u;
   constexpr int PF = 3;  // fragments ahead (each feeds two MFMAs)
-  constexpr int NF = NM16 / 2;
+  constexpr int NF = NM16 / SHARE;  // SHARE = 2: one fragment feeds two MFMAs (a wave's two 16-row halves); 1: a 16-row wave, one MFMA per fragment
   bf16x8 fr[4];
   auto frag_read = [&](int f) -> bf16x8 {
     const u32x4 raw = *(LDSAS const u32x4*)(smem + ((f * 1024) & 0xffff) + lane * 16);
@@ -197,8 +197,12 @@ __global__ __launch_bounds__(256) void probe_mix16(const Args a) {
           lds_dma(rsrc, lds0 + (uint32_t)(((wave * NDMA + piece) * 1024) & (128u * 1024u - 1)), voff, soff + (uint32_t)piece * 1024u);
         }
       }
-      acc[(2 * f) & 63] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[f & 3], b0, acc[(2 * f) & 63], 0, 0, 0);
-      acc[(2 * f + 1) & 63] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[f & 3], b1, acc[(2 * f + 1) & 63], 0, 0, 0);
+      if constexpr (SHARE == 2) {
+        acc[(2 * f) & 63] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[f & 3], b0, acc[(2 * f) & 63], 0, 0, 0);
+        acc[(2 * f + 1) & 63] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[f & 3], b1, acc[(2 * f + 1) & 63], 0, 0, 0);
+      } else {
+        acc[f & 63] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[f & 3], (f & 1) ? b1 : b0, acc[f & 63], 0, 0, 0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     soff += per_tile;
@@ -218,9 +222,9 @@ __global__ __launch_bounds__(256) void probe_mix16(const Args a) {
   if (s == 12345.678f) a.sink[0] = s;
 }
 
-template <int NM16, int NDMA, int MODE>
+template <int NM16, int NDMA, int MODE, int SHARE = 2>
 static void run16(const char* name, Args a, const uint32_t* brand, int tiles) {
-  auto k = probe_mix16<NM16, NDMA, MODE>;
+  auto k = probe_mix16<NM16, NDMA, MODE, SHARE>;
   const int lds = 144 * 1024;
   CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   a.tiles = tiles;
@@ -382,6 +386,9 @@ int main(int argc, char** argv) {
   run16<256, 32, 0>("16x16x32: D512mix +barrier", a, brand, T / 2);
   run16<128, 32, 1>("16x16x32: D1024mix (128 mfma16+32 dma)", a, brand, T);
   run16<128, 32, 0>("16x16x32: D1024mix +barrier", a, brand, T);
+  // a 16-row wave (D = 1024 unsplit: every fragment feeds ONE MFMA — twice the LDS reads per FLOP, no partial-S exchange)
+  run16<256, 0, 1, 1>("16x16x32: mfma + one read per mfma", a, brand, T);
+  run16<128, 32, 0, 1>("16x16x32: D1024mix, read per mfma +barrier", a, brand, T);
   // (5) would TWO waves per SIMD (8 per CU, 256 registers each: 128 accumulators) hide the in-order stalls?  Same work per CU and
   // tile as the D = 512 / D = 1024 mixes, split over 8 waves (half the MFMAs, pieces and reads per wave)
   run<64, 0, 0, 2, true, 0, 8>("8 waves: mfma_only", a, 512, brand, bzero, false, T * 2);
