@@ -1,13 +1,13 @@
-// ffpa_fwd_m16_kernel.h — the unmasked prefill kernel rebuilt on the 16x16x32 MFMA shape.
+// ffpa_fwd_m16_kernel.h — the prefill kernel mapped onto the 16x16x32 MFMA shape.
 //
 // Same algorithm, same pipeline (LDS-DMA K / V tiles, barriers A1 / A2 / B, lazy-rescale online softmax in the log2 domain)
-// and same numbers-per-row order as ffpa_fwd_split_d_kernel<.., ND = 1, .., MK = 0> (ffpa_fwd_kernel.h, which follows the
+// and same per-row recurrence as ffpa_fwd_split_d_kernel's prefill tiles (ffpa_fwd_kernel.h, which follows the
 // reference's split_d_fwd_sm80: csrc/cuffpa/native/sm_80/split_d.cuh:96-777); only the mapping of the two products onto the
 // matrix core differs.  Why a second mapping: v_mfma_f32_16x16x32 sustains a 14 - 21 % higher power-capped rate than
 // v_mfma_f32_32x32x16 on random operands, and the D = 512 instruction mix built on it has a 9 % higher ceiling
 // (tools/probes/stream_probe.hip, profiles/r02_stream_probe.txt).
 //
-// Mapping (one wave = 32 query rows as two 16-row halves rh, all of D; 4 waves = 128 rows; 64 keys per tile):
+// Mapping (one wave = 32 query rows as two 16-row halves rh; D <= 512: all of D per wave, 4 waves = 128 rows):
 //   * S^T = K.Q^T per 16-key block kb and row half rh: A = K[16 keys][32 d] (one ds_read_b128 per lane: key lane % 16, d chunk
 //     lane / 16), B = Q^T (resident fragments: row 16 rh + lane % 16, d chunk lane / 16).  One K fragment feeds BOTH row
 //     halves, so LDS bytes per FLOP equal the 32x32x16 kernel's.  C layout: lane (n = lane % 16, c = lane / 16) holds keys
@@ -21,7 +21,7 @@
 //     each stores whole 16-byte runs of ONE row.
 // Built for every head dim with the 32x32x16 build's tiles, so that launch plans do not depend on the build (D <= 512: 128 rows x
 // 128 keys up to D = 320, 64 keys above; D > 512: D split over two waves, 64 rows x 32 keys, partial S^T tiles summed through LDS);
-// launched for calls without an additive bias or dropout.
+// launched for unmasked, boolean-mask and dropout calls (ffpa_fwd_inst.hip; additive biases without dropout stay on the other build).
 #pragma once
 
 #include "ffpa_fwd_kernel.h"
@@ -51,12 +51,14 @@
 
 namespace ffpa {
 
+// The MFMAs are inline asm: the S^T accumulators must be VGPRs and the O^T tiles exactly the 256 AGPRs, in place (left to hipcc,
+// parts of O^T end up in VGPRs and the Q fragments in scratch); first / acc: S^T (VGPR form), acc_a: O^T (AGPR form).  The
+// operands come from ds_read / global loads / v_cvt long before: tools/check_mfma_hazards.py checks the generated ISA.
 template <typename T>
 struct Mfma16;
 template <>
 struct Mfma16<__bf16> {
   typedef Elem<__bf16>::v8 v8;
-  static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
   static __device__ __forceinline__ void first(f32x4& d, v8 a, v8 b) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b)); }
   static __device__ __forceinline__ void acc(f32x4& d, v8 a, v8 b) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b)); }
   static __device__ __forceinline__ void acc_a(f32x4& d, v8 a, v8 b) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b)); }
@@ -64,7 +66,6 @@ struct Mfma16<__bf16> {
 template <>
 struct Mfma16<_Float16> {
   typedef Elem<_Float16>::v8 v8;
-  static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
   static __device__ __forceinline__ void first(f32x4& d, v8 a, v8 b) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b)); }
   static __device__ __forceinline__ void acc(f32x4& d, v8 a, v8 b) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b)); }
   static __device__ __forceinline__ void acc_a(f32x4& d, v8 a, v8 b) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b)); }
@@ -96,8 +97,6 @@ __device__ __forceinline__ void row4_reduce2(float& t0, float& t1) {
 #endif
 }
 
-// MK (mask kind, as in ffpa_fwd_split_d_kernel): 0 = the build for calls without attn_bias / mask ranges, 2 = boolean masks
-// (FFPA_BIAS_BOOL8 bytes and / or kv_bounds ranges: what ffpa_attn_func(attn_mask=<bool>) launches).
 // LDS images of the K / V tiles: row-major [BC][D], 16-byte slot s of row `key` stored at slot s ^ swizzle(key) (applied on the
 // DMA's per-lane source offset).  K fragments are fetched by ds_read_b128 whose 16-lane groups hold 16 different keys and two
 // neighbouring slots; V^T fragments by ds_read_b64_tr_b16 whose 32-lane halves hold 8 keys x 32 bytes.  Row strides that are whole
@@ -145,7 +144,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   // would not fit next to the mask path's registers).  Everything else keeps tile-invariant per-lane offsets in registers: measured equal
   // or better (D = 512 unmasked: + 0 ... 2 %; D = 1024: 927 vs 776 TFLOPS — the scalar row form loses 16 % there on this build).
   constexpr bool kRowDma = RB % 1024 == 0 && ND == 1 && MK != 0;  // (MK = 1 / dropout builds included)
-  constexpr int RPP = kRowDma ? RB / 1024 : 1;  // pieces per row
+  static_assert(!kRowDma || RB == 1024, "the scalar row form is used where a tile row is exactly one piece");
   constexpr int KPW = BC / 4;                // keys staged per wave per tile
   constexpr int PF1 = FFPA_M16_PF1, PF2 = FFPA_M16_PF2;
   constexpr int kPreReq = ND == 2 ? FFPA_M16_K_PRE_ND2 : FFPA_M16_K_PRE;
@@ -213,8 +212,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   // ---- LDS-DMA.  A caller's head dim below D (a multiple of 8): K columns at and past it read as zeros (lanes whose source slot
   // lies there get an out-of-range offset: the descriptor's range check zero-fills them), Q columns are not loaded, O columns are
   // not stored.  Two addressing forms:
-  //   * rows that are whole pieces (D = 512): wave w stages keys 16 a + 4 w + b4, lane l -> slot l of the row; everything but the
-  //     swizzled lane offset is scalar;
+  //   * D = 512 builds with a mask path (a row = one piece): wave w stages keys 16 a + 4 w + b4, lane l -> slot l of the row;
+  //     everything but the swizzled lane offset is scalar;
   //   * other head dims: piece p = wave * PPW + i covers slots [64 p, 64 p + 64) of the row-major image; the per-lane source
   //     offsets are tile-invariant and live in PPW + PPW registers.
   const uint32_t rb_valid = (uint32_t)a.d_valid * 2u;
@@ -227,7 +226,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) {
       kvo[bb] = (uint32_t)((lane ^ m16_k_swizzle<D>(4 * wave + bb)) << 4);
-      if (RPP == 1 && (lane ^ m16_k_swizzle<D>(4 * wave + bb)) >= slots_valid) kvo[bb] = kDmaOob;  // (two-piece rows: masked per piece below)
+      if ((lane ^ m16_k_swizzle<D>(4 * wave + bb)) >= slots_valid) kvo[bb] = kDmaOob;
       vvo[bb] = (uint32_t)((lane ^ m16_v_swizzle<D>(4 * wave + bb)) << 4);
     }
 #pragma unroll
@@ -255,16 +254,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     constexpr int i = decltype(ic)::value;
     const TileSrc ts = tile_src<BC>(Kg, k_row_bytes, key0, a.Nkv, rb_valid);
     if constexpr (kRowDma) {
-      constexpr int jk = i / RPP, half = i % RPP;
-      uint32_t kv = kvo[jk & 3];
-      if constexpr (RPP > 1 && half == RPP - 1) {
-        // the row's last piece: lanes whose slot lies at or past the caller's head dim fetch zeros (a wave-uniform branch: launches
-        // whose head dim is the kernel's own skip the per-lane test)
-        if (a.d_valid != D) {
-          if (half * 64 + (opaque_lane(lane) ^ m16_k_swizzle<D>(4 * wave + (jk & 3))) >= slots_valid) kv = kDmaOob;
-        }
-      }
-      lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(ts.rsrc, k_lds, kv, kro[jk]);
+      lds_dma_row<(16 * (i >> 2) + (i & 3)) * RB, 0>(ts.rsrc, k_lds, kvo[i & 3], kro[i]);
     } else {
       lds_dma_16(ts.rsrc, (uint32_t)(uintptr_t)(Kt + (wave * PPW + i) * 1024), krel[i], 0u);
     }
@@ -273,8 +263,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     constexpr int i = decltype(ic)::value;
     const TileSrc ts = tile_src<BC>(Vg, v_row_bytes, key0, a.Nkv, rb_valid);
     if constexpr (kRowDma) {
-      constexpr int jk = i / RPP, half = i % RPP;
-      lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(ts.rsrc, v_lds, vvo[jk & 3], vro[jk]);
+      lds_dma_row<(16 * (i >> 2) + (i & 3)) * RB, 0>(ts.rsrc, v_lds, vvo[i & 3], vro[i]);
     } else {
       lds_dma_16(ts.rsrc, (uint32_t)(uintptr_t)(Vt + (wave * PPW + i) * 1024), vrel[i], 0u);
     }
