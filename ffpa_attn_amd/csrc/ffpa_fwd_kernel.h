@@ -769,8 +769,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
       }
     }
     const int tf = first / BC, te = (end + BC - 1) / BC;
-    t0 = t0 > tf ? t0 : tf;
-    nt = nt < te ? nt : te;
+    // (wave-uniform by construction; pinned to scalar registers: they feed the tile descriptors of the LDS-DMA asm)
+    t0 = __builtin_amdgcn_readfirstlane(t0 > tf ? t0 : tf);
+    nt = __builtin_amdgcn_readfirstlane(nt < te ? nt : te);
     const int r32w = q0 / 32 + qb;
     if (r32w * 32 < a.Nq) {
       free_lo = __builtin_amdgcn_readfirstlane(bp[4 * r32w + 2]);
