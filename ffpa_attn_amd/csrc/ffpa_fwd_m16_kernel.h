@@ -388,15 +388,18 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         constexpr int n = decltype(ic)::value;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (n + PF1 < N1) kf[n + PF1] = k_frag(n + PF1);
-        if constexpr (n % kStep1 == 0 && n / kStep1 < PPW) issue_v(std::integral_constant<int, n / kStep1>{}, k0);
         constexpr int s = n / NKB, kb = n % NKB;
-        if constexpr (s == 0) {
-          M::first(sacc[kb][0], kf[n], qf[s][0]);
-          M::first(sacc[kb][1], kf[n], qf[s][1]);
-        } else {
-          M::acc(sacc[kb][0], kf[n], qf[s][0]);
-          M::acc(sacc[kb][1], kf[n], qf[s][1]);
-        }
+        constexpr bool kPiece = n % kStep1 == 0 && n / kStep1 < PPW;
+#ifndef FFPA_M16_DMA_POS
+#define FFPA_M16_DMA_POS 1  // where a DMA piece sits relative to the fragment's two MFMAs: 0 in front, 1 between (+ 0.4 ... 1.7 %), 2 behind
+#endif
+        if constexpr (kPiece && FFPA_M16_DMA_POS == 0) issue_v(std::integral_constant<int, n / kStep1>{}, k0);
+        if constexpr (s == 0) M::first(sacc[kb][0], kf[n], qf[s][0]);
+        else M::acc(sacc[kb][0], kf[n], qf[s][0]);
+        if constexpr (kPiece && FFPA_M16_DMA_POS == 1) issue_v(std::integral_constant<int, n / kStep1>{}, k0);
+        if constexpr (s == 0) M::first(sacc[kb][1], kf[n], qf[s][1]);
+        else M::acc(sacc[kb][1], kf[n], qf[s][1]);
+        if constexpr (kPiece && FFPA_M16_DMA_POS == 2) issue_v(std::integral_constant<int, n / kStep1>{}, k0);
       });
       // MFMA result -> VALU reader wait states (invisible to the compiler inside asm); every accumulator is named so that no read
       // of one can be scheduled ahead of the statement
@@ -668,10 +671,13 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         constexpr int n = decltype(ic)::value;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (n + PF2 < N2) vf[n + PF2] = v_frag(n + PF2);
-        if constexpr (n % kStep2 == 0 && n / kStep2 + kPre < PPW) issue_k(std::integral_constant<int, n / kStep2 + kPre>{}, k0 + BC);
+        constexpr bool kPiece = n % kStep2 == 0 && n / kStep2 + kPre < PPW;
         constexpr int db = n % NDB, ks = n / NDB;
+        if constexpr (kPiece && FFPA_M16_DMA_POS == 0) issue_k(std::integral_constant<int, n / kStep2 + kPre>{}, k0 + BC);
         M::acc_a(oacc[db][0], vf[n], pf[ks][0]);
+        if constexpr (kPiece && FFPA_M16_DMA_POS == 1) issue_k(std::integral_constant<int, n / kStep2 + kPre>{}, k0 + BC);
         M::acc_a(oacc[db][1], vf[n], pf[ks][1]);
+        if constexpr (kPiece && FFPA_M16_DMA_POS == 2) issue_k(std::integral_constant<int, n / kStep2 + kPre>{}, k0 + BC);
       });
       __builtin_amdgcn_sched_barrier(0);
     }

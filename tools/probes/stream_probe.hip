@@ -12,6 +12,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probes/stream_probe.hip -o tools/probes/bin/stream_probe
 //   tools/probes/bin/stream_probe            (prints one PROBE line per configuration)
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) void probe_mfma16(const Args a) {
 // The kernel's instruction mix rebuilt on the 16x16x32 shape: one ds_read_b128 A fragment feeds TWO MFMAs (the two 16-row halves
 // of a wave's 32 query rows are its B operands), so LDS bytes per FLOP equal the 32x32x16 mix; NM16 MFMAs of 16 K FLOP, NDMA
 // pieces and NM16 / 2 fragment reads per wave and tile.
-template <int NM16, int NDMA, int MODE, int SHARE = 2>
+template <int NM16, int NDMA, int MODE, int SHARE = 2, int ORDER = 0>
 __global__ __launch_bounds__(256) void probe_mix16(const Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -187,23 +188,42 @@ __global__ __launch_bounds__(256) void probe_mix16(const Args a) {
   for (int f = 0; f < PF; ++f) fr[f] = frag_read(f);
   for (int t = 0; t < a.tiles; ++t) {
     constexpr int STEP = NDMA > 0 ? NF / NDMA : 1;
+    // ORDER: where the DMA piece sits relative to the fragment's two MFMAs: 0 = in front, 1 = between, 2 = behind.  (Giving every wave
+    // its own slot between two pieces was tried with one unrolled loop body per wave: 749 TFLOPS — four bodies thrash the instruction
+    // cache; with a wave-uniform branch per fragment instead: 1082.)
+    auto tile_body = [&](auto slotc) {
+      constexpr int SLOT = decltype(slotc)::value;
 #pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      __builtin_amdgcn_sched_barrier(0);
-      fr[(f + PF) & 3] = frag_read((f + PF) % NF);
-      if constexpr (NDMA > 0) {
-        if (f % STEP == 0 && f / STEP < NDMA) {
-          const int piece = f / STEP;
-          lds_dma(rsrc, lds0 + (uint32_t)(((wave * NDMA + piece) * 1024) & (128u * 1024u - 1)), voff, soff + (uint32_t)piece * 1024u);
+      for (int f = 0; f < NF; ++f) {
+        __builtin_amdgcn_sched_barrier(0);
+        fr[(f + PF) & 3] = frag_read((f + PF) % NF);
+        auto dma = [&]() {
+          if constexpr (NDMA > 0) {
+            if (f % STEP == SLOT % STEP && f / STEP < NDMA) {
+              const int piece = f / STEP;
+              lds_dma(rsrc, lds0 + (uint32_t)(((wave * NDMA + piece) * 1024) & (128u * 1024u - 1)), voff, soff + (uint32_t)piece * 1024u);
+            }
+          }
+        };
+        if constexpr (ORDER == 0) dma();
+        if constexpr (SHARE == 2) {
+          acc[(2 * f) & 63] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[f & 3], b0, acc[(2 * f) & 63], 0, 0, 0);
+          if constexpr (ORDER == 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            dma();
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          acc[(2 * f + 1) & 63] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[f & 3], b1, acc[(2 * f + 1) & 63], 0, 0, 0);
+        } else {
+          acc[f & 63] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[f & 3], (f & 1) ? b1 : b0, acc[f & 63], 0, 0, 0);
+        }
+        if constexpr (ORDER == 2) {
+          __builtin_amdgcn_sched_barrier(0);
+          dma();
         }
       }
-      if constexpr (SHARE == 2) {
-        acc[(2 * f) & 63] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[f & 3], b0, acc[(2 * f) & 63], 0, 0, 0);
-        acc[(2 * f + 1) & 63] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[f & 3], b1, acc[(2 * f + 1) & 63], 0, 0, 0);
-      } else {
-        acc[f & 63] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[f & 3], (f & 1) ? b1 : b0, acc[f & 63], 0, 0, 0);
-      }
-    }
+    };
+    tile_body(std::integral_constant<int, 0>{});
     __builtin_amdgcn_sched_barrier(0);
     soff += per_tile;
     if (soff + per_tile > a.region) soff = (uint32_t)wave * (uint32_t)(NDMA > 0 ? NDMA : 1) * 1024u;
@@ -222,9 +242,9 @@ __global__ __launch_bounds__(256) void probe_mix16(const Args a) {
   if (s == 12345.678f) a.sink[0] = s;
 }
 
-template <int NM16, int NDMA, int MODE, int SHARE = 2>
+template <int NM16, int NDMA, int MODE, int SHARE = 2, int ORDER = 0>
 static void run16(const char* name, Args a, const uint32_t* brand, int tiles) {
-  auto k = probe_mix16<NM16, NDMA, MODE, SHARE>;
+  auto k = probe_mix16<NM16, NDMA, MODE, SHARE, ORDER>;
   const int lds = 144 * 1024;
   CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   a.tiles = tiles;
@@ -389,6 +409,11 @@ int main(int argc, char** argv) {
   // a 16-row wave (D = 1024 unsplit: every fragment feeds ONE MFMA — twice the LDS reads per FLOP, no partial-S exchange)
   run16<256, 0, 1, 1>("16x16x32: mfma + one read per mfma", a, brand, T);
   run16<128, 32, 0, 1>("16x16x32: D1024mix, read per mfma +barrier", a, brand, T);
+  // what a DMA piece costs the 16x16x32 stream, and whether its place among the MFMAs matters
+  run16<256, 16, 1>("16x16x32: 256 mfma16 + 16 dma", a, brand, T / 2);
+  run16<256, 64, 1>("16x16x32: 256 mfma16 + 64 dma", a, brand, T / 2);
+  run16<256, 32, 1, 2, 1>("16x16x32: D512mix, dma between the pair", a, brand, T / 2);
+  run16<256, 32, 1, 2, 2>("16x16x32: D512mix, dma behind the pair", a, brand, T / 2);
   // (5) would TWO waves per SIMD (8 per CU, 256 registers each: 128 accumulators) hide the in-order stalls?  Same work per CU and
   // tile as the D = 512 / D = 1024 mixes, split over 8 waves (half the MFMAs, pieces and reads per wave)
   run<64, 0, 0, 2, true, 0, 8>("8 waves: mfma_only", a, 512, brand, bzero, false, T * 2);
