@@ -242,6 +242,110 @@ __global__ __launch_bounds__(256) void probe_mix16(const Args a) {
   if (s == 12345.678f) a.sink[0] = s;
 }
 
+// Loader-wave layout (D = 1024 candidate): waves 0 .. 2 are 16-row MFMA waves (NM16 MFMAs per tile, one fragment read per MFMA, HELP DMA
+// pieces each, spread over their MFMAs), wave 3 only issues LDS-DMA (NLOAD pieces per tile in two bursts); three workgroup barriers
+// per tile like the kernel (the loader drains its queue before the second and third).  FLOPs counted for the three MFMA waves.
+template <int NM16, int NLOAD, int HELP>
+__global__ __launch_bounds__(256) void probe_loader(const Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xcd = blockIdx.x & 7;
+  const char* base = a.src + (size_t)xcd * a.region;
+  const uint64_t ba = (uint64_t)base;
+  const u32x4 rsrc = {(uint32_t)ba, (uint32_t)(ba >> 32) & 0xffffu, a.region, 0x00020000u};
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(LDSAS char*)smem;
+  for (int i = threadIdx.x; i < 16384; i += blockDim.x) ((LDSAS uint32_t*)smem)[i] = 0x3f803f80u ^ (uint32_t)(i * 2654435761u >> 12 & 0x00ff00ffu);
+  __syncthreads();
+  const uint32_t voff = (uint32_t)lane * 16u;
+  constexpr uint32_t per_tile = (uint32_t)(NLOAD + 3 * HELP) * 1024u;
+  uint32_t soff = 0;
+  if (wave == 3) {
+    for (int t = 0; t < a.tiles; ++t) {
+#pragma unroll
+      for (int i = 0; i < NLOAD / 2; ++i) lds_dma(rsrc, lds0 + (uint32_t)((i * 1024) & (128u * 1024u - 1)), voff, soff + (uint32_t)i * 1024u);
+      __builtin_amdgcn_s_barrier();  // A1
+#pragma unroll
+      for (int i = NLOAD / 2; i < NLOAD; ++i) lds_dma(rsrc, lds0 + (uint32_t)((i * 1024) & (128u * 1024u - 1)), voff, soff + (uint32_t)i * 1024u);
+      __builtin_amdgcn_s_waitcnt(0x0F70 | ((NLOAD / 2) & 15) | (((NLOAD / 2) >> 4) << 14));  // the first burst has landed
+      __builtin_amdgcn_s_barrier();  // A2
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __builtin_amdgcn_s_barrier();  // B
+      soff += per_tile;
+      if (soff + per_tile > a.region) soff = 0;
+    }
+    return;
+  }
+  const u32x4 braw = *(const u32x4*)(a.bsrc + lane * 4);
+  const bf16x8 b0 = __builtin_bit_cast(bf16x8, braw);
+  f32x4p acc[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) acc[i] = (f32x4p)(0.f);
+  constexpr int PF = 3;
+  bf16x8 fr[4];
+  auto frag_read = [&](int f) -> bf16x8 {
+    const u32x4 raw = *(LDSAS const u32x4*)(smem + ((f * 1024) & 0xffff) + lane * 16);
+    return __builtin_bit_cast(bf16x8, raw);
+  };
+#pragma unroll
+  for (int f = 0; f < PF; ++f) fr[f] = frag_read(f);
+  constexpr int HALF = NM16 / 2;
+  constexpr int STEP = HELP > 0 ? NM16 / HELP : 1;
+  for (int t = 0; t < a.tiles; ++t) {
+#pragma unroll
+    for (int f = 0; f < NM16; ++f) {
+      __builtin_amdgcn_sched_barrier(0);
+      fr[(f + PF) & 3] = frag_read((f + PF) % NM16);
+      if constexpr (HELP > 0) {
+        if (f % STEP == 0 && f / STEP < HELP)
+          lds_dma(rsrc, lds0 + (uint32_t)(((NLOAD + wave * HELP + f / STEP) * 1024) & (128u * 1024u - 1)), voff, soff + (uint32_t)(NLOAD + wave * HELP + f / STEP) * 1024u);
+      }
+      acc[f & 63] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[f & 3], b0, acc[f & 63], 0, 0, 0);
+      if (f == HALF - 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();  // A1 (after the first GEMM)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_s_barrier();  // A2 (before the second)
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_barrier();  // B
+    soff += per_tile;
+    if (soff + per_tile > a.region) soff = 0;
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 64; ++i) sum += acc[i][0];
+  if (sum == 12345.678f) a.sink[0] = sum;
+}
+
+template <int NM16, int NLOAD, int HELP>
+static void run_loader(const char* name, Args a, const uint32_t* brand, int tiles) {
+  auto k = probe_loader<NM16, NLOAD, HELP>;
+  const int lds = 144 * 1024;
+  CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  a.tiles = tiles;
+  a.bsrc = brand;
+  hipLaunchKernelGGL(k, dim3(256), dim3(256), lds, 0, a);
+  CHECK(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  CHECK(hipEventRecord(e0));
+  for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(k, dim3(256), dim3(256), lds, 0, a);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= 3;
+  const double flops = (double)NM16 * tiles * 3 * 256 * 16384.0;
+  const double bytes_cu = (double)(NLOAD + 3 * HELP) * 1024.0 * tiles;
+  printf("PROBE %-46s 3 mfma waves + loader tiles %5d | %8.3f ms | MFMA %7.1f TFLOP/s (%5.1f%% of 2500) | LDS-DMA %6.2f TB/s chip | %.0f ns per tile\n", name, tiles,
+         ms, flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 2.5e15 * 100.0, bytes_cu * 256 / (ms * 1e-3) / 1e12, ms * 1e6 / tiles);
+  fflush(stdout);
+}
+
 template <int NM16, int NDMA, int MODE, int SHARE = 2, int ORDER = 0>
 static void run16(const char* name, Args a, const uint32_t* brand, int tiles) {
   auto k = probe_mix16<NM16, NDMA, MODE, SHARE, ORDER>;
@@ -409,6 +513,11 @@ int main(int argc, char** argv) {
   // a 16-row wave (D = 1024 unsplit: every fragment feeds ONE MFMA — twice the LDS reads per FLOP, no partial-S exchange)
   run16<256, 0, 1, 1>("16x16x32: mfma + one read per mfma", a, brand, T);
   run16<128, 32, 0, 1>("16x16x32: D1024mix, read per mfma +barrier", a, brand, T);
+  // D = 1024 with a loader wave: 3 x 16-row MFMA waves (128 MFMA16 per 32-key tile each), 128 pieces per tile
+  run_loader<128, 128, 0>("loader: 128 mfma16 x3, loader issues all 128", a, brand, T);
+  run_loader<128, 104, 8>("loader: 128 mfma16 x3, loader 104 + 8 per mfma wave", a, brand, T);
+  run_loader<128, 80, 16>("loader: 128 mfma16 x3, loader 80 + 16 per mfma wave", a, brand, T);
+  run_loader<128, 0, 0>("loader: 128 mfma16 x3, no dma at all", a, brand, T);
   // what a DMA piece costs the 16x16x32 stream, and whether its place among the MFMAs matters
   run16<256, 16, 1>("16x16x32: 256 mfma16 + 16 dma", a, brand, T / 2);
   run16<256, 64, 1>("16x16x32: 256 mfma16 + 64 dma", a, brand, T / 2);
