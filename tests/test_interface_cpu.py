@@ -103,3 +103,21 @@ def test_mask_kv_bounds_per_32_row_block():
   assert pad[0, 0].tolist() == [[0, 60, 0, 60], [0, 60, 0, 60]]
   alibi = mask_kv_bounds(-torch.arange(64.0).view(1, 1, 1, 64).expand(1, 1, 32, 64) * 0.5, 32, 64)  # a real bias: only key 0 adds 0
   assert alibi[0, 0].tolist() == [[0, 64, 0, 1]]
+
+
+def test_bench_names_the_kernel_the_dispatch_launches():
+  """bench.py's roofline.kernel label follows csrc/ffpa_fwd_inst.hip: the 16x16x32-MFMA build from FFPA_M16_MIN_D up, except for
+  additive biases and short-query launches."""
+  import os
+  import re
+  import sys
+
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  sys.path.insert(0, root)
+  import bench
+
+  text = open(os.path.join(root, "ffpa_attn_amd", "csrc", "ffpa_fwd_m16_kernel.h")).read()
+  min_d = int(re.search(r"#define FFPA_M16_MIN_D (\d+)", text).group(1))
+  for name, w in bench.WORKLOADS.items():
+    want_m16 = w["D"] >= min_d and w["Nq"] > 32 and w["mask"] != "key_bias"
+    assert (bench.dominant_kernel(w) == "ffpa_fwd_m16_kernel") == want_m16, name
