@@ -272,6 +272,7 @@ def forward(
   num_splits: int = 0,
   plan_out: dict | None = None,
   kv_bounds: torch.Tensor | bool | None = None,
+  causal_row_mod: int = 0,
 ) -> tuple[torch.Tensor, torch.Tensor | None]:
   """Run the gfx950 kernel on the current stream of ``q.device``; returns ``(o, lse)``.
 
@@ -323,8 +324,7 @@ def forward(
     q, k, v = (torch.nn.functional.pad(t, pad) for t in (q, k, v))
   group = Hq // Hkv if Hkv and Hq % Hkv == 0 else 1
   has_bias = attn_bias is not None and attn_bias.numel() > 0
-  causal_row_mod = 0
-  packed = group > 1 and Nq <= 7 and group * Nq <= 32 and not has_bias and dropout_p == 0.0
+  packed = causal_row_mod == 0 and group > 1 and Nq <= 7 and group * Nq <= 32 and not has_bias and dropout_p == 0.0
   if packed:
     # [B, Hq, Nq, D] -> [B, Hkv, group*Nq, D]: packed row r = (head in group) * Nq + (query row)
     q = q.contiguous().view(B, Hkv, group * Nq, Dp)

@@ -203,3 +203,18 @@ def test_dropout_keeps_the_same_scores_as_the_other_build(hip, D):
       _same_up_to_rounding(o16, l16, o32, l32, q.dtype, f"dropout {name} causal={causal}")
       o_nodrop, _ = hip.forward(q, k, v, bias, causal, D ** -0.5, kv_bounds=False)
       assert (o16.float() - o_nodrop.float()).abs().max().item() > 0.02
+
+
+@pytest.mark.parametrize("D", [128, 512, 1024])
+def test_caller_packed_query_heads_at_prefill_sizes(hip, D):
+  """ffpa_fwd_params.causal_row_mod with more than 32 packed rows (prefill tiles, both builds): a caller that packs the query heads
+  of a KV group into the row axis gets, row for row, the bits of the unpacked call — each row's recurrence is the same, only its
+  place in a tile differs."""
+  B, Hkv, g, Nq, Nkv = 2, 2, 4, 40, 333
+  q = _rand((B, Hkv * g, Nq, D), seed=91)
+  k, v = _rand((B, Hkv, Nkv, D), seed=92), _rand((B, Hkv, Nkv, D), seed=93)
+  for off in (Nkv - Nq, 0, 100):
+    o_ref, l_ref = hip.forward(q, k, v, None, True, D ** -0.5, causal_offset=off, num_splits=1)
+    qp = q.view(B, Hkv, g * Nq, D)
+    o, lse = hip.forward(qp, k, v, None, True, D ** -0.5, causal_offset=off, causal_row_mod=Nq, num_splits=1)
+    assert torch.equal(o.view(B, Hkv * g, Nq, D), o_ref) and torch.equal(lse.view(B, Hkv * g, Nq), l_ref), (D, off)
