@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import argparse
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -138,6 +139,12 @@ def build(force: bool = False, jobs: int | None = None, save_temps: bool = True,
       tasks.append((tcapi, [hipcc, *CXXFLAGS, "-DFFPA_INST_SAFE=1", "-c", os.path.join(CSRC, "ffpa_capi.hip"), "-o", tcapi], None))
   if verbose:
     print(f"[ffpa_attn_amd.build] compiling {len(tasks)} objects for {ARCH} with {jobs} jobs", flush=True)
+  # longest jobs first (head dims >= 320 carry the 16x16x32 builds as well: 2 - 3 x the compile time of the small ones)
+  def cost(t):
+    m = re.search(r"ffpa_fwd_d(\d+)", t[0])
+    return -(int(m.group(1)) + (2048 if m and int(m.group(1)) >= 320 else 0)) if m else 0
+
+  tasks.sort(key=cost)
   with ThreadPoolExecutor(max_workers=jobs) as pool:
     list(pool.map(lambda t: _run(t[1], cwd=t[2]), tasks))
   if save_temps:
