@@ -49,6 +49,23 @@
 #define FFPA_M16_X 0
 #endif
 
+// Developer instrumentation (-DFFPA_M16_TIMING, tools/gpu_phase_times.py; never in the shipped build): every wave accumulates the shader
+// clock cycles it spends in six phases of the KV-tile loop and lane 0 writes the totals over the LSE of its first rows.
+#ifdef FFPA_M16_TIMING
+#define FFPA_TSTAMP(i)                                         \
+  do {                                                         \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    tacc[i] += t_ - tprev;                                     \
+    tprev = t_;                                                \
+    __builtin_amdgcn_sched_barrier(0);                         \
+  } while (0)
+#else
+#define FFPA_TSTAMP(i) \
+  do {                 \
+  } while (0)
+#endif
+
 namespace ffpa {
 
 // The MFMAs are inline asm: the S^T accumulators must be VGPRs and the O^T tiles exactly the 256 AGPRs, in place (left to hipcc,
@@ -370,6 +387,11 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     __syncthreads();
   }
 
+#ifdef FFPA_M16_TIMING
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = __builtin_amdgcn_s_memtime();
+  const unsigned long long tstart = tprev;
+#endif
   for (int j = t0; j < nt; ++j) {
     const int k0 = j * BC;
 
@@ -429,8 +451,10 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 #pragma unroll
         for (int rh = 0; rh < 2; ++rh) *(FFPA_LDS f32x4*)(xw + (kb * 2 + rh) * 1024) = sacc[kb][rh];
     }
+    FFPA_TSTAMP(0);  // QK^T loop (+ ND == 2: partial S^T stores)
     // barrier A1: every wave is done reading K(j) (ND == 2: and the partial S^T tiles are visible)
     __syncthreads();
+    FFPA_TSTAMP(1);  // wait at barrier A1
     __builtin_amdgcn_sched_barrier(0);
     pre_k_group(std::integral_constant<int, 0>{});
 
@@ -654,9 +678,11 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     // ================= O^T += V^T.P^T =================
     {
       __builtin_amdgcn_sched_barrier(0);
+      FFPA_TSTAMP(2);  // softmax + the K(j+1) pieces issued inside it
       // barrier A2: V(j) has landed on every wave (all but the kPre younger K pieces have retired)
       dma_wait_except<kPre>();
       __syncthreads();
+      FFPA_TSTAMP(3);  // V(j) drain + wait at barrier A2
       v8 vf[N2];
       auto v_frag = [&](int n) -> v8 {
         const int db = n % NDB, ks = n / NDB;
@@ -682,9 +708,11 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    FFPA_TSTAMP(4);  // PV loop
     // barrier B: every wave is done reading V(j); K(j+1) has landed and is visible
     dma_wait_all();
     __syncthreads();
+    FFPA_TSTAMP(5);  // K(j+1) drain + wait at barrier B
   }
 
   // ================= epilogue (prefill.cuh:1018-1093) =================
@@ -740,11 +768,20 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       }
       if (ok && dh * DW + db * 16 + 4 * (c & ~1) < a.d_valid) *(u32x4*)(op + db * 16) = run;
     }
+#ifdef FFPA_M16_TIMING
+    if (a.lse != nullptr && lane == 0) {  // 8 floats per wave at LSE row q0 + 8 * wave: six phase totals, whole kernel, KV tiles
+      float* tp = a.lse + ((int64_t)b * a.Hq + hq) * a.Nq + q0 + 8 * wave;
+      for (int i = 0; i < 6; ++i) tp[i] = (float)tacc[i];
+      tp[6] = (float)(__builtin_amdgcn_s_memtime() - tstart);
+      tp[7] = (float)(nt - t0);
+    }
+#else
     if (a.lse != nullptr && c == 0 && dh == 0) {
 #pragma unroll
       for (int rh = 0; rh < 2; ++rh)
         if (qrow[rh] < a.Nq) a.lse[((int64_t)b * a.Hq + hq) * a.Nq + qrow[rh]] = __logf(l_tot[rh]) + m_run[rh] * 0.6931471805599453f;
     }
+#endif
   }
 }
 
