@@ -242,6 +242,129 @@ __global__ __launch_bounds__(256) void probe_mix16(const Args a) {
   if (s == 12345.678f) a.sink[0] = s;
 }
 
+// One wave per SIMD vs two: the D = 512 tile WITH its softmax phase.  Per tile and wave: NM16 MFMAs in two halves (QK^T, PV) with
+// their fragment reads (SHARE MFMAs per read) and NDMA pieces, NV VALU instructions (a quarter of them v_exp_f32) between the halves,
+// three barriers.  WAVES = 4: 32-row waves (NM16 = 256, SHARE = 2, NV = 300); WAVES = 8: 16-row waves, two per SIMD, each half the
+// work (NM16 = 128, SHARE = 1, NV = 150, 128 accumulator registers) — the second wave of a SIMD can run MFMAs under the first one's VALU.
+template <int WAVES, int NM16, int NDMA, int SHARE, int NV, bool PINGPONG = false>
+__global__ __launch_bounds__(WAVES * 64) void probe_soft(const Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xcd = blockIdx.x & 7;
+  const char* base = a.src + (size_t)xcd * a.region;
+  const uint64_t ba = (uint64_t)base;
+  const u32x4 rsrc = {(uint32_t)ba, (uint32_t)(ba >> 32) & 0xffffu, a.region, 0x00020000u};
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(LDSAS char*)smem;
+  for (int i = threadIdx.x; i < 16384; i += blockDim.x) ((LDSAS uint32_t*)smem)[i] = 0x3f803f80u ^ (uint32_t)(i * 2654435761u >> 12 & 0x00ff00ffu);
+  __syncthreads();
+  const u32x4 braw = *(const u32x4*)(a.bsrc + lane * 4);
+  const u32x4 braw2 = *(const u32x4*)(a.bsrc + ((lane + 7) & 63) * 4);
+  const bf16x8 b0 = __builtin_bit_cast(bf16x8, braw), b1 = __builtin_bit_cast(bf16x8, braw2);
+  constexpr int NACC = WAVES == 4 ? 64 : 32;
+  f32x4p acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = (f32x4p)(0.f);
+  float vs[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) vs[i] = (float)(lane + i) * 1e-3f;
+  const uint32_t voff = (uint32_t)lane * 16u;
+  constexpr uint32_t per_tile = (uint32_t)(WAVES * NDMA) * 1024u;
+  uint32_t soff = (uint32_t)wave * (uint32_t)NDMA * 1024u;
+  constexpr int PF = 3;
+  constexpr int NF = NM16 / SHARE;
+  constexpr int STEP = NF / NDMA;
+  bf16x8 fr[4];
+  auto frag_read = [&](int f) -> bf16x8 {
+    const u32x4 raw = *(LDSAS const u32x4*)(smem + ((f * 1024) & 0xffff) + lane * 16);
+    return __builtin_bit_cast(bf16x8, raw);
+  };
+#pragma unroll
+  for (int f = 0; f < PF; ++f) fr[f] = frag_read(f);
+  auto mfma_half = [&](auto hc) {
+    constexpr int h = decltype(hc)::value;
+#pragma unroll
+    for (int f = h * (NF / 2); f < (h + 1) * (NF / 2); ++f) {
+      __builtin_amdgcn_sched_barrier(0);
+      fr[(f + PF) & 3] = frag_read((f + PF) % NF);
+      if (f % STEP == 0 && f / STEP < NDMA)
+        lds_dma(rsrc, lds0 + (uint32_t)(((wave * NDMA + f / STEP) * 1024) & (128u * 1024u - 1)), voff, soff + (uint32_t)(f / STEP) * 1024u);
+      if constexpr (SHARE == 2) {
+        acc[(2 * f) & (NACC - 1)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[f & 3], b0, acc[(2 * f) & (NACC - 1)], 0, 0, 0);
+        acc[(2 * f + 1) & (NACC - 1)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[f & 3], b1, acc[(2 * f + 1) & (NACC - 1)], 0, 0, 0);
+      } else {
+        acc[f & (NACC - 1)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[f & 3], (f & 1) ? b1 : b0, acc[f & (NACC - 1)], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto valu = [&]() {
+    // the softmax stand-in: NV VALU instructions, 8 independent chains, every fourth a quarter-rate exponential
+#pragma unroll
+    for (int i = 0; i < NV / 4; ++i) {
+      float& v = vs[i & 7];
+      v = v * 1.0001f + 0.5f;
+      v = v - 0.25f;
+      v = __builtin_amdgcn_exp2f(v);
+      v = v + vs[(i + 3) & 7] * 0.125f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_barrier();
+  };
+  // PINGPONG: the second wave of every SIMD (waves 4 .. 7) runs one phase behind the first: while one of the two is in its softmax
+  // stand-in the other issues MFMAs (phases are still separated by workgroup barriers, three per tile)
+  const bool late = PINGPONG && wave >= WAVES / 2;
+  if (late) {  // one MFMA phase ahead of the common loop: from here on this wave is one barrier-to-barrier slot behind its SIMD partner
+    mfma_half(std::integral_constant<int, 1>{});
+    bar();
+  }
+  for (int t = 0; t < a.tiles; ++t) {
+    mfma_half(std::integral_constant<int, 0>{});
+    bar();
+    valu();
+    bar();
+    mfma_half(std::integral_constant<int, 1>{});
+    bar();
+    soff += per_tile;
+    if (soff + per_tile > a.region) soff = (uint32_t)wave * (uint32_t)NDMA * 1024u;
+  }
+  if (PINGPONG && !late) bar();  // (the early waves meet the late waves' last barrier)
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) sum += acc[i][0];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sum += vs[i];
+  if (sum == 12345.678f) a.sink[0] = sum;
+}
+
+template <int WAVES, int NM16, int NDMA, int SHARE, int NV, bool PINGPONG = false>
+static void run_soft(const char* name, Args a, const uint32_t* brand, int tiles) {
+  auto k = probe_soft<WAVES, NM16, NDMA, SHARE, NV, PINGPONG>;
+  const int lds = 144 * 1024;
+  CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  a.tiles = tiles;
+  a.bsrc = brand;
+  hipLaunchKernelGGL(k, dim3(256), dim3(WAVES * 64), lds, 0, a);
+  CHECK(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  CHECK(hipEventRecord(e0));
+  for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(k, dim3(256), dim3(WAVES * 64), lds, 0, a);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= 3;
+  const double flops = (double)NM16 * tiles * WAVES * 256 * 16384.0;
+  printf("PROBE %-52s waves/CU %2d tiles %5d | %8.3f ms | MFMA %7.1f TFLOP/s (%5.1f%% of 2500) | %.0f ns per tile\n", name, WAVES, tiles, ms,
+         flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 2.5e15 * 100.0, ms * 1e6 / tiles);
+  fflush(stdout);
+}
+
 // Loader-wave layout (D = 1024 candidate): waves 0 .. 2 are 16-row MFMA waves (NM16 MFMAs per tile, one fragment read per MFMA, HELP DMA
 // pieces each, spread over their MFMAs), wave 3 only issues LDS-DMA (NLOAD pieces per tile in two bursts); three workgroup barriers
 // per tile like the kernel (the loader drains its queue before the second and third).  FLOPs counted for the three MFMA waves.
@@ -513,6 +636,13 @@ int main(int argc, char** argv) {
   // a 16-row wave (D = 1024 unsplit: every fragment feeds ONE MFMA — twice the LDS reads per FLOP, no partial-S exchange)
   run16<256, 0, 1, 1>("16x16x32: mfma + one read per mfma", a, brand, T);
   run16<128, 32, 0, 1>("16x16x32: D1024mix, read per mfma +barrier", a, brand, T);
+  // the D = 512 tile with its softmax phase: one 32-row wave per SIMD vs two 16-row waves per SIMD
+  run_soft<4, 256, 32, 2, 0>("D512 tile, 4 waves, no softmax stand-in", a, brand, T / 2);
+  run_soft<4, 256, 32, 2, 300>("D512 tile, 4 waves x 32 rows, 300 VALU", a, brand, T / 2);
+  run_soft<8, 128, 16, 1, 0>("D512 tile, 8 waves x 16 rows, no softmax stand-in", a, brand, T / 2);
+  run_soft<8, 128, 16, 1, 150>("D512 tile, 8 waves x 16 rows, 150 VALU each", a, brand, T / 2);
+  run_soft<8, 128, 16, 1, 150, true>("D512 tile, 8 waves x 16 rows, 150 VALU, ping-pong", a, brand, T / 2);
+  run_soft<8, 128, 16, 1, 0, true>("D512 tile, 8 waves x 16 rows, no VALU, ping-pong", a, brand, T / 2);
   // D = 1024 with a loader wave: 3 x 16-row MFMA waves (128 MFMA16 per 32-key tile each), 128 pieces per tile
   run_loader<128, 128, 0>("loader: 128 mfma16 x3, loader issues all 128", a, brand, T);
   run_loader<128, 104, 8>("loader: 128 mfma16 x3, loader 104 + 8 per mfma wave", a, brand, T);
