@@ -115,7 +115,7 @@ int FFPA_CAT(launch_fwd_d, FFPA_INST_D)(int dtype, int safe, int variant, const 
   }
   if (a.bias_dtype == 0 && a.kv_bounds == nullptr) {  // no attn_bias, no mask ranges: the build without any bias path
     if constexpr (D >= FFPA_M16_MIN_D) {
-      if (!(a.flags & 0x10u)) {  // (FFPA_FLAG_NO_M16 keeps the 32x32x16 build: A/B runs, tests)
+      if (!(a.flags & 0x10u) && a.scale_log2 > 0.f) {  // (FFPA_FLAG_NO_M16 keeps the 32x32x16 build: A/B runs, tests; so do scales <= 0: this build folds the scale into the exponent's FMA)
         if (dtype == 0) return launch_m16<__bf16, D, 0>(a, stream);
         if (dtype == 1) return launch_m16<_Float16, D, 0>(a, stream);
         return -4;
@@ -127,7 +127,7 @@ int FFPA_CAT(launch_fwd_d, FFPA_INST_D)(int dtype, int safe, int variant, const 
   }
   if (a.bias_dtype == 4) {  // boolean mask (+ ranges): the build that carries only that path
     if constexpr (D >= FFPA_M16_MIN_D) {
-      if (!(a.flags & 0x10u)) {
+      if (!(a.flags & 0x10u) && a.scale_log2 > 0.f) {
         if (dtype == 0) return launch_m16<__bf16, D, 2>(a, stream);
         if (dtype == 1) return launch_m16<_Float16, D, 2>(a, stream);
         return -4;

@@ -48,6 +48,9 @@
 #ifndef FFPA_M16_X
 #define FFPA_M16_X 0
 #endif
+#ifndef FFPA_M16_FUSE_SCALE
+#define FFPA_M16_FUSE_SCALE 1  // 0 (A/B): multiply the scores by the softmax scale up front, as the 32x32x16 build does
+#endif
 
 // Developer instrumentation (-DFFPA_M16_TIMING, tools/gpu_phase_times.py; never in the shipped build): every wave accumulates the shader
 // clock cycles it spends in six phases of the KV-tile loop and lane 0 writes the totals over the LSE of its first rows.
@@ -458,14 +461,18 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     pre_k_group(std::integral_constant<int, 0>{});
 
-    // x[kb][rh][r] = score(row 16 rh + n, key k0 + 16 kb + 4 c + r)
+    // x[kb][rh][r] = score(row 16 rh + n, key k0 + 16 kb + 4 c + r) / sc: the softmax scale is folded into the exponent's FMA
+    // (p = exp2(x sc - m): one instruction instead of a multiply here and a subtract there, 32 VALU instructions per tile less) and
+    // applied to the row max after its reduction — max(x sc) = sc max(x) needs sc > 0 (the launch side sends other scales to the
+    // 32x32x16 build), and an additive bias needs the scaled score: the MK = 1 build multiplies here and subtracts there.
     float x[NKB][2][4];
+    constexpr bool kFuse = MK != 1 && FFPA_M16_FUSE_SCALE != 0;  // (launch side: these builds only see softmax_scale > 0)
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int rh = 0; rh < 2; ++rh)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[kb][rh][r] = sacc[kb][rh][r] * a.scale_log2;
+        for (int r = 0; r < 4; ++r) x[kb][rh][r] = kFuse ? sacc[kb][rh][r] : sacc[kb][rh][r] * a.scale_log2;
     if constexpr (ND == 2) {
       // + the other D-half's partial (a + b == b + a: both waves of a row block see bit-identical scores, so their softmax states agree)
       FFPA_LDS const char* xr = Xb + (wave ^ 1) * 4096 + lane * 16;
@@ -475,7 +482,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         for (int rh = 0; rh < 2; ++rh) {
           const f32x4 t = *(FFPA_LDS const f32x4*)(xr + (kb * 2 + rh) * 1024);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) x[kb][rh][r] = (sacc[kb][rh][r] + t[r]) * a.scale_log2;
+          for (int r = 0; r < 4; ++r) x[kb][rh][r] = kFuse ? sacc[kb][rh][r] + t[r] : (sacc[kb][rh][r] + t[r]) * a.scale_log2;
         }
     }
     pre_k_group(std::integral_constant<int, 1>{});
@@ -611,6 +618,10 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       tmax[rh] = t;
     }
     row4_reduce2<true>(tmax[0], tmax[1]);
+    if constexpr (kFuse) {  // (exact: rounding is monotonic, fl(sc max x) = max fl(sc x); -inf stays -inf)
+      tmax[0] *= a.scale_log2;
+      tmax[1] *= a.scale_log2;
+    }
     pre_k_group(std::integral_constant<int, 2>{});
     const float m_new0 = fmaxf(m_run[0], tmax[0]), m_new1 = fmaxf(m_run[1], tmax[1]);
     const bool grow0 = m_new0 > m_run[0] + a.thr, grow1 = m_new1 > m_run[1] + a.thr;
@@ -647,7 +658,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(x[kb][rh][r] - m_use);
+          const float p = __builtin_amdgcn_exp2f(kFuse ? __builtin_fmaf(x[kb][rh][r], a.scale_log2, -m_use) : x[kb][rh][r] - m_use);
           psum += p;  // row sum from the unrounded P (prefill.cuh:755-756)
           pf[kb >> 1][rh][4 * (kb & 1) + r] = (T)p;
         }
