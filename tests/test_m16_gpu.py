@@ -218,3 +218,19 @@ def test_caller_packed_query_heads_at_prefill_sizes(hip, D):
     qp = q.view(B, Hkv, g * Nq, D)
     o, lse = hip.forward(qp, k, v, None, True, D ** -0.5, causal_offset=off, causal_row_mod=Nq, num_splits=1)
     assert torch.equal(o.view(B, Hkv * g, Nq, D), o_ref) and torch.equal(lse.view(B, Hkv * g, Nq), l_ref), (D, off)
+
+
+def test_non_positive_scale_takes_the_other_build(hip):
+  """This build folds softmax_scale into the exponent's FMA and scales the row max after its reduction — exact only for a positive
+  scale; zero / negative scales (legal, if unusual) are served by the 32x32x16 build: same bits as with FFPA_FLAG_NO_M16, and right."""
+  q, k, v = _rand((1, 2, 200, D), seed=101), _rand((1, 2, 333, D), seed=102), _rand((1, 2, 333, D), seed=103)
+  for scale in (-0.044, 0.0):
+    o, lse = hip.forward(q, k, v, None, True, scale)
+    o32, l32 = hip.forward(q, k, v, None, True, scale, flags=hip.FLAG_NO_M16)
+    assert torch.equal(o, o32) and torch.equal(lse, l32), scale
+    s = (q.float() @ k.float().transpose(-1, -2)) * scale
+    r, c = torch.arange(200, device="cuda")[:, None], torch.arange(333, device="cuda")[None, :]
+    s = s.masked_fill(c > r + 133, float("-inf"))
+    want = torch.softmax(s, -1) @ v.float()
+    assert (o.float() - want).abs().max().item() < 1e-2, scale
+    assert (lse - torch.logsumexp(s, -1)).abs().max().item() < 1e-3, scale
