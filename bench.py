@@ -2,8 +2,10 @@
 
     python bench.py                                  # BASELINE metric: cfg2 = B1 H32 N8192 D512 bf16, 1 GPU
     python bench.py --workload cfg3 | cfg4_mask | cfg4_offset0 | cross | gqa | attn_mask | dropout | non_aligned | decode | ...
+    python bench.py --sweep [--sweep-dims 320,512,1024]   # the reference bench's one-shot case table (one process, one table per head dim)
+    python bench.py --gpus N [--workload cfg5] [--gather]  # N > 1 without a launcher: spawns its own N ranks (free port, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N [--workload cfg5] [--gather]
+        bench.py --gpus N [--workload cfg5] [--gather]     # ... or under torchrun (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env)
 
 One "step" = one pass of the hot path (ffpa_attn_func -> ffpa_attn::_fwd_hip -> C-ABI -> HIP kernel) over one
 synthetic batch already resident in HBM.  FLOPs = 4*B*Hq*D*valid_pairs, the reference's own model
@@ -33,8 +35,11 @@ timed on this box's host cores on a bounded sample.  `ref_protocol` repeats the 
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -82,12 +87,42 @@ WORKLOADS = {
 }
 
 
-def dominant_kernel(w: dict) -> str:
-  """The kernel the roofline object is about (csrc/ffpa_fwd_inst.hip's dispatch): head dims above 256 without an additive bias
-  run the 16x16x32-MFMA build, everything else the 32x32x16-MFMA build."""
-  if w["D"] > 256 and w["Nq"] > 32 and w["mask"] != "key_bias":
-    return "ffpa_fwd_m16_kernel"
-  return "ffpa_fwd_split_d_kernel"
+def build_identity() -> dict:
+  """What binary produced the numbers: sha256 of the loaded library (first 16 hex digits), its version string, and the git head of the
+  tree it was built from when that is knowable (`git rev-parse`; the GPU box receives a snapshot without .git, where
+  `tools/gpu_round.sh` exports FFPA_GIT_HEAD)."""
+  from ffpa_attn_amd import hip
+
+  out = {"lib": os.path.relpath(hip.LIB_PATH, ROOT)}
+  try:
+    out["lib_sha16"] = hashlib.sha256(open(hip.LIB_PATH, "rb").read()).hexdigest()[:16]
+    out["lib_version"] = hip.load_library().ffpa_attn_version().decode()
+  except OSError:
+    pass
+  head = os.environ.get("FFPA_GIT_HEAD")
+  if not head:
+    try:
+      head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip()
+      dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--untracked-files=no"], capture_output=True, text=True, timeout=5).stdout.strip()
+      if head and dirty:
+        head += "+dirty"
+    except (OSError, subprocess.SubprocessError):
+      head = ""
+  if head:
+    out["git_head"] = head
+  return out
+
+
+def planned_kernel(w: dict, q, k, v, mask, scale: float) -> dict:
+  """The launch plan of this workload's call, from the C-ABI (ffpa_attn_fwd_plan / ffpa_attn_fwd_kernel): the kernel the roofline
+  object is about is whatever the library says it launches — no copy of the dispatch rule lives here."""
+  from ffpa_attn_amd import hip
+
+  plan = {}
+  bias = None if (w["via"] == "op_offset0" or mask is None) else (mask if mask.dim() == 4 else mask.view(1, 1, *mask.shape))
+  hip.forward(q, k, v, bias, bool(w["causal"]), scale, causal_offset=0 if w["via"] == "op_offset0" else None, dropout_p=w["dropout"],
+              philox_seed=1, return_lse=False, plan_out=plan)
+  return plan
 
 
 def metric_name(name: str, w: dict) -> str:
@@ -126,7 +161,7 @@ def measured_traffic(workload: str):
   (`rocprofv3 --pmc FETCH_SIZE` x2 — gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md §HBM — plus
   `--pmc WRITE_SIZE`; tools/gpu_round.sh stage wprof, summarised by tools/pmc_summary.py).  bench.py cannot profile
   itself, so this is a profile artefact named by `traffic_source`, or (None, None) when none is committed."""
-  for rnd in ("r02", "r01"):
+  for rnd in ("r03", "r02", "r01"):
     path = os.path.join(ROOT, "profiles", f"{rnd}_bench_{workload}_pmc.json")
     if os.path.exists(path):
       try:
@@ -220,7 +255,9 @@ def accuracy(w: dict, q, k, v, mask, scale: float) -> dict:
   d = (o.float() - ref.float()).abs()
   res["max_abs_err_vs_sdpa"] = round(d.max().item(), 6)
   res["mean_abs_err_vs_sdpa"] = round(d.mean().item(), 8)
-  lse_err = 0.0
+  # the same two outputs against fp32 MATH (softmax(scale*QK^T [+mask]) V in fp32, heads {0, Hq-1} of batch 0): which side of a
+  # kernel-vs-SDPA difference is off.  Both store bf16, so neither can beat half an output ulp (2^-9 |O|).
+  lse_err = err_math = err_math_sdpa = 0.0
   g = w["Hq"] // w["Hkv"]
   rows = torch.arange(w["Nq"], device=q.device)[:, None]
   cols = torch.arange(w["Nkv"], device=q.device)[None, :]
@@ -233,9 +270,14 @@ def accuracy(w: dict, q, k, v, mask, scale: float) -> dict:
     elif mask is not None:
       s = s + mask.float().reshape(-1, w["Nkv"])  # the bench's additive masks are key biases: [1, Nkv] broadcasts over the rows
     lse_err = max(lse_err, (lse[0, h] - torch.logsumexp(s, -1)).abs().max().item())
-    del s
+    want = torch.softmax(s, -1) @ v[0, h // g].float()
+    err_math = max(err_math, (o[0, h].float() - want).abs().max().item())
+    err_math_sdpa = max(err_math_sdpa, (ref[0, h].float() - want).abs().max().item())
+    del s, want
   res["max_abs_lse_err"] = round(lse_err, 7)
-  res["lse_ref"] = "fp32 logsumexp(scale*QK^T [+mask]) of heads {0, Hq-1} of batch 0"
+  res["max_abs_err_vs_fp32_math"] = round(err_math, 6)
+  res["sdpa_max_abs_err_vs_fp32_math"] = round(err_math_sdpa, 6)
+  res["lse_ref"] = "fp32 logsumexp(scale*QK^T [+mask]) of heads {0, Hq-1} of batch 0 (the fp32-math errors use the same heads)"
   flops = valid_pairs_flops(w, w["B"])
   for _ in range(2):
     torch.nn.functional.scaled_dot_product_attention(q, k, v, **sdpa_kw)
@@ -252,6 +294,136 @@ def accuracy(w: dict, q, k, v, mask, scale: float) -> dict:
   return res
 
 
+def stub_main(args, world: int, rank: int) -> None:
+  """(tests) The launch / barrier / max-over-ranks / one-JSON-line plumbing of this script on CPU over `--stub-backend` (gloo), with a
+  short sleep standing in for the step: what tests/test_bench_spawn.py runs at world size 2.  Not a benchmark."""
+  import torch.distributed as dist
+
+  if world > 1:
+    dist.init_process_group(args.stub_backend)
+  for _ in range(args.warmup):
+    time.sleep(0.001)
+  if world > 1:
+    dist.barrier()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    time.sleep(0.002 * (1 + rank))  # ranks differ: the reported time must be the slowest rank's
+  local = time.perf_counter() - t0
+  if world > 1:
+    dist.barrier()
+  total = time.perf_counter() - t0
+  every = [local]
+  if world > 1:
+    t = torch.tensor([total], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    total = float(t.item())
+    mine = torch.tensor([local], dtype=torch.float64)
+    got = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    every = [float(x.item()) for x in got]
+  if rank == 0:
+    print(json.dumps({"stub": True, "backend": args.stub_backend, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": round(total / args.steps * 1e3, 4), "per_rank_s": [round(x, 4) for x in every]}), flush=True)
+  if world > 1:
+    dist.destroy_process_group()
+
+
+def sweep_main(args) -> None:
+  """The reference bench's one-shot sweep (`python -m ffpa_attn.bench`: cli/_runner_fwd.py:599-672 runs self / cross / decode / gqa /
+  causal / attn-mask / dropout / non-aligned for a head dim in one process and prints one table, :473): the same eight cases at its
+  defaults (B 1, H 32, N 8192) for every head dim of --sweep-dims, this kernel next to SDPA on the same GPU, one table per head dim on
+  stderr and ONE JSON line on stdout."""
+  from ffpa_attn_amd import hip
+
+  dev = torch.device("cuda", 0)
+  hip.load_library()
+  B, H, N = 1, 32, 8192
+  out = {}
+  for D in [int(x) for x in args.sweep_dims.split(",") if x]:
+    cases = {
+      "self": _w(B, H, H, N, N, D), "cross": _w(B, H, H, 1024, N, D), "decode": _w(B, H, H, 1, N, D, bound="hbm"), "gqa": _w(B, H, H // 4, N, N, D),
+      "causal": _w(B, H, H, N, N, D, causal=True), "attn_mask": _w(B, H, H, N, N, D, mask="key_bias"), "dropout": _w(B, H, H, N, N, D, dropout=0.1),
+      "non_aligned": _w(B, H // 4, H // 4, N - 1, N - 1, D),
+    }
+    rows = []
+    for cname, w in cases.items():
+      torch.manual_seed(0)
+      q = torch.randn(w["B"], w["Hq"], w["Nq"], D, dtype=torch.bfloat16, device=dev)
+      k = torch.randn(w["B"], w["Hkv"], w["Nkv"], D, dtype=torch.bfloat16, device=dev)
+      v = torch.randn(w["B"], w["Hkv"], w["Nkv"], D, dtype=torch.bfloat16, device=dev)
+      mask = make_mask(w, torch.bfloat16, dev)
+      kw = dict(attn_mask=mask, dropout_p=w["dropout"], is_causal=w["causal"], enable_gqa=w["Hq"] != w["Hkv"])
+
+      def timeit(fn, reps):
+        for _ in range(2):
+          fn()
+        a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+          fn()
+        b_.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b_) / reps
+
+      ms = timeit(lambda: ffpa_attn_func(q, k, v, **kw), args.steps)
+      flops = valid_pairs_flops(w, w["B"])
+      rec = {"ms": round(ms, 4), "tflops": round(flops / ms / 1e9, 1)}
+      if w["bound"] == "hbm":
+        rec["gbps"] = round(algorithmic_bytes(w, w["B"]) / ms / 1e6, 1)
+      if not w["dropout"]:
+        sdpa = lambda: torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=mask, is_causal=w["causal"], enable_gqa=w["Hq"] != w["Hkv"])  # noqa: E731
+        try:
+          sms = timeit(sdpa, 3)
+          rec["sdpa_ms"], rec["speedup"] = round(sms, 4), round(sms / ms, 2)
+          rec["max_abs_err_vs_sdpa"] = round((ffpa_attn_func(q, k, v, **kw).float() - sdpa().float()).abs().max().item(), 6)
+        except Exception as e:  # noqa: BLE001
+          rec["sdpa_error"] = str(e)[:80]
+      rec["kernel"] = planned_kernel(w, q, k, v, mask, D ** -0.5).get("kernel")
+      rows.append((cname, rec))
+      del q, k, v, mask
+    out[str(D)] = dict(rows)
+    print(f"\n== D = {D}  (B {B}, H {H}, N {N}, bf16; bench.py --sweep) ==", file=sys.stderr)
+    print(f"{'case':<12} {'ms':>9} {'TFLOPS':>8} {'SDPA ms':>9} {'speedup':>8} {'max|err|':>9}  kernel", file=sys.stderr)
+    for cname, r in rows:
+      print(f"{cname:<12} {r['ms']:>9.4f} {r['tflops']:>8.1f} {r.get('sdpa_ms', float('nan')):>9.4f} {r.get('speedup', float('nan')):>8.2f} "
+            f"{r.get('max_abs_err_vs_sdpa', float('nan')):>9.2e}  {r['kernel']}", file=sys.stderr)
+  print(json.dumps({"sweep": out, "shape": f"B={B} H={H} N={N} bf16", "steps": args.steps, "build": build_identity(),
+                    "cases": "self / cross (Nq 1024) / decode (Nq 1) / gqa (H/4) / causal / attn_mask ([1,1,1,Nkv]*0.25) / dropout 0.1 / non_aligned (N-1, H/4): cli/_runner_fwd.py:599-672"}),
+        flush=True)
+
+
+def free_port() -> int:
+  with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+    sk.bind(("127.0.0.1", 0))
+    return sk.getsockname()[1]
+
+
+def spawn_ranks(n: int, argv: list[str]) -> int:
+  """`python bench.py --gpus N` without a launcher: start N copies of this script, one per GPU, with the torchrun environment
+  (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free MASTER_PORT).  Rank 0 keeps this process's stdout (its one JSON
+  line is the bench line), the other ranks' stdout is dropped, every rank's stderr is passed through.  Returns the worst exit code."""
+  port = free_port()
+  procs = []
+  for r in range(n):
+    env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+  worst = 0
+  try:
+    for pr in procs:
+      rc = pr.wait()
+      worst = worst or rc
+      if rc != 0:  # one rank died: the others would wait in a collective forever
+        for other in procs:
+          if other.poll() is None:
+            other.terminate()
+  finally:
+    for pr in procs:
+      if pr.poll() is None:
+        pr.kill()
+  return worst
+
+
 def main() -> None:
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -263,13 +435,27 @@ def main() -> None:
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-sdpa", action="store_true", help="skip the SDPA-on-GPU accuracy / speed comparison")
   ap.add_argument("--no-ref-protocol", action="store_true", help="skip the reference bench's own timing protocol (2 warm-ups + 10 iterations)")
+  ap.add_argument("--no-gather-extra", action="store_true", help="N > 1: skip the second timed region that adds the all_gather of O")
+  ap.add_argument("--sweep", action="store_true", help="the reference bench's case table for --sweep-dims in one process (python -m ffpa_attn.bench)")
+  ap.add_argument("--sweep-dims", default="320,512,1024")
+  ap.add_argument("--stub-backend", default="", help="(tests) run the launch / barrier / reduction plumbing on CPU over this torch.distributed "
+                  "backend (gloo) with a sleep for a step: no GPU, no kernel, NOT a benchmark")
   args = ap.parse_args()
 
+  if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    # no launcher around us: be our own (the torchrun form keeps working: it sets WORLD_SIZE)
+    sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if world != args.gpus:
+    sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+  if args.stub_backend:
+    return stub_main(args, world, rank)
   if not torch.cuda.is_available():
     sys.exit("bench.py needs a GPU (the HIP kernel has no CPU fallback)")
+  if args.sweep:
+    return sweep_main(args)
   torch.cuda.set_device(local_rank)
   dev = torch.device("cuda", local_rank)
   dist = None
@@ -277,7 +463,6 @@ def main() -> None:
     import torch.distributed as dist
 
     dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
-  assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
   from ffpa_attn_amd import hip, sharding
 
@@ -300,18 +485,25 @@ def main() -> None:
     local_units = u1 - u0
     flops_local = valid_pairs_flops(w, 1) // Hkv * local_units  # FLOPs are uniform over the units
     flops_global = valid_pairs_flops(w, global_B)
-    gathered = torch.empty((n_units, grp, Nq, D), dtype=torch.bfloat16, device=dev) if (args.gather and world > 1) else None
+    want_gather_extra = world > 1 and not args.gather and not args.no_gather_extra
+    gathered = torch.empty((n_units, grp, Nq, D), dtype=torch.bfloat16, device=dev) if (world > 1 and (args.gather or want_gather_extra)) else None
     api_kw = dict(is_causal=w["causal"], dropout_p=w["dropout"])
     if mask is not None:
       api_kw["attn_mask"] = mask
 
-    def step():
+    def step_kernel():
       if w["via"] == "op_offset0":  # the op's structured top-left causal mask (the public is_causal is tail-aligned and needs Nkv >= Nq)
-        o = hip.ffpa_attn_forward_hip(q, k, v, None, causal=True, softmax_scale=scale, causal_offset=0)[0]
-        return sharding.gather_units(o, n_units, out=gathered) if gathered is not None else o
-      if gathered is not None:  # the block in pieces, each piece all-gathered (RCCL's stream) while the next one computes
-        return sharding.attend_and_gather_units(q, k, v, n_units, chunks=args.gather_chunks, out=gathered, **api_kw)
+        return hip.ffpa_attn_forward_hip(q, k, v, None, causal=True, softmax_scale=scale, causal_offset=0)[0]
       return sharding.attend_units(q, k, v, **api_kw)
+
+    def step_gather():
+      if w["via"] == "op_offset0":
+        o = hip.ffpa_attn_forward_hip(q, k, v, None, causal=True, softmax_scale=scale, causal_offset=0)[0]
+        return sharding.gather_units(o, n_units, out=gathered)
+      # the block in pieces, each piece all-gathered (RCCL's stream) while the next one computes
+      return sharding.attend_and_gather_units(q, k, v, n_units, chunks=args.gather_chunks, out=gathered, **api_kw)
+
+    step = step_gather if (args.gather and world > 1) else step_kernel
   else:
     global_B = B
     torch.manual_seed(0)
@@ -320,6 +512,7 @@ def main() -> None:
     v = torch.randn(B, Hkv, Nkv, D, dtype=torch.bfloat16, device=dev)
     flops_local = flops_global = valid_pairs_flops(w, B)
     gathered = None
+    want_gather_extra = False
     if w["via"] == "op_offset0":
       def step():
         return hip.ffpa_attn_forward_hip(q, k, v, None, causal=True, softmax_scale=scale, causal_offset=0)[0]
@@ -327,39 +520,46 @@ def main() -> None:
       def step():
         return ffpa_attn_func(q, k, v, attn_mask=mask, dropout_p=w["dropout"], is_causal=w["causal"], enable_gqa=Hq != Hkv)
 
-  for _ in range(args.warmup):
-    step()
-  torch.cuda.synchronize()
+  def timed(fn):
+    """W untimed warm-ups, then EXACTLY K steps between barrier + synchronize on both sides; elapsed = max over ranks."""
+    for _ in range(args.warmup):
+      fn()
+    torch.cuda.synchronize()
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    if dist is not None:
+      dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+      starts[i].record()  # the kernel is launched on torch's current stream; so are these events
+      fn()
+      ends[i].record()
+    torch.cuda.synchronize()
+    local = time.perf_counter() - t0
+    if dist is not None:
+      dist.barrier()
+    total = time.perf_counter() - t0
+    per_rank = None
+    if dist is not None:
+      t = torch.tensor([total], dtype=torch.float64, device=dev)
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      total = float(t.item())
+      mine = torch.tensor([flops_local * args.steps / local / 1e12], dtype=torch.float64, device=dev)
+      every = [torch.zeros_like(mine) for _ in range(world)]
+      dist.all_gather(every, mine)
+      per_rank = [round(float(x.item()), 2) for x in every]
+    return total, per_rank, sorted(a.elapsed_time(b) for a, b in zip(starts, ends))
 
-  # ---- timed region: exactly K steps, barrier + synchronize on both sides -----------------
-  starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-  ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-  if dist is not None:
-    dist.barrier()
-  torch.cuda.synchronize()
-  t0 = time.perf_counter()
-  for i in range(args.steps):
-    starts[i].record()  # the kernel is launched on torch's current stream; so are these events
-    out = step()
-    ends[i].record()
-  torch.cuda.synchronize()
-  local_elapsed = time.perf_counter() - t0
-  if dist is not None:
-    dist.barrier()
-  elapsed = time.perf_counter() - t0
-  per_rank_tflops = None
-  if dist is not None:
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    mine = torch.tensor([flops_local * args.steps / local_elapsed / 1e12], dtype=torch.float64, device=dev)
-    every = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(every, mine)
-    per_rank_tflops = [round(float(x.item()), 2) for x in every]
-  kernel_ms = sorted(s.elapsed_time(e) for s, e in zip(starts, ends))
+  elapsed, per_rank_tflops, kernel_ms = timed(step)
   kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
-
   value = flops_global * args.steps / elapsed / 1e12
+  gather_extra = None
+  if want_gather_extra:  # the same K steps once more with the all_gather of O inside the step: both figures in one line
+    g_elapsed, g_per_rank, _ = timed(step_gather)
+    gather_extra = {"value": round(flops_global * args.steps / g_elapsed / 1e12, 2), "unit": "TFLOPS", "ms_per_step": round(g_elapsed / args.steps * 1e3, 4),
+                    "per_rank_tflops": g_per_rank, "what": f"the step + RCCL all_gather_into_tensor of O ({args.gather_chunks} pieces overlapped with compute)"}
+  plan = planned_kernel(w, q[:1], k[:1], v[:1], mask, scale) if rank == 0 else {}
 
   if rank == 0:
     traffic, traffic_src = measured_traffic(name) if world == 1 else (None, None)
@@ -367,13 +567,13 @@ def main() -> None:
       bytes_launch = algorithmic_bytes(w, global_B)
       achieved = bytes_launch / (kernel_ms_avg * 1e-3) / 1e9
       roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-              "traffic": traffic, "traffic_source": traffic_src, "kernel": "ffpa_fwd_split_d_kernel<.,.,4> + ffpa_fwd_merge_kernel",
+              "traffic": traffic, "traffic_source": traffic_src, "kernel": plan.get("kernel"),
               "kernel_ms_avg": round(kernel_ms_avg, 4), "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 4), "bytes_per_launch": bytes_launch}
     else:
       achieved = flops_local / (kernel_ms_avg * 1e-3) / 1e12
       roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
               "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-              "kernel": dominant_kernel(w), "kernel_ms_avg": round(kernel_ms_avg, 4),
+              "kernel": plan.get("kernel"), "kernel_ms_avg": round(kernel_ms_avg, 4),
               "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 4), "flops_per_launch": flops_local,
               "algorithmic_bytes_per_launch": algorithmic_bytes(w, max(1, (u1 - u0) // Hkv) if sharded else B)}
     shape = f"B={global_B} Hq={Hq} Hkv={Hkv} Nq={Nq} Nkv={Nkv} D={D}"
@@ -401,10 +601,16 @@ def main() -> None:
                 ("sharding.attend_units -> ffpa_attn_func" if sharded else "ffpa_attn_func"),
       },
       "roofline": roof,
+      "build": build_identity(),
+      "plan": {k_: plan.get(k_) for k_ in ("variant", "block_rows", "block_keys", "splits")},
     }
     if per_rank_tflops is not None:
-      line["per_rank_tflops_kernel_path"] = per_rank_tflops
+      line["per_rank_tflops"] = per_rank_tflops
+      line["rccl_world_size"] = world
       line["frac_of_mfma_peak_aggregate"] = round(value / (MFMA_BF16_PEAK_TFLOPS * world), 4)
+      line["timed_step_includes_gather"] = bool(args.gather)
+      if gather_extra is not None:
+        line["with_gather"] = gather_extra
     if world == 1 and not sharded and not args.no_ref_protocol:
       # the reference bench's protocol: 2 warm-ups, 10 iterations, perf_counter around a synchronize (cli/_runner_fwd.py:84-103)
       for _ in range(2):

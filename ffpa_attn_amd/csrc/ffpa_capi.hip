@@ -15,6 +15,7 @@
 
 #include "ffpa_attn.h"
 #include "ffpa_fwd_kernel.h"
+#include "ffpa_fwd_m16_kernel.h"  // (FFPA_M16_MIN_D: the head dims whose prefill launches run the 16x16x32 build)
 #include "ffpa_launch.h"
 
 namespace {
@@ -60,7 +61,10 @@ const DimEntry* find_dim(int d) {
 // Launch plan: which tile variant, and over how many workgroups the KV axis is split.
 struct Plan {
   int variant, br, bc, lds, nqt, nt, splits, tiles_per_split;
-  int btile;  // 1: a 16-bit bias with a row axis goes through LDS tiles (the 64-key-tile build)
+  int btile;  // 1: a bias with a row axis goes through LDS tiles staged one KV step ahead
+  int m16;    // 1: the launch runs ffpa_fwd_m16_kernel (prefill tiles, head dim >= FFPA_M16_MIN_D), 0: ffpa_fwd_split_d_kernel
+  int mk;     // m16: the mask kind of the build (0 none, 1 additive bias, 2 boolean mask / ranges)
+  int bias_lds;  // FwdArgs.bias_lds: > 0 bytes of the key-bias row cache, < 0 -(bytes of the bias-tile staging areas), 0 neither
   size_t ws_bytes;
 };
 
@@ -133,9 +137,36 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
     if (want < 1) want = 1;
     pl.splits = (int)want;
   }
-  // A 16-bit bias with a real row axis is staged through LDS by LDS-DMA one KV step ahead (4 waves x [32 rows x 64 keys]); those
-  // launches run the build with 64-key tiles at every head dim (tile config variant 2)
-  if (pl.variant == 0 && pl.splits == 1 && p->bias != nullptr && p->bias_stride[2] != 0 && p->bias_stride[3] == 1 &&
+  const bool safe_path = (p->flags & FFPA_FLAG_DEBUG_SAFE_PATH) != 0;
+  const int dk = kernel_head_dim(p->head_dim);
+  pl.m16 = (pl.variant == 0 && !safe_path && dk >= FFPA_M16_MIN_D) ? 1 : 0;
+  if (pl.m16) {
+    // the build (ffpa_fwd_inst.hip): no bias / boolean masks and mask ranges / additive biases (and anything next to dropout)
+    const bool no_bias = p->bias == nullptr && p->kv_bounds == nullptr;
+    const bool additive = p->bias != nullptr && p->bias_dtype >= FFPA_BIAS_FP16 && p->bias_dtype <= FFPA_BIAS_FP32;
+    pl.mk = no_bias ? 0 : ((additive || p->dropout_p > 0.f) ? 1 : 2);
+    if (pl.mk == 1) {
+      // 64-key tiles at every head dim <= 512 (the LDS also holds the bias); where the initial S^T accumulators come from:
+      de->config(2, &pl.br, &pl.bc, &pl.lds);
+      pl.nt = (p->seqlen_kv + pl.bc - 1) / pl.bc;
+      const int esz = p->bias_dtype == FFPA_BIAS_FP32 ? 4 : 2;
+      const int stagers = dk > 512 ? 2 : 4;  // waves that carry a bias tile (D > 512: one of the two waves of a row block)
+      const bool lds_ok = additive && pl.splits == 1 && !(p->flags & FFPA_FLAG_NO_BIAS_LDS);
+      const int64_t cache = (int64_t)pl.nt * pl.bc * 4;  // a key bias as fp32 / scale, a whole number of tiles
+      const int64_t stage = (int64_t)stagers * 32 * pl.bc * esz;
+      bool stage_ok = lds_ok && p->bias_stride[3] == 1 && reinterpret_cast<uintptr_t>(p->bias) % 16 == 0 && p->bias_stride[2] < (1LL << 24) &&
+                      pl.lds + stage <= 160 * 1024;
+      for (int i = 0; i < 3 && stage_ok; ++i) stage_ok = (p->bias_stride[i] * esz) % 16 == 0;
+      if (lds_ok && p->bias_stride[2] == 0 && pl.lds + cache <= 160 * 1024) pl.bias_lds = (int)cache;
+      else if (stage_ok) {
+        pl.btile = 1;
+        pl.bias_lds = -(int)stage;
+      }
+    }
+  }
+  // 32x32x16 build (head dims <= 256): a 16-bit bias with a real row axis is staged through LDS by LDS-DMA one KV step ahead
+  // (4 waves x [32 rows x 64 keys]); those launches run the build with 64-key tiles at every head dim (tile config variant 2)
+  if (!pl.m16 && pl.variant == 0 && pl.splits == 1 && p->bias != nullptr && p->bias_stride[2] != 0 && p->bias_stride[3] == 1 &&
       (p->bias_dtype == FFPA_BIAS_FP16 || p->bias_dtype == FFPA_BIAS_BF16) && !(p->flags & (FFPA_FLAG_NO_BIAS_LDS | FFPA_FLAG_DEBUG_SAFE_PATH)) &&
       !(p->dropout_p > 0.f)) {
     bool ok = reinterpret_cast<uintptr_t>(p->bias) % 16 == 0 && p->bias_stride[2] < (1LL << 24);
@@ -275,6 +306,20 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   a.causal = p->causal ? 1 : 0;
   a.causal_offset = p->causal_offset;
   a.scale_log2 = p->softmax_scale * 1.4426950408889634f;  // FFPA_M_LOG2E, csrc/cuffpa/common.cuh:9-18
+  a.inv_scale = 1.f;
+  if (pl.m16) {
+    // the 16x16x32 build folds the scale into its exponent (needs scale > 0) and takes additive biases in units of 1 / scale: a zero scale
+    // (scores = bias) reaches it as "Q = 0, scale = 1", a negative one as "-Q, |scale|" — the same scores
+    if (p->softmax_scale == 0.f) {
+      a.scale_log2 = 1.4426950408889634f;
+      a.q_mode = 1;
+    } else {
+      const float mag = fabsf(p->softmax_scale);  // a negative scale: (-Q, |scale|) — exact, and the kernel's fused exponent needs scale > 0
+      a.scale_log2 = mag * 1.4426950408889634f;
+      a.inv_scale = (float)(1.0 / (double)mag);
+      if (p->softmax_scale < 0.f) a.q_mode = 2;
+    }
+  }
   a.thr = p->rescale_threshold < 0.f ? 8.0f : p->rescale_threshold;
   a.flags = p->flags;
   a.nsplit = pl.splits;
@@ -298,7 +343,7 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   }
   // A key bias (no row axis, unit key stride, 16-byte aligned rows, 16- or 32-bit) is cached in LDS once per workgroup when the
   // head dim's tiles leave room for a whole number of tiles' worth of it (ffpa_fwd_kernel.h: FwdArgs.bias_lds)
-  if (p->bias != nullptr && pl.variant == 0 && pl.splits == 1 && p->seqlen_q > 1 && p->bias_stride[2] == 0 && p->bias_stride[3] == 1 &&
+  if (!pl.m16 && p->bias != nullptr && pl.variant == 0 && pl.splits == 1 && p->seqlen_q > 1 && p->bias_stride[2] == 0 && p->bias_stride[3] == 1 &&
       p->bias_dtype >= FFPA_BIAS_FP16 && p->bias_dtype <= FFPA_BIAS_FP32 && !(p->flags & FFPA_FLAG_NO_BIAS_LDS) && !safe) {
     const int esz = p->bias_dtype == FFPA_BIAS_FP32 ? 4 : 2;
     const int64_t row_bytes = (int64_t)p->seqlen_kv * esz;
@@ -307,7 +352,10 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
                     (p->bias_stride[1] * esz) % 16 == 0 && pl.lds + bytes <= 160 * 1024;
     if (ok) a.bias_lds = (int)bytes;
   }
-  if (pl.btile) {
+  if (pl.m16) {
+    a.bias_tile = pl.btile;
+    a.bias_lds = pl.bias_lds;
+  } else if (pl.btile) {
     a.bias_tile = 1;
     a.bias_lds = -(4 * 32 * pl.bc * 2);  // negative: LDS bytes reserved for the tile staging (no key-bias row cache)
   }
@@ -399,6 +447,25 @@ int ffpa_attn_fwd_plan(const ffpa_fwd_params* params, int out[4]) {
   out[1] = pl.br;
   out[2] = pl.bc;
   out[3] = pl.splits;
+  return FFPA_OK;
+}
+
+int ffpa_attn_fwd_kernel(const ffpa_fwd_params* params, char* buf, size_t n) {
+  const DimEntry* de = nullptr;
+  const int rc = check_basic(params, &de);
+  if (rc != FFPA_OK) return rc;
+  if (buf == nullptr || n == 0) return fail(FFPA_ERR_NULL_POINTER, "buf is NULL / empty");
+  const Plan pl = make_plan(params, de);
+  const char* dt = params->dtype == FFPA_DTYPE_FP16 ? "fp16" : "bf16";
+  const int drop = params->dropout_p > 0.f ? 1 : 0;
+  const char* merge = pl.splits > 1 ? " + ffpa_fwd_merge_kernel" : "";
+  if (pl.m16) {
+    snprintf(buf, n, "ffpa_fwd_m16_kernel<%s, %d, MK=%d, DROP=%d>%s", dt, de->d, pl.mk, drop, merge);
+  } else {
+    const int nd = pl.variant == 1 ? ((de->d % 128 == 0) ? 4 : 2) : (de->d <= 512 ? 1 : 2);
+    snprintf(buf, n, "ffpa_fwd_split_d_kernel<%s, %d, ND=%d%s%s%s>%s", dt, de->d, nd, (params->flags & FFPA_FLAG_DEBUG_SAFE_PATH) ? ", SAFE" : "",
+             drop ? ", DROP" : "", pl.btile ? ", BTILE" : "", merge);
+  }
   return FFPA_OK;
 }
 

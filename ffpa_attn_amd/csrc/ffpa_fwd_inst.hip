@@ -45,11 +45,12 @@ static int launch_one(const FwdArgs& a, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-// The unmasked / boolean-mask prefill kernel on the 16x16x32 MFMA shape (ffpa_fwd_m16_kernel.h): same tiles, same plan.
+// The prefill kernel on the 16x16x32 MFMA shape (ffpa_fwd_m16_kernel.h): every prefill launch at head dims >= FFPA_M16_MIN_D.
 template <typename T, int D, int MK, bool DROP = false>
 static int launch_m16(const FwdArgs& a, hipStream_t stream) {
-  constexpr int LDS_BASE = D > 512 ? 2 * 32 * D * 2 + 4 * 4096 : 2 * ((D <= FFPA_BC128_MAX_D) ? 128 : 64) * D * 2;
-  const int LDS = LDS_BASE + (a.bias_lds > 0 ? a.bias_lds : 0);  // + the key-bias row cache, sized by the C-ABI layer
+  constexpr int BC = D > 512 ? 32 : ((D <= FFPA_BC128_MAX_D && MK != 1) ? 128 : 64);
+  constexpr int LDS_BASE = 2 * BC * D * 2 + (D > 512 ? 4 * 4096 : 0);
+  const int LDS = LDS_BASE + (a.bias_lds > 0 ? a.bias_lds : -a.bias_lds);  // + the key-bias row cache or the bias-tile staging areas, sized by the C-ABI layer (<= 160 KiB in total)
   auto kern = ffpa_fwd_m16_kernel<T, D, MK, DROP>;
   static std::atomic<bool> attr_done[64];
   int dev = 0;
@@ -68,8 +69,13 @@ static int launch_m16(const FwdArgs& a, hipStream_t stream) {
 #define FFPA_CAT2(a, b) a##b
 #define FFPA_CAT(a, b) FFPA_CAT2(a, b)
 
-int FFPA_CAT(launch_fwd_d, FFPA_INST_D)(int dtype, int safe, int variant, const FwdArgs& a, hipStream_t stream) {
-  constexpr int D = FFPA_INST_D;
+// Which kernel a launch runs (also reported by ffpa_attn_fwd_plan: FFPA_KERNEL_* in include/ffpa_attn.h):
+//   short-query tiles (variant 1)           -> ffpa_fwd_split_d_kernel<ND = 4 / 2>  (32x32x16 MFMA, split-KV)
+//   prefill, head dim >= FFPA_M16_MIN_D     -> ffpa_fwd_m16_kernel<MK, DROP>        (16x16x32 MFMA): the one prefill family of the large head dims
+//   prefill, smaller head dims              -> ffpa_fwd_split_d_kernel<ND = 1>      (32x32x16 MFMA)
+// (a template, so that `if constexpr` really discards the other family's instantiations)
+template <int D>
+static int launch_fwd_impl(int dtype, int safe, int variant, const FwdArgs& a, hipStream_t stream) {
   constexpr int ND = (D <= 512) ? 1 : 2;
   if (variant == 1) {
     // short-query launches: D split over all 4 waves (one 32-row block per workgroup) when the D/4
@@ -94,59 +100,68 @@ int FFPA_CAT(launch_fwd_d, FFPA_INST_D)(int dtype, int safe, int variant, const 
 #else
   if (safe) return -3;
 #endif
-  if (a.dropout_p > 0.f) {
-    if constexpr (D >= FFPA_M16_MIN_D) {
-      if (!(a.flags & 0x10u)) {
-        if (dtype == 0) return launch_m16<__bf16, D, 1, true>(a, stream);
-        if (dtype == 1) return launch_m16<_Float16, D, 1, true>(a, stream);
+  const bool no_bias = a.bias_dtype == 0 && a.kv_bounds == nullptr;  // no attn_bias, no mask ranges: the builds without any bias path
+  if constexpr (D >= FFPA_M16_MIN_D) {
+    if (a.dropout_p > 0.f) {
+      if (no_bias) {
+        if (dtype == 0) return launch_m16<__bf16, D, 0, true>(a, stream);
+        if (dtype == 1) return launch_m16<_Float16, D, 0, true>(a, stream);
         return -4;
       }
+      if (dtype == 0) return launch_m16<__bf16, D, 1, true>(a, stream);
+      if (dtype == 1) return launch_m16<_Float16, D, 1, true>(a, stream);
+      return -4;
     }
-    if (dtype == 0) return launch_one<__bf16, D, ND, false, true>(a, stream);
-    if (dtype == 1) return launch_one<_Float16, D, ND, false, true>(a, stream);
-    return -4;
-  }
-  // 16-bit bias with a row axis, staged through LDS one step ahead (the build with 64-key tiles at every head dim, so that the
-  // LDS holds the bias tiles next to K and V; the plan of the C-ABI layer uses tile_config variant 2 for these launches)
-  if (a.bias_tile) {
-    if (dtype == 0) return launch_one<__bf16, D, ND, false, false, true>(a, stream);
-    if (dtype == 1) return launch_one<_Float16, D, ND, false, false, true>(a, stream);
-    return -4;
-  }
-  if (a.bias_dtype == 0 && a.kv_bounds == nullptr) {  // no attn_bias, no mask ranges: the build without any bias path
-    if constexpr (D >= FFPA_M16_MIN_D) {
-      if (!(a.flags & 0x10u) && a.scale_log2 > 0.f) {  // (FFPA_FLAG_NO_M16 keeps the 32x32x16 build: A/B runs, tests; so do scales <= 0: this build folds the scale into the exponent's FMA)
-        if (dtype == 0) return launch_m16<__bf16, D, 0>(a, stream);
-        if (dtype == 1) return launch_m16<_Float16, D, 0>(a, stream);
-        return -4;
-      }
+    if (no_bias) {
+      if (dtype == 0) return launch_m16<__bf16, D, 0>(a, stream);
+      if (dtype == 1) return launch_m16<_Float16, D, 0>(a, stream);
+      return -4;
     }
-    if (dtype == 0) return launch_one<__bf16, D, ND, false, false, false, 0>(a, stream);
-    if (dtype == 1) return launch_one<_Float16, D, ND, false, false, false, 0>(a, stream);
-    return -4;
-  }
-  if (a.bias_dtype == 4) {  // boolean mask (+ ranges): the build that carries only that path
-    if constexpr (D >= FFPA_M16_MIN_D) {
-      if (!(a.flags & 0x10u) && a.scale_log2 > 0.f) {
-        if (dtype == 0) return launch_m16<__bf16, D, 2>(a, stream);
-        if (dtype == 1) return launch_m16<_Float16, D, 2>(a, stream);
-        return -4;
-      }
+    if (a.bias_dtype == 4 || a.bias_dtype == 0) {  // boolean mask and / or mask ranges: the build that carries only that path
+      if (dtype == 0) return launch_m16<__bf16, D, 2>(a, stream);
+      if (dtype == 1) return launch_m16<_Float16, D, 2>(a, stream);
+      return -4;
     }
-    if (dtype == 0) return launch_one<__bf16, D, ND, false, false, false, 2>(a, stream);
-    if (dtype == 1) return launch_one<_Float16, D, ND, false, false, false, 2>(a, stream);
+    if (dtype == 0) return launch_m16<__bf16, D, 1>(a, stream);
+    if (dtype == 1) return launch_m16<_Float16, D, 1>(a, stream);
+    return -4;
+  } else {
+    if (a.dropout_p > 0.f) {
+      if (dtype == 0) return launch_one<__bf16, D, ND, false, true>(a, stream);
+      if (dtype == 1) return launch_one<_Float16, D, ND, false, true>(a, stream);
+      return -4;
+    }
+    // 16-bit bias with a row axis, staged through LDS one step ahead (the build with 64-key tiles at every head dim, so that the
+    // LDS holds the bias tiles next to K and V; the plan of the C-ABI layer uses tile_config variant 2 for these launches)
+    if (a.bias_tile) {
+      if (dtype == 0) return launch_one<__bf16, D, ND, false, false, true>(a, stream);
+      if (dtype == 1) return launch_one<_Float16, D, ND, false, false, true>(a, stream);
+      return -4;
+    }
+    if (no_bias) {
+      if (dtype == 0) return launch_one<__bf16, D, ND, false, false, false, 0>(a, stream);
+      if (dtype == 1) return launch_one<_Float16, D, ND, false, false, false, 0>(a, stream);
+      return -4;
+    }
+    if (a.bias_dtype == 4 || a.bias_dtype == 0) {  // boolean mask (+ ranges): the build that carries only that path
+      if (dtype == 0) return launch_one<__bf16, D, ND, false, false, false, 2>(a, stream);
+      if (dtype == 1) return launch_one<_Float16, D, ND, false, false, false, 2>(a, stream);
+      return -4;
+    }
+    if (dtype == 0) return launch_one<__bf16, D, ND, false>(a, stream);
+    if (dtype == 1) return launch_one<_Float16, D, ND, false>(a, stream);
     return -4;
   }
-  // (additive biases stay on the 32x32x16 build: its lanes hold 16 consecutive keys per block — two 16-byte bias loads — where the
-  // 16x16x32 layout holds 4 keys of two rows; measured 5 ... 25 % slower there, tools/gpu_bias_m16_ab.py)
-  if (dtype == 0) return launch_one<__bf16, D, ND, false>(a, stream);
-  if (dtype == 1) return launch_one<_Float16, D, ND, false>(a, stream);
-  return -4;
+}
+
+int FFPA_CAT(launch_fwd_d, FFPA_INST_D)(int dtype, int safe, int variant, const FwdArgs& a, hipStream_t stream) {
+  return launch_fwd_impl<FFPA_INST_D>(dtype, safe, variant, a, stream);
 }
 
 void FFPA_CAT(tile_config_d, FFPA_INST_D)(int variant, int* br, int* bc, int* lds) {
   constexpr int D = FFPA_INST_D;
-  // variant 0: prefill tiles, 1: short-query tiles, 2: prefill tiles of the bias-tile build (64 keys at every head dim)
+  // variant 0: prefill tiles, 1: short-query tiles, 2: prefill tiles of the additive-bias builds (64 keys at every head dim <= 512:
+  // the 16x16x32 build with any additive bias, the 32x32x16 build with LDS-staged bias tiles)
   const int ND = variant == 1 ? ((D % 128 == 0) ? 4 : 2) : ((D <= 512) ? 1 : 2);
   const int BC = (ND == 1) ? ((D <= FFPA_BC128_MAX_D && variant != 2) ? 128 : 64) : 32;
   *br = 32 * (4 / ND);

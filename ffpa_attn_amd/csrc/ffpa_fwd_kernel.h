@@ -157,7 +157,10 @@ struct FwdArgs {
   int bias_dtype;     // 0 none, 1 fp16, 2 bf16, 3 fp32 (additive), 4 bool8 (byte != 0 <=> key visible, else -inf)
   int causal;
   int causal_offset;  // visible iff key <= row + causal_offset
-  float scale_log2;   // softmax_scale * log2(e)
+  float scale_log2;   // softmax_scale * log2(e); the 16x16x32 build only ever sees a POSITIVE value here (q_mode below)
+  float inv_scale;    // 16x16x32 build: 1 / (the scale behind scale_log2) — additive biases enter the S^T accumulators in units of 1 / scale
+  int q_mode;         // 16x16x32 build: 0 = Q as stored; 1 = Q fragments zeroed (softmax_scale == 0: scores = 0 * q.k + bias, scale pair (log2 e, 1));
+                      //   2 = Q fragments negated (softmax_scale < 0: scores = |scale| * (-q).k + bias, scale pair (|scale| log2 e, 1 / |scale|))
   float thr;          // lazy-rescale threshold, log2 units (0 = exact recurrence)
   unsigned flags;
   // split-KV (short-query / decode launches): workgroup (tile, split) handles KV tiles
@@ -266,6 +269,15 @@ __device__ __forceinline__ void lds_dma_16(u32x4 rsrc, uint32_t lds_addr, uint32
                :
                : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
                : "memory");
+}
+
+// The same with the destination given as scalar base + compile-time constant (nothing to precompute and keep in a register per piece).
+template <int LCONST>
+__device__ __forceinline__ void lds_dma_16_at(u32x4 rsrc, uint32_t lds_base, uint32_t voff, uint32_t soff) {
+  asm volatile("s_add_u32 m0, %0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff), "n"(LCONST)
+               : "memory", "scc");
 }
 
 // Row-uniform form (one LDS image row == whole pieces: D = 512).  Everything but the per-lane swizzled
@@ -439,6 +451,37 @@ __device__ __forceinline__ void dropout_keep4(unsigned long long seed, unsigned 
     const float u = ((float)word + 1.0f) * 2.3283064365386963e-10f;  // (0, 1]  (prefill.cuh:437-440)
     keep[t] = (u > p) ? keep_scale : 0.f;
   }
+}
+
+// The same decision as 4 bits (bit t <-> element e0 + t is kept): the 16x16x32 build draws the bits of a whole KV step before its
+// exponentials and applies them when it packs P (the Philox temporaries are dead by then).  u = (word + 1) * 2^-32 as one FMA: the
+// scaling by a power of two is exact, so fl(word * 2^-32 + 2^-32) is the reference's ((float)word + 1.0f) * 2^-32 bit for bit.
+__device__ __forceinline__ uint32_t dropout_keep_bits4(unsigned long long seed, unsigned long long e0, float p) {
+  uint32_t blk[4];
+  const unsigned a = (unsigned)(e0 & 3ull);
+  philox4x32_10(seed, e0 >> 2, blk);
+  uint32_t bits = 0u;
+  if (__builtin_amdgcn_ballot_w64(a != 0) == 0ull) {  // every lane's group is one whole Philox block (the usual case)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float u = __builtin_fmaf((float)blk[t], 2.3283064365386963e-10f, 2.3283064365386963e-10f);  // (0, 1]  (prefill.cuh:437-440)
+      bits |= (u > p ? 1u : 0u) << t;
+    }
+    return bits;
+  }
+  uint32_t w[8] = {blk[0], blk[1], blk[2], blk[3], 0, 0, 0, 0};
+  if (a != 0) {  // the group straddles two Philox blocks
+    philox4x32_10(seed, (e0 >> 2) + 1, blk);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[4 + i] = blk[i];
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const uint32_t word = a == 0 ? w[t] : a == 1 ? w[t + 1] : a == 2 ? w[t + 2] : w[t + 3];
+    const float u = __builtin_fmaf((float)word, 2.3283064365386963e-10f, 2.3283064365386963e-10f);
+    bits |= (u > p ? 1u : 0u) << t;
+  }
+  return bits;
 }
 
 // Additive bias for the 16 scores one lane holds of a 32-key block:

@@ -19,9 +19,19 @@
 //   * a query row lives in 4 lanes (c = 0 .. 3): row max / row sum take two cross-lane steps (lane ^ 16, lane ^ 32).
 //   * epilogue: a lane owns 4 consecutive columns of two rows; lanes c and c ^ 1 trade one group (v_permlane16_swap) so that
 //     each stores whole 16-byte runs of ONE row.
-// Built for every head dim with the 32x32x16 build's tiles, so that launch plans do not depend on the build (D <= 512: 128 rows x
-// 128 keys up to D = 320, 64 keys above; D > 512: D split over two waves, 64 rows x 32 keys, partial S^T tiles summed through LDS);
-// launched for unmasked, boolean-mask and dropout calls (ffpa_fwd_inst.hip; additive biases without dropout stay on the other build).
+// Tiles: D <= 512: 128 rows x 128 keys up to D = 320 (64 keys in the additive-bias build, whose LDS also holds the bias), 64 keys above;
+// D > 512: D split over two waves, 64 rows x 32 keys, partial S^T tiles summed through LDS.  Every prefill launch at head dims
+// >= FFPA_M16_MIN_D runs this kernel (ffpa_fwd_inst.hip): unmasked, boolean masks, additive biases, dropout, any softmax scale.
+//
+// Additive biases enter through the ACCUMULATOR: S^T(j) starts from bias / softmax_scale instead of zero, so that
+// (K.Q^T + bias / scale) * scale = scale * K.Q^T + bias comes out of the same MFMA chain and the softmax below is the unmasked
+// kernel's, instruction for instruction (prefill.cuh:556-658 adds the bias to the scaled score: same value up to fp32 rounding).
+// Where the initial accumulators come from:
+//   * a key bias (no row axis) is converted to fp32 / scale ONCE per workgroup into an LDS row cache: one ds_read_b128 per 16-key block;
+//   * a bias with a row axis (fp16 / bf16 / fp32, unit key stride, 16-byte aligned rows) is staged through LDS by LDS-DMA one KV step
+//     ahead: every wave fetches the [32 rows x BC keys] tile of step j + 1 into a private area between the PV MFMAs of step j (its own
+//     queue drain at barrier B is all the synchronisation that needs) and converts it at the top of step j + 1;
+//   * anything else (odd strides, boolean masks next to dropout) is read element by element from global memory (slow, rare).
 #pragma once
 
 #include "ffpa_fwd_kernel.h"
@@ -41,16 +51,13 @@
 #ifndef FFPA_M16_K_PRE
 #define FFPA_M16_K_PRE 8  // K(j+1) pieces issued between the softmax stages (a multiple of 4); the rest go out between the PV MFMAs
 #endif
+#ifndef FFPA_M16_ROWDMA
+#define FFPA_M16_ROWDMA 1  // D = 512 mask / bias / dropout builds: scalar row addressing of the LDS-DMA (0: per-lane offset tables, as the other builds)
+#endif
 #ifndef FFPA_M16_K_PRE_ND2
 #define FFPA_M16_K_PRE_ND2 64  // ditto for the split-D tiles (D > 512; clamped to the tile's pieces: all of K(j+1) goes out between the softmax stages)
 #endif
 
-#ifndef FFPA_M16_X
-#define FFPA_M16_X 0
-#endif
-#ifndef FFPA_M16_FUSE_SCALE
-#define FFPA_M16_FUSE_SCALE 1  // 0 (A/B): multiply the scores by the softmax scale up front, as the 32x32x16 build does
-#endif
 
 // Developer instrumentation (-DFFPA_M16_TIMING, tools/gpu_phase_times.py; never in the shipped build): every wave accumulates the shader
 // clock cycles it spends in six phases of the KV-tile loop and lane 0 writes the totals over the LSE of its first rows.
@@ -132,16 +139,13 @@ __device__ __forceinline__ int m16_v_swizzle(int key) {
   return (D % 128 == 0) ? ((key & 7) << 1) : (((key >> 1) & 3) << 1);
 }
 
-// MK (mask kind, as in ffpa_fwd_split_d_kernel): 0 = the build for calls without attn_bias / mask ranges, 2 = boolean masks
-// (FFPA_BIAS_BOOL8 bytes and / or kv_bounds ranges: what ffpa_attn_func(attn_mask=<bool>) launches), 1 = additive biases too (fp16 /
-// bf16 / fp32, any broadcast: key biases from the LDS row cache, everything else straight from global memory).  DROP: the
-// dropout-capable build (Philox4x32-10 at the logical score index, applied to the rounded P: prefill.cuh:398-546), carried by the
-// MK = 1 kernel — the only MK = 1 instantiation that is launched: dropout is + 2 ... 15 % faster on this MFMA shape, additive
-// biases without dropout are 5 ... 25 % slower than on the 32x32x16 build (4 keys of two rows per lane and block instead of 16
-// keys of one row: more, narrower bias loads) and stay there.
+// MK (mask kind): 0 = the build for calls without attn_bias / mask ranges, 2 = boolean masks (FFPA_BIAS_BOOL8 bytes and / or kv_bounds
+// ranges: what ffpa_attn_func(attn_mask=<bool>) launches), 1 = additive biases (fp16 / bf16 / fp32, any broadcast; boolean masks too when
+// they come with dropout).  DROP: the dropout-capable builds (Philox4x32-10 at the logical score index, applied to the rounded P:
+// prefill.cuh:398-546) — of the bias-free kernel (MK = 0: nothing but the Philox code rides along) and of the additive-bias kernel.
 template <typename T, int D, int MK = 0, bool DROP = false>
 __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
-  static_assert(MK >= 0 && MK <= 2 && (!DROP || MK == 1), "mask kinds 0 / 1 / 2; dropout rides on the full build");
+  static_assert(MK >= 0 && MK <= 2 && (!DROP || MK != 2), "mask kinds 0 / 1 / 2; dropout builds: MK = 0 (no bias) and MK = 1 (any bias or mask)");
   constexpr bool MASK = MK != 0;
   using E = Elem<T>;
   using M = Mfma16<T>;
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   // 32 qb .. + 32 and columns dh * D/2 .. of both contractions; the two partial S^T tiles of a row block are summed through LDS.
   constexpr int ND = (D <= 512) ? 1 : 2;
   constexpr int DW = D / ND;    // columns owned by one wave
-  constexpr int BC = ND == 2 ? 32 : ((D <= FFPA_BC128_MAX_D) ? 128 : 64), BR = 128 / ND;
+  constexpr int BC = ND == 2 ? 32 : ((D <= FFPA_BC128_MAX_D && MK != 1) ? 128 : 64), BR = 128 / ND;  // (additive-bias build: 64 keys, the LDS holds the bias too)
   constexpr int KS = DW / 32;   // QK contraction steps per wave
   constexpr int NKB = BC / 16;  // 16-key S^T blocks per tile
   constexpr int NKS = BC / 32;  // PV contraction steps per tile
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   // D = 512 with masks: a tile row is one whole piece -> wave-uniform rows, scalar addressing (the per-lane offset tables of the other form
   // would not fit next to the mask path's registers).  Everything else keeps tile-invariant per-lane offsets in registers: measured equal
   // or better (D = 512 unmasked: + 0 ... 2 %; D = 1024: 927 vs 776 TFLOPS — the scalar row form loses 16 % there on this build).
-  constexpr bool kRowDma = RB % 1024 == 0 && ND == 1 && MK != 0;  // (MK = 1 / dropout builds included)
+  constexpr bool kRowDma = RB % 1024 == 0 && ND == 1 && (MK != 0 || DROP) && FFPA_M16_ROWDMA;
   static_assert(!kRowDma || RB == 1024, "the scalar row form is used where a tile row is exactly one piece");
   constexpr int KPW = BC / 4;                // keys staged per wave per tile
   constexpr int PF1 = FFPA_M16_PF1, PF2 = FFPA_M16_PF2;
@@ -248,6 +252,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       kvo[bb] = (uint32_t)((lane ^ m16_k_swizzle<D>(4 * wave + bb)) << 4);
       if ((lane ^ m16_k_swizzle<D>(4 * wave + bb)) >= slots_valid) kvo[bb] = kDmaOob;
       vvo[bb] = (uint32_t)((lane ^ m16_v_swizzle<D>(4 * wave + bb)) << 4);
+      if ((lane ^ m16_v_swizzle<D>(4 * wave + bb)) >= slots_valid) vvo[bb] = kDmaOob;  // (V too: O^T columns past the head dim stay exact zeros)
     }
 #pragma unroll
     for (int jk = 0; jk < KPW; ++jk) {
@@ -268,7 +273,11 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       krel[i] = (uint32_t)key * k_row_bytes + (uint32_t)(ks << 4);
       if (ks >= slots_valid) krel[i] = kDmaOob;
       vrel[i] = (uint32_t)key * v_row_bytes + (uint32_t)(vs << 4);
+      if (vs >= slots_valid) vrel[i] = kDmaOob;  // (V too: O^T columns past the head dim stay exact zeros)
     }
+    // this wave's pieces land at base + i KiB: one scalar base per tile image, the piece index is an immediate of the DMA asm
+    k_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(uintptr_t)Kt + (uint32_t)(wave * PPW * 1024)));
+    v_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(uintptr_t)Vt + (uint32_t)(wave * PPW * 1024)));
   }
   auto issue_k = [&](auto ic, int key0) {
     constexpr int i = decltype(ic)::value;
@@ -276,7 +285,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     if constexpr (kRowDma) {
       lds_dma_row<(16 * (i >> 2) + (i & 3)) * RB, 0>(ts.rsrc, k_lds, kvo[i & 3], kro[i]);
     } else {
-      lds_dma_16(ts.rsrc, (uint32_t)(uintptr_t)(Kt + (wave * PPW + i) * 1024), krel[i], 0u);
+      lds_dma_16_at<i * 1024>(ts.rsrc, k_lds, krel[i], 0u);
     }
   };
   auto issue_v = [&](auto ic, int key0) {
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     if constexpr (kRowDma) {
       lds_dma_row<(16 * (i >> 2) + (i & 3)) * RB, 0>(ts.rsrc, v_lds, vvo[i & 3], vro[i]);
     } else {
-      lds_dma_16(ts.rsrc, (uint32_t)(uintptr_t)(Vt + (wave * PPW + i) * 1024), vrel[i], 0u);
+      lds_dma_16_at<i * 1024>(ts.rsrc, v_lds, vrel[i], 0u);
     }
   };
 
@@ -330,6 +339,12 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     }
   }
 
+#ifndef FFPA_M16_K_FIRST
+#define FFPA_M16_K_FIRST 0  // (experiment) 1: the first K tile's DMA pieces are issued ahead of the Q fragment loads
+#endif
+  if constexpr (FFPA_M16_K_FIRST != 0) {
+    if (nt > t0) static_for<PPW>([&](auto ic) { issue_k(ic, t0 * BC); });
+  }
   // ---- Q fragments (B operand of S^T): lane (n, c) holds Q[row 16 rh + n][32 s + 8 c .. + 8]
   v8 qf[KS][2];
 #pragma unroll
@@ -338,8 +353,18 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const u32x4 z = {0u, 0u, 0u, 0u};
-      qf[s][rh] = (dh * DW + s * 32 + c * 8 < a.d_valid) ? *(const v8*)(qp + s * 32) : __builtin_bit_cast(v8, z);
+      qf[s][rh] = (dh * DW + s * 32 + c * 8 < a.d_valid && a.q_mode != 1) ? *(const v8*)(qp + s * 32) : __builtin_bit_cast(v8, z);
     }
+  }
+  if (a.q_mode == 2) {  // a negative softmax scale reaches the kernel as (-Q, |scale|): exact (a sign flip), and the scale below is always > 0
+#pragma unroll
+    for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        u32x4 w = __builtin_bit_cast(u32x4, qf[s][rh]);
+        w ^= (u32x4)(0x80008000u);
+        qf[s][rh] = __builtin_bit_cast(v8, w);
+      }
   }
 
   f32x4 oacc[NDB][2];
@@ -372,20 +397,85 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         vaddr[hf][i] = Vt + (64 * hf + vkey) * RB + (((dh * (DW / 8) + 2 * i + ((n16 & 3) >> 1)) ^ sw) << 4) + 8 * (n16 & 1);
   }
 
+  // ---- additive bias (MK == 1): where the initial S^T accumulators of a KV step come from (see the header)
+  //   a.bias_lds > 0: key bias, fp32 / scale row cache in LDS (this many bytes: a whole number of tiles of fp32);
+  //   a.bias_tile:    [32 rows x BC keys] tiles of the caller's dtype staged by LDS-DMA one step ahead, a.bias_lds = -(bytes of all staging areas);
+  //   else:           element-wise global loads.
+  // D > 512 (two waves per row block, partial S^T tiles summed): the dh = 0 wave alone carries the bias.
+  const bool bias_owner = MK == 1 && dh == 0 && a.bias_dtype != 0;
+  const int b_esz = a.bias_dtype == 3 ? 4 : 2;        // staged dtypes: fp16 / bf16 / fp32
+  const int b_rowb = BC * b_esz;                      // bytes of one staged row: 64 ... 256
+  const int b_slots = b_rowb >> 4;                    // 16-byte slots per staged row: 4, 8 or 16
+  const int b_sh = b_slots == 16 ? 0 : (b_slots == 8 ? 1 : 2);  // staged rows per 256-byte bank row = 1 << b_sh
+  const int b_pieces = (MK == 1 && a.bias_tile && bias_owner) ? (b_slots >> 1) : 0;  // 1 KiB pieces per [32 rows x BC keys] tile: 2, 4 or 8
+  constexpr int kBtMax = BC == 64 ? 8 : 4;            // ... at most (fp32)
+  FFPA_LDS char* const Bt = Bl + qb * (32 * b_rowb);  // this wave's staging area
+  const uint32_t bt_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)Bt);
+  // staged image: row-major [32][BC], 16-byte slot s of row r stored at slot s ^ g(r), g(r) = (r >> b_sh) & (b_slots - 1) (source-side swizzle:
+  // the ds_read_b64 / b128 lane groups below — 16 rows x one or two slots — are conflict-free).  Piece i covers rows i * rpp .. + rpp
+  // (rpp = 64 / b_slots); its lane l fetches (row l / b_slots, slot (l % b_slots) ^ g): g = (4 i & (b_slots - 1)) | ((l / b_slots) >> b_sh).
+  uint32_t b_rowoff = 0, b_col = 0;
+  uint32_t b_piece_rows = 0;          // bytes between the first rows of two consecutive pieces: (64 / b_slots) row strides
+  u32x4 b_rsrc = {0u, 0u, 0u, 0u};    // this wave's 32 bias rows, from key 0 on: the step's first key goes into the scalar offset
+  FFPA_LDS const char* baddr[NKB];  // staged tile: this lane's read address of key block kb, row half 0 (row half 1: + 16 rows)
+  if constexpr (MK == 1) {
+    if (b_pieces > 0) {
+      const uint32_t b_rs = (uint32_t)a.sbias[2] * (uint32_t)b_esz;
+      const int r = lane / b_slots, sl = lane % b_slots;
+      b_rowoff = (uint32_t)r * b_rs;
+      b_col = (uint32_t)((sl ^ (r >> b_sh)) << 4);
+      b_piece_rows = (uint32_t)(4 << b_sh) * b_rs;
+      // descriptor over [this wave's first row, end of the plane's last row): rows past Nq read as zeros; 32 rows span < 2 GiB (row stride < 2^24
+      // elements), so the 32-bit offsets never wrap however large the bias tensor is
+      const int64_t plane = (int64_t)b_esz * (b * a.sbias[0] + hq * a.sbias[1]);
+      const int64_t first = (int64_t)wq0 * b_rs;
+      int64_t left = (int64_t)(a.Nq - 1) * b_rs + (int64_t)b_esz * a.Nkv - first;
+      left = left < 0 ? 0 : (left > 0x7fffffff ? 0x7fffffff : left);
+      b_rsrc = make_rsrc((const char*)a.bias + plane + first, (uint32_t)left);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) b_rsrc[w] = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_rsrc[w]);
+      const int g = (n16 >> b_sh) & (b_slots - 1);
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const int slot = b_esz == 4 ? 4 * kb + c : 2 * kb + (c >> 1);
+        baddr[kb] = Bt + n16 * b_rowb + ((slot ^ g) << 4) + (b_esz == 4 ? 0 : 8 * (c & 1));
+      }
+    }
+  }
+  // piece i of the bias tile of the KV step starting at key0, for this wave's 32 rows
+  auto issue_bias = [&](auto ic, int key0) {
+    if constexpr (MK == 1) {
+      constexpr int i = decltype(ic)::value;
+      const uint32_t voff = (b_col ^ (uint32_t)((64 * i) & (b_rowb - 1))) + b_rowoff;
+      // (wave-uniform values, pinned to scalar registers: M0 and the scalar offset of the DMA asm)
+      const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)i * b_piece_rows + (uint32_t)(key0 * b_esz)));
+      lds_dma_16_at<i * 1024>(b_rsrc, bt_s, voff, soff);
+    }
+  };
+  FFPA_LDS const char* const bl_lane = Bl + 16 * c;  // row cache: this lane's 4 keys of block kb of the step at k0 sit at bl_lane + 4 k0 + 64 kb
+
   if (MK == 1 && a.bias_lds > 0 && nt > t0) {
-    // key bias [.., .., 1, Nkv]: every row of the workgroup adds the same Nkv values — fetched once into LDS (bytes past Nkv are
+    // key bias [.., .., 1, Nkv]: every row of the workgroup adds the same Nkv values — converted once to fp32 / scale (entries past Nkv are
     // zeros: those keys get the tail mask); made visible by the barrier below
-    const int esz = a.bias_dtype == 3 ? 4 : 2;
-    const char* src = (const char*)a.bias + (int64_t)esz * (b * a.sbias[0] + hq * a.sbias[1]);
-    const int valid = a.Nkv * esz;
-    for (int i = tid * 16; i < a.bias_lds; i += 256 * 16) {
-      u32x4 w = {0u, 0u, 0u, 0u};
-      if (i < valid) w = *(const u32x4*)(src + i);
-      *(FFPA_LDS u32x4*)(Bl + i) = w;
+    const int n_ent = a.bias_lds >> 2;
+    const int64_t src0 = b * a.sbias[0] + hq * a.sbias[1];
+    for (int i = tid; i < n_ent; i += 256) {
+      float w = 0.f;
+      if (i < a.Nkv) {
+        const int64_t e = src0 + i * a.sbias[3];
+        w = a.bias_dtype == 3 ? ((const float*)a.bias)[e] : a.bias_dtype == 2 ? (float)((const __bf16*)a.bias)[e] : (float)((const _Float16*)a.bias)[e];
+        w *= a.inv_scale;
+      }
+      *(FFPA_LDS float*)(Bl + 4 * i) = w;
     }
   }
   if (nt > t0) {
-    static_for<PPW>([&](auto ic) { issue_k(ic, t0 * BC); });
+    if constexpr (FFPA_M16_K_FIRST == 0) static_for<PPW>([&](auto ic) { issue_k(ic, t0 * BC); });
+    if constexpr (MK == 1) {
+      static_for<kBtMax>([&](auto ic) {
+        if (decltype(ic)::value < b_pieces) issue_bias(ic, t0 * BC);
+      });
+    }
     dma_wait_all();
     __syncthreads();
   }
@@ -398,8 +488,79 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   for (int j = t0; j < nt; ++j) {
     const int k0 = j * BC;
 
+
     // ================= S^T = K.Q^T =================
     f32x4 sacc[NKB][2];
+    if constexpr (MK == 1) {
+      // the accumulators start from bias / softmax_scale (zeros where there is no bias): see the header
+      // (mask_free, wave-uniform: this step lies in the neutral interior of the caller's mask (kv_bounds): nothing to read, nothing to add)
+      const bool mask_free = k0 >= free_lo && k0 + BC <= free_hi;
+      if (bias_owner && !mask_free) {
+        if (a.bias_lds > 0) {  // key bias: fp32 / scale from the LDS row cache, the same 4 keys for both of the lane's rows
+          FFPA_LDS const char* bp = bl_lane + 4 * k0;
+#pragma unroll
+          for (int kb = 0; kb < NKB; ++kb) {
+            sacc[kb][0] = *(FFPA_LDS const f32x4*)(bp + 64 * kb);
+            sacc[kb][1] = sacc[kb][0];
+          }
+        } else if (a.bias_tile) {  // the tile this wave staged during the previous step's PV loop (drained at barrier B)
+          typedef __attribute__((ext_vector_type(4))) __bf16 b4;
+          typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+          const int half_rows = 16 * b_rowb;
+          if (a.bias_dtype == 3) {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+              for (int rh = 0; rh < 2; ++rh) sacc[kb][rh] = *(FFPA_LDS const f32x4*)(baddr[kb] + rh * half_rows) * a.inv_scale;
+          } else if (a.bias_dtype == 2) {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+              for (int rh = 0; rh < 2; ++rh) {
+                const b4 w = *(FFPA_LDS const b4*)(baddr[kb] + rh * half_rows);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sacc[kb][rh][r] = (float)w[r] * a.inv_scale;
+              }
+          } else {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+              for (int rh = 0; rh < 2; ++rh) {
+                const h4 w = *(FFPA_LDS const h4*)(baddr[kb] + rh * half_rows);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sacc[kb][rh][r] = (float)w[r] * a.inv_scale;
+              }
+          }
+        } else {  // element-wise from global memory: any strides, any dtype (boolean: 0 / -inf)
+#pragma unroll
+          for (int rh = 0; rh < 2; ++rh) {
+            const int64_t brow = b * a.sbias[0] + hq * a.sbias[1] + (int64_t)qrow_c[rh] * a.sbias[2];
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                int key = k0 + kb * 16 + 4 * c + r;
+                key = key < a.Nkv ? key : a.Nkv - 1;
+                const int64_t e = brow + key * a.sbias[3];
+                float w;
+                if (a.bias_dtype == 4) w = ((const uint8_t*)a.bias)[e] != 0 ? 0.f : -INFINITY;
+                else w = (a.bias_dtype == 3 ? ((const float*)a.bias)[e] : a.bias_dtype == 2 ? (float)((const __bf16*)a.bias)[e] : (float)((const _Float16*)a.bias)[e]) * a.inv_scale;
+                sacc[kb][rh][r] = w;
+              }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+          sacc[kb][0] = (f32x4)(0.f);
+          sacc[kb][1] = (f32x4)(0.f);
+        }
+      }
+      // VALU write -> MFMA SrcC read wait states (the MFMAs are inline asm); every accumulator is named so that all writes precede the pad
+      static_assert(NKB == 2 || NKB == 4, "additive-bias build: 32- or 64-key tiles");
+      if constexpr (NKB == 4) asm volatile("" : "+v"(sacc[2][0]), "+v"(sacc[2][1]), "+v"(sacc[3][0]), "+v"(sacc[3][1]));
+      asm volatile("s_nop 1" : "+v"(sacc[0][0]), "+v"(sacc[0][1]), "+v"(sacc[1][0]), "+v"(sacc[1][1]));
+    }
     {
       v8 kf[N1];
       auto k_frag = [&](int n) -> v8 {
@@ -419,10 +580,10 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 #define FFPA_M16_DMA_POS 1  // where a DMA piece sits relative to the fragment's two MFMAs: 0 in front, 1 between (+ 0.4 ... 1.7 %), 2 behind
 #endif
         if constexpr (kPiece && FFPA_M16_DMA_POS == 0) issue_v(std::integral_constant<int, n / kStep1>{}, k0);
-        if constexpr (s == 0) M::first(sacc[kb][0], kf[n], qf[s][0]);
+        if constexpr (s == 0 && MK != 1) M::first(sacc[kb][0], kf[n], qf[s][0]);
         else M::acc(sacc[kb][0], kf[n], qf[s][0]);
         if constexpr (kPiece && FFPA_M16_DMA_POS == 1) issue_v(std::integral_constant<int, n / kStep1>{}, k0);
-        if constexpr (s == 0) M::first(sacc[kb][1], kf[n], qf[s][1]);
+        if constexpr (s == 0 && MK != 1) M::first(sacc[kb][1], kf[n], qf[s][1]);
         else M::acc(sacc[kb][1], kf[n], qf[s][1]);
         if constexpr (kPiece && FFPA_M16_DMA_POS == 2) issue_v(std::integral_constant<int, n / kStep1>{}, k0);
       });
@@ -461,18 +622,17 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     pre_k_group(std::integral_constant<int, 0>{});
 
-    // x[kb][rh][r] = score(row 16 rh + n, key k0 + 16 kb + 4 c + r) / sc: the softmax scale is folded into the exponent's FMA
-    // (p = exp2(x sc - m): one instruction instead of a multiply here and a subtract there, 32 VALU instructions per tile less) and
-    // applied to the row max after its reduction — max(x sc) = sc max(x) needs sc > 0 (the launch side sends other scales to the
-    // 32x32x16 build), and an additive bias needs the scaled score: the MK = 1 build multiplies here and subtracts there.
+    // x[kb][rh][r] = score(row 16 rh + n, key k0 + 16 kb + 4 c + r) / sc, bias included (it entered in units of 1 / sc): the softmax scale
+    // is folded into the exponent's FMA (p = exp2(x sc - m): one instruction instead of a multiply here and a subtract there, 32 VALU
+    // instructions per tile less) and applied to the row max after its reduction — max(x sc) = sc max(x) for sc > 0, and the kernel only
+    // ever sees sc > 0: the launch side turns a negative scale into (-Q, |sc|) and a zero scale into (Q = 0, 1) (FwdArgs.q_mode).
     float x[NKB][2][4];
-    constexpr bool kFuse = MK != 1 && FFPA_M16_FUSE_SCALE != 0;  // (launch side: these builds only see softmax_scale > 0)
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int rh = 0; rh < 2; ++rh)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[kb][rh][r] = kFuse ? sacc[kb][rh][r] : sacc[kb][rh][r] * a.scale_log2;
+        for (int r = 0; r < 4; ++r) x[kb][rh][r] = sacc[kb][rh][r];
     if constexpr (ND == 2) {
       // + the other D-half's partial (a + b == b + a: both waves of a row block see bit-identical scores, so their softmax states agree)
       FFPA_LDS const char* xr = Xb + (wave ^ 1) * 4096 + lane * 16;
@@ -482,14 +642,14 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         for (int rh = 0; rh < 2; ++rh) {
           const f32x4 t = *(FFPA_LDS const f32x4*)(xr + (kb * 2 + rh) * 1024);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) x[kb][rh][r] = kFuse ? sacc[kb][rh][r] + t[r] : (sacc[kb][rh][r] + t[r]) * a.scale_log2;
+          for (int r = 0; r < 4; ++r) x[kb][rh][r] = sacc[kb][rh][r] + t[r];
         }
     }
     pre_k_group(std::integral_constant<int, 1>{});
 
-    if constexpr (MASK) {
+    if constexpr (MK == 2) {
       // boolean mask bytes (non-zero = visible), straight from the caller's tensor; the lane's 4 keys of a block are consecutive
-      const bool mask_free = k0 >= free_lo && k0 + BC <= free_hi;  // wave-uniform
+      const bool mask_free = k0 >= free_lo && k0 + BC <= free_hi;  // wave-uniform: the step lies in the mask's neutral interior (kv_bounds)
       if (a.bias_dtype == 4 && !mask_free) {
         const uint8_t* mp = (const uint8_t*)a.bias + b * a.sbias[0] + hq * a.sbias[1];
 #pragma unroll
@@ -513,78 +673,6 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
                 key = key < a.Nkv ? key : a.Nkv - 1;
                 if (mr[key * a.sbias[3]] == 0) x[kb][rh][r] = -INFINITY;
               }
-          }
-        }
-      }
-      if constexpr (MK == 1) {
-        typedef __attribute__((ext_vector_type(4))) __bf16 b4;
-        typedef __attribute__((ext_vector_type(4))) _Float16 h4;
-        constexpr float kLog2e = 1.4426950408889634f;
-        if (a.bias_dtype != 0 && a.bias_dtype != 4 && !mask_free) {
-          if (a.bias_lds > 0) {
-            // key bias from the LDS row cache: the lane's 4 keys of a block, the same values for both of its rows
-#pragma unroll
-            for (int kb = 0; kb < NKB; ++kb) {
-              const int key = k0 + kb * 16 + 4 * c;
-              float t[4];
-              if (a.bias_dtype == 3) {
-                const f32x4 w = *(FFPA_LDS const f32x4*)(Bl + key * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) t[r] = w[r];
-              } else {
-                const u32x2 raw = *(FFPA_LDS const u32x2*)(Bl + key * 2);
-                if (a.bias_dtype == 2) {
-                  const b4 w = __builtin_bit_cast(b4, raw);
-#pragma unroll
-                  for (int r = 0; r < 4; ++r) t[r] = (float)w[r];
-                } else {
-                  const h4 w = __builtin_bit_cast(h4, raw);
-#pragma unroll
-                  for (int r = 0; r < 4; ++r) t[r] = (float)w[r];
-                }
-              }
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                x[kb][0][r] += t[r] * kLog2e;
-                x[kb][1][r] += t[r] * kLog2e;
-              }
-            }
-          } else {
-#pragma unroll
-            for (int rh = 0; rh < 2; ++rh) {
-              const int64_t brow = b * a.sbias[0] + hq * a.sbias[1] + (int64_t)qrow_c[rh] * a.sbias[2];
-#pragma unroll
-              for (int kb = 0; kb < NKB; ++kb) {
-                const int kbase = k0 + kb * 16 + 4 * c;
-                if (a.bias_vec && k0 + BC <= a.Nkv) {  // full tile, unit key stride, rows aligned to >= 4 elements
-                  if (a.bias_dtype == 3) {
-                    const f32x4 w = *(const f32x4*)((const float*)a.bias + brow + kbase);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) x[kb][rh][r] += w[r] * kLog2e;
-                  } else {
-                    const u32x2 raw = *(const u32x2*)((const uint16_t*)a.bias + brow + kbase);
-                    if (a.bias_dtype == 2) {
-                      const b4 w = __builtin_bit_cast(b4, raw);
-#pragma unroll
-                      for (int r = 0; r < 4; ++r) x[kb][rh][r] += (float)w[r] * kLog2e;
-                    } else {
-                      const h4 w = __builtin_bit_cast(h4, raw);
-#pragma unroll
-                      for (int r = 0; r < 4; ++r) x[kb][rh][r] += (float)w[r] * kLog2e;
-                    }
-                  }
-                } else {
-#pragma unroll
-                  for (int r = 0; r < 4; ++r) {
-                    int key = kbase + r;
-                    key = key < a.Nkv ? key : a.Nkv - 1;
-                    const int64_t e = brow + key * a.sbias[3];
-                    const float w = a.bias_dtype == 3 ? ((const float*)a.bias)[e] : a.bias_dtype == 2 ? (float)((const __bf16*)a.bias)[e] : (float)((const _Float16*)a.bias)[e];
-                    x[kb][rh][r] += w * kLog2e;
-                  }
-                }
-              }
-            }
           }
         }
       }
@@ -618,17 +706,15 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       tmax[rh] = t;
     }
     row4_reduce2<true>(tmax[0], tmax[1]);
-    if constexpr (kFuse) {  // (exact: rounding is monotonic, fl(sc max x) = max fl(sc x); -inf stays -inf)
-      tmax[0] *= a.scale_log2;
-      tmax[1] *= a.scale_log2;
-    }
+    tmax[0] *= a.scale_log2;  // (exact: rounding is monotonic, fl(sc max x) = max fl(sc x) for sc > 0; -inf stays -inf)
+    tmax[1] *= a.scale_log2;
     pre_k_group(std::integral_constant<int, 2>{});
     const float m_new0 = fmaxf(m_run[0], tmax[0]), m_new1 = fmaxf(m_run[1], tmax[1]);
     const bool grow0 = m_new0 > m_run[0] + a.thr, grow1 = m_new1 > m_run[1] + a.thr;
     if (__any(grow0 || grow1)) {
       const float alpha0 = grow0 ? __builtin_amdgcn_exp2f(m_run[0] - m_new0) : 1.f;
       const float alpha1 = grow1 ? __builtin_amdgcn_exp2f(m_run[1] - m_new1) : 1.f;
-      if (j > t0 && !(FFPA_M16_X & 1)) {
+      if (j > t0) {
         // rare path: O^T lives in AGPRs; scale in place through one temporary VGPR (see ffpa_fwd_kernel.h)
 #pragma unroll
         for (int i = 0; i < NDB; ++i)
@@ -648,6 +734,24 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       m_run[1] = grow1 ? m_new1 : m_run[1];
     }
 
+    // dropout keep bits of this step (bit 4 kb + r of keep_bits[rh][.] <-> key 16 kb + 4 c + r), drawn BEFORE the exponentials: the Philox
+    // temporaries are dead by the time the P^T fragments come alive.  The lane's 4 keys of a block are one Philox group of the row's
+    // counter stream (element offset = ((b Hq + hq) Nq + row) Nkv + key).
+    uint32_t keep_bits[2][NKB > 8 ? NKB / 8 : 1] = {};
+    if constexpr (DROP) {
+#pragma unroll
+      for (int rh = 0; rh < 2; ++rh) {
+        const unsigned long long erow =
+            a.philox_offset + (((unsigned long long)b * a.Hq + hq) * a.Nq + (unsigned long long)qrow_c[rh]) * (unsigned long long)a.Nkv;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+          __builtin_amdgcn_sched_barrier(0);  // one Philox group at a time: bounded register pressure
+          keep_bits[rh][kb >> 3] |= dropout_keep_bits4(a.philox_seed, erow + (unsigned long long)(k0 + kb * 16 + 4 * c), a.dropout_p) << (4 * (kb & 7));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
     // P^T fragments: contraction slot 8 c + e of key step ks <-> key 32 ks + 16 (e / 4) + 4 c + e % 4 = x[2 ks + e / 4][rh][e % 4]
     v8 pf[NKS][2];
 #pragma unroll
@@ -658,33 +762,21 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(kFuse ? __builtin_fmaf(x[kb][rh][r], a.scale_log2, -m_use) : x[kb][rh][r] - m_use);
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(x[kb][rh][r], a.scale_log2, -m_use));
           psum += p;  // row sum from the unrounded P (prefill.cuh:755-756)
-          pf[kb >> 1][rh][4 * (kb & 1) + r] = (T)p;
+          if constexpr (DROP) {
+            // dropout: applied to the ROUNDED P, after the row sum (LSE is undropped), scaled by 1 / (1 - p) and rounded again
+            // (prefill.cuh:508-546); the keep bit was drawn above: AND with 0 / ~0 (P >= 0: no sign games)
+            const float scaled = (float)(T)p * a.keep_scale;
+            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)keep_bits[rh][kb >> 3], 4 * (kb & 7) + r, 1);
+            pf[kb >> 1][rh][4 * (kb & 1) + r] = (T)__uint_as_float(__float_as_uint(scaled) & m);
+          } else {
+            pf[kb >> 1][rh][4 * (kb & 1) + r] = (T)p;
+          }
         }
       l_run[rh] += psum;
     }
     pre_k_group(std::integral_constant<int, 3>{});
-    if constexpr (DROP) {
-      // applied to the ROUNDED P, after the row sum (LSE is undropped): prefill.cuh:508-546.  The lane's 4 keys of a block are one
-      // Philox group of the row's counter stream (element offset = ((b Hq + hq) Nq + row) Nkv + key).
-#pragma unroll
-      for (int rh = 0; rh < 2; ++rh) {
-        const unsigned long long erow =
-            a.philox_offset + (((unsigned long long)b * a.Hq + hq) * a.Nq + (unsigned long long)qrow_c[rh]) * (unsigned long long)a.Nkv;
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-          __builtin_amdgcn_sched_barrier(0);  // one Philox group at a time: bounded register pressure
-          float keep[4];
-          dropout_keep4(a.philox_seed, erow + (unsigned long long)(k0 + kb * 16 + 4 * c), a.dropout_p, a.keep_scale, keep);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float dropped = (float)pf[kb >> 1][rh][4 * (kb & 1) + r] * keep[r];
-            pf[kb >> 1][rh][4 * (kb & 1) + r] = (T)dropped;
-          }
-        }
-      }
-    }
 
     // ================= O^T += V^T.P^T =================
     {
@@ -694,6 +786,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       dma_wait_except<kPre>();
       __syncthreads();
       FFPA_TSTAMP(3);  // V(j) drain + wait at barrier A2
+      // pieces of the next step's bias tile to stage (none when that step lies in the mask's neutral interior or past the last tile)
+      const int b_next = (MK == 1 && j + 1 < nt && !(k0 + BC >= free_lo && k0 + 2 * BC <= free_hi)) ? b_pieces : 0;
       v8 vf[N2];
       auto v_frag = [&](int n) -> v8 {
         const int db = n % NDB, ks = n / NDB;
@@ -715,7 +809,18 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         if constexpr (kPiece && FFPA_M16_DMA_POS == 1) issue_k(std::integral_constant<int, n / kStep2 + kPre>{}, k0 + BC);
         M::acc_a(oacc[db][1], vf[n], pf[ks][1]);
         if constexpr (kPiece && FFPA_M16_DMA_POS == 2) issue_k(std::integral_constant<int, n / kStep2 + kPre>{}, k0 + BC);
+        if constexpr (MK == 1) {
+          // the bias tile of step j + 1 (this wave's rows, its private staging area) in the slots the K pieces leave free
+          constexpr int kBStep = kStep2 >= 2 ? kStep2 : 2;
+          if constexpr (n % kBStep == kBStep / 2 && n / kBStep < kBtMax) {
+            if (n / kBStep < b_next) issue_bias(std::integral_constant<int, n / kBStep>{}, k0 + BC);
+          }
+        }
       });
+      if constexpr (MK == 1) {
+        constexpr int kBStep = kStep2 >= 2 ? kStep2 : 2;
+        static_assert((kBtMax - 1) * kBStep + kBStep / 2 < N2, "every bias piece has a slot in the PV loop");
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
 

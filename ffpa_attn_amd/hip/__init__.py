@@ -50,10 +50,10 @@ _STATUS_EXC = {
 FLAG_DEBUG_SAFE_PATH = 0x1
 FLAG_NO_XCD_REMAP = 0x2
 FLAG_NO_BIAS_LDS = 0x8
-FLAG_NO_M16 = 0x10  # bench-only: unmasked launches stay on the 32x32x16-MFMA build
 
 # enum ffpa_bias_dtype: additive fp16 / bf16 / fp32, or a boolean mask read as bytes (non-zero = visible)
-_BIAS_DTYPE = {torch.float16: 1, torch.bfloat16: 2, torch.float32: 3, torch.bool: 4, torch.uint8: 4}
+# (torch.uint8 is NOT accepted: the public API and the reference take bool / float masks only, functional.py:860-898)
+_BIAS_DTYPE = {torch.float16: 1, torch.bfloat16: 2, torch.float32: 3, torch.bool: 4}
 _DTYPE = {torch.bfloat16: 0, torch.float16: 1}
 
 
@@ -108,6 +108,7 @@ EXPORTS = (
   "ffpa_attn_fwd_workspace_bytes",
   "ffpa_attn_mask_kv_bounds",
   "ffpa_attn_fwd_plan",
+  "ffpa_attn_fwd_kernel",
   "ffpa_attn_query",
   "ffpa_attn_fwd_tile_config",
   "ffpa_attn_last_error",
@@ -141,6 +142,9 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.ffpa_attn_fwd_workspace_bytes.restype = ctypes.c_size_t
     lib.ffpa_attn_fwd_plan.argtypes = [ctypes.POINTER(FfpaFwdParams), ctypes.POINTER(ctypes.c_int)]
     lib.ffpa_attn_fwd_plan.restype = ctypes.c_int
+    if path is None or hasattr(lib, "ffpa_attn_fwd_kernel"):  # (developer A/B runs may load a saved build of an older commit by path)
+      lib.ffpa_attn_fwd_kernel.argtypes = [ctypes.POINTER(FfpaFwdParams), ctypes.c_char_p, ctypes.c_size_t]
+      lib.ffpa_attn_fwd_kernel.restype = ctypes.c_int
     lib.ffpa_attn_query.argtypes = [ctypes.c_int]
     lib.ffpa_attn_query.restype = ctypes.c_int
     lib.ffpa_attn_fwd_tile_config.argtypes = [
@@ -240,6 +244,34 @@ def mask_kv_bounds(attn_bias: torch.Tensor, nq: int, nkv: int) -> torch.Tensor:
   none = ff >= nkv
   ff, fe = torch.where(none, torch.zeros_like(ff), ff), torch.where(none, torch.zeros_like(fe), fe)
   return torch.stack((first, end, ff, fe), dim=-1).to(torch.int32).contiguous()
+
+
+# One scan per mask, not per call: a static mask (the usual case: the same causal / padding / sliding-window tensor for every layer
+# and step) is scanned once.  An entry is valid only while the very tensor object it was computed from (the view's base: the public
+# API re-views the caller's mask on every call) is still alive — so its memory cannot have been recycled for another mask — and torch's
+# in-place version counter (shared by all views of a storage, bumped by every in-place write) has not moved.  Holds the small int32
+# result only.
+_BOUNDS_CACHE: "dict[tuple, tuple]" = {}
+_BOUNDS_CACHE_MAX = 16
+
+
+def cached_mask_kv_bounds(attn_bias: torch.Tensor, nq: int, nkv: int) -> torch.Tensor:
+  import weakref
+
+  owner = attn_bias._base if attn_bias._base is not None else attn_bias
+  key = (id(owner), attn_bias.data_ptr(), attn_bias.dtype, tuple(attn_bias.shape), tuple(attn_bias.stride()), nq, nkv)
+  hit = _BOUNDS_CACHE.get(key)
+  if hit is not None:
+    ref, version, out = hit
+    if ref() is owner and version == attn_bias._version:
+      return out
+  out = mask_kv_bounds(attn_bias, nq, nkv)
+  for k_ in [k_ for k_, (r, _, _) in _BOUNDS_CACHE.items() if r() is None]:  # owners that died
+    del _BOUNDS_CACHE[k_]
+  if len(_BOUNDS_CACHE) >= _BOUNDS_CACHE_MAX:
+    _BOUNDS_CACHE.pop(next(iter(_BOUNDS_CACHE)))
+  _BOUNDS_CACHE[key] = (weakref.ref(owner), attn_bias._version, out)
+  return out
 
 
 def _want_mask_bounds(attn_bias: torch.Tensor, b: int, hq: int, nq: int, nkv: int) -> bool:
@@ -361,7 +393,10 @@ def forward(
     p.bias_dtype = _BIAS_DTYPE[attn_bias.dtype]
     p.bias_stride[:] = strides
     if kv_bounds is True or (kv_bounds is None and _want_mask_bounds(attn_bias, B, Hq, Nq, Nkv)):
-      kv_bounds = mask_kv_bounds(attn_bias, Nq, Nkv)
+      # (the scan is skipped under stream capture / compile tracing only in the sense that the cache is not consulted there: a
+      # captured graph must contain the scan kernel it depends on)
+      capturing = torch.cuda.is_current_stream_capturing()
+      kv_bounds = mask_kv_bounds(attn_bias, Nq, Nkv) if (capturing or os.environ.get("FFPA_HIP_MASK_BOUNDS_CACHE") == "0") else cached_mask_kv_bounds(attn_bias, Nq, Nkv)
     if isinstance(kv_bounds, torch.Tensor):
       nblk = (Nq + 31) // 32
       if kv_bounds.dtype != torch.int32 or kv_bounds.dim() != 4 or kv_bounds.shape[2:] != (nblk, 4) or not kv_bounds.is_contiguous():
@@ -396,6 +431,9 @@ def forward(
       plan = (ctypes.c_int * 4)()
       if lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0:
         plan_out.update(variant=plan[0], block_rows=plan[1], block_keys=plan[2], splits=plan[3], packed=bool(packed))
+      name = ctypes.create_string_buffer(160)
+      if hasattr(lib, "ffpa_attn_fwd_kernel") and lib.ffpa_attn_fwd_kernel(ctypes.byref(p), name, len(name)) == 0:
+        plan_out["kernel"] = name.value.decode()
     stream = torch.cuda.current_stream(q.device).cuda_stream
     rc = lib.ffpa_attn_fwd(ctypes.byref(p), ctypes.c_void_p(stream))
   if rc != 0:

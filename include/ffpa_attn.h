@@ -64,7 +64,6 @@ enum ffpa_bias_dtype {
 #define FFPA_FLAG_NO_XCD_REMAP    0x2u /* bench-only: dispatch-order block mapping          */
 #define FFPA_FLAG_NO_PERSISTENT   0x4u /* bench-only (builds with FFPA_PERSISTENT): one workgroup per id */
 #define FFPA_FLAG_NO_BIAS_LDS     0x8u /* bench-only: read a key bias from global memory in every tile   */
-#define FFPA_FLAG_NO_M16          0x10u /* bench-only: keep unmasked launches on the 32x32x16-MFMA build    */
 
 /*
  * One forward call.  Layout contract (replaces the dense-[B,H,N,D] assumption of
@@ -172,6 +171,13 @@ size_t ffpa_attn_fwd_workspace_bytes(const ffpa_fwd_params* params);
  * tile, out[3] = number of KV splits given params->workspace_bytes.  Returns an ffpa_status.
  */
 int ffpa_attn_fwd_plan(const ffpa_fwd_params* params, int out[4]);
+
+/*
+ * The kernel the launch described by `params` runs, as text ("ffpa_fwd_m16_kernel<bf16, 512, MK=0, DROP=0>", with
+ * " + ffpa_fwd_merge_kernel" appended for KV-split launches): what benches put next to their numbers and what a profile's
+ * kernel column must show.  Written to buf (n bytes, NUL-terminated).  Returns an ffpa_status.
+ */
+int ffpa_attn_fwd_kernel(const ffpa_fwd_params* params, char* buf, size_t n);
 
 /*
  * Visible-key bounds of an additive (-inf = hidden) or boolean (0 = hidden) mask, in the layout

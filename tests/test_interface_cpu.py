@@ -105,19 +105,16 @@ def test_mask_kv_bounds_per_32_row_block():
   assert alibi[0, 0].tolist() == [[0, 64, 0, 1]]
 
 
-def test_bench_names_the_kernel_the_dispatch_launches():
-  """bench.py's roofline.kernel label follows csrc/ffpa_fwd_inst.hip: the 16x16x32-MFMA build from FFPA_M16_MIN_D up, except for
-  additive biases and short-query launches."""
+def test_bench_takes_the_kernel_name_from_the_library_not_from_a_copy_of_the_dispatch_rule():
+  """bench.py's roofline.kernel is what ffpa_attn_fwd_kernel (C-ABI) reports for the workload's call: no hand-kept copy of
+  csrc/ffpa_fwd_inst.hip's dispatch lives in the bench."""
   import os
-  import re
   import sys
 
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   sys.path.insert(0, root)
   import bench
 
-  text = open(os.path.join(root, "ffpa_attn_amd", "csrc", "ffpa_fwd_m16_kernel.h")).read()
-  min_d = int(re.search(r"#define FFPA_M16_MIN_D (\d+)", text).group(1))
-  for name, w in bench.WORKLOADS.items():
-    want_m16 = w["D"] >= min_d and w["Nq"] > 32 and w["mask"] != "key_bias"
-    assert (bench.dominant_kernel(w) == "ffpa_fwd_m16_kernel") == want_m16, name
+  assert not hasattr(bench, "dominant_kernel")
+  src = open(os.path.join(root, "bench.py")).read()
+  assert 'plan.get("kernel")' in src and "ffpa_fwd_m16_kernel" not in src and "ffpa_fwd_split_d_kernel" not in src

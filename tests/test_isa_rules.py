@@ -28,36 +28,44 @@ def test_asm_mfma_operands_have_no_valu_writer_inside_the_hazard_window(monkeypa
   assert "asm MFMAs checked" in out and " 0 preceded" in out
 
 
-@pytest.mark.skipif(not TEMPS, reason="no --save-temps assembly in csrc/build")
-def test_headline_kernel_has_no_spill_code_inside_its_mfma_loops(capsys, monkeypatch):
-  """D = 512 bf16 prefill kernels: 256 + 256 registers, no scratch and no SGPR lane spills inside the MFMA loops; the build the
-  headline workload launches has none between the two loops either."""
-  monkeypatch.setattr(sys, "argv", ["isa_stats", "512"])
+def _stats(monkeypatch, capsys, *dims):
+  monkeypatch.setattr(sys, "argv", ["isa_stats", *[str(d) for d in dims]])
   _tool("isa_stats").main()
-  # template flags after "<D> <ND>": SAFE, DROP, BTILE, mask kind.  The four non-dropout builds of the prefill kernel: without
-  # any bias path (mask kind 0: what the headline workload launches), boolean masks only (2), every bias / mask path (1), and
-  # bias tiles staged through LDS (BTILE).
-  lines = [l for l in capsys.readouterr().out.splitlines() if "bf16  512 1 b0 b0" in l]
-  assert len(lines) == 4, lines
-  for l in lines:
-    assert "vgpr 256 agpr 256" in l and "inside MFMA loops: scratch 0, lane spills 0" in l, l
-  headline = [l for l in lines if "512 1 b0 b0 b0 0 " in l]
-  assert len(headline) == 1 and "first..last MFMA: scratch ops 0, lane spills 0" in headline[0], headline
+  return capsys.readouterr().out.splitlines()
 
 
 @pytest.mark.skipif(not TEMPS, reason="no --save-temps assembly in csrc/build")
-def test_16x16x32_builds_have_no_spill_code_inside_their_mfma_loops(capsys, monkeypatch):
-  """The builds the headline shape (D = 512, no mask) and config 4 (D = 320, boolean mask) launch: O^T in the AGPRs (D / 2 of
-  them), no scratch at all, no SGPR lane spills inside the MFMA loops (one at D = 320); the headline build has none anywhere between its first and
-  last MFMA."""
-  monkeypatch.setattr(sys, "argv", ["isa_stats", "320", "384", "448", "512"])
-  _tool("isa_stats").main()
-  lines = [l for l in capsys.readouterr().out.splitlines() if " m16 " in l and " 1 b1 " not in l]  # (the dropout builds carry every bias path and do spill)
-  assert len(lines) == 4 * 4, lines  # {bf16, fp16} x {no mask, boolean mask} per head dim
+def test_headline_kernel_has_no_spill_code(capsys, monkeypatch):
+  """The kernel the headline workload launches (ffpa_fwd_m16_kernel<bf16, 512, MK=0>): 256 + 256 registers (O^T = the 256 AGPRs), 256
+  MFMAs per KV step, no scratch, and not one SGPR lane spill between its first and its last MFMA."""
+  lines = _stats(monkeypatch, capsys, 512)
+  headline = [l for l in lines if "m16 bf16  512 0 b0" in l]
+  assert len(headline) == 1, lines
+  assert "vgpr 256 agpr 256" in headline[0] and "scratch    0 B" in headline[0] and "mfma 256" in headline[0], headline
+  assert "first..last MFMA: scratch ops 0, lane spills 0" in headline[0], headline
+  # head dims >= 320 have ONE prefill family: no 32x32x16 prefill instantiation (ND = 1 at D <= 512) is left in this TU
+  assert not [l for l in lines if " m16 " not in l and "  512 1 " in l], lines
+
+
+@pytest.mark.skipif(not TEMPS, reason="no --save-temps assembly in csrc/build")
+def test_prefill_builds_have_no_scratch_inside_their_mfma_loops(capsys, monkeypatch):
+  """Every 16x16x32 prefill build (D = 320 ... 1024; no mask / boolean mask / additive bias, with and without dropout): a scratch
+  reload inside an MFMA loop would drain the LDS-DMA queue (vmcnt) — none anywhere; the builds without dropout keep their SGPR lane
+  spills out of the MFMA loops (a handful at D = 512 in the additive-bias build, whose scalar row tables do not fit)."""
   import re
+  lines = [l for l in _stats(monkeypatch, capsys, 320, 384, 448, 512, 640, 1024) if " m16 " in l]
+  assert len(lines) == 6 * 5 * 2, len(lines)  # {MK0, MK2, MK1, MK0+DROP, MK1+DROP} x {bf16, fp16} per head dim
   for l in lines:
-    hot = int(re.search(r"inside MFMA loops: scratch 0, lane spills (\d+)", l).group(1))
-    # (D = 320, 128-key tiles: hipcc parks ONE scalar in a VGPR lane inside the QK^T loop of the unmasked build)
-    assert "scratch    0 B" in l and hot <= (1 if " 320 " in l else 0), l
-  headline = [l for l in lines if "m16 bf16  512 0 " in l]
-  assert len(headline) == 1 and "vgpr 256 agpr 256" in headline[0] and "first..last MFMA: scratch ops 0, lane spills 0" in headline[0] and "mfma 256" in headline[0], headline
+    m = re.search(r"inside MFMA loops: scratch (\d+), lane spills (\d+)", l)
+    hot_scratch, hot_lane = int(m.group(1)), int(m.group(2))
+    assert hot_scratch == 0, l
+    drop = bool(re.search(r" [012] b1 ", l))
+    mk1 = bool(re.search(r" 1 b[01] ", l))
+    if not drop:
+      assert "scratch    0 B" in l or " 1024 1 b0" in l, l
+      assert hot_lane <= (8 if mk1 else 0), l
+  # the 32x32x16 prefill kernels of the small head dims (what D <= 256 launches): no spill code inside their MFMA loops either
+  small = [l for l in _stats(monkeypatch, capsys, 256) if "bf16  256 1 b0 b0 b0" in l]
+  assert len(small) == 3, small  # mask kinds 0 / 2 / 1
+  for l in small:
+    assert "inside MFMA loops: scratch 0, lane spills 0" in l, l

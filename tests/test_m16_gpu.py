@@ -1,9 +1,10 @@
 """The prefill kernel on the 16x16x32 MFMA shape (csrc/ffpa_fwd_m16_kernel.h; `pytest -m gpu`).
 
-Unmasked and boolean-mask launches at head dims above 256 take this build by default; FFPA_FLAG_NO_M16 keeps them on the
-32x32x16 build (same tiles, same recurrence, another summation order inside the matrix core).  Pinned here: the oracle (the
-reference's recurrence restated on the CPU), the other build within output rounding, exact NaN / -inf patterns, and the
-properties that must hold to the bit inside one build (determinism, head independence, KV splits merge, strided views).
+EVERY prefill launch at head dims >= 320 runs this kernel (unmasked, boolean masks, additive biases, dropout, any softmax scale).
+Pinned here: the oracle (the reference's recurrence restated on the CPU), the register-staged 32x32x16 twin of the test library
+(another mapping of the same tiles onto the matrix core: same recurrence, another summation order) within output rounding where
+that twin exists (bf16; head dims 320 / 512 / 640 / 1024), exact NaN / -inf patterns, and the properties that must hold to the bit
+inside one build (determinism, head independence, KV splits merge, strided views, every bias source giving the same bits).
 """
 
 import numpy as np
@@ -19,13 +20,28 @@ D = 512  # the headline head dim; DIMS: head dims this build is launched for (12
 DIMS = [320, 384, 448, 512, 576, 640, 960, 1024]
 
 
+TWIN_DIMS = (320, 512, 640, 1024)  # head dims whose register-staged 32x32x16 twin is built into libffpa_attn_hip_test.so (bf16 only)
+
+
+def _has_twin(q):
+  return q.dtype == torch.bfloat16 and q.size(-1) in TWIN_DIMS
+
+
+def _twin(hip, q, k, v, bias, causal, scale=None, **kw):
+  """The same launch on the register-staged 32x32x16 twin kernel of the test library."""
+  kw.pop("num_splits", None)
+  return hip.forward(q, k, v, bias, causal, q.size(-1) ** -0.5 if scale is None else scale, flags=hip.FLAG_DEBUG_SAFE_PATH, num_splits=1, **kw)
+
+
 def _both(hip, q, k, v, bias, causal, **kw):
   o16, l16 = hip.forward(q, k, v, bias, causal, q.size(-1) ** -0.5, **kw)
-  o32, l32 = hip.forward(q, k, v, bias, causal, q.size(-1) ** -0.5, flags=hip.FLAG_NO_M16, **kw)
+  o32, l32 = _twin(hip, q, k, v, bias, causal, **kw) if _has_twin(q) else (None, None)
   return o16, l16, o32, l32
 
 
 def _same_up_to_rounding(o16, l16, o32, l32, dtype, name):
+  if o32 is None:  # no twin for this dtype / head dim
+    return
   a, b = o16.float(), o32.float()
   assert torch.equal(torch.isnan(a), torch.isnan(b)), f"{name}: NaN pattern"
   fin = ~torch.isnan(a)
@@ -45,7 +61,7 @@ def _same_up_to_rounding(o16, l16, o32, l32, dtype, name):
 @pytest.mark.parametrize("D", DIMS)
 @pytest.mark.parametrize("case", [(1, 2, 2, 128, 64, False), (1, 2, 1, 200, 333, False), (2, 4, 2, 384, 384, True), (1, 2, 2, 77, 1000, True),
                                   (1, 1, 1, 640, 1500, False), (1, 4, 4, 33, 65, True), (1, 2, 2, 1, 64, False), (2, 2, 1, 129, 63, False)])
-def test_matches_the_oracle_and_the_other_build(hip, dtype, D, case):
+def test_matches_the_oracle_and_the_twin_build(hip, dtype, D, case):
   B, Hq, Hkv, Nq, Nkv, causal = case
   q, k, v = _rand((B, Hq, Nq, D), dtype, seed=Nq), _rand((B, Hkv, Nkv, D), dtype, seed=Nkv + 1), _rand((B, Hkv, Nkv, D), dtype, seed=Nkv + 2)
   o16, l16, o32, l32 = _both(hip, q, k, v, None, causal, num_splits=1)
@@ -53,19 +69,33 @@ def test_matches_the_oracle_and_the_other_build(hip, dtype, D, case):
   _check_vs_oracle(o16, l16, q, k, v, causal=causal, block_keys=hip.tile_config(D)["block_keys"], name=f"m16 D{D} {case}")
 
 
-def test_the_default_launch_is_this_build(hip):
-  """The two builds sum in different orders: on random data their outputs cannot agree in every bit — if they do, the flag (or
-  the dispatch) is not doing anything."""
+def test_the_launch_plan_names_this_build(hip):
+  """The C-ABI says which kernel a launch runs (ffpa_attn_fwd_kernel): every prefill launch at D >= 320 names ffpa_fwd_m16_kernel with
+  the mask kind of its build; the two mappings sum in different orders, so on random data the twin cannot agree in every bit."""
   q, k, v = _rand((1, 4, 512, D), seed=1), _rand((1, 4, 2048, D), seed=2), _rand((1, 4, 2048, D), seed=3)
-  o16, _, o32, _ = _both(hip, q, k, v, None, False)
+  plan = {}
+  o16, _ = hip.forward(q, k, v, None, False, D ** -0.5, plan_out=plan)
+  assert plan["splits"] > 1 and plan["kernel"] == "ffpa_fwd_m16_kernel<bf16, 512, MK=0, DROP=0> + ffpa_fwd_merge_kernel", plan  # (4 row tiles: the KV axis is split)
+  o16, _ = hip.forward(q, k, v, None, False, D ** -0.5, plan_out=plan, num_splits=1)
+  assert plan["kernel"] == "ffpa_fwd_m16_kernel<bf16, 512, MK=0, DROP=0>", plan
+  o32, _ = _twin(hip, q, k, v, None, False)
   assert not torch.equal(o16, o32)
   mask = torch.ones(1, 1, 512, 2048, dtype=torch.bool, device="cuda")
-  ob16, _, ob32, _ = _both(hip, q, k, v, mask, False, kv_bounds=False)
-  assert torch.equal(ob16, o16) and torch.equal(ob32, o32)  # an all-True mask changes nothing, in either build
-  # additive biases stay on the 32x32x16 build whatever the flag says
+  ob16, _ = hip.forward(q, k, v, mask, False, D ** -0.5, kv_bounds=False, plan_out=plan, num_splits=1)
+  assert plan["kernel"] == "ffpa_fwd_m16_kernel<bf16, 512, MK=2, DROP=0>", plan
+  assert torch.equal(ob16, o16)  # an all-True mask changes nothing
   zero = torch.zeros(1, 1, 512, 2048, dtype=q.dtype, device="cuda")
-  oz, _ = hip.forward(q, k, v, zero, False, D ** -0.5, kv_bounds=False)
-  assert torch.equal(oz, o32)
+  oz, _ = hip.forward(q, k, v, zero, False, D ** -0.5, kv_bounds=False, plan_out=plan, num_splits=1)
+  assert plan["kernel"] == "ffpa_fwd_m16_kernel<bf16, 512, MK=1, DROP=0>" and plan["block_keys"] == 64, plan
+  assert torch.equal(oz, o16)  # an all-zero bias: the accumulators start from 0.0 either way
+  hip.forward(q, k, v, None, False, D ** -0.5, dropout_p=0.1, philox_seed=1, plan_out=plan, num_splits=1)
+  assert plan["kernel"] == "ffpa_fwd_m16_kernel<bf16, 512, MK=0, DROP=1>", plan
+  hip.forward(q, k, v, mask, False, D ** -0.5, dropout_p=0.1, philox_seed=1, kv_bounds=False, plan_out=plan, num_splits=1)
+  assert plan["kernel"] == "ffpa_fwd_m16_kernel<bf16, 512, MK=1, DROP=1>", plan
+  hip.forward(q[..., :256].contiguous(), k[..., :256].contiguous(), v[..., :256].contiguous(), None, False, 256 ** -0.5, plan_out=plan, num_splits=1)
+  assert plan["kernel"].startswith("ffpa_fwd_split_d_kernel<bf16, 256, ND=1"), plan
+  hip.forward(q[:, :, :1], k, v, None, False, D ** -0.5, plan_out=plan)
+  assert plan["kernel"].startswith("ffpa_fwd_split_d_kernel<bf16, 512, ND=4") and plan["kernel"].endswith("ffpa_fwd_merge_kernel"), plan
 
 
 @pytest.mark.parametrize("D", [320, 512, 1024])
@@ -74,7 +104,7 @@ def test_causal_offsets_tails_and_fully_masked_rows(hip, D):
   q, k, v = _rand((1, 2, Nq, D), seed=11), _rand((1, 2, Nkv, D), seed=12), _rand((1, 2, Nkv, D), seed=13)
   for off in (0, 400, -40, 650):  # SDPA-style, tail-aligned, rows with no visible key (NaN), almost everything visible
     o16, l16 = hip.forward(q, k, v, None, True, D ** -0.5, causal_offset=off)
-    o32, l32 = hip.forward(q, k, v, None, True, D ** -0.5, causal_offset=off, flags=hip.FLAG_NO_M16)
+    o32, l32 = _twin(hip, q, k, v, None, True, causal_offset=off)
     _same_up_to_rounding(o16, l16, o32, l32, q.dtype, f"offset {off}")
     _check_vs_oracle(o16, l16, q, k, v, causal=True, causal_offset=off, block_keys=hip.tile_config(D)["block_keys"], name=f"m16 offset {off}")
   assert torch.isnan(o16).sum().item() == 0
@@ -86,7 +116,7 @@ def test_causal_offsets_tails_and_fully_masked_rows(hip, D):
 @pytest.mark.parametrize("D", DIMS)
 def test_boolean_masks_vector_and_byte_paths(hip, D):
   """Mask bytes are read 4 at a time (unit key stride, 16-byte aligned rows, full tile) or one by one; ranges skip tiles and
-  mask reads.  Same visible keys as the 32x32x16 build: same NaN rows, outputs equal up to rounding; with and without the
+  mask reads.  Same visible keys as the 32x32x16 twin: same NaN rows, outputs equal up to rounding; with and without the
   ranges the SAME bits."""
   for Nq, Nkv in ((513, 1024), (513, 1000), (130, 777)):
     q, k, v = _rand((1, 2, Nq, D), seed=61), _rand((1, 2, Nkv, D), seed=62), _rand((1, 2, Nkv, D), seed=63)
@@ -164,8 +194,9 @@ def test_ragged_head_dims_equal_the_padded_run(hip, d):
     qp, kp, vp = (F.pad(t, (0, D - d)) for t in (q, k, v))
     op, lsep = hip.forward(qp, kp, vp, None, causal, d ** -0.5)
     assert torch.equal(o, op[..., :d]) and torch.equal(lse, lsep), (d, Nq, Nkv, causal)
-    o32, l32 = hip.forward(q, k, v, None, causal, d ** -0.5, flags=hip.FLAG_NO_M16)
-    _same_up_to_rounding(o, lse, o32, l32, q.dtype, f"d{d}")
+    # O^T columns past the caller's head dim are exact zeros in the accumulators (K AND V slots there are zero-filled by the range
+    # check): the padded run must not see anything but zeros in the columns it drops
+    assert not torch.isnan(op[..., d:].float()).any() and (op[..., d:] == 0).all(), (d, Nq, Nkv, causal)
 
 
 def test_public_api_headline_shape_slice(hip):
@@ -182,11 +213,31 @@ def test_public_api_headline_shape_slice(hip):
   assert (outc.float() - F.scaled_dot_product_attention(q, k, v, is_causal=True).float()).abs().max().item() <= 1e-2
 
 
+def _dropout_reference(q, k, v, bias, causal, p, seed, offset, scale):
+  """fp32 math with the kernel's dropout convention (ffpa_attn_amd/philox.py: the torch-ops Philox the backward uses to rebuild the
+  forward's mask): softmax first, then the keep mask on the rounded P, 1 / (1 - p) scaling."""
+  from ffpa_attn_amd.philox import dropout_keep_mask
+
+  B, Hq, Nq, _ = q.shape
+  Hkv, Nkv = k.size(1), k.size(2)
+  g = Hq // Hkv
+  s = (q.float() @ k.float().repeat_interleave(g, 1).transpose(-1, -2)) * scale
+  if bias is not None:
+    s = s.masked_fill(~bias, float("-inf")) if bias.dtype == torch.bool else s + bias.float()
+  if causal:
+    r, c = torch.arange(Nq, device=q.device)[:, None], torch.arange(Nkv, device=q.device)[None, :]
+    s = s.masked_fill(c > r + (Nkv - Nq), float("-inf"))
+  pr = torch.softmax(s, -1).to(q.dtype).float()
+  idx = torch.arange(B * Hq * Nq * Nkv, device=q.device, dtype=torch.int64).view(B, Hq, Nq, Nkv)
+  keep = dropout_keep_mask(seed, offset, idx, p)
+  return ((pr * keep / (1.0 - p)).to(q.dtype).float() @ v.float().repeat_interleave(g, 1)), torch.logsumexp(s, -1)
+
+
 @pytest.mark.parametrize("D", [320, 512, 1024])
-def test_dropout_keeps_the_same_scores_as_the_other_build(hip, D):
-  """Dropout launches take this build too (Philox at the logical score index: the kept set does not depend on the lane layout), with
-  and without a mask or an additive bias riding along — the only launches of its additive-bias code.  Same kept scores as the
-  32x32x16 build: outputs equal up to rounding (one flipped keep decision would move O by ~ p_ij / (1 - p) ~ 1e-1 at these sizes)."""
+def test_dropout_builds_with_and_without_a_bias(hip, D):
+  """Dropout launches: the bias-free build (MK = 0) when nothing rides along, the additive-bias build with a mask or a bias.  Philox at
+  the logical score index: the kept set does not depend on the lane layout — checked against fp32 math with the same keep mask (one
+  flipped keep decision would move O by ~ p_ij / (1 - p) ~ 1e-1 at these sizes)."""
   B, Hq, Hkv, Nq, Nkv = 1, 4, 2, 200, 333
   q, k, v = _rand((B, Hq, Nq, D), seed=81), _rand((B, Hkv, Nkv, D), seed=82), _rand((B, Hkv, Nkv, D), seed=83)
   g = torch.Generator(device="cuda").manual_seed(5)
@@ -197,12 +248,20 @@ def test_dropout_keeps_the_same_scores_as_the_other_build(hip, D):
            "bf16_strided": (torch.randn(1, 1, Nq, 2 * Nkv, device="cuda", generator=g) * 0.5).to(q.dtype)[..., ::2]}
   for name, bias in cases.items():
     for causal in (False, True):
-      kw = dict(dropout_p=0.3, philox_seed=99, philox_offset=12, kv_bounds=False)
-      o16, l16 = hip.forward(q, k, v, bias, causal, D ** -0.5, **kw)
-      o32, l32 = hip.forward(q, k, v, bias, causal, D ** -0.5, flags=hip.FLAG_NO_M16, **kw)
-      _same_up_to_rounding(o16, l16, o32, l32, q.dtype, f"dropout {name} causal={causal}")
-      o_nodrop, _ = hip.forward(q, k, v, bias, causal, D ** -0.5, kv_bounds=False)
-      assert (o16.float() - o_nodrop.float()).abs().max().item() > 0.02
+      for off in (12, 13):  # Philox groups aligned / straddling two blocks
+        kw = dict(dropout_p=0.3, philox_seed=99, philox_offset=off, kv_bounds=False)
+        o16, l16 = hip.forward(q, k, v, bias, causal, D ** -0.5, **kw)
+        want, lse_want = _dropout_reference(q, k, v, bias, causal, 0.3, 99, off, D ** -0.5)
+        d = (o16.float() - want).abs()
+        assert d.max().item() <= 2.5e-2 and d.mean().item() <= 1.5e-3, (name, causal, off, d.max().item(), d.mean().item())
+        assert (l16 - lse_want).abs().max().item() <= 2e-4, (name, causal)
+        o_nodrop, _ = hip.forward(q, k, v, bias, causal, D ** -0.5, kv_bounds=False)
+        assert (o16.float() - o_nodrop.float()).abs().max().item() > 0.02
+  # a non-positive softmax scale next to dropout (the multiply-first form / the zeroed-Q form of the kernel)
+  for scale in (-0.05, 0.0):
+    o16, _ = hip.forward(q, k, v, cases["key_bias"], False, scale, dropout_p=0.3, philox_seed=99, philox_offset=12, kv_bounds=False)
+    want, _ = _dropout_reference(q, k, v, cases["key_bias"], False, 0.3, 99, 12, scale)
+    assert (o16.float() - want).abs().max().item() <= 2.5e-2, scale
 
 
 @pytest.mark.parametrize("D", [128, 512, 1024])
@@ -220,17 +279,101 @@ def test_caller_packed_query_heads_at_prefill_sizes(hip, D):
     assert torch.equal(o.view(B, Hkv * g, Nq, D), o_ref) and torch.equal(lse.view(B, Hkv * g, Nq), l_ref), (D, off)
 
 
-def test_non_positive_scale_takes_the_other_build(hip):
-  """This build folds softmax_scale into the exponent's FMA and scales the row max after its reduction — exact only for a positive
-  scale; zero / negative scales (legal, if unusual) are served by the 32x32x16 build: same bits as with FFPA_FLAG_NO_M16, and right."""
+def test_non_positive_softmax_scales(hip):
+  """The kernel folds softmax_scale into the exponent's FMA and scales the row max after its reduction — exact only for a positive
+  scale.  A negative scale takes its multiply-first form (a wave-uniform branch), a zero scale reaches it as "Q = 0, scale = 1" (the
+  same scores: 0 * q.k + bias): legal, if unusual — and right, with and without a bias."""
   q, k, v = _rand((1, 2, 200, D), seed=101), _rand((1, 2, 333, D), seed=102), _rand((1, 2, 333, D), seed=103)
+  g = torch.Generator(device="cuda").manual_seed(7)
+  biases = (None, (torch.randn(1, 2, 200, 333, device="cuda", generator=g)).to(q.dtype), torch.randn(1, 1, 1, 333, device="cuda", generator=g))
   for scale in (-0.044, 0.0):
-    o, lse = hip.forward(q, k, v, None, True, scale)
-    o32, l32 = hip.forward(q, k, v, None, True, scale, flags=hip.FLAG_NO_M16)
-    assert torch.equal(o, o32) and torch.equal(lse, l32), scale
-    s = (q.float() @ k.float().transpose(-1, -2)) * scale
-    r, c = torch.arange(200, device="cuda")[:, None], torch.arange(333, device="cuda")[None, :]
-    s = s.masked_fill(c > r + 133, float("-inf"))
-    want = torch.softmax(s, -1) @ v.float()
-    assert (o.float() - want).abs().max().item() < 1e-2, scale
-    assert (lse - torch.logsumexp(s, -1)).abs().max().item() < 1e-3, scale
+    for bias in biases:
+      o, lse = hip.forward(q, k, v, bias, True, scale, kv_bounds=False)
+      s = (q.float() @ k.float().transpose(-1, -2)) * scale
+      if bias is not None:
+        s = s + bias.float()
+      r, c = torch.arange(200, device="cuda")[:, None], torch.arange(333, device="cuda")[None, :]
+      s = s.masked_fill(c > r + 133, float("-inf"))
+      want = torch.softmax(s, -1) @ v.float()
+      assert (o.float() - want).abs().max().item() < 1e-2, (scale, None if bias is None else tuple(bias.shape))
+      assert (lse - torch.logsumexp(s, -1)).abs().max().item() < 1e-3, scale
+      if bias is None and scale < 0:
+        o32, l32 = _twin(hip, q, k, v, None, True, scale=scale)
+        _same_up_to_rounding(o, lse, o32, l32, q.dtype, f"scale {scale}")
+
+
+def _bias_cases(B, Hq, Nq, Nkv, dtype, gen):
+  """Additive biases by where the kernel takes them from: key biases (LDS row cache), row-axis biases with unit key stride and 16-byte
+  aligned rows (LDS-DMA staged tiles), everything else (element loads)."""
+  def r(*shape, dt=dtype):
+    return (torch.randn(*shape, device="cuda", generator=gen) * 0.7).to(dt)
+
+  wide = r(1, 1, Nq, 2 * Nkv + 8)
+  cases = {
+    "key_bias": r(1, 1, 1, Nkv),
+    "key_bias_per_head_f32": r(B, Hq, 1, Nkv, dt=torch.float32),
+    "key_bias_strided": r(1, 1, 1, 2 * Nkv)[..., ::2],
+    "dense": r(1, 1, Nq, Nkv),
+    "dense_per_head": r(B, Hq, Nq, Nkv),
+    "dense_f32": r(1, Hq, Nq, Nkv, dt=torch.float32),
+    "dense_key_strided": wide[..., : 2 * Nkv : 2],
+    "dense_row_padded": wide[..., 8 : 8 + Nkv] if Nkv % 8 == 0 else wide[..., 1 : 1 + Nkv],
+    "dense_misaligned": wide[..., 1 : 1 + Nkv],
+    "row_bias": r(1, 1, Nq, 1),
+    "neg_inf_entries": None,
+  }
+  m = r(1, Hq, Nq, Nkv)
+  m[0, 0, 3, :] = float("-inf")          # a fully masked row: NaN like SDPA
+  m[0, :, 7, Nkv // 2 :] = float("-inf")
+  m[0, -1, 11, 1:] = float("-inf")       # a row that sees one key
+  cases["neg_inf_entries"] = m
+  return cases
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("D", [320, 384, 512, 640, 1024])
+def test_additive_biases_from_every_source(hip, dtype, D):
+  """Additive biases enter this kernel through the S^T accumulators (bias / scale) from three sources — the fp32 row cache in LDS, the
+  LDS-DMA staged tiles, element loads; FFPA_FLAG_NO_BIAS_LDS forces the last one.  All three must give the SAME bits (the same
+  fp32 values reach the same accumulators), match the oracle (which adds the bias to the scaled score, prefill.cuh:556-658) within
+  output rounding, and reproduce NaN rows / single-key rows exactly."""
+  B, Hq, Hkv = 2, 4, 2
+  for Nq, Nkv, causal in ((130, 333, False), (257, 512, True), (64, 1000, False)):
+    q, k, v = _rand((B, Hq, Nq, D), dtype, seed=Nq), _rand((B, Hkv, Nkv, D), dtype, seed=Nkv + 1), _rand((B, Hkv, Nkv, D), dtype, seed=Nkv + 2)
+    gen = torch.Generator(device="cuda").manual_seed(D + Nq)
+    for name, bias in _bias_cases(B, Hq, Nq, Nkv, dtype, gen).items():
+      o, lse = hip.forward(q, k, v, bias, causal, D ** -0.5, kv_bounds=False, num_splits=1)
+      og, lg = hip.forward(q, k, v, bias, causal, D ** -0.5, kv_bounds=False, num_splits=1, flags=hip.FLAG_NO_BIAS_LDS)
+      tag = f"{name} D{D} {Nq}x{Nkv} causal={causal} {dtype}"
+      assert torch.equal(torch.nan_to_num(o.float(), nan=7.0), torch.nan_to_num(og.float(), nan=7.0)) and torch.equal(lse, lg), tag
+      _check_vs_oracle(o, lse, q, k, v, causal=causal, bias=_f32(bias), block_keys=32 if D > 512 else 64, name=tag)
+      if name == "neg_inf_entries":
+        assert torch.isnan(o[0, 0, 3]).all() and torch.equal(o[0, -1, 11], v[0, -1, 0]), tag
+      if _has_twin(q) and name in ("dense", "key_bias", "neg_inf_entries"):
+        o32, l32 = _twin(hip, q, k, v, bias, causal, kv_bounds=False)
+        _same_up_to_rounding(o, lse, o32, l32, dtype, tag)
+
+
+def test_additive_mask_ranges_and_long_key_biases(hip):
+  """kv_bounds with an additive mask: tiles in the neutral interior start from zero accumulators and stage nothing, tiles outside the
+  visible range are skipped — the same bits as without the ranges.  A key bias too long for the LDS row cache goes through the staged
+  tiles (row stride 0): the same bits as the element loads."""
+  Nq, Nkv = 900, 2048
+  q, k, v = _rand((1, 4, Nq, D), seed=701), _rand((1, 2, Nkv, D), seed=702), _rand((1, 2, Nkv, D), seed=703)
+  rows, cols = torch.arange(Nq, device="cuda")[:, None], torch.arange(Nkv, device="cuda")[None, :]
+  for name, keep in (("causal", cols <= rows + 600), ("window", (cols <= rows + 700) & (cols + 200 >= rows)), ("padding", (cols < 1500).expand(Nq, Nkv))):
+    for dt in (torch.bfloat16, torch.float32):
+      m = torch.zeros(1, 1, Nq, Nkv, dtype=dt, device="cuda").masked_fill(~keep, float("-inf"))
+      a, la = hip.forward(q, k, v, m, False, D ** -0.5, kv_bounds=False)
+      b, lb = hip.forward(q, k, v, m, False, D ** -0.5, kv_bounds=True)
+      assert torch.equal(a, b) and torch.equal(la, lb), (name, dt)
+      c, lc = hip.forward(q, k, v, keep.view(1, 1, Nq, Nkv).contiguous(), False, D ** -0.5, kv_bounds=False)
+      assert torch.equal(a, c) and torch.equal(la, lc), (name, dt)  # 0 / -inf additive == boolean: the same scores
+  Nkv = 20000  # 80 KB of fp32 row cache: does not fit next to the K / V tiles
+  q, k, v = _rand((1, 2, 200, D), seed=711), _rand((1, 2, Nkv, D), seed=712), _rand((1, 2, Nkv, D), seed=713)
+  kb = _rand((1, 2, 1, Nkv), seed=714)
+  a, la = hip.forward(q, k, v, kb, False, D ** -0.5, num_splits=1)
+  b, lb = hip.forward(q, k, v, kb, False, D ** -0.5, num_splits=1, flags=hip.FLAG_NO_BIAS_LDS)
+  assert torch.equal(a, b) and torch.equal(la, lb)
+  s = (q.float() @ k.float().transpose(-1, -2)) * D ** -0.5 + kb.float()
+  assert (a.float() - torch.softmax(s, -1) @ v.float()).abs().max().item() < 1e-2

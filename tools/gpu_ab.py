@@ -1,11 +1,17 @@
-"""Interleaved A/B timing of kernel variants on one MI355X (developer tool).
+"""Interleaved A/B timing of library builds on one MI355X (developer tool; replaces the single-purpose gpu_*_ab.py scripts).
 
-    python tools/gpu_ab.py [--shape B,H,N,D] [--rounds 5] [--reps 5] TAG[:flags] TAG ...
+    python tools/gpu_ab.py [--case NAME[,NAME...]] [--shape B,H,N,D ...] [--rounds 5] [--reps 5] TAG[:flags] TAG ...
 
-Each TAG is a library built by `python -m ffpa_attn_amd.build --variant TAG DEF...` ("main" = the
-shipped ffpa_attn_amd/libffpa_attn_hip.so).  Variants are timed in interleaved rounds inside ONE
-process (cdna guide §5.4 rule 24) with HIP events; the report gives median / min ms and TFLOPS per
-variant, plus max |O - O_main| to flag variants that changed results (ablations do, by design).
+Each TAG is a library: "main" = the shipped ffpa_attn_amd/libffpa_attn_hip.so, anything else =
+ffpa_attn_amd/variants/libffpa_attn_hip_TAG.so (built by `python -m ffpa_attn_amd.build --variant TAG DEF...`, or a saved
+build of another commit).  `:flags` ORs ffpa_fwd_params.flags bits into that arm's launches.  Arms are timed in interleaved
+rounds inside ONE process (cdna guide section 5.4 rule 24) with HIP events; per case and arm: median / best ms, TFLOPS (valid
+pairs), and max |O - O_first arm| (ablation builds change results by design; A/B arms of one kernel must not).
+
+Cases (`--case`, default cfg2; `--shape` / `--hkv` / `--nkv` / `--causal` / `--dropout` override the "custom" case):
+  cfg2 cfg3 cfg4_mask cfg4_offset0 cfg4_nomask causal cross gqa non_aligned dropout   (bench.py's workloads)
+  key_bias dense_bias dense_bias_f32 dense_bias_heads key_bias_d320 dense_bias_d320 key_bias_d1024 dense_bias_d1024
+  dropout_d320 dropout_d1024 n1024 n2048 causal4k d320 d384 d448 d640 d768 d1024_causal decode decode_b8
 """
 import argparse
 import os
@@ -24,10 +30,59 @@ def lib_for(tag):
   return hip.load_library(os.path.join(ROOT, "ffpa_attn_amd", "variants", f"libffpa_attn_hip_{tag}.so"))
 
 
+def _c(B, H, Nq, D, hkv=0, nkv=0, causal=False, bias=None, dropout=0.0, offset0=False):
+  return dict(B=B, H=H, Hkv=hkv or H, Nq=Nq, Nkv=nkv or Nq, D=D, causal=causal, bias=bias, dropout=dropout, offset0=offset0)
+
+
+CASES = {
+  "cfg2": _c(1, 32, 8192, 512), "cfg3": _c(1, 32, 8192, 1024),
+  "cfg4_mask": _c(2, 32, 8192, 320, hkv=8, nkv=2048, bias="tril_bool"), "cfg4_offset0": _c(2, 32, 8192, 320, hkv=8, nkv=2048, causal=True, offset0=True),
+  "cfg4_nomask": _c(2, 32, 8192, 320, hkv=8, nkv=2048),
+  "causal": _c(1, 32, 8192, 512, causal=True), "cross": _c(1, 32, 1024, 512, nkv=8192), "gqa": _c(1, 32, 8192, 512, hkv=8),
+  "non_aligned": _c(1, 8, 8191, 512), "dropout": _c(1, 32, 8192, 512, dropout=0.1),
+  "key_bias": _c(1, 32, 8192, 512, bias="key"), "dense_bias": _c(1, 32, 8192, 512, bias="dense"), "dense_bias_f32": _c(1, 32, 8192, 512, bias="dense_f32"),
+  "dense_bias_heads": _c(1, 32, 8192, 512, bias="dense_heads"),
+  "key_bias_d320": _c(1, 32, 8192, 320, bias="key"), "dense_bias_d320": _c(1, 32, 8192, 320, bias="dense"),
+  "key_bias_d1024": _c(1, 32, 8192, 1024, bias="key"), "dense_bias_d1024": _c(1, 32, 8192, 1024, bias="dense"),
+  "dropout_d320": _c(1, 32, 8192, 320, dropout=0.1), "dropout_d1024": _c(1, 32, 8192, 1024, dropout=0.1),
+  "n1024": _c(1, 32, 1024, 512), "n2048": _c(1, 32, 2048, 512), "causal4k": _c(1, 32, 4096, 512, causal=True),
+  "d320": _c(1, 32, 8192, 320), "d384": _c(1, 32, 8192, 384), "d448": _c(1, 32, 8192, 448), "d640": _c(1, 32, 8192, 640), "d768": _c(1, 32, 8192, 768),
+  "d1024_causal": _c(1, 32, 8192, 1024, causal=True),
+  "decode": _c(1, 32, 1, 512, nkv=8192), "decode_b8": _c(8, 32, 1, 512, hkv=8, nkv=8192),
+}
+
+
+def make_bias(kind, c, dtype, dev):
+  if kind is None:
+    return None
+  g = torch.Generator(device=dev).manual_seed(1)
+  Nq, Nkv, H = c["Nq"], c["Nkv"], c["H"]
+  if kind == "tril_bool":
+    return torch.ones(Nq, Nkv, dtype=torch.bool, device=dev).tril().view(1, 1, Nq, Nkv)
+  if kind == "key":
+    return (torch.randn(1, 1, 1, Nkv, device=dev, generator=g) * 0.25).to(dtype)
+  if kind == "dense":
+    return (torch.randn(1, 1, Nq, Nkv, device=dev, generator=g) * 0.25).to(dtype)
+  if kind == "dense_f32":
+    return torch.randn(1, 1, Nq, Nkv, device=dev, generator=g) * 0.25
+  if kind == "dense_heads":
+    return (torch.randn(1, H, Nq, Nkv, device=dev, generator=g) * 0.25).to(dtype)
+  raise KeyError(kind)
+
+
+def flops_of(c):
+  from ffpa_attn_amd.flops import attention_fwd_flops
+
+  if c["offset0"] or c["bias"] == "tril_bool":
+    return 4 * c["B"] * c["H"] * c["D"] * sum(min(c["Nkv"], r + 1) for r in range(c["Nq"]))
+  return attention_fwd_flops(c["B"], c["H"], c["Nq"], c["Nkv"], c["D"], c["causal"])
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("tags", nargs="+")
-  ap.add_argument("--shape", default="1,32,8192,512")
+  ap.add_argument("--case", default="")
+  ap.add_argument("--shape", default="")
   ap.add_argument("--hkv", type=int, default=0)
   ap.add_argument("--nkv", type=int, default=0)
   ap.add_argument("--causal", action="store_true")
@@ -35,49 +90,61 @@ def main():
   ap.add_argument("--rounds", type=int, default=5)
   ap.add_argument("--reps", type=int, default=5)
   args = ap.parse_args()
-  B, H, N, D = (int(x) for x in args.shape.split(","))
-  Hkv = args.hkv or H
-  Nkv = args.nkv or N
-  torch.manual_seed(0)
-  q = torch.randn(B, H, N, D, dtype=torch.bfloat16, device="cuda")
-  k = torch.randn(B, Hkv, Nkv, D, dtype=torch.bfloat16, device="cuda")
-  v = torch.randn(B, Hkv, Nkv, D, dtype=torch.bfloat16, device="cuda")
-  from ffpa_attn_amd.flops import attention_fwd_flops
-
-  flops = attention_fwd_flops(B, H, N, Nkv, D, args.causal)
+  cases = []
+  if args.shape:
+    B, H, N, D = (int(x) for x in args.shape.split(","))
+    cases.append(("custom", _c(B, H, N, D, hkv=args.hkv, nkv=args.nkv, causal=args.causal, dropout=args.dropout)))
+  for name in [n for n in args.case.split(",") if n]:
+    cases.append((name, CASES[name]))
+  if not cases:
+    cases.append(("cfg2", CASES["cfg2"]))
   variants = []
   for t in args.tags:
     tag, _, fl = t.partition(":")
-    variants.append((t, lib_for(tag), int(fl or 0)))
+    variants.append((t, lib_for(tag), int(fl or 0, 0)))
 
-  def run(lib, flags):
-    hip._lib = lib
-    return hip.forward(q, k, v, None, args.causal, D ** -0.5, flags=flags, return_lse=False, dropout_p=args.dropout, philox_seed=7)[0]
+  for cname, c in cases:
+    torch.manual_seed(0)
+    dt = torch.bfloat16
+    q = torch.randn(c["B"], c["H"], c["Nq"], c["D"], dtype=dt, device="cuda")
+    k = torch.randn(c["B"], c["Hkv"], c["Nkv"], c["D"], dtype=dt, device="cuda")
+    v = torch.randn(c["B"], c["Hkv"], c["Nkv"], c["D"], dtype=dt, device="cuda")
+    bias = make_bias(c["bias"], c, dt, "cuda")
+    flops = flops_of(c)
+    kw = dict(flags=0, return_lse=False, dropout_p=c["dropout"], philox_seed=7)
+    if c["offset0"]:
+      kw["causal_offset"] = 0
 
-  base = None
-  times = {t: [] for t, _, _ in variants}
-  diffs = {}
-  for t, lib, fl in variants:
-    o = run(lib, fl)
-    torch.cuda.synchronize()
-    if base is None:
-      base = o.float()
-    diffs[t] = (o.float() - base).abs().max().item()
-  for _ in range(args.rounds):
+    def run(lib, flags):
+      hip._lib = lib
+      kw["flags"] = flags
+      return hip.forward(q, k, v, bias, c["causal"], c["D"] ** -0.5, **kw)[0]
+
+    base = None
+    times = {t: [] for t, _, _ in variants}
+    diffs = {}
     for t, lib, fl in variants:
-      s = torch.cuda.Event(enable_timing=True)
-      e = torch.cuda.Event(enable_timing=True)
-      s.record()
-      for _ in range(args.reps):
-        run(lib, fl)
-      e.record()
+      o = run(lib, fl)
       torch.cuda.synchronize()
-      times[t].append(s.elapsed_time(e) / args.reps)
-  print(f"shape B={B} H={H}/{Hkv} Nq={N} Nkv={Nkv} D={D} causal={args.causal}  flops={flops:.3e}")
-  for t, _, _ in variants:
-    ts = sorted(times[t])
-    med, mn = ts[len(ts) // 2], ts[0]
-    print(f"AB {t:28s} median {med:8.4f} ms {flops / med / 1e9:8.1f} TF | best {mn:8.4f} ms {flops / mn / 1e9:8.1f} TF | maxdiff vs first {diffs[t]:.3e}")
+      if base is None:
+        base = o.float()
+      diffs[t] = (torch.nan_to_num(o.float()) - torch.nan_to_num(base)).abs().max().item()
+    for _ in range(args.rounds):
+      for t, lib, fl in variants:
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(args.reps):
+          run(lib, fl)
+        e.record()
+        torch.cuda.synchronize()
+        times[t].append(s.elapsed_time(e) / args.reps)
+    print(f"CASE {cname}: B={c['B']} H={c['H']}/{c['Hkv']} Nq={c['Nq']} Nkv={c['Nkv']} D={c['D']} causal={c['causal']} bias={c['bias']} dropout={c['dropout']}  flops={flops:.3e}", flush=True)
+    for t, _, _ in variants:
+      ts = sorted(times[t])
+      med, mn = ts[len(ts) // 2], ts[0]
+      print(f"AB {cname:18s} {t:24s} median {med:9.4f} ms {flops / med / 1e9:8.1f} TF | best {mn:9.4f} ms {flops / mn / 1e9:8.1f} TF | maxdiff vs first {diffs[t]:.3e}", flush=True)
+    del q, k, v, bias, base
 
 
 if __name__ == "__main__":

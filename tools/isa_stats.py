@@ -6,7 +6,7 @@ instructions sit inside the KV-tile loop (between the first and the last MFMA of
 """
 import glob, os, re, sys
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ffpa_attn_amd", "csrc", "build")
+ROOT = os.environ.get("FFPA_ISA_ROOT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ffpa_attn_amd", "csrc", "build")
 
 
 def kernels(path):
