@@ -157,8 +157,10 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
       bool stage_ok = lds_ok && p->bias_stride[3] == 1 && reinterpret_cast<uintptr_t>(p->bias) % 16 == 0 && p->bias_stride[2] < (1LL << 24) &&
                       pl.lds + stage <= 160 * 1024;
       for (int i = 0; i < 3 && stage_ok; ++i) stage_ok = (p->bias_stride[i] * esz) % 16 == 0;
-      if (lds_ok && p->bias_stride[2] == 0 && pl.lds + cache <= 160 * 1024) pl.bias_lds = (int)cache;
-      else if (stage_ok) {
+      if (lds_ok && p->bias_stride[2] == 0 && pl.lds + cache <= 160 * 1024) {
+        pl.bias_lds = (int)cache;
+        if (p->kv_bounds == nullptr && !(p->dropout_p > 0.f)) pl.mk = 3;  // nothing but a cached key bias: the lean key-bias build
+      } else if (stage_ok) {
         pl.btile = 1;
         pl.bias_lds = -(int)stage;
       }
@@ -271,6 +273,8 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
     return fail(FFPA_ERR_BAD_STRIDE, "kv_bounds strides must be >= 0");
   if (p->workspace != nullptr && !aligned16(p->workspace))
     return fail(FFPA_ERR_MISALIGNED, "workspace must be 16-byte aligned");
+  if (p->split_tickets != nullptr && (reinterpret_cast<uintptr_t>(p->split_tickets) & 3u) != 0)
+    return fail(FFPA_ERR_MISALIGNED, "split_tickets must be 4-byte aligned");
   if ((rc = check_device()) != FFPA_OK) return rc;
   const Plan pl = make_plan(p, de);
   const int lds = pl.lds;
@@ -366,10 +370,11 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   if (pl.splits > 1) {
     a.ws_o = static_cast<float*>(p->workspace);
     a.ws_lse = a.ws_o + (size_t)pl.splits * p->batch * p->heads_q * p->seqlen_q * kernel_head_dim(p->head_dim);
+    a.tickets = p->split_tickets;  // non-NULL: the kernel merges the partials itself (last split of a row tile to arrive)
   }
 
   int st = de->launch(p->dtype, safe, pl.variant, a, static_cast<hipStream_t>(stream));
-  if (st == 0 && pl.splits > 1) {
+  if (st == 0 && pl.splits > 1 && a.tickets == nullptr) {
     const unsigned rows = (unsigned)((int64_t)p->batch * p->heads_q * p->seqlen_q);
     if (p->dtype == FFPA_DTYPE_BF16)
       hipLaunchKernelGGL(ffpa::ffpa_fwd_merge_kernel<__bf16>, dim3(rows, (unsigned)(p->head_dim + 255) / 256), dim3(64), 0, static_cast<hipStream_t>(stream), a, kernel_head_dim(p->head_dim));
@@ -394,6 +399,16 @@ size_t ffpa_attn_fwd_workspace_bytes(const ffpa_fwd_params* params) {
   q.workspace = reinterpret_cast<void*>(16);
   q.workspace_bytes = ~0ull;
   return make_plan(&q, de).ws_bytes;
+}
+
+size_t ffpa_attn_fwd_split_tickets(const ffpa_fwd_params* params) {
+  const DimEntry* de = nullptr;
+  if (check_basic(params, &de) != FFPA_OK) return 0;
+  ffpa_fwd_params q = *params;
+  q.workspace = reinterpret_cast<void*>(16);
+  q.workspace_bytes = ~0ull;
+  const Plan pl = make_plan(&q, de);
+  return pl.splits > 1 ? (size_t)params->batch * params->heads_q * pl.nqt : 0;
 }
 
 int ffpa_attn_mask_kv_bounds(const void* bias, int bias_dtype, const int64_t bias_stride[4], int bb, int hb, int nq,
@@ -458,7 +473,7 @@ int ffpa_attn_fwd_kernel(const ffpa_fwd_params* params, char* buf, size_t n) {
   const Plan pl = make_plan(params, de);
   const char* dt = params->dtype == FFPA_DTYPE_FP16 ? "fp16" : "bf16";
   const int drop = params->dropout_p > 0.f ? 1 : 0;
-  const char* merge = pl.splits > 1 ? " + ffpa_fwd_merge_kernel" : "";
+  const char* merge = pl.splits > 1 ? (params->split_tickets != nullptr ? " (in-launch split merge)" : " + ffpa_fwd_merge_kernel") : "";
   if (pl.m16) {
     snprintf(buf, n, "ffpa_fwd_m16_kernel<%s, %d, MK=%d, DROP=%d>%s", dt, de->d, pl.mk, drop, merge);
   } else {

@@ -48,7 +48,7 @@ static int launch_one(const FwdArgs& a, hipStream_t stream) {
 // The prefill kernel on the 16x16x32 MFMA shape (ffpa_fwd_m16_kernel.h): every prefill launch at head dims >= FFPA_M16_MIN_D.
 template <typename T, int D, int MK, bool DROP = false>
 static int launch_m16(const FwdArgs& a, hipStream_t stream) {
-  constexpr int BC = D > 512 ? 32 : ((D <= FFPA_BC128_MAX_D && MK != 1) ? 128 : 64);
+  constexpr int BC = D > 512 ? 32 : ((D <= FFPA_BC128_MAX_D && MK != 1 && MK != 3) ? 128 : 64);
   constexpr int LDS_BASE = 2 * BC * D * 2 + (D > 512 ? 4 * 4096 : 0);
   const int LDS = LDS_BASE + (a.bias_lds > 0 ? a.bias_lds : -a.bias_lds);  // + the key-bias row cache or the bias-tile staging areas, sized by the C-ABI layer (<= 160 KiB in total)
   auto kern = ffpa_fwd_m16_kernel<T, D, MK, DROP>;
@@ -72,6 +72,7 @@ static int launch_m16(const FwdArgs& a, hipStream_t stream) {
 // Which kernel a launch runs (also reported by ffpa_attn_fwd_plan: FFPA_KERNEL_* in include/ffpa_attn.h):
 //   short-query tiles (variant 1)           -> ffpa_fwd_split_d_kernel<ND = 4 / 2>  (32x32x16 MFMA, split-KV)
 //   prefill, head dim >= FFPA_M16_MIN_D     -> ffpa_fwd_m16_kernel<MK, DROP>        (16x16x32 MFMA): the one prefill family of the large head dims
+//                                              (MK: 0 no bias, 2 boolean mask / ranges, 3 key bias from the LDS row cache, 1 any other additive bias or mask)
 //   prefill, smaller head dims              -> ffpa_fwd_split_d_kernel<ND = 1>      (32x32x16 MFMA)
 // (a template, so that `if constexpr` really discards the other family's instantiations)
 template <int D>
@@ -120,6 +121,11 @@ static int launch_fwd_impl(int dtype, int safe, int variant, const FwdArgs& a, h
     if (a.bias_dtype == 4 || a.bias_dtype == 0) {  // boolean mask and / or mask ranges: the build that carries only that path
       if (dtype == 0) return launch_m16<__bf16, D, 2>(a, stream);
       if (dtype == 1) return launch_m16<_Float16, D, 2>(a, stream);
+      return -4;
+    }
+    if (a.bias_lds > 0 && a.kv_bounds == nullptr) {  // a key bias that fits the LDS row cache, nothing else: the lean key-bias build
+      if (dtype == 0) return launch_m16<__bf16, D, 3>(a, stream);
+      if (dtype == 1) return launch_m16<_Float16, D, 3>(a, stream);
       return -4;
     }
     if (dtype == 0) return launch_m16<__bf16, D, 1>(a, stream);

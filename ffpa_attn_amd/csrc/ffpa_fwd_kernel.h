@@ -169,6 +169,7 @@ struct FwdArgs {
   int tiles_per_split;
   float* ws_o;          // [nsplit, B, Hq, Nq, D] fp32
   float* ws_lse;        // [nsplit, B, Hq, Nq]    fp32
+  int* tickets;         // [B * Hq * nqt] zeroed counters, or NULL: with them the last split of a row tile to arrive merges the partials in this launch
   // rows of several query heads of one KV group packed into one row axis (host reshape): the causal
   // limit of packed row r is (r % causal_row_mod) + causal_offset; 0 = rows are plain query rows
   int causal_row_mod;
@@ -531,6 +532,94 @@ __device__ __forceinline__ void apply_bool_block_vec(float (&x)[16], const void*
 #pragma unroll
   for (int r = 0; r < 16; ++r)
     if (((raw[r >> 2] >> (8 * (r & 3))) & 0xffu) == 0u) x[r] = -INFINITY;
+}
+
+// ---------------------------------------------------------------------------------
+// KV-split launches: merging the partials inside the launch (FwdArgs.tickets != NULL).
+//
+// Every split workgroup of a row tile calls this after storing its normalised fp32 partial + LSE to the workspace.  Hand-off in the
+// counter form of the cdna guide's Guideline 16: every wave drains its stores -> workgroup barrier -> lane 0: agent-scope release fence,
+// the post-write-back wait restated in asm (ROCm 7.2 drops the compiler's own when the wave's scoreboard is empty), ONE relaxed
+// agent-scope fetch_add on the tile's ticket.  The workgroup that draws nsplit - 1 is the last to arrive: lane 0 takes ONE agent-scope
+// acquire (invalidates this CU's L1: the other splits' partials were written by other CUs, possibly on other XCDs), barrier, then all
+// waves read the partials with plain loads and combine them exactly as ffpa_fwd_merge_kernel does (O = sum_s w_s O_s / sum_s w_s,
+// w_s = exp(LSE_s - max LSE), LSE = max + ln sum w_s: csrc/cuffpa/native/sm_80/split_kv.cuh:329-455), and the ticket goes back to
+// zero for the next launch.  Placement-independent: nothing assumes which CU / XCD ran which split, or in which order.
+// `scratch`: >= 16 + 4 * kMergeMaxSplits * 4 bytes of LDS nobody else uses any more (the K / V tile area after the tile loop).
+// ---------------------------------------------------------------------------------
+constexpr int kMergeMaxSplits = 1024;
+template <typename T>
+__device__ __forceinline__ void split_arrive_and_merge(const FwdArgs& a, int D, int tile_id, int b, int hq, int row0, int nrows, FFPA_LDS char* scratch) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial stores have left the CU
+  __syncthreads();
+  FFPA_LDS int* flag = (FFPA_LDS int*)scratch;
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int t = __hip_atomic_fetch_add(a.tickets + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == a.nsplit - 1) ? 1 : 0;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *flag = last;
+  }
+  __syncthreads();
+  if (*flag == 0) return;
+  FFPA_LDS float* wsh = (FFPA_LDS float*)(scratch + 16) + wave * kMergeMaxSplits;
+  const int64_t rows = (int64_t)a.B * a.Hq * a.Nq;
+  const int64_t sstride = rows * D;
+  for (int r0 = 0; r0 < nrows; r0 += 4) {  // one row per wave and round (uniform trip count: the barriers below are workgroup barriers)
+    const int qrow = row0 + r0 + wave;
+    const bool act = r0 + wave < nrows && qrow < a.Nq;
+    const int64_t row = ((int64_t)b * a.Hq + hq) * a.Nq + (act ? qrow : 0);
+    float mx = -INFINITY;
+    if (act)
+      for (int s = lane; s < a.nsplit; s += 64) mx = fmaxf(mx, a.ws_lse[s * rows + row]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float wsum = 0.f;
+    if (act)
+      for (int s = lane; s < a.nsplit; s += 64) {
+        const float w = (mx == -INFINITY) ? 0.f : __expf(a.ws_lse[s * rows + row] - mx);
+        wsh[s] = w;
+        wsum += w;
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o);
+    __syncthreads();  // the weights are visible to the whole wave
+    if (act) {
+      const float inv = 1.f / wsum;  // every share empty -> 0 * inf = NaN, like an unsplit fully masked row
+      T* op = (T*)a.o + b * a.so[0] + hq * a.so[1] + (int64_t)qrow * a.so[2];
+      for (int d = lane * 4; d < a.d_valid; d += 256) {
+        const float* src = a.ws_o + row * D + d;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        int s = 0;
+        for (; s + 8 <= a.nsplit; s += 8) {
+          f32x4 t[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t[u] = *(const f32x4*)(src + (s + u) * sstride);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const float w = wsh[s + u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += w * t[u][e];
+          }
+        }
+        for (; s < a.nsplit; ++s) {
+          const f32x4 t = *(const f32x4*)(src + s * sstride);
+          const float w = wsh[s];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] += w * t[e];
+        }
+        typename Elem<T>::v4 w4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w4[e] = (T)(acc[e] * inv);
+        *(typename Elem<T>::v4*)(op + d) = w4;
+      }
+      if (a.lse != nullptr && lane == 0) a.lse[row] = (mx == -INFINITY) ? -INFINITY : mx + __logf(wsum);
+    }
+    __syncthreads();  // the weights are free for the next round
+  }
+  if (tid == 0) a.tickets[tile_id] = 0;  // (the next launch that uses these tickets is ordered behind this one by its stream)
 }
 
 // DROP selects the dropout-capable build of the kernel: kept out of the default instantiation because its
@@ -1360,6 +1449,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
       }
     }
   }
+  // KV-split launch with tickets: the last split of this row tile to arrive merges all partials here (one launch per call)
+  if (a.nsplit > 1 && a.tickets != nullptr) split_arrive_and_merge<T>(a, D, bh * a.nqt + qt, b, hq, q0, BR, Kt);
 #if FFPA_PERSISTENT
   }  // persistent rounds
 #endif
@@ -1371,7 +1462,6 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
 // the lanes first share out the splits (max, weights -> LDS, sum: wave reductions), then each accumulates its 4
 // columns over the splits with the loads of 8 splits in flight at a time.  (The first version walked the splits
 // serially per lane and recomputed the weights per chunk: 60 us for a 64-split launch, 2.6x the main kernel.)
-constexpr int kMergeMaxSplits = 1024;
 template <typename T>
 __global__ __launch_bounds__(64) void ffpa_fwd_merge_kernel(const FwdArgs a, int D) {
   __shared__ float wsh[kMergeMaxSplits];

@@ -141,12 +141,15 @@ __device__ __forceinline__ int m16_v_swizzle(int key) {
 
 // MK (mask kind): 0 = the build for calls without attn_bias / mask ranges, 2 = boolean masks (FFPA_BIAS_BOOL8 bytes and / or kv_bounds
 // ranges: what ffpa_attn_func(attn_mask=<bool>) launches), 1 = additive biases (fp16 / bf16 / fp32, any broadcast; boolean masks too when
-// they come with dropout).  DROP: the dropout-capable builds (Philox4x32-10 at the logical score index, applied to the rounded P:
+// they come with dropout), 3 = key biases only (no row axis: [B|1, H|1, 1, Nkv], the reference bench's "attn-mask" case, key padding as an
+// additive mask) from the LDS row cache — the bias-free kernel plus one LDS read per 16-key block and row half, nothing else rides along.
+// DROP: the dropout-capable builds (Philox4x32-10 at the logical score index, applied to the rounded P:
 // prefill.cuh:398-546) — of the bias-free kernel (MK = 0: nothing but the Philox code rides along) and of the additive-bias kernel.
 template <typename T, int D, int MK = 0, bool DROP = false>
 __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
-  static_assert(MK >= 0 && MK <= 2 && (!DROP || MK != 2), "mask kinds 0 / 1 / 2; dropout builds: MK = 0 (no bias) and MK = 1 (any bias or mask)");
-  constexpr bool MASK = MK != 0;
+  static_assert(MK >= 0 && MK <= 3 && (!DROP || MK <= 1), "mask kinds 0 ... 3; dropout builds: MK = 0 (no bias) and MK = 1 (any bias or mask)");
+  constexpr bool MASK = MK == 1 || MK == 2;  // builds that honour mask ranges (kv_bounds)
+  constexpr bool kBias = MK == 1 || MK == 3;  // builds whose S^T accumulators start from bias / scale
   using E = Elem<T>;
   using M = Mfma16<T>;
   using v8 = typename E::v8;
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   // 32 qb .. + 32 and columns dh * D/2 .. of both contractions; the two partial S^T tiles of a row block are summed through LDS.
   constexpr int ND = (D <= 512) ? 1 : 2;
   constexpr int DW = D / ND;    // columns owned by one wave
-  constexpr int BC = ND == 2 ? 32 : ((D <= FFPA_BC128_MAX_D && MK != 1) ? 128 : 64), BR = 128 / ND;  // (additive-bias build: 64 keys, the LDS holds the bias too)
+  constexpr int BC = ND == 2 ? 32 : ((D <= FFPA_BC128_MAX_D && !kBias) ? 128 : 64), BR = 128 / ND;  // (additive-bias builds: 64 keys, the LDS holds the bias too)
   constexpr int KS = DW / 32;   // QK contraction steps per wave
   constexpr int NKB = BC / 16;  // 16-key S^T blocks per tile
   constexpr int NKS = BC / 32;  // PV contraction steps per tile
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   // D = 512 with masks: a tile row is one whole piece -> wave-uniform rows, scalar addressing (the per-lane offset tables of the other form
   // would not fit next to the mask path's registers).  Everything else keeps tile-invariant per-lane offsets in registers: measured equal
   // or better (D = 512 unmasked: + 0 ... 2 %; D = 1024: 927 vs 776 TFLOPS — the scalar row form loses 16 % there on this build).
-  constexpr bool kRowDma = RB % 1024 == 0 && ND == 1 && (MK != 0 || DROP) && FFPA_M16_ROWDMA;
+  constexpr bool kRowDma = RB % 1024 == 0 && ND == 1 && (MK == 1 || MK == 2 || DROP) && FFPA_M16_ROWDMA;
   static_assert(!kRowDma || RB == 1024, "the scalar row form is used where a tile row is exactly one piece");
   constexpr int KPW = BC / 4;                // keys staged per wave per tile
   constexpr int PF1 = FFPA_M16_PF1, PF2 = FFPA_M16_PF2;
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   //   a.bias_tile:    [32 rows x BC keys] tiles of the caller's dtype staged by LDS-DMA one step ahead, a.bias_lds = -(bytes of all staging areas);
   //   else:           element-wise global loads.
   // D > 512 (two waves per row block, partial S^T tiles summed): the dh = 0 wave alone carries the bias.
-  const bool bias_owner = MK == 1 && dh == 0 && a.bias_dtype != 0;
+  const bool bias_owner = kBias && dh == 0 && a.bias_dtype != 0;
   const int b_esz = a.bias_dtype == 3 ? 4 : 2;        // staged dtypes: fp16 / bf16 / fp32
   const int b_rowb = BC * b_esz;                      // bytes of one staged row: 64 ... 256
   const int b_slots = b_rowb >> 4;                    // 16-byte slots per staged row: 4, 8 or 16
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   };
   FFPA_LDS const char* const bl_lane = Bl + 16 * c;  // row cache: this lane's 4 keys of block kb of the step at k0 sit at bl_lane + 4 k0 + 64 kb
 
-  if (MK == 1 && a.bias_lds > 0 && nt > t0) {
+  if (kBias && a.bias_lds > 0 && nt > t0) {
     // key bias [.., .., 1, Nkv]: every row of the workgroup adds the same Nkv values — converted once to fp32 / scale (entries past Nkv are
     // zeros: those keys get the tail mask); made visible by the barrier below
     const int n_ent = a.bias_lds >> 2;
@@ -491,19 +494,21 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 
     // ================= S^T = K.Q^T =================
     f32x4 sacc[NKB][2];
-    if constexpr (MK == 1) {
+    if constexpr (kBias) {
       // the accumulators start from bias / softmax_scale (zeros where there is no bias): see the header
       // (mask_free, wave-uniform: this step lies in the neutral interior of the caller's mask (kv_bounds): nothing to read, nothing to add)
-      const bool mask_free = k0 >= free_lo && k0 + BC <= free_hi;
+      const bool mask_free = MK == 1 && k0 >= free_lo && k0 + BC <= free_hi;
       if (bias_owner && !mask_free) {
-        if (a.bias_lds > 0) {  // key bias: fp32 / scale from the LDS row cache, the same 4 keys for both of the lane's rows
+        if (MK == 3 || a.bias_lds > 0) {  // key bias: fp32 / scale from the LDS row cache, the same 4 keys for both of the lane's rows
           FFPA_LDS const char* bp = bl_lane + 4 * k0;
+          FFPA_LDS const char* bp2 = bp;
+          asm volatile("" : "+v"(bp2));  // (two reads, no register copies: the LDS has the bandwidth, the VALU slots are what the softmax needs)
 #pragma unroll
           for (int kb = 0; kb < NKB; ++kb) {
             sacc[kb][0] = *(FFPA_LDS const f32x4*)(bp + 64 * kb);
-            sacc[kb][1] = sacc[kb][0];
+            sacc[kb][1] = *(FFPA_LDS const f32x4*)(bp2 + 64 * kb);
           }
-        } else if (a.bias_tile) {  // the tile this wave staged during the previous step's PV loop (drained at barrier B)
+        } else if (MK == 1 && a.bias_tile) {  // the tile this wave staged during the previous step's PV loop (drained at barrier B)
           typedef __attribute__((ext_vector_type(4))) __bf16 b4;
           typedef __attribute__((ext_vector_type(4))) _Float16 h4;
           const int half_rows = 16 * b_rowb;
@@ -531,7 +536,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
                 for (int r = 0; r < 4; ++r) sacc[kb][rh][r] = (float)w[r] * a.inv_scale;
               }
           }
-        } else {  // element-wise from global memory: any strides, any dtype (boolean: 0 / -inf)
+        } else if constexpr (MK == 1) {  // element-wise from global memory: any strides, any dtype (boolean: 0 / -inf)
 #pragma unroll
           for (int rh = 0; rh < 2; ++rh) {
             const int64_t brow = b * a.sbias[0] + hq * a.sbias[1] + (int64_t)qrow_c[rh] * a.sbias[2];
@@ -580,10 +585,10 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 #define FFPA_M16_DMA_POS 1  // where a DMA piece sits relative to the fragment's two MFMAs: 0 in front, 1 between (+ 0.4 ... 1.7 %), 2 behind
 #endif
         if constexpr (kPiece && FFPA_M16_DMA_POS == 0) issue_v(std::integral_constant<int, n / kStep1>{}, k0);
-        if constexpr (s == 0 && MK != 1) M::first(sacc[kb][0], kf[n], qf[s][0]);
+        if constexpr (s == 0 && !kBias) M::first(sacc[kb][0], kf[n], qf[s][0]);
         else M::acc(sacc[kb][0], kf[n], qf[s][0]);
         if constexpr (kPiece && FFPA_M16_DMA_POS == 1) issue_v(std::integral_constant<int, n / kStep1>{}, k0);
-        if constexpr (s == 0 && MK != 1) M::first(sacc[kb][1], kf[n], qf[s][1]);
+        if constexpr (s == 0 && !kBias) M::first(sacc[kb][1], kf[n], qf[s][1]);
         else M::acc(sacc[kb][1], kf[n], qf[s][1]);
         if constexpr (kPiece && FFPA_M16_DMA_POS == 2) issue_v(std::integral_constant<int, n / kStep1>{}, k0);
       });
@@ -856,6 +861,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       }
       if (c == 0 && dh == 0) a.ws_lse[prow] = dead ? -INFINITY : __logf(l_tot[rh]) + m_run[rh] * 0.6931471805599453f;
     }
+    // with tickets: the last split of this row tile to arrive merges all partials here (one launch per call)
+    if (a.tickets != nullptr) split_arrive_and_merge<T>(a, D, bh * a.nqt + qt, b, hq, q0, BR, Kt);
     return;
   }
   {

@@ -31,7 +31,7 @@ _PKG = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_PKG, "libffpa_attn_hip.so")
 TEST_LIB_PATH = os.path.join(_PKG, "libffpa_attn_hip_test.so")  # product kernels + the register-staged SAFE twins (tests only)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # enum ffpa_status (include/ffpa_attn.h)
 _STATUS_EXC = {
@@ -96,6 +96,7 @@ class FfpaFwdParams(ctypes.Structure):
     ("causal_row_mod", ctypes.c_int32),
     ("kv_bounds", ctypes.c_void_p),
     ("kv_bounds_stride", ctypes.c_int64 * 2),
+    ("split_tickets", ctypes.c_void_p),
   ]
 
 
@@ -106,6 +107,7 @@ _lib_lock = threading.Lock()
 EXPORTS = (
   "ffpa_attn_fwd",
   "ffpa_attn_fwd_workspace_bytes",
+  "ffpa_attn_fwd_split_tickets",
   "ffpa_attn_mask_kv_bounds",
   "ffpa_attn_fwd_plan",
   "ffpa_attn_fwd_kernel",
@@ -140,6 +142,9 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.ffpa_attn_mask_kv_bounds.restype = ctypes.c_int
     lib.ffpa_attn_fwd_workspace_bytes.argtypes = [ctypes.POINTER(FfpaFwdParams)]
     lib.ffpa_attn_fwd_workspace_bytes.restype = ctypes.c_size_t
+    if path is None or hasattr(lib, "ffpa_attn_fwd_split_tickets"):
+      lib.ffpa_attn_fwd_split_tickets.argtypes = [ctypes.POINTER(FfpaFwdParams)]
+      lib.ffpa_attn_fwd_split_tickets.restype = ctypes.c_size_t
     lib.ffpa_attn_fwd_plan.argtypes = [ctypes.POINTER(FfpaFwdParams), ctypes.POINTER(ctypes.c_int)]
     lib.ffpa_attn_fwd_plan.restype = ctypes.c_int
     if path is None or hasattr(lib, "ffpa_attn_fwd_kernel"):  # (developer A/B runs may load a saved build of an older commit by path)
@@ -155,7 +160,7 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.ffpa_attn_last_error.restype = ctypes.c_char_p
     lib.ffpa_attn_version.argtypes = []
     lib.ffpa_attn_version.restype = ctypes.c_char_p
-    if lib.ffpa_attn_query(0) != ABI_VERSION:
+    if lib.ffpa_attn_query(0) != ABI_VERSION and path is None:
       raise RuntimeError(f"ffpa_attn_amd: {p} has ABI {lib.ffpa_attn_query(0)}, expected {ABI_VERSION}")
     if path is None:
       _lib = lib
@@ -286,6 +291,24 @@ def _want_mask_bounds(attn_bias: torch.Tensor, b: int, hq: int, nq: int, nkv: in
   return b * hq >= 2 * attn_bias.size(0) * attn_bias.size(1)
 
 
+# Zeroed int32 counters for the in-launch merge of KV-split launches (ffpa_fwd_params.split_tickets): one buffer per (device, stream),
+# zeroed once — the kernel leaves every counter at zero — and grown on demand.  Launches on one stream are ordered, so they may share
+# it; launches on different streams may overlap and get their own.
+_TICKETS: "dict[tuple, torch.Tensor]" = {}
+
+
+def _split_tickets(device: torch.device, stream: int, n: int) -> torch.Tensor:
+  if torch.cuda.is_current_stream_capturing():
+    # inside a stream capture: a buffer of the graph's own pool, zeroed by a node of the graph (like the workspace, it is replayed in place)
+    return torch.zeros(n, dtype=torch.int32, device=device)
+  key = (device.index, stream)
+  t = _TICKETS.get(key)
+  if t is None or t.numel() < n:
+    t = torch.zeros(max(4096, n), dtype=torch.int32, device=device)
+    _TICKETS[key] = t
+  return t
+
+
 def forward(
   q: torch.Tensor,
   k: torch.Tensor,
@@ -305,6 +328,7 @@ def forward(
   plan_out: dict | None = None,
   kv_bounds: torch.Tensor | bool | None = None,
   causal_row_mod: int = 0,
+  merge_in_launch: bool | None = None,
 ) -> tuple[torch.Tensor, torch.Tensor | None]:
   """Run the gfx950 kernel on the current stream of ``q.device``; returns ``(o, lse)``.
 
@@ -317,6 +341,9 @@ def forward(
   per query head), the library splits the KV axis over workgroups (``num_splits``: 0 = heuristic,
   1 = never) and merges by LSE; the scratch for the partials is allocated here with torch.
   ``plan_out``, if given, receives the launch plan (variant, block_rows, block_keys, splits, packed).
+
+  ``merge_in_launch``: KV-split launches merge their partials inside the launch (the last split of a row tile to arrive does it:
+  one launch per call; ``FFPA_HIP_MERGE_IN_LAUNCH=0`` or ``False`` keeps the separate merge kernel — the same numbers).
 
   ``kv_bounds``: key ranges of the mask (``mask_kv_bounds``) — the kernel then skips the KV tiles the mask hides
   entirely and does not read the mask for the tiles it leaves untouched (an explicit causal mask costs what ``is_causal``
@@ -427,6 +454,12 @@ def forward(
       workspace = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=q.device)  # caching allocator
       p.workspace = workspace.data_ptr()
       p.workspace_bytes = ws_bytes
+      if merge_in_launch is None:
+        merge_in_launch = os.environ.get("FFPA_HIP_MERGE_IN_LAUNCH", "1") not in ("0", "")
+      if merge_in_launch and hasattr(lib, "ffpa_attn_fwd_split_tickets"):
+        n_tickets = lib.ffpa_attn_fwd_split_tickets(ctypes.byref(p))
+        if n_tickets:
+          p.split_tickets = _split_tickets(q.device, torch.cuda.current_stream(q.device).cuda_stream, n_tickets).data_ptr()
     if plan_out is not None:
       plan = (ctypes.c_int * 4)()
       if lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FFPA_ATTN_ABI_VERSION 3
+#define FFPA_ATTN_ABI_VERSION 4
 
 /* status codes (0 == success).  The Python host maps them onto the exception
  * classes the reference raises (TORCH_CHECK -> RuntimeError,
@@ -150,6 +150,15 @@ typedef struct ffpa_fwd_params {
    * for is_causal only). */
   const int32_t* kv_bounds;
   int64_t kv_bounds_stride[2];
+
+  /* Optional, KV-split launches only (NULL = none): ffpa_attn_fwd_split_tickets(params) int32 counters, ZERO on entry.  With them the
+   * split partials are merged inside the same launch — the last split of a row tile to arrive (agent-scope release of its partial, one
+   * relaxed atomic ticket, agent-scope acquire by the merger) combines all of them by LSE, writes O / LSE and puts its counter back to
+   * zero: one launch per call instead of two, the role of the reference's split_kv_decode stage 2 (native/sm_80/split_kv.cuh:329-455)
+   * without its second kernel.  The counters must not be shared by launches that may run concurrently (other streams); after a launch
+   * completes they are zero again, so one buffer zeroed once serves every later call on that stream, HIP-graph replays included.
+   * Without them a second kernel (ffpa_fwd_merge_kernel) follows the first on the same stream: the same numbers. */
+  int32_t* split_tickets;
 } ffpa_fwd_params;
 
 /*
@@ -164,6 +173,12 @@ int ffpa_attn_fwd(const ffpa_fwd_params* params, void* stream);
  * Replaces the in-launcher allocations of native/launch.cuh:314-318,503-509.
  */
 size_t ffpa_attn_fwd_workspace_bytes(const ffpa_fwd_params* params);
+
+/*
+ * Number of int32 counters ffpa_fwd_params.split_tickets must hold for this call (one per (batch, head, row tile); 0 when the
+ * call does not split).
+ */
+size_t ffpa_attn_fwd_split_tickets(const ffpa_fwd_params* params);
 
 /*
  * The launch plan for `params` (for benches / roofline maths / tests): out[0] = kernel variant

@@ -12,12 +12,18 @@ this generator only — they choose a launch configuration, not arithmetic:
   * ``lookup_persistent_config`` reads ``torch.cuda.current_device`` (_persistent_autotune.py:534) -> None, i.e. the
     launcher's built-in default tile (BLOCK_M 128, BLOCK_N 64, head-dim blocks of 64: :985-992).
 
-What was found (recorded in DESIGN.md §4): float16 runs and agrees with fp32 math to 5e-4; bfloat16 does NOT run
-correctly under the interpreter (numpy has no bf16: the interpreter computes on the raw uint16 patterns, outputs ~1e8), so
-the executed-reference pin is float16-only.  The kernel template, the oracle and the HIP kernel treat both 16-bit dtypes
-with the same code, differing in the rounding of P and O alone.
+bfloat16: triton's interpreter keeps bf16 tensors as their uint16 storage bits (numpy has no bf16) and converts correctly only in
+explicit casts; its ``create_dot`` multiplies the raw bit patterns as integers (outputs ~1e8) and its fp32 -> bf16 cast truncates
+instead of rounding to nearest even.  Both are gaps of the INTERPRETER, not of the reference kernel, and are closed HERE, in this
+generator only, by wrapping two interpreter functions (the reference source is imported unchanged):
 
-Nothing of the reference travels: the fixture holds OUTPUTS only (O in fp16 bits, LSE fp32).  Inputs are re-created by
+  * ``InterpreterBuilder.create_dot``: bf16 operands are widened to fp32 first (exact) — what the matrix unit does;
+  * ``_convert_float`` for fp32 -> bf16: round to nearest even (``tl.Tensor.to`` on hardware), bf16 -> fp32: bits << 16.
+
+With that the reference's kernel body executes on bf16 inputs with hardware semantics: bf16 products accumulated in fp32, P and O
+rounded to bf16 (RTNE).  The fp16 cases do not touch either wrapper.
+
+Nothing of the reference travels: the fixture holds OUTPUTS only (O in fp16 / bf16 storage bits, LSE fp32).  Inputs are re-created by
 ``triton_cases.triton_case_inputs`` from numpy's frozen legacy generator (``RandomState``), identically in the tests.
 """
 
@@ -32,7 +38,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
-from triton_cases import CASES, triton_case_inputs  # the input recipe shared with the tests (tests/golden/triton_cases.py)
+from triton_cases import CASES, bf16_bits_to_f32, f32_to_bf16_bits, triton_case_inputs  # the input recipe shared with the tests
 
 
 def main():
@@ -47,10 +53,36 @@ def main():
     sys.exit("the reference is only available in the authoring container (/root/reference)")
   ref._get_decode_num_splits = lambda *a, **k: 1     # device query -> the generic kernel
   ref.lookup_persistent_config = lambda req: None    # device query -> the launcher's default tile
+
+  # ---- the interpreter's bf16 gaps (see the module docstring); nothing in the reference is touched
+  import triton.language as tl
+  import triton.runtime.interpreter as ti
+
+  orig_convert, orig_dot = ti._convert_float, ti.InterpreterBuilder.create_dot
+
+  def convert(inp, in_dt, out_dt, rounding_mode):
+    if in_dt == tl.float32 and out_dt == tl.bfloat16:
+      return f32_to_bf16_bits(np.ascontiguousarray(inp, dtype=np.float32))
+    if in_dt == tl.bfloat16 and out_dt == tl.float32:
+      return bf16_bits_to_f32(np.ascontiguousarray(inp).view(np.uint16)).view(np.uint32)
+    return orig_convert(inp, in_dt, out_dt, rounding_mode)
+
+  def dot(self, a, b, d, input_precision, max_num_imprecise_acc):
+    if a.dtype.scalar == tl.bfloat16 or b.dtype.scalar == tl.bfloat16:
+      af = bf16_bits_to_f32(a.data) if a.dtype.scalar == tl.bfloat16 else a.data.astype(np.float32)
+      bf = bf16_bits_to_f32(b.data) if b.dtype.scalar == tl.bfloat16 else b.data.astype(np.float32)
+      return ti.TensorHandle(np.matmul(af, bf, dtype=np.float32) + d.data, d.dtype.scalar)
+    return orig_dot(self, a, b, d, input_precision, max_num_imprecise_acc)
+
+  ti._convert_float = convert
+  ti.InterpreterBuilder.create_dot = dot
+
   store, meta = {}, []
   for case in CASES:
-    name, B, Hq, Hkv, Nq, Nkv, D, causal, bshape = case
-    q, k, v, bias = (None if a is None else torch.from_numpy(a) for a in triton_case_inputs(case))
+    name, B, Hq, Hkv, Nq, Nkv, D, causal, bshape, dtype, spike = case
+    tdt = torch.float16 if dtype == "fp16" else torch.bfloat16
+    arrs = triton_case_inputs(case)
+    q, k, v, bias = (None if a is None else (torch.from_numpy(a) if dtype == "fp16" else torch.from_numpy(a.view(np.int16)).view(tdt)) for a in arrs)
     o = torch.zeros_like(q)
     lse = torch.zeros(B, Hq, (Nq + 127) // 128 * 128, dtype=torch.float32)
     ref._ffpa_attn_forward_impl(q, k, v, o, lse, attn_bias=bias, causal=causal)
@@ -65,11 +97,12 @@ def main():
     want = torch.softmax(s, -1) @ v.float().repeat_interleave(g, 1)
     err = (o.float() - want).abs().max().item()
     lerr = (lse[..., :Nq] - torch.logsumexp(s, -1)).abs().max().item()
-    print(f"{name}: max |O_triton - fp32 math| = {err:.2e}, max |LSE - ref| = {lerr:.2e}")
-    assert err < 3e-3 and lerr < 1e-3, name
+    print(f"{name} [{dtype}]: max |O_triton - fp32 math| = {err:.2e}, max |LSE - ref| = {lerr:.2e}", flush=True)
+    assert err < (3e-3 if dtype == "fp16" else 2e-2) and lerr < 1e-3, name
     store[f"{name}.o"] = o.contiguous().view(torch.int16).numpy().view(np.uint16).copy()
     store[f"{name}.lse"] = lse[..., :Nq].contiguous().numpy()
-    meta.append({"name": name, "B": B, "Hq": Hq, "Hkv": Hkv, "Nq": Nq, "Nkv": Nkv, "D": D, "causal": causal, "bias_shape": bshape, "dtype": "fp16"})
+    meta.append({"name": name, "B": B, "Hq": Hq, "Hkv": Hkv, "Nq": Nq, "Nkv": Nkv, "D": D, "causal": causal, "bias_shape": bshape, "dtype": dtype,
+                 "late_spikes": spike})
   np.savez_compressed(os.path.join(HERE, "ref_triton_cases.npz"), **store)
   with open(os.path.join(HERE, "ref_triton_cases.json"), "w") as f:
     json.dump({"source": f"reference src/ffpa_attn/triton/_ffpa_fwd.py::_ffpa_attn_forward_impl under TRITON_INTERPRET=1, triton {triton.__version__}, "

@@ -4,29 +4,64 @@ only; q / k / v / bias are re-created here from numpy's frozen legacy generator.
 
 import numpy as np
 
-# name, B, Hq, Hkv, Nq, Nkv, D, causal (tail-aligned, the reference's convention), bias shape or None
+# name, B, Hq, Hkv, Nq, Nkv, D, causal (tail-aligned, the reference's convention), bias shape or None, dtype, late spikes
 CASES = [
-  ("d320_tail", 1, 2, 2, 200, 333, 320, False, None),
-  ("d512_gqa_causal", 1, 2, 1, 192, 320, 512, True, None),
-  ("d1024_bias", 1, 1, 1, 130, 257, 1024, False, (1, 1, 130, 257)),
-  ("d512_keybias_tail", 2, 2, 2, 72, 777, 512, False, (2, 1, 1, 777)),
+  ("d320_tail", 1, 2, 2, 200, 333, 320, False, None, "fp16", False),
+  ("d512_gqa_causal", 1, 2, 1, 192, 320, 512, True, None, "fp16", False),
+  ("d1024_bias", 1, 1, 1, 130, 257, 1024, False, (1, 1, 130, 257), "fp16", False),
+  ("d512_keybias_tail", 2, 2, 2, 72, 777, 512, False, (2, 1, 1, 777), "fp16", False),
+  # a long row with late score spikes: keys 900 and 1400 are scaled up so that the running row max jumps by far more than the
+  # native kernel's lazy-rescale threshold late in the KV walk (the reference's Triton statement rescales every step)
+  ("d512_late_spike", 1, 1, 1, 128, 1536, 512, False, None, "fp16", True),
+  # bfloat16 — the dtype of every BASELINE config
+  ("bf16_d512_tail", 1, 2, 2, 640, 2049, 512, False, None, "bf16", False),
+  ("bf16_d320_gqa_causal", 1, 4, 2, 192, 320, 320, True, None, "bf16", False),
+  ("bf16_d1024_bias", 1, 1, 1, 130, 257, 1024, False, (1, 1, 130, 257), "bf16", False),
+  ("bf16_d512_keybias_spike", 2, 2, 2, 72, 1100, 512, False, (2, 1, 1, 1100), "bf16", True),
 ]
 
 
+def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
+  """fp32 -> bfloat16 storage bits, round to nearest even (NaN kept quiet): what every bf16 store of the hardware does."""
+  u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+  rounded = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+  nan = np.isnan(x)
+  if nan.any():
+    rounded = np.where(nan, np.uint16(0x7FC0), rounded)
+  return rounded.reshape(np.shape(x))
+
+
+def bf16_bits_to_f32(b: np.ndarray) -> np.ndarray:
+  return (np.ascontiguousarray(b, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32).reshape(np.shape(b))
+
+
 def triton_case_inputs(case):
-  """fp16 q, k, v (and additive fp16 bias) of a case as numpy arrays — the ONE recipe shared by this generator and the tests."""
-  name, B, Hq, Hkv, Nq, Nkv, D, causal, bshape = case
+  """q, k, v (and additive bias) of a case as numpy arrays — float16 arrays for fp16 cases, uint16 bfloat16 STORAGE BITS for bf16
+  cases.  The ONE recipe shared by the generator and the tests."""
+  name, B, Hq, Hkv, Nq, Nkv, D, causal, bshape, dtype, spike = case
   rs = np.random.RandomState(abs(hash_name(name)) % (2 ** 31))
-  q = rs.standard_normal((B, Hq, Nq, D)).astype(np.float16)
-  k = rs.standard_normal((B, Hkv, Nkv, D)).astype(np.float16)
-  v = rs.standard_normal((B, Hkv, Nkv, D)).astype(np.float16)
+  q = rs.standard_normal((B, Hq, Nq, D)).astype(np.float32)
+  k = rs.standard_normal((B, Hkv, Nkv, D)).astype(np.float32)
+  v = rs.standard_normal((B, Hkv, Nkv, D)).astype(np.float32)
+  if spike:
+    k[:, :, 900 % Nkv] *= 6.0
+    k[:, :, 1400 % Nkv] *= 9.0
   bias = None
   if bshape is not None:
-    bias = (rs.standard_normal(bshape) * 0.5).astype(np.float16)
+    bias = (rs.standard_normal(bshape) * 0.5).astype(np.float32)
     hide = rs.random_sample(bshape) < 0.15  # some -inf entries, never a whole row
     hide[..., 0] = False
-    bias = np.where(hide, np.float16(-np.inf), bias).astype(np.float16)
-  return q, k, v, bias
+    bias = np.where(hide, np.float32(-np.inf), bias).astype(np.float32)
+  if dtype == "fp16":
+    cast = lambda a: None if a is None else a.astype(np.float16)  # noqa: E731
+  else:
+    cast = lambda a: None if a is None else f32_to_bf16_bits(a)  # noqa: E731
+  return cast(q), cast(k), cast(v), cast(bias)
+
+
+def to_f32(a, dtype):
+  """The fp32 values of an input array of a case (float16 array or bf16 bits)."""
+  return None if a is None else (a.astype(np.float32) if dtype == "fp16" else bf16_bits_to_f32(a))
 
 
 def hash_name(name: str) -> int:

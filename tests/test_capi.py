@@ -40,7 +40,7 @@ def test_struct_layout_matches_header(lib):
   p.abi_version = hip.ABI_VERSION
   assert lib.ffpa_attn_fwd(ctypes.byref(p), None) == 10
   assert b"ABI mismatch" in lib.ffpa_attn_last_error()
-  assert ctypes.sizeof(hip.FfpaFwdParams) == 304
+  assert ctypes.sizeof(hip.FfpaFwdParams) == 312  # (ABI 4: + split_tickets)
 
 
 def test_ctypes_mirror_matches_the_c_header(tmp_path):

@@ -121,20 +121,23 @@ def test_small_cases_vs_oracle_and_sdpa_fixtures(hip, small_cases):
 
 
 def test_kernel_matches_the_executed_reference_triton_kernel(hip):
-  """fp16 outputs of the reference's own Triton forward (tests/golden/make_triton_golden.py, run under TRITON_INTERPRET=1
+  """fp16 and bf16 outputs of the reference's own Triton forward (tests/golden/make_triton_golden.py, run under TRITON_INTERPRET=1
   in the authoring container) vs the HIP kernel on the re-created inputs: tails, tail-aligned causal + GQA, additive
-  biases with -inf entries, D = 320 / 512 / 1024."""
-  from test_oracle import _triton_cases
+  biases with -inf entries, late score spikes (the lazy-rescale branch), D = 320 / 512 / 1024."""
+  from test_oracle import _bits_to_f32, _triton_cases
 
   for case, (q, k, v, bias), o_ref_bits, lse_ref in _triton_cases():
-    name, D, causal = case[0], case[6], case[7]
-    qt, kt, vt = (torch.from_numpy(a).cuda() for a in (q, k, v))
-    bt = None if bias is None else torch.from_numpy(bias).cuda()
+    name, D, causal, dtype = case[0], case[6], case[7], case[9]
+    tdt = torch.float16 if dtype == "fp16" else torch.bfloat16
+    qt, kt, vt = (torch.from_numpy(a.view(np.int16).copy()).view(tdt).cuda() for a in (q, k, v))
+    bt = None if bias is None else torch.from_numpy(bias.view(np.int16).copy()).view(tdt).cuda()
     o, lse = hip.forward(qt, kt, vt, bt, causal, D ** -0.5)
-    want = torch.from_numpy(o_ref_bits.view(np.float16).copy()).cuda().float()
+    want = torch.from_numpy(_bits_to_f32(o_ref_bits, dtype)).cuda()
     d = (o.float() - want).abs()
-    assert d.max().item() <= 1e-3 and d.mean().item() <= 5e-5, (name, d.max().item(), d.mean().item())
-    assert (lse.cpu() - torch.from_numpy(lse_ref)).abs().max().item() <= 2e-5, name
+    ulp = 2.0 ** -11 if dtype == "fp16" else 2.0 ** -8
+    lim = 2.0 * ulp * torch.clamp(want.abs(), min=0.5 * max(1.0, want.abs().max().item())) + 1e-4  # one output ulp of the binade above (row scale for the spike cases)
+    assert bool((d <= lim).all()) and d.mean().item() <= (5e-5 if dtype == "fp16" else 4e-4), (name, d.max().item(), d.mean().item())
+    assert (lse.cpu() - torch.from_numpy(lse_ref)).abs().max().item() <= 3e-5, name
 
 
 # ----------------------------------------------------------------------------- fast path == safe path
@@ -557,6 +560,31 @@ def test_short_query_split_kv(hip, D, Nq, Hq, Hkv):
   o3, _ = hip.forward(q, k, v, None, False, D ** -0.5, num_splits=3, plan_out=plan)
   assert 1 < plan["splits"] <= 3
   assert (o3.float() - o1.float()).abs().max().item() <= 4e-3
+
+
+def test_split_partials_merged_inside_the_launch_equal_the_merge_kernel(hip):
+  """KV-split launches with ffpa_fwd_params.split_tickets: the last split of a row tile to arrive merges the partials itself (agent-scope
+  release / ticket / acquire: one launch per call).  Same arithmetic as ffpa_fwd_merge_kernel: the same bits, on decode and on underfilled
+  prefill launches, call after call with changing inputs and the workspace recycled (a stale partial from the previous call, or a split
+  missed by the merger, would show in some word), under uneven load (ragged causal tiles) and with another kernel keeping the chip busy."""
+  shapes = [(8, 32, 8, 1, 8192 + 77, 512, False), (1, 32, 32, 1, 8192, 512, False), (3, 8, 8, 20, 5000, 320, True), (2, 16, 4, 7, 4097, 1024, False),
+            (1, 4, 4, 512, 16384, 512, False), (1, 8, 2, 640, 9000, 512, True), (1, 2, 2, 512, 8192, 1024, False), (1, 8, 8, 1, 3000, 128, False)]
+  busy_a = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
+  for (B, Hq, Hkv, Nq, Nkv, D, causal) in shapes:
+    k, v = _rand((B, Hkv, Nkv, D), seed=302), _rand((B, Hkv, Nkv, D), seed=303)
+    plan = {}
+    for it in range(6):
+      q = _rand((B, Hq, Nq, D), seed=310 + it)
+      if it % 2:
+        busy_a @ busy_a  # something else on the chip while the splits arrive
+      o1, l1 = hip.forward(q, k, v, None, causal, D ** -0.5, merge_in_launch=True, plan_out=plan)
+      assert plan["splits"] > 1 and "in-launch" in plan["kernel"], plan
+      o2, l2 = hip.forward(q, k, v, None, causal, D ** -0.5, merge_in_launch=False, plan_out=plan)
+      assert plan["kernel"].endswith("ffpa_fwd_merge_kernel"), plan
+      assert torch.equal(o1, o2) and torch.equal(l1, l2), ((B, Hq, Hkv, Nq, Nkv, D, causal), it)
+  # the tickets are back to zero after every launch: the buffer of this stream holds nothing but zeros
+  for t in hip._TICKETS.values():
+    assert int(t.abs().max()) == 0
 
 
 @pytest.mark.parametrize("Nq,Hq,Hkv", [(1, 8, 2), (7, 4, 1), (5, 8, 8), (24, 4, 4)])

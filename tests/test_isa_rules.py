@@ -54,7 +54,7 @@ def test_prefill_builds_have_no_scratch_inside_their_mfma_loops(capsys, monkeypa
   spills out of the MFMA loops (a handful at D = 512 in the additive-bias build, whose scalar row tables do not fit)."""
   import re
   lines = [l for l in _stats(monkeypatch, capsys, 320, 384, 448, 512, 640, 1024) if " m16 " in l]
-  assert len(lines) == 6 * 5 * 2, len(lines)  # {MK0, MK2, MK1, MK0+DROP, MK1+DROP} x {bf16, fp16} per head dim
+  assert len(lines) == 6 * 6 * 2, len(lines)  # {MK0, MK2, MK3, MK1, MK0+DROP, MK1+DROP} x {bf16, fp16} per head dim
   for l in lines:
     m = re.search(r"inside MFMA loops: scratch (\d+), lane spills (\d+)", l)
     hot_scratch, hot_lane = int(m.group(1)), int(m.group(2))
@@ -62,7 +62,9 @@ def test_prefill_builds_have_no_scratch_inside_their_mfma_loops(capsys, monkeypa
     drop = bool(re.search(r" [012] b1 ", l))
     mk1 = bool(re.search(r" 1 b[01] ", l))
     if not drop:
-      assert "scratch    0 B" in l or " 1024 1 b0" in l, l
+      # (a few bytes of scratch in the prologue / rare paths of two builds; what matters is "first..last MFMA: scratch ops 0")
+      assert "scratch    0 B" in l or " 1024 1 b0" in l or " 512 3 b0" in l, l
+      assert "first..last MFMA: scratch ops 0" in l, l
       assert hot_lane <= (8 if mk1 else 0), l
   # the 32x32x16 prefill kernels of the small head dims (what D <= 256 launches): no spill code inside their MFMA loops either
   small = [l for l in _stats(monkeypatch, capsys, 256) if "bf16  256 1 b0 b0 b0" in l]

@@ -4,7 +4,8 @@
 
 Each TAG is a library: "main" = the shipped ffpa_attn_amd/libffpa_attn_hip.so, anything else =
 ffpa_attn_amd/variants/libffpa_attn_hip_TAG.so (built by `python -m ffpa_attn_amd.build --variant TAG DEF...`, or a saved
-build of another commit).  `:flags` ORs ffpa_fwd_params.flags bits into that arm's launches.  Arms are timed in interleaved
+build of another commit).  `:flags` ORs ffpa_fwd_params.flags bits into that arm's launches (tool-level bit 0x10000: KV-split launches
+keep the separate merge kernel instead of merging inside the launch).  Arms are timed in interleaved
 rounds inside ONE process (cdna guide section 5.4 rule 24) with HIP events; per case and arm: median / best ms, TFLOPS (valid
 pairs), and max |O - O_first arm| (ablation builds change results by design; A/B arms of one kernel must not).
 
@@ -101,7 +102,7 @@ def main():
   variants = []
   for t in args.tags:
     tag, _, fl = t.partition(":")
-    variants.append((t, lib_for(tag), int(fl or 0, 0)))
+    variants.append((t, lib_for(tag), int(fl, 0) if fl else 0))
 
   for cname, c in cases:
     torch.manual_seed(0)
@@ -117,7 +118,8 @@ def main():
 
     def run(lib, flags):
       hip._lib = lib
-      kw["flags"] = flags
+      kw["flags"] = flags & 0xFFFF
+      kw["merge_in_launch"] = not (flags & 0x10000)
       return hip.forward(q, k, v, bias, c["causal"], c["D"] ** -0.5, **kw)[0]
 
     base = None
