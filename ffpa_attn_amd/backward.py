@@ -123,7 +123,9 @@ def _chunked_recompute_backward(grad_out, q, k, v, o, lse, causal, scale, attn_b
 # capability refusals are remembered; a failure that may be specific to one call (bias layout, alignment, out of
 # memory) falls back for that call only and aten is tried again next time.
 _aten_unsupported: dict = {}
-_CAPABILITY_MARKERS = ("head_dim", "head dim", "headdim", "not supported", "unsupported", "no available kernel", "not implemented", "no kernel")
+# (generic words such as "not supported" / "unsupported" are NOT markers: aten uses them for per-call refusals too — a bias stride, an
+# alignment — and remembering one of those would send every later backward of that (dtype, D) down the slower recompute path)
+_CAPABILITY_MARKERS = ("head_dim", "head dim", "headdim", "head size", "last dimension", "dtype", "data type", "no available kernel", "no kernel")
 
 
 def _is_capability_error(exc: Exception) -> bool:

@@ -114,29 +114,31 @@ def build(force: bool = False, jobs: int | None = None, save_temps: bool = True,
   def stale(obj: str) -> bool:
     return force or not os.path.exists(obj) or os.path.getmtime(obj) < newest
 
+  # the product define: the kernel headers then refuse any developer switch that is not at its shipped default
+  product = ["-DFFPA_PRODUCT_BUILD=1"]
   for d in HEAD_DIMS:
     obj = os.path.join(OBJ_DIR, f"ffpa_fwd_d{d}.o")
     objs.append(obj)
     if stale(obj):
       tmp = os.path.join(OBJ_DIR, f"temps_d{d}")
       os.makedirs(tmp, exist_ok=True)
-      tasks.append((obj, [hipcc, *CXXFLAGS, *extra, f"-DFFPA_INST_D={d}", "-c", os.path.join(CSRC, "ffpa_fwd_inst.hip"), "-o", obj], tmp))
+      tasks.append((obj, [hipcc, *CXXFLAGS, *product, *extra, f"-DFFPA_INST_D={d}", "-c", os.path.join(CSRC, "ffpa_fwd_inst.hip"), "-o", obj], tmp))
     if test_lib and d in SAFE_HEAD_DIMS:
       tobj = os.path.join(OBJ_DIR, f"ffpa_fwd_d{d}_test.o")
       test_objs.append(tobj)
       if stale(tobj):
-        tasks.append((tobj, [hipcc, *CXXFLAGS, f"-DFFPA_INST_D={d}", "-DFFPA_INST_SAFE=1", "-c", os.path.join(CSRC, "ffpa_fwd_inst.hip"), "-o", tobj], None))
+        tasks.append((tobj, [hipcc, *CXXFLAGS, *product, f"-DFFPA_INST_D={d}", "-DFFPA_INST_SAFE=1", "-c", os.path.join(CSRC, "ffpa_fwd_inst.hip"), "-o", tobj], None))
     elif test_lib:
       test_objs.append(obj)
   capi = os.path.join(OBJ_DIR, "ffpa_capi.o")
   objs.append(capi)
   if stale(capi):
-    tasks.append((capi, [hipcc, *CXXFLAGS, "-c", os.path.join(CSRC, "ffpa_capi.hip"), "-o", capi], None))
+    tasks.append((capi, [hipcc, *CXXFLAGS, *product, "-c", os.path.join(CSRC, "ffpa_capi.hip"), "-o", capi], None))
   if test_lib:
     tcapi = os.path.join(OBJ_DIR, "ffpa_capi_test.o")
     test_objs.append(tcapi)
     if stale(tcapi):
-      tasks.append((tcapi, [hipcc, *CXXFLAGS, "-DFFPA_INST_SAFE=1", "-c", os.path.join(CSRC, "ffpa_capi.hip"), "-o", tcapi], None))
+      tasks.append((tcapi, [hipcc, *CXXFLAGS, *product, "-DFFPA_INST_SAFE=1", "-c", os.path.join(CSRC, "ffpa_capi.hip"), "-o", tcapi], None))
   if verbose:
     print(f"[ffpa_attn_amd.build] compiling {len(tasks)} objects for {ARCH} with {jobs} jobs", flush=True)
   # longest jobs first (head dims >= 320 carry the 16x16x32 builds as well: 2 - 3 x the compile time of the small ones)

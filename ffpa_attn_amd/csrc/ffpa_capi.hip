@@ -370,7 +370,10 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   if (pl.splits > 1) {
     a.ws_o = static_cast<float*>(p->workspace);
     a.ws_lse = a.ws_o + (size_t)pl.splits * p->batch * p->heads_q * p->seqlen_q * kernel_head_dim(p->head_dim);
-    a.tickets = p->split_tickets;  // non-NULL: the kernel merges the partials itself (last split of a row tile to arrive)
+    // short-query launches with tickets: the kernel merges the partials itself (last split of a row tile to arrive).  Prefill tiles always
+    // take the merge kernel: their row tiles are 64 - 128 rows, one workgroup merging a whole tile serialises what the merge kernel
+    // spreads over thousands of workgroups (measured 2x slower: profiles/r03_split_merge.txt)
+    a.tickets = pl.variant == 1 ? p->split_tickets : nullptr;
   }
 
   int st = de->launch(p->dtype, safe, pl.variant, a, static_cast<hipStream_t>(stream));
@@ -408,7 +411,7 @@ size_t ffpa_attn_fwd_split_tickets(const ffpa_fwd_params* params) {
   q.workspace = reinterpret_cast<void*>(16);
   q.workspace_bytes = ~0ull;
   const Plan pl = make_plan(&q, de);
-  return pl.splits > 1 ? (size_t)params->batch * params->heads_q * pl.nqt : 0;
+  return (pl.splits > 1 && pl.variant == 1) ? (size_t)params->batch * params->heads_q * pl.nqt : 0;
 }
 
 int ffpa_attn_mask_kv_bounds(const void* bias, int bias_dtype, const int64_t bias_stride[4], int bb, int hb, int nq,
@@ -473,7 +476,7 @@ int ffpa_attn_fwd_kernel(const ffpa_fwd_params* params, char* buf, size_t n) {
   const Plan pl = make_plan(params, de);
   const char* dt = params->dtype == FFPA_DTYPE_FP16 ? "fp16" : "bf16";
   const int drop = params->dropout_p > 0.f ? 1 : 0;
-  const char* merge = pl.splits > 1 ? (params->split_tickets != nullptr ? " (in-launch split merge)" : " + ffpa_fwd_merge_kernel") : "";
+  const char* merge = pl.splits > 1 ? ((params->split_tickets != nullptr && pl.variant == 1) ? " (in-launch split merge)" : " + ffpa_fwd_merge_kernel") : "";
   if (pl.m16) {
     snprintf(buf, n, "ffpa_fwd_m16_kernel<%s, %d, MK=%d, DROP=%d>%s", dt, de->d, pl.mk, drop, merge);
   } else {
@@ -515,6 +518,10 @@ int ffpa_attn_fwd_tile_config(int head_dim, int* block_rows, int* block_keys, in
 
 const char* ffpa_attn_last_error(void) { return g_err; }
 
-const char* ffpa_attn_version(void) { return "ffpa-attn-amd 0.1.0 gfx950"; }
+#ifdef FFPA_PRODUCT_BUILD
+const char* ffpa_attn_version(void) { return "ffpa-attn-amd 0.3.0 gfx950"; }
+#else
+const char* ffpa_attn_version(void) { return "ffpa-attn-amd 0.3.0 gfx950 (developer variant: NOT a product build)"; }
+#endif
 
 }  // extern "C"

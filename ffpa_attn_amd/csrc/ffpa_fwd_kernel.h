@@ -100,6 +100,14 @@
 #ifndef FFPA_V_EARLY
 #define FFPA_V_EARLY 1  // issue the first PV fragment reads right after barrier A (latency hides under softmax)
 #endif
+#ifndef FFPA_DMA_M0_CLOBBER
+#define FFPA_DMA_M0_CLOBBER 1  // the LDS-DMA asm declares M0 clobbered (0: as rounds 1 - 2 shipped it, for the A/B that showed no difference)
+#endif
+#if FFPA_DMA_M0_CLOBBER
+#define FFPA_M0_CLOBBER , "m0"
+#else
+#define FFPA_M0_CLOBBER
+#endif
 #ifndef FFPA_ABL
 // developer ablations (WRONG RESULTS; tools/gpu_ab.py): 1 no in-loop DMA, 2 no exp, 4 no barriers, 8 no softmax,
 // 16 no DMA drain, 32 s_nop 1 in front of every S MFMA, 64 no LDS fragment reads, 128 no MFMA, 256 no QK MFMA, 512 no PV MFMA
@@ -264,12 +272,13 @@ __device__ __forceinline__ int v_slot_swizzle(int key) {  // in 16-byte slots
 // follows a builtin DMA (measured: 561 vs 1030 TFLOP/s).  The asm is invisible to that pass, so the
 // kernel drains the DMA queue itself (dma_wait_all) before each workgroup barrier.  Compiler-counted
 // vmcnt waits for its own loads stay correct (loads retire in order; hidden younger ops only make a
-// counted wait conservative).  M0 is written in the same statement that consumes it.
+// counted wait conservative).  M0 is written in the same statement that consumes it and is declared clobbered (the compiler
+// keeps no value of its own in M0 across the statement; tools/check_mfma_hazards.py still verifies that nothing else writes it).
 __device__ __forceinline__ void lds_dma_16(u32x4 rsrc, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                :
                : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
-               : "memory");
+               : "memory" FFPA_M0_CLOBBER);
 }
 
 // The same with the destination given as scalar base + compile-time constant (nothing to precompute and keep in a register per piece).
@@ -278,7 +287,7 @@ __device__ __forceinline__ void lds_dma_16_at(u32x4 rsrc, uint32_t lds_base, uin
   asm volatile("s_add_u32 m0, %0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                :
                : "s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff), "n"(LCONST)
-               : "memory", "scc");
+               : "memory", "scc" FFPA_M0_CLOBBER);
 }
 
 // Row-uniform form (one LDS image row == whole pieces: D = 512).  Everything but the per-lane swizzled
@@ -293,7 +302,23 @@ __device__ __forceinline__ void lds_dma_row(u32x4 rsrc, uint32_t lds_base, uint3
       "buffer_load_dwordx4 %1, %2, %3 offen offset:%5 lds"
       :
       : "s"(lds_base), "v"(voff), "s"(rsrc), "s"(row_off), "n"(LCONST), "n"(IMM)
-      : "memory", "scc");
+      : "memory", "scc" FFPA_M0_CLOBBER);
+}
+
+// The same with the source row offset computed in place: row_bytes * KEY + base_off (KEY a compile-time row of the tile, base_off the
+// wave's first row) — two scalar instructions instead of a table of one scalar register per staged row (BC / 4 for K and as many for V:
+// registers the mask / bias builds do not have; spilled, every entry costs a v_readlane + its hazard wait states in front of the piece).
+template <int LCONST, int KEY>
+__device__ __forceinline__ void lds_dma_row_at(u32x4 rsrc, uint32_t lds_base, uint32_t voff, uint32_t row_bytes, uint32_t base_off) {
+  uint32_t tmp;
+  asm volatile(
+      "s_mul_i32 %0, %4, %6\n\t"
+      "s_add_u32 m0, %1, %7\n\t"
+      "s_add_u32 %0, %0, %5\n\t"
+      "buffer_load_dwordx4 %2, %3, %0 offen lds"
+      : "=&s"(tmp)
+      : "s"(lds_base), "v"(voff), "s"(rsrc), "s"(row_bytes), "s"(base_off), "n"(KEY), "n"(LCONST)
+      : "memory", "scc" FFPA_M0_CLOBBER);
 }
 
 // s_waitcnt vmcnt(0) as a BUILTIN (gfx9 encoding 0x0F70: vmcnt = 0, expcnt / lgkmcnt = no wait): the
@@ -548,14 +573,20 @@ __device__ __forceinline__ void apply_bool_block_vec(float (&x)[16], const void*
 // `scratch`: >= 16 + 4 * kMergeMaxSplits * 4 bytes of LDS nobody else uses any more (the K / V tile area after the tile loop).
 // ---------------------------------------------------------------------------------
 constexpr int kMergeMaxSplits = 1024;
-template <typename T>
+// 16-byte write-through store (sc0 sc1: the line goes to memory, not just to this XCD's L2): a partial stored this way needs no
+// release fence (buffer_wbl2: 2 - 6 us per workgroup) before the ticket, only the wave's own vmcnt(0) (Guideline 16, form R1).
+__device__ __forceinline__ void store_write_through(float* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+// kWriteThrough: the caller stored its partial with store_write_through / agent-scope atomic stores.
+template <typename T, bool kWriteThrough = false>
 __device__ __forceinline__ void split_arrive_and_merge(const FwdArgs& a, int D, int tile_id, int b, int hq, int row0, int nrows, FFPA_LDS char* scratch) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial stores have left the CU
   __syncthreads();
   FFPA_LDS int* flag = (FFPA_LDS int*)scratch;
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if constexpr (!kWriteThrough) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int t = __hip_atomic_fetch_add(a.tickets + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = (t == a.nsplit - 1) ? 1 : 0;
@@ -1414,9 +1445,14 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
           f32x4 w;
 #pragma unroll
           for (int t = 0; t < 4; ++t) w[t] = dead ? 0.f : oacc[db][4 * i + t] * inv;
-          *(f32x4*)(wp + db * 32 + 8 * i) = w;
+          if (a.tickets != nullptr) store_write_through(wp + db * 32 + 8 * i, w);  // (merged in this launch: see split_arrive_and_merge)
+          else *(f32x4*)(wp + db * 32 + 8 * i) = w;
         }
-      if (h == 0 && dh == 0) a.ws_lse[prow] = dead ? -INFINITY : __logf(l_tot) + m_run * 0.6931471805599453f;
+      if (h == 0 && dh == 0) {
+        const float lse_part = dead ? -INFINITY : __logf(l_tot) + m_run * 0.6931471805599453f;
+        if (a.tickets != nullptr) __hip_atomic_store(&a.ws_lse[prow], lse_part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else a.ws_lse[prow] = lse_part;
+      }
     } else {
       // The lane owns 4-element groups d = 32 db + 8 i + 4 h + (0..3); its partner lane ^ 32 owns the other half
       // of each 8-element run.  The two trade groups (v_permlane32_swap: this lane's odd group for the partner's
@@ -1450,7 +1486,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
     }
   }
   // KV-split launch with tickets: the last split of this row tile to arrive merges all partials here (one launch per call)
-  if (a.nsplit > 1 && a.tickets != nullptr) split_arrive_and_merge<T>(a, D, bh * a.nqt + qt, b, hq, q0, BR, Kt);
+  if (a.nsplit > 1 && a.tickets != nullptr) split_arrive_and_merge<T, true>(a, D, bh * a.nqt + qt, b, hq, q0, BR, Kt);
 #if FFPA_PERSISTENT
   }  // persistent rounds
 #endif

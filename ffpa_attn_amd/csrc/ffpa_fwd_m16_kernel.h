@@ -54,6 +54,9 @@
 #ifndef FFPA_M16_ROWDMA
 #define FFPA_M16_ROWDMA 1  // D = 512 mask / bias / dropout builds: scalar row addressing of the LDS-DMA (0: per-lane offset tables, as the other builds)
 #endif
+#ifndef FFPA_M16_ROW_TABLES
+#define FFPA_M16_ROW_TABLES 1  // scalar row form: 1 = a table of one scalar register per staged row, 0 = row offsets computed per piece (2 SALU)
+#endif
 #ifndef FFPA_M16_K_PRE_ND2
 #define FFPA_M16_K_PRE_ND2 64  // ditto for the split-D tiles (D > 512; clamped to the tile's pieces: all of K(j+1) goes out between the softmax stages)
 #endif
@@ -139,6 +142,17 @@ __device__ __forceinline__ int m16_v_swizzle(int key) {
   return (D % 128 == 0) ? ((key & 7) << 1) : (((key >> 1) & 3) << 1);
 }
 
+// The product library is built with -DFFPA_PRODUCT_BUILD (ffpa_attn_amd/build.py: libffpa_attn_hip.so and its test twin): none of the
+// developer switches of this file and of ffpa_fwd_kernel.h — ablations that compute WRONG results, cycle-counter instrumentation that
+// overwrites LSE rows, experimental schedules — may be anything but its shipped default there.  Variant libraries (build.py --variant)
+// are built without the define, get another file name and say so in ffpa_attn_version().
+#ifdef FFPA_PRODUCT_BUILD
+#if FFPA_ABL != 0 || defined(FFPA_M16_TIMING) || FFPA_PERSISTENT != 0 || FFPA_M16_ROWDMA != 1 || FFPA_M16_PF1 != 6 || FFPA_M16_PF2 != 4 || \
+    FFPA_M16_K_PRE != 8 || FFPA_M16_K_PRE_ND2 != 64 || FFPA_M16_ROW_TABLES != 1 || FFPA_DMA_M0_CLOBBER != 1 || FFPA_M16_SWAP_REDUCE != 1 || FFPA_M16_MIN_D != 320
+#error "FFPA_PRODUCT_BUILD: a developer switch is not at its shipped default"
+#endif
+#endif
+
 // MK (mask kind): 0 = the build for calls without attn_bias / mask ranges, 2 = boolean masks (FFPA_BIAS_BOOL8 bytes and / or kv_bounds
 // ranges: what ffpa_attn_func(attn_mask=<bool>) launches), 1 = additive biases (fp16 / bf16 / fp32, any broadcast; boolean masks too when
 // they come with dropout), 3 = key biases only (no row axis: [B|1, H|1, 1, Nkv], the reference bench's "attn-mask" case, key padding as an
@@ -183,6 +197,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 #endif
 #ifndef FFPA_M16_STEP2_DIV
 #define FFPA_M16_STEP2_DIV 1
+#endif
+#ifdef FFPA_PRODUCT_BUILD
+  static_assert(FFPA_M16_STEP1_DIV == 1 && FFPA_M16_STEP2_DIV == 1, "FFPA_PRODUCT_BUILD: a developer switch is not at its shipped default");
 #endif
   constexpr int kStep1 = (N1 / PPW) / FFPA_M16_STEP1_DIV > 0 ? (N1 / PPW) / FFPA_M16_STEP1_DIV : 1;  // one V piece every this many K fragments
   constexpr int kStep2 = (N2 / PPW) / FFPA_M16_STEP2_DIV > 0 ? (N2 / PPW) / FFPA_M16_STEP2_DIV : 1;  // one K piece every this many V^T fragments
@@ -249,6 +266,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   uint32_t kro[kRowDma ? KPW : 1], vro[kRowDma ? KPW : 1];
   uint32_t krel[kRowDma ? 1 : PPW], vrel[kRowDma ? 1 : PPW];
   uint32_t k_lds = 0, v_lds = 0;
+  const uint32_t k_wave_off = (uint32_t)(4 * wave) * k_row_bytes, v_wave_off = (uint32_t)(4 * wave) * v_row_bytes;  // (row form: the wave's first staged row)
   if constexpr (kRowDma) {
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) {
@@ -286,7 +304,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     constexpr int i = decltype(ic)::value;
     const TileSrc ts = tile_src<BC>(Kg, k_row_bytes, key0, a.Nkv, rb_valid);
     if constexpr (kRowDma) {
-      lds_dma_row<(16 * (i >> 2) + (i & 3)) * RB, 0>(ts.rsrc, k_lds, kvo[i & 3], kro[i]);
+      if constexpr (FFPA_M16_ROW_TABLES != 0) lds_dma_row<(16 * (i >> 2) + (i & 3)) * RB, 0>(ts.rsrc, k_lds, kvo[i & 3], kro[i]);
+      else lds_dma_row_at<(16 * (i >> 2) + (i & 3)) * RB, 16 * (i >> 2) + (i & 3)>(ts.rsrc, k_lds, kvo[i & 3], k_row_bytes, k_wave_off);
     } else {
       lds_dma_16_at<i * 1024>(ts.rsrc, k_lds, krel[i], 0u);
     }
@@ -295,7 +314,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     constexpr int i = decltype(ic)::value;
     const TileSrc ts = tile_src<BC>(Vg, v_row_bytes, key0, a.Nkv, rb_valid);
     if constexpr (kRowDma) {
-      lds_dma_row<(16 * (i >> 2) + (i & 3)) * RB, 0>(ts.rsrc, v_lds, vvo[i & 3], vro[i]);
+      if constexpr (FFPA_M16_ROW_TABLES != 0) lds_dma_row<(16 * (i >> 2) + (i & 3)) * RB, 0>(ts.rsrc, v_lds, vvo[i & 3], vro[i]);
+      else lds_dma_row_at<(16 * (i >> 2) + (i & 3)) * RB, 16 * (i >> 2) + (i & 3)>(ts.rsrc, v_lds, vvo[i & 3], v_row_bytes, v_wave_off);
     } else {
       lds_dma_16_at<i * 1024>(ts.rsrc, v_lds, vrel[i], 0u);
     }
@@ -344,6 +364,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 
 #ifndef FFPA_M16_K_FIRST
 #define FFPA_M16_K_FIRST 0  // (experiment) 1: the first K tile's DMA pieces are issued ahead of the Q fragment loads
+#endif
+#ifdef FFPA_PRODUCT_BUILD
+  static_assert(FFPA_M16_K_FIRST == 0, "FFPA_PRODUCT_BUILD: a developer switch is not at its shipped default");
 #endif
   if constexpr (FFPA_M16_K_FIRST != 0) {
     if (nt > t0) static_for<PPW>([&](auto ic) { issue_k(ic, t0 * BC); });
@@ -583,6 +606,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         constexpr bool kPiece = n % kStep1 == 0 && n / kStep1 < PPW;
 #ifndef FFPA_M16_DMA_POS
 #define FFPA_M16_DMA_POS 1  // where a DMA piece sits relative to the fragment's two MFMAs: 0 in front, 1 between (+ 0.4 ... 1.7 %), 2 behind
+#endif
+#ifdef FFPA_PRODUCT_BUILD
+        static_assert(FFPA_M16_DMA_POS == 1, "FFPA_PRODUCT_BUILD: a developer switch is not at its shipped default");
 #endif
         if constexpr (kPiece && FFPA_M16_DMA_POS == 0) issue_v(std::integral_constant<int, n / kStep1>{}, k0);
         if constexpr (s == 0 && !kBias) M::first(sacc[kb][0], kf[n], qf[s][0]);
@@ -861,8 +887,6 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       }
       if (c == 0 && dh == 0) a.ws_lse[prow] = dead ? -INFINITY : __logf(l_tot[rh]) + m_run[rh] * 0.6931471805599453f;
     }
-    // with tickets: the last split of this row tile to arrive merges all partials here (one launch per call)
-    if (a.tickets != nullptr) split_arrive_and_merge<T>(a, D, bh * a.nqt + qt, b, hq, q0, BR, Kt);
     return;
   }
   {

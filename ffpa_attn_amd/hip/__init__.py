@@ -342,8 +342,10 @@ def forward(
   1 = never) and merges by LSE; the scratch for the partials is allocated here with torch.
   ``plan_out``, if given, receives the launch plan (variant, block_rows, block_keys, splits, packed).
 
-  ``merge_in_launch``: KV-split launches merge their partials inside the launch (the last split of a row tile to arrive does it:
-  one launch per call; ``FFPA_HIP_MERGE_IN_LAUNCH=0`` or ``False`` keeps the separate merge kernel — the same numbers).
+  ``merge_in_launch``: short-query KV-split launches merge their partials inside the launch (the last split of a row tile to arrive does
+  it: one launch per call) instead of launching the merge kernel behind the split kernel — the same numbers.  OFF by default
+  (``FFPA_HIP_MERGE_IN_LAUNCH=1`` or ``True`` turns it on): measured on MI355X the hand-off costs every split workgroup more than
+  the second launch costs the call (decode B1 H32 Nkv 8192 D512: 115 vs 110 us; profiles/r03_split_merge.txt).
 
   ``kv_bounds``: key ranges of the mask (``mask_kv_bounds``) — the kernel then skips the KV tiles the mask hides
   entirely and does not read the mask for the tiles it leaves untouched (an explicit causal mask costs what ``is_causal``
@@ -455,7 +457,7 @@ def forward(
       p.workspace = workspace.data_ptr()
       p.workspace_bytes = ws_bytes
       if merge_in_launch is None:
-        merge_in_launch = os.environ.get("FFPA_HIP_MERGE_IN_LAUNCH", "1") not in ("0", "")
+        merge_in_launch = os.environ.get("FFPA_HIP_MERGE_IN_LAUNCH", "0") not in ("0", "")
       if merge_in_launch and hasattr(lib, "ffpa_attn_fwd_split_tickets"):
         n_tickets = lib.ffpa_attn_fwd_split_tickets(ctypes.byref(p))
         if n_tickets:

@@ -94,6 +94,16 @@ def attend_units(qu: torch.Tensor, ku: torch.Tensor, vu: torch.Tensor, **kwargs)
   return ffpa_attn_func(qu, ku, vu, enable_gqa=qu.size(1) != ku.size(1), **kwargs)
 
 
+def _check_out(out: "torch.Tensor | None", shape: tuple, like: torch.Tensor) -> None:
+  """A caller-supplied result buffer is written by slices and by RCCL: a wrong shape / dtype / device / layout must fail here, with
+  words, not as a partial fill or an opaque collective error."""
+  if out is None:
+    return
+  if tuple(out.shape) != tuple(shape) or out.dtype != like.dtype or out.device != like.device or not out.is_contiguous():
+    raise ValueError(f"out must be a contiguous {like.dtype} tensor of shape {tuple(shape)} on {like.device}, got {out.dtype} "
+                     f"{tuple(out.shape)} on {out.device} (contiguous: {out.is_contiguous()})")
+
+
 def gather_units(o_local: torch.Tensor, n_units: int, group: "dist.ProcessGroup | None" = None,
                  out: torch.Tensor | None = None) -> torch.Tensor:
   """All ranks' blocks -> ``[n_units, group, Nq, D]`` on every rank with ONE ``all_gather_into_tensor``.
@@ -102,7 +112,10 @@ def gather_units(o_local: torch.Tensor, n_units: int, group: "dist.ProcessGroup 
   in place afterwards (the only copy, of the tail blocks)."""
   world = dist.get_world_size(group)
   g, nq, d = o_local.shape[1:]
+  _check_out(out, (n_units, g, nq, d), o_local)
   per = -(-n_units // world)
+  if n_units == 0:  # nothing to gather (no collective over empty buffers)
+    return out if out is not None else o_local.new_empty((0, g, nq, d))
   if n_units % world == 0:
     if out is None:
       out = o_local.new_empty((n_units, g, nq, d))
@@ -116,11 +129,10 @@ def gather_units(o_local: torch.Tensor, n_units: int, group: "dist.ProcessGroup 
     s, e = partition_units(n_units, world, r)
     if s != r * per:
       padded[s:e] = padded[r * per : r * per + (e - s)].clone()
-  res = padded[:n_units]
-  if out is not None:
-    out.copy_(res)
-    return out
-  return res
+  if out is None:
+    return padded[:n_units]
+  out.copy_(padded[:n_units])  # (uneven split with a caller's buffer: the collective needs equal shards, so this one copy stays)
+  return out
 
 
 def attend_and_gather_units(qu: torch.Tensor, ku: torch.Tensor, vu: torch.Tensor, n_units: int, *, chunks: int = 4,
@@ -137,8 +149,11 @@ def attend_and_gather_units(qu: torch.Tensor, ku: torch.Tensor, vu: torch.Tensor
   if qu.size(0) != per:
     raise ValueError(f"this rank holds {qu.size(0)} units, expected {per} (= {n_units} / {world})")
   g, nq, d = qu.shape[1:]
+  _check_out(out, (n_units, g, nq, d), qu)
   if out is None:
     out = qu.new_empty((n_units, g, nq, d))
+  if per == 0:
+    return out
   chunks = max(1, min(chunks, per))
   bounds = [per * c // chunks for c in range(chunks + 1)]
   works = []

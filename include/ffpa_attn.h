@@ -151,13 +151,15 @@ typedef struct ffpa_fwd_params {
   const int32_t* kv_bounds;
   int64_t kv_bounds_stride[2];
 
-  /* Optional, KV-split launches only (NULL = none): ffpa_attn_fwd_split_tickets(params) int32 counters, ZERO on entry.  With them the
+  /* Optional, short-query (seqlen_q <= 32) KV-split launches only (NULL = none; ignored by other launches):
+   * ffpa_attn_fwd_split_tickets(params) int32 counters, ZERO on entry.  With them the
    * split partials are merged inside the same launch — the last split of a row tile to arrive (agent-scope release of its partial, one
    * relaxed atomic ticket, agent-scope acquire by the merger) combines all of them by LSE, writes O / LSE and puts its counter back to
    * zero: one launch per call instead of two, the role of the reference's split_kv_decode stage 2 (native/sm_80/split_kv.cuh:329-455)
    * without its second kernel.  The counters must not be shared by launches that may run concurrently (other streams); after a launch
    * completes they are zero again, so one buffer zeroed once serves every later call on that stream, HIP-graph replays included.
-   * Without them a second kernel (ffpa_fwd_merge_kernel) follows the first on the same stream: the same numbers. */
+   * Without them a second kernel (ffpa_fwd_merge_kernel) follows the first on the same stream: the same numbers.  Which of the two is
+   * faster is a measurement (profiles/r03_split_merge.txt), the Python host's default follows it. */
   int32_t* split_tickets;
 } ffpa_fwd_params;
 
@@ -175,8 +177,8 @@ int ffpa_attn_fwd(const ffpa_fwd_params* params, void* stream);
 size_t ffpa_attn_fwd_workspace_bytes(const ffpa_fwd_params* params);
 
 /*
- * Number of int32 counters ffpa_fwd_params.split_tickets must hold for this call (one per (batch, head, row tile); 0 when the
- * call does not split).
+ * Number of int32 counters ffpa_fwd_params.split_tickets must hold for this call (one per (batch, head); 0 when the
+ * call is not a KV-split short-query launch).
  */
 size_t ffpa_attn_fwd_split_tickets(const ffpa_fwd_params* params);
 

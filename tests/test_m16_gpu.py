@@ -75,7 +75,7 @@ def test_the_launch_plan_names_this_build(hip):
   q, k, v = _rand((1, 4, 512, D), seed=1), _rand((1, 4, 2048, D), seed=2), _rand((1, 4, 2048, D), seed=3)
   plan = {}
   o16, _ = hip.forward(q, k, v, None, False, D ** -0.5, plan_out=plan)
-  assert plan["splits"] > 1 and plan["kernel"] == "ffpa_fwd_m16_kernel<bf16, 512, MK=0, DROP=0> (in-launch split merge)", plan  # (4 row tiles: the KV axis is split)
+  assert plan["splits"] > 1 and plan["kernel"] == "ffpa_fwd_m16_kernel<bf16, 512, MK=0, DROP=0> + ffpa_fwd_merge_kernel", plan  # (4 row tiles: the KV axis is split)
   o16, _ = hip.forward(q, k, v, None, False, D ** -0.5, plan_out=plan, num_splits=1)
   assert plan["kernel"] == "ffpa_fwd_m16_kernel<bf16, 512, MK=0, DROP=0>", plan
   o32, _ = _twin(hip, q, k, v, None, False)
@@ -95,7 +95,9 @@ def test_the_launch_plan_names_this_build(hip):
   hip.forward(q[..., :256].contiguous(), k[..., :256].contiguous(), v[..., :256].contiguous(), None, False, 256 ** -0.5, plan_out=plan, num_splits=1)
   assert plan["kernel"].startswith("ffpa_fwd_split_d_kernel<bf16, 256, ND=1"), plan
   hip.forward(q[:, :, :1], k, v, None, False, D ** -0.5, plan_out=plan)
-  assert plan["kernel"].startswith("ffpa_fwd_split_d_kernel<bf16, 512, ND=4") and plan["kernel"].endswith("(in-launch split merge)"), plan
+  assert plan["kernel"].startswith("ffpa_fwd_split_d_kernel<bf16, 512, ND=4") and plan["kernel"].endswith("+ ffpa_fwd_merge_kernel"), plan
+  hip.forward(q[:, :, :1], k, v, None, False, D ** -0.5, plan_out=plan, merge_in_launch=True)
+  assert plan["kernel"].endswith("(in-launch split merge)"), plan
   kb = _rand((1, 1, 1, 2048), seed=9)
   hip.forward(q, k, v, kb, False, D ** -0.5, plan_out=plan, num_splits=1)
   assert plan["kernel"] == "ffpa_fwd_m16_kernel<bf16, 512, MK=3, DROP=0>" and plan["block_keys"] == 64, plan  # a key bias: the lean build
