@@ -13,7 +13,8 @@ import collections, csv, glob, json, os, re, sys
 
 
 def bench_line(src):
-  for path in sorted(glob.glob(os.path.join(src, "*.log"))):
+  # (the --kernel-trace pass's own bench line first: its steps / warm-ups are what the trace statistics below count)
+  for path in sorted(glob.glob(os.path.join(src, "*.log")), key=lambda p: (os.path.basename(p) != "trace.log", p)):
     for line in open(path, errors="replace"):
       line = line.strip()
       if line.startswith("{") and '"roofline"' in line:
@@ -21,6 +22,25 @@ def bench_line(src):
           return json.loads(line)
         except ValueError:
           pass
+  return None
+
+
+def trace_stats(src, kernel, warmup, steps=None):
+  """Durations (ms) of the dominant kernel's dispatches in the --kernel-trace pass of the same command (<dir>/**/trace_kernel_trace.csv),
+  in dispatch order, warm-up launches dropped: median / mean / min / max / count — what profiles/ must reproduce of the bench line."""
+  for path in sorted(glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True)):
+    if not os.path.basename(path).startswith("trace"):  # (the --stats pass is written with -o trace; the PMC passes carry their own names)
+      continue
+    rows = [(int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6) for r in csv.DictReader(open(path))
+            if re.search(kernel, r["Kernel_Name"])]
+    if not rows:
+      continue
+    d = [x for _, x in sorted(rows)][warmup:(warmup + steps) if steps else None]  # the timed region's launches only
+    if not d:
+      continue
+    sd = sorted(d)
+    return {"file": os.path.relpath(path, src), "dispatches_counted": len(d), "warmup_dispatches_dropped": warmup, "median_ms": sd[len(sd) // 2],
+            "mean_ms": sum(d) / len(d), "min_ms": sd[0], "max_ms": sd[-1]}
   return None
 
 
@@ -90,6 +110,22 @@ def main():
   if m("TCC_HIT_sum") is not None and m("TCC_MISS_sum") is not None and m("TCC_HIT_sum") + m("TCC_MISS_sum") > 0:
     d["l2_hit_rate"] = m("TCC_HIT_sum") / (m("TCC_HIT_sum") + m("TCC_MISS_sum"))
   line = bench_line(src)
+  # provenance: which binary, which tree, which clock (a profile that does not name its binary cannot back a bench line)
+  prov = {"git_head": os.environ.get("FFPA_GIT_HEAD") or (line or {}).get("build", {}).get("git_head"),
+          "lib_sha16": (line or {}).get("build", {}).get("lib_sha16"), "lib_version": (line or {}).get("build", {}).get("lib_version"),
+          "bench_kernel": (line or {}).get("roofline", {}).get("kernel"), "effective_clock_ghz_under_pmc": d.get("effective_clock_ghz_in_that_pass")}
+  res["provenance"] = prov
+  ts = trace_stats(src, kernel, int((line or {}).get("warmup", os.environ.get("PMC_TRACE_WARMUP", "5"))), (line or {}).get("steps"))
+  if ts:
+    d["kernel_trace"] = ts
+    roof = (line or {}).get("roofline", {})
+    work = roof.get("flops_per_launch") or roof.get("bytes_per_launch")
+    if work and roof.get("peak"):
+      unit = 1e12 if roof.get("bound") == "mfma" else 1e9
+      d["kernel_trace"]["frac_of_peak_at_median"] = work / (ts["median_ms"] * 1e-3) / unit / roof["peak"]
+      d["kernel_trace"]["frac_of_peak_at_mean"] = work / (ts["mean_ms"] * 1e-3) / unit / roof["peak"]
+      d["kernel_trace"]["bench_line_frac"] = roof.get("frac")
+      d["kernel_trace"]["bench_line_kernel_ms_avg"] = roof.get("kernel_ms_avg")
   if line:
     wl = line.get("config", {}).get("workload", "")
     d["workload"] = wl
