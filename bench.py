@@ -410,12 +410,17 @@ def spawn_ranks(n: int, argv: list[str]) -> int:
     procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, stdout=None if r == 0 else subprocess.DEVNULL))
   worst = 0
   try:
-    for pr in procs:
-      rc = pr.wait()
-      worst = worst or rc
-      if rc != 0:  # one rank died: the others would wait in a collective forever
-        for other in procs:
-          if other.poll() is None:
+    live = list(procs)
+    while live:  # poll ALL ranks: a rank that dies leaves the others waiting in a rendezvous / collective for minutes
+      time.sleep(0.2)
+      for pr in list(live):
+        rc = pr.poll()
+        if rc is None:
+          continue
+        live.remove(pr)
+        worst = worst or rc
+        if rc != 0:
+          for other in live:
             other.terminate()
   finally:
     for pr in procs:
@@ -444,6 +449,8 @@ def main() -> None:
 
   if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
     # no launcher around us: be our own (the torchrun form keeps working: it sets WORLD_SIZE)
+    if not args.stub_backend and torch.cuda.device_count() < args.gpus:
+      sys.exit(f"bench.py: --gpus {args.gpus} but this node shows {torch.cuda.device_count()} GPU(s)")
     sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))

@@ -64,6 +64,7 @@ struct Plan {
   int btile;  // 1: a bias with a row axis goes through LDS tiles staged one KV step ahead
   int m16;    // 1: the launch runs ffpa_fwd_m16_kernel (prefill tiles, head dim >= FFPA_M16_MIN_D), 0: ffpa_fwd_split_d_kernel
   int mk;     // m16: the mask kind of the build (0 none, 1 additive bias, 2 boolean mask / ranges)
+  int bias_raw;  // FwdArgs.bias_cache_raw
   int bias_lds;  // FwdArgs.bias_lds: > 0 bytes of the key-bias row cache, < 0 -(bytes of the bias-tile staging areas), 0 neither
   size_t ws_bytes;
 };
@@ -157,8 +158,10 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
       bool stage_ok = lds_ok && p->bias_stride[3] == 1 && reinterpret_cast<uintptr_t>(p->bias) % 16 == 0 && p->bias_stride[2] < (1LL << 24) &&
                       pl.lds + stage <= 160 * 1024;
       for (int i = 0; i < 3 && stage_ok; ++i) stage_ok = (p->bias_stride[i] * esz) % 16 == 0;
-      if (lds_ok && p->bias_stride[2] == 0 && pl.lds + cache <= 160 * 1024) {
-        pl.bias_lds = (int)cache;
+      const bool cache16 = esz == 2 && pl.lds + cache / 2 <= 160 * 1024;  // ... or as the caller's 16-bit elements, converted per step
+      if (lds_ok && p->bias_stride[2] == 0 && (pl.lds + cache <= 160 * 1024 || cache16)) {
+        pl.bias_raw = pl.lds + cache <= 160 * 1024 ? 0 : 1;
+        pl.bias_lds = (int)(pl.bias_raw ? cache / 2 : cache);
         if (p->kv_bounds == nullptr && !(p->dropout_p > 0.f)) pl.mk = 3;  // nothing but a cached key bias: the lean key-bias build
       } else if (stage_ok) {
         pl.btile = 1;
@@ -359,6 +362,7 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   if (pl.m16) {
     a.bias_tile = pl.btile;
     a.bias_lds = pl.bias_lds;
+    a.bias_cache_raw = pl.bias_raw;
   } else if (pl.btile) {
     a.bias_tile = 1;
     a.bias_lds = -(4 * 32 * pl.bc * 2);  // negative: LDS bytes reserved for the tile staging (no key-bias row cache)

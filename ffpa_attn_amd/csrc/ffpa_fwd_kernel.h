@@ -186,6 +186,8 @@ struct FwdArgs {
   int64_t s_bounds[2];  // element strides: batch, head (0 = broadcast)
   int bias_lds;  // < 0: -bytes of LDS reserved for bias_tile staging.  > 0: the bias is a key bias (no row axis): its [Nkv] row of this (batch, head) is copied to LDS once per workgroup
                  //      (this many bytes, a whole number of tiles) and the tiles read it from there instead of from global memory
+  int bias_cache_raw;  // 16x16x32 build, bias_lds > 0: 1 = the row cache holds the caller's 16-bit elements (a key row too long for the fp32 / scale form:
+                       //   converted at the top of every KV step), 0 = fp32 values already divided by the scale
   int bias_tile; // 1: a 16-bit bias with a real row axis is staged through LDS: every wave LDS-DMAs the [32 rows x BC keys] tile of
                  //    the NEXT step into a private area while the PV MFMAs run, and reads it there when it is needed
   int bias_vec;  // W in {0, 4, 8, 16}: bias key stride is 1 and base / strides are W-element aligned -> W-wide loads (16: bool8 masks)

@@ -483,16 +483,21 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   if (kBias && a.bias_lds > 0 && nt > t0) {
     // key bias [.., .., 1, Nkv]: every row of the workgroup adds the same Nkv values — converted once to fp32 / scale (entries past Nkv are
     // zeros: those keys get the tail mask); made visible by the barrier below
-    const int n_ent = a.bias_lds >> 2;
     const int64_t src0 = b * a.sbias[0] + hq * a.sbias[1];
-    for (int i = tid; i < n_ent; i += 256) {
-      float w = 0.f;
-      if (i < a.Nkv) {
-        const int64_t e = src0 + i * a.sbias[3];
-        w = a.bias_dtype == 3 ? ((const float*)a.bias)[e] : a.bias_dtype == 2 ? (float)((const __bf16*)a.bias)[e] : (float)((const _Float16*)a.bias)[e];
-        w *= a.inv_scale;
+    if (a.bias_cache_raw) {  // (a key row too long for the fp32 form: the caller's 16-bit elements, converted at the top of every step)
+      const int n_ent = a.bias_lds >> 1;
+      for (int i = tid; i < n_ent; i += 256) *(FFPA_LDS uint16_t*)(Bl + 2 * i) = i < a.Nkv ? ((const uint16_t*)a.bias)[src0 + i * a.sbias[3]] : (uint16_t)0;
+    } else {
+      const int n_ent = a.bias_lds >> 2;
+      for (int i = tid; i < n_ent; i += 256) {
+        float w = 0.f;
+        if (i < a.Nkv) {
+          const int64_t e = src0 + i * a.sbias[3];
+          w = a.bias_dtype == 3 ? ((const float*)a.bias)[e] : a.bias_dtype == 2 ? (float)((const __bf16*)a.bias)[e] : (float)((const _Float16*)a.bias)[e];
+          w *= a.inv_scale;
+        }
+        *(FFPA_LDS float*)(Bl + 4 * i) = w;
       }
-      *(FFPA_LDS float*)(Bl + 4 * i) = w;
     }
   }
   if (nt > t0) {
@@ -522,7 +527,26 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       // (mask_free, wave-uniform: this step lies in the neutral interior of the caller's mask (kv_bounds): nothing to read, nothing to add)
       const bool mask_free = MK == 1 && k0 >= free_lo && k0 + BC <= free_hi;
       if (bias_owner && !mask_free) {
-        if (MK == 3 || a.bias_lds > 0) {  // key bias: fp32 / scale from the LDS row cache, the same 4 keys for both of the lane's rows
+        if ((MK == 3 || a.bias_lds > 0) && a.bias_cache_raw) {  // key bias, 16-bit row cache: 4 keys = one ds_read_b64, converted here
+          typedef __attribute__((ext_vector_type(4))) __bf16 b4;
+          typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+          FFPA_LDS const char* bp = Bl + 8 * c + 2 * k0;
+#pragma unroll
+          for (int kb = 0; kb < NKB; ++kb) {
+            f32x4 w;
+            if (a.bias_dtype == 2) {
+              const b4 t = *(FFPA_LDS const b4*)(bp + 32 * kb);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) w[r] = (float)t[r] * a.inv_scale;
+            } else {
+              const h4 t = *(FFPA_LDS const h4*)(bp + 32 * kb);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) w[r] = (float)t[r] * a.inv_scale;
+            }
+            sacc[kb][0] = w;
+            sacc[kb][1] = w;
+          }
+        } else if (MK == 3 || a.bias_lds > 0) {  // key bias: fp32 / scale from the LDS row cache, the same 4 keys for both of the lane's rows
           FFPA_LDS const char* bp = bl_lane + 4 * k0;
           FFPA_LDS const char* bp2 = bp;
           asm volatile("" : "+v"(bp2));  // (two reads, no register copies: the LDS has the bandwidth, the VALU slots are what the softmax needs)

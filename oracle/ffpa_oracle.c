@@ -19,11 +19,17 @@
  *   csrc/cuffpa/native/prefill.cuh:1063-1073       LSE = ln(l) + m*ln2  (natural log)
  * Fully masked rows give NaN (exp2(-inf - -inf) in the reference; 0 * inf here) — same as SDPA.
  *
+ * One deliberate simplification: the exponent's argument is formed as (s*c) - m in two fp32 roundings where the reference's kernel
+ * (prefill.cuh:748) and the HIP kernel use one FMA.  The difference is at most one fp32 ulp of the score — three orders of
+ * magnitude below the bf16 / fp16 rounding of P that every comparison against this oracle allows for.
+ *
  * Parity pinning: the reference holds no golden vectors for this path (every forward test is
  * "allclose to PyTorch SDPA on seeded randn", tests/test_ffpa_fwd.py:106-121), so this oracle is
- * pinned (tests/test_oracle.py) against (i) PyTorch CPU SDPA — the reference's own test oracle —
- * on the committed fixtures in tests/golden/, (ii) the output of the reference's ffpa_attn_func
- * itself, run in the authoring container on config 1 (tests/golden/make_golden.py), and (iii) an
+ * pinned (tests/test_oracle.py) against (i) OUTPUTS OF THE REFERENCE'S OWN large-head-dim kernel executed in the authoring
+ * container — its Triton forward under TRITON_INTERPRET=1, fp16 and bf16, nine cases incl. late score spikes that walk the
+ * lazy-rescale branch (tests/golden/make_triton_golden.py -> ref_triton_cases.npz), (ii) PyTorch CPU SDPA — the reference's own
+ * test oracle — on the committed fixtures in tests/golden/, (iii) the output of the reference's ffpa_attn_func
+ * itself, run in the authoring container on config 1 (tests/golden/make_golden.py), and (iv) an
  * fp64 plain-math evaluation.
  *
  * Build:  gcc -O3 -march=native -fopenmp -shared -fPIC ffpa_oracle.c -o libffpa_oracle.so -lm

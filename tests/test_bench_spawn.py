@@ -35,9 +35,25 @@ def test_bench_under_a_launcher_does_not_spawn_and_checks_the_world_size():
   assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
 
 
-def test_a_failing_rank_fails_the_launcher():
-  # no GPU here: the real (non-stub) path exits with a message on every rank; the wrapper must report failure, not hang
+def test_a_failing_rank_fails_the_launcher_promptly(tmp_path):
+  """A rank that dies must take the launch down at once (the other ranks would wait for it in the rendezvous for minutes): rank 1 of a
+  stub launch is made to crash through an unusable backend name for that rank only."""
+  import time
+
+  # no GPU here: the real (non-stub) path refuses before spawning when the node has fewer GPUs than ranks
   r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], env={"CUDA_VISIBLE_DEVICES": "", "HIP_VISIBLE_DEVICES": ""})
-  if r.returncode == 0:  # a GPU box with >= 2 devices visible despite the env: nothing to check here
-    return
-  assert "needs a GPU" in r.stderr or r.returncode != 0
+  assert r.returncode != 0 and ("GPU(s)" in r.stderr or "needs a GPU" in r.stderr), r.stderr[-500:]
+  # the polling loop itself, driven directly: one child exits 3 at once, the other would sleep for a minute
+  sys.path.insert(0, ROOT)
+  import bench
+
+  script = tmp_path / "rank.py"
+  script.write_text("import os, sys, time\nsys.exit(3) if os.environ['RANK'] == '1' else time.sleep(60)\n")
+  real = bench.__file__
+  bench.__file__ = str(script)
+  try:
+    t0 = time.time()
+    rc = bench.spawn_ranks(2, [])
+  finally:
+    bench.__file__ = real
+  assert rc == 3 and time.time() - t0 < 20

@@ -382,3 +382,15 @@ def test_additive_mask_ranges_and_long_key_biases(hip):
   assert torch.equal(a, b) and torch.equal(la, lb)
   s = (q.float() @ k.float().transpose(-1, -2)) * D ** -0.5 + kb.float()
   assert (a.float() - torch.softmax(s, -1) @ v.float()).abs().max().item() < 1e-2
+  # in between: a 16-bit key row that does not fit the LDS as fp32 / scale but does as its own 16-bit elements (D = 1024: 16 KiB to spare,
+  # 8192 keys) stays on the lean key-bias build, converted at the top of every step — the same bits as the element loads
+  D2, Nkv = 1024, 8192
+  q, k, v = _rand((1, 2, 200, D2), seed=721), _rand((1, 2, Nkv, D2), seed=722), _rand((1, 2, Nkv, D2), seed=723)
+  for dt in (torch.bfloat16, torch.float16):
+    kb = (_rand((1, 2, 1, Nkv), seed=724) * 0.5).to(dt)
+    kb[..., 100:200] = float("-inf")
+    plan = {}
+    a, la = hip.forward(q.to(dt), k.to(dt), v.to(dt), kb, False, D2 ** -0.5, num_splits=1, plan_out=plan)
+    assert "MK=3" in plan["kernel"], plan
+    b, lb = hip.forward(q.to(dt), k.to(dt), v.to(dt), kb, False, D2 ** -0.5, num_splits=1, flags=hip.FLAG_NO_BIAS_LDS, plan_out=plan)
+    assert "MK=1" in plan["kernel"] and torch.equal(a, b) and torch.equal(la, lb), dt
