@@ -188,7 +188,7 @@ def build_variant(tag: str, defs: list[str], jobs: int | None = None, head_dims:
     tasks.append([hipcc, *CXXFLAGS, *defs, f"-DFFPA_INST_D={d}", "-c", os.path.join(CSRC, "ffpa_fwd_inst.hip"), "-o", obj])
   capi = os.path.join(odir, "ffpa_capi.o")
   objs.append(capi)
-  tasks.append([hipcc, *CXXFLAGS, "-c", os.path.join(CSRC, "ffpa_capi.hip"), "-o", capi])
+  tasks.append([hipcc, *CXXFLAGS, *defs, "-c", os.path.join(CSRC, "ffpa_capi.hip"), "-o", capi])  # (the plan must see the same tunables as the kernels)
   with ThreadPoolExecutor(max_workers=jobs or (os.cpu_count() or 4)) as pool:
     list(pool.map(_run, tasks))
   _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib, *objs, "-Wl,-rpath,/opt/rocm/lib"])

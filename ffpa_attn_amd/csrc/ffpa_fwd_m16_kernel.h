@@ -37,10 +37,12 @@
 #include "ffpa_fwd_kernel.h"
 
 #ifndef FFPA_M16_MIN_D
-// head dims from here up launch this build (measured A/B against the 32x32x16 build, profiles/r02_m16_ab.txt: + 4 ... 5 % at
-// D = 320 ... 512, + 0.5 ... 2.5 % at D = 576 ... 960, + 5 ... 6 % at D = 1024, even at D = 192 / 256, - 11 % at D = 128 — there the
-// 128-key tiles' S^T / P^T registers and the per-piece DMA offsets leave the compiler spilling scalars inside the loops)
-#define FFPA_M16_MIN_D 320
+// head dims from here up launch this kernel.  Round 2 (A/B against the 32x32x16 kernel, profiles/r02_m16_ab.txt): + 4 ... 5 % at D = 320 ... 512,
+// + 0.5 ... 2.5 % at D = 576 ... 960, + 5 ... 6 % at D = 1024, even at D = 192 / 256, - 11 % at D = 128 -> 320.  Round 3, once the LDS-DMA
+// destinations had become scalar base + immediate (no scalar register per piece: the small head dims had been spilling exactly those inside
+// their loops): D = 256 1271 vs 1159 TFLOPS (+ 9.6 %), D = 192 1180 vs 1082 (+ 9 %), causal D = 256 + 8 %, N = 2048 + 6.6 %, dropout D = 256 + 22 %,
+// key bias + 1.5 %, dense bias - 4 %; D = 128 still - 14 % (128-key tiles: 64 score registers per lane) -> 192 (profiles/r03_m16_small_d.txt)
+#define FFPA_M16_MIN_D 192
 #endif
 #ifndef FFPA_M16_PF1
 #define FFPA_M16_PF1 6  // K fragments requested ahead of their (two) MFMAs
@@ -148,7 +150,7 @@ __device__ __forceinline__ int m16_v_swizzle(int key) {
 // are built without the define, get another file name and say so in ffpa_attn_version().
 #ifdef FFPA_PRODUCT_BUILD
 #if FFPA_ABL != 0 || defined(FFPA_M16_TIMING) || FFPA_PERSISTENT != 0 || FFPA_M16_ROWDMA != 1 || FFPA_M16_PF1 != 6 || FFPA_M16_PF2 != 4 || \
-    FFPA_M16_K_PRE != 8 || FFPA_M16_K_PRE_ND2 != 64 || FFPA_M16_ROW_TABLES != 1 || FFPA_DMA_M0_CLOBBER != 1 || FFPA_M16_SWAP_REDUCE != 1 || FFPA_M16_MIN_D != 320
+    FFPA_M16_K_PRE != 8 || FFPA_M16_K_PRE_ND2 != 64 || FFPA_M16_ROW_TABLES != 1 || FFPA_DMA_M0_CLOBBER != 1 || FFPA_M16_SWAP_REDUCE != 1 || FFPA_M16_MIN_D != 192
 #error "FFPA_PRODUCT_BUILD: a developer switch is not at its shipped default"
 #endif
 #endif
@@ -442,7 +444,11 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   // (rpp = 64 / b_slots); its lane l fetches (row l / b_slots, slot (l % b_slots) ^ g): g = (4 i & (b_slots - 1)) | ((l / b_slots) >> b_sh).
   uint32_t b_rowoff = 0, b_col = 0;
   uint32_t b_piece_rows = 0;          // bytes between the first rows of two consecutive pieces: (64 / b_slots) row strides
-  u32x4 b_rsrc = {0u, 0u, 0u, 0u};    // this wave's 32 bias rows, from key 0 on: the step's first key goes into the scalar offset
+  // descriptor of this wave's 32 bias rows, from key 0 on (the step's first key goes into the scalar offset): kept as base + byte count and
+  // assembled right in front of each piece, like the K / V tile descriptors (a 4-dword descriptor held live across the kernel gets parked in
+  // VGPR lanes under scalar pressure, and an inline-asm "s" operand of vector type is then handed over as VGPRs: an assembler error at best)
+  const char* b_base = nullptr;
+  uint32_t b_left = 0;
   FFPA_LDS const char* baddr[NKB];  // staged tile: this lane's read address of key block kb, row half 0 (row half 1: + 16 rows)
   if constexpr (MK == 1) {
     if (b_pieces > 0) {
@@ -457,9 +463,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       const int64_t first = (int64_t)wq0 * b_rs;
       int64_t left = (int64_t)(a.Nq - 1) * b_rs + (int64_t)b_esz * a.Nkv - first;
       left = left < 0 ? 0 : (left > 0x7fffffff ? 0x7fffffff : left);
-      b_rsrc = make_rsrc((const char*)a.bias + plane + first, (uint32_t)left);
-#pragma unroll
-      for (int w = 0; w < 4; ++w) b_rsrc[w] = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_rsrc[w]);
+      b_base = (const char*)a.bias + plane + first;
+      b_left = (uint32_t)left;
       const int g = (n16 >> b_sh) & (b_slots - 1);
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
@@ -469,13 +474,20 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     }
   }
   // piece i of the bias tile of the KV step starting at key0, for this wave's 32 rows
-  auto issue_bias = [&](auto ic, int key0) {
+  // (the descriptor is assembled from its scalars once per KV step, right in front of the pieces that use it)
+  auto bias_rsrc = [&]() -> u32x4 {
+    const uint64_t bb = (uint64_t)b_base;  // (wave-uniform by construction; pinned to scalar registers for the asm's "s" operands)
+    const u32x4 r = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bb), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bb >> 32)) & 0xffffu,
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)b_left), 0x00020000u};
+    return r;
+  };
+  auto issue_bias = [&](auto ic, int key0, u32x4 rsrc) {
     if constexpr (MK == 1) {
       constexpr int i = decltype(ic)::value;
       const uint32_t voff = (b_col ^ (uint32_t)((64 * i) & (b_rowb - 1))) + b_rowoff;
       // (wave-uniform values, pinned to scalar registers: M0 and the scalar offset of the DMA asm)
       const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)i * b_piece_rows + (uint32_t)(key0 * b_esz)));
-      lds_dma_16_at<i * 1024>(b_rsrc, bt_s, voff, soff);
+      lds_dma_16_at<i * 1024>(rsrc, bt_s, voff, soff);
     }
   };
   FFPA_LDS const char* const bl_lane = Bl + 16 * c;  // row cache: this lane's 4 keys of block kb of the step at k0 sit at bl_lane + 4 k0 + 64 kb
@@ -503,8 +515,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   if (nt > t0) {
     if constexpr (FFPA_M16_K_FIRST == 0) static_for<PPW>([&](auto ic) { issue_k(ic, t0 * BC); });
     if constexpr (MK == 1) {
+      const u32x4 brs = bias_rsrc();
       static_for<kBtMax>([&](auto ic) {
-        if (decltype(ic)::value < b_pieces) issue_bias(ic, t0 * BC);
+        if (decltype(ic)::value < b_pieces) issue_bias(ic, t0 * BC, brs);
       });
     }
     dma_wait_all();
@@ -843,6 +856,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       FFPA_TSTAMP(3);  // V(j) drain + wait at barrier A2
       // pieces of the next step's bias tile to stage (none when that step lies in the mask's neutral interior or past the last tile)
       const int b_next = (MK == 1 && j + 1 < nt && !(k0 + BC >= free_lo && k0 + 2 * BC <= free_hi)) ? b_pieces : 0;
+      const u32x4 brs = bias_rsrc();
       v8 vf[N2];
       auto v_frag = [&](int n) -> v8 {
         const int db = n % NDB, ks = n / NDB;
@@ -868,13 +882,19 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
           // the bias tile of step j + 1 (this wave's rows, its private staging area) in the slots the K pieces leave free
           constexpr int kBStep = kStep2 >= 2 ? kStep2 : 2;
           if constexpr (n % kBStep == kBStep / 2 && n / kBStep < kBtMax) {
-            if (n / kBStep < b_next) issue_bias(std::integral_constant<int, n / kBStep>{}, k0 + BC);
+            if (n / kBStep < b_next) issue_bias(std::integral_constant<int, n / kBStep>{}, k0 + BC, brs);
           }
         }
       });
       if constexpr (MK == 1) {
+        // (short PV loops — small head dims — do not have a slot for every bias piece: the rest go out here)
         constexpr int kBStep = kStep2 >= 2 ? kStep2 : 2;
-        static_assert((kBtMax - 1) * kBStep + kBStep / 2 < N2, "every bias piece has a slot in the PV loop");
+        static_for<kBtMax>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          if constexpr (i * kBStep + kBStep / 2 >= N2) {
+            if (i < b_next) issue_bias(ic, k0 + BC, brs);
+          }
+        });
       }
       __builtin_amdgcn_sched_barrier(0);
     }

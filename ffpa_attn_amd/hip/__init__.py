@@ -128,7 +128,7 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
   with _lib_lock:
     if _lib is not None and path is None:
       return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("FFPA_HIP_LIBRARY") or LIB_PATH  # (FFPA_HIP_LIBRARY: developer override — run the tests against a variant build)
     if not os.path.exists(p):
       raise RuntimeError(
         f"ffpa_attn_amd: {p} not found. The HIP extension is required (there is no fallback "
