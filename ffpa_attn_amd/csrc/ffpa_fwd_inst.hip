@@ -48,7 +48,7 @@ static int launch_one(const FwdArgs& a, hipStream_t stream) {
 // The prefill kernel on the 16x16x32 MFMA shape (ffpa_fwd_m16_kernel.h): every prefill launch at head dims >= FFPA_M16_MIN_D.
 template <typename T, int D, int MK, bool DROP = false>
 static int launch_m16(const FwdArgs& a, hipStream_t stream) {
-  constexpr int BC = D > 512 ? 32 : ((D <= FFPA_BC128_MAX_D && MK != 1 && MK != 3) ? 128 : 64);
+  constexpr int BC = m16_block_keys(D, MK == 1 || MK == 3);
   constexpr int LDS_BASE = 2 * BC * D * 2 + (D > 512 ? 4 * 4096 : 0);
   const int LDS = LDS_BASE + (a.bias_lds > 0 ? a.bias_lds : -a.bias_lds);  // + the key-bias row cache or the bias-tile staging areas, sized by the C-ABI layer (<= 160 KiB in total)
   auto kern = ffpa_fwd_m16_kernel<T, D, MK, DROP>;
@@ -169,7 +169,8 @@ void FFPA_CAT(tile_config_d, FFPA_INST_D)(int variant, int* br, int* bc, int* ld
   // variant 0: prefill tiles, 1: short-query tiles, 2: prefill tiles of the additive-bias builds (64 keys at every head dim <= 512:
   // the 16x16x32 build with any additive bias, the 32x32x16 build with LDS-staged bias tiles)
   const int ND = variant == 1 ? ((D % 128 == 0) ? 4 : 2) : ((D <= 512) ? 1 : 2);
-  const int BC = (ND == 1) ? ((D <= FFPA_BC128_MAX_D && variant != 2) ? 128 : 64) : 32;
+  int BC = (ND == 1) ? ((D <= FFPA_BC128_MAX_D && variant != 2) ? 128 : 64) : 32;
+  if (variant != 1 && D >= FFPA_M16_MIN_D) BC = m16_block_keys(D, variant == 2);  // (the 16x16x32 kernel's own rule)
   *br = 32 * (4 / ND);
   *bc = BC;
   *lds = 2 * BC * D * 2 + (ND > 1 ? 4 * 4096 : 0);

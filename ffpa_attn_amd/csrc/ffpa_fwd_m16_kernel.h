@@ -41,8 +41,16 @@
 // + 0.5 ... 2.5 % at D = 576 ... 960, + 5 ... 6 % at D = 1024, even at D = 192 / 256, - 11 % at D = 128 -> 320.  Round 3, once the LDS-DMA
 // destinations had become scalar base + immediate (no scalar register per piece: the small head dims had been spilling exactly those inside
 // their loops): D = 256 1271 vs 1159 TFLOPS (+ 9.6 %), D = 192 1180 vs 1082 (+ 9 %), causal D = 256 + 8 %, N = 2048 + 6.6 %, dropout D = 256 + 22 %,
-// key bias + 1.5 %, dense bias - 4 %; D = 128 still - 14 % (128-key tiles: 64 score registers per lane) -> 192 (profiles/r03_m16_small_d.txt)
-#define FFPA_M16_MIN_D 192
+// key bias + 1.5 %, dense bias - 4 %; D = 128 - 14 % with 128-key tiles (64 score registers per lane) but, with 64-key tiles
+// (FFPA_M16_BC128_MIN_D below), 1237 vs 1159 (+ 6.7 %), causal + 7.7 %, key bias + 46 %, dropout + 31 %, dense bias - 6 %, boolean mask at
+// Nkv 2048 - 11 %; D = 64 - 5 % -> 128 (profiles/r03_m16_small_d.txt): the 32x32x16 prefill kernel is left with D = 64
+#define FFPA_M16_MIN_D 128
+#endif
+#ifndef FFPA_M16_BC128_MIN_D
+// 128-key tiles from this head dim up to FFPA_BC128_MAX_D (= 320: the LDS limit), 64-key tiles below: at D <= 192 the 128-key tile's 64 score
+// registers per lane cost more than its fewer barriers return (D = 192: 1238 vs 1162 TFLOPS with 64 keys, D = 128: 1156 vs 923; D = 256: 1164 vs
+// 1264, D = 320: 1250 vs 1307 — profiles/r03_m16_small_d.txt)
+#define FFPA_M16_BC128_MIN_D 256
 #endif
 #ifndef FFPA_M16_PF1
 #define FFPA_M16_PF1 6  // K fragments requested ahead of their (two) MFMAs
@@ -82,6 +90,12 @@
 #endif
 
 namespace ffpa {
+
+// Keys per KV tile of ffpa_fwd_m16_kernel<., D, MK>: 32 for the split-D head dims, 64 for the additive-bias builds (their LDS also holds the
+// bias) and for head dims outside [FFPA_M16_BC128_MIN_D, FFPA_BC128_MAX_D], 128 inside.  The launch plan (ffpa_capi.hip) uses the same rule.
+constexpr int m16_block_keys(int D, bool bias_build) {
+  return D > 512 ? 32 : ((!bias_build && D >= FFPA_M16_BC128_MIN_D && D <= FFPA_BC128_MAX_D) ? 128 : 64);
+}
 
 // The MFMAs are inline asm: the S^T accumulators must be VGPRs and the O^T tiles exactly the 256 AGPRs, in place (left to hipcc,
 // parts of O^T end up in VGPRs and the Q fragments in scratch); first / acc: S^T (VGPR form), acc_a: O^T (AGPR form).  The
@@ -150,7 +164,7 @@ __device__ __forceinline__ int m16_v_swizzle(int key) {
 // are built without the define, get another file name and say so in ffpa_attn_version().
 #ifdef FFPA_PRODUCT_BUILD
 #if FFPA_ABL != 0 || defined(FFPA_M16_TIMING) || FFPA_PERSISTENT != 0 || FFPA_M16_ROWDMA != 1 || FFPA_M16_PF1 != 6 || FFPA_M16_PF2 != 4 || \
-    FFPA_M16_K_PRE != 8 || FFPA_M16_K_PRE_ND2 != 64 || FFPA_M16_ROW_TABLES != 1 || FFPA_DMA_M0_CLOBBER != 1 || FFPA_M16_SWAP_REDUCE != 1 || FFPA_M16_MIN_D != 192
+    FFPA_M16_K_PRE != 8 || FFPA_M16_K_PRE_ND2 != 64 || FFPA_M16_ROW_TABLES != 1 || FFPA_DMA_M0_CLOBBER != 1 || FFPA_M16_SWAP_REDUCE != 1 || FFPA_M16_MIN_D != 128 || FFPA_M16_BC128_MIN_D != 256
 #error "FFPA_PRODUCT_BUILD: a developer switch is not at its shipped default"
 #endif
 #endif
@@ -175,7 +189,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   // 32 qb .. + 32 and columns dh * D/2 .. of both contractions; the two partial S^T tiles of a row block are summed through LDS.
   constexpr int ND = (D <= 512) ? 1 : 2;
   constexpr int DW = D / ND;    // columns owned by one wave
-  constexpr int BC = ND == 2 ? 32 : ((D <= FFPA_BC128_MAX_D && !kBias) ? 128 : 64), BR = 128 / ND;  // (additive-bias builds: 64 keys, the LDS holds the bias too)
+  constexpr int BC = m16_block_keys(D, kBias), BR = 128 / ND;
   constexpr int KS = DW / 32;   // QK contraction steps per wave
   constexpr int NKB = BC / 16;  // 16-key S^T blocks per tile
   constexpr int NKS = BC / 32;  // PV contraction steps per tile

@@ -124,7 +124,9 @@ def test_tile_configs():
   for d in range(64, 1025, 64):
     c = hip.tile_config(d)
     if d <= 512:
-      bc = 128 if d <= 320 else 64  # 128-key tiles while K+V of a tile stay within 160 KiB
+      # 128-key tiles at D = 64 (32x32x16 kernel) and at D = 256 / 320 (16x16x32 kernel: worth their 64 score registers per lane only there;
+      # above 320 K + V of a 128-key tile would not fit the 160 KiB of LDS), 64-key tiles elsewhere
+      bc = 128 if d in (64, 256, 320) else 64
       assert (c["block_rows"], c["block_keys"]) == (128, bc) and c["lds_bytes"] == 2 * bc * d * 2
     else:
       assert (c["block_rows"], c["block_keys"]) == (64, 32) and c["lds_bytes"] == 2 * 32 * d * 2 + 16384

@@ -43,18 +43,18 @@ def test_headline_kernel_has_no_spill_code(capsys, monkeypatch):
   assert len(headline) == 1, lines
   assert "vgpr 256 agpr 256" in headline[0] and "scratch    0 B" in headline[0] and "mfma 256" in headline[0], headline
   assert "first..last MFMA: scratch ops 0, lane spills 0" in headline[0], headline
-  # head dims >= 192 have ONE prefill family: no 32x32x16 prefill instantiation (ND = 1 at D <= 512) is left in this TU
+  # head dims >= 128 have ONE prefill family: no 32x32x16 prefill instantiation (ND = 1 at D <= 512) is left in this TU
   assert not [l for l in lines if " m16 " not in l and "  512 1 " in l], lines
 
 
 @pytest.mark.skipif(not TEMPS, reason="no --save-temps assembly in csrc/build")
 def test_prefill_builds_have_no_scratch_inside_their_mfma_loops(capsys, monkeypatch):
-  """Every 16x16x32 prefill build (D = 192 ... 1024; no mask / boolean mask / additive bias, with and without dropout): a scratch
+  """Every 16x16x32 prefill build (D = 128 ... 1024; no mask / boolean mask / additive bias, with and without dropout): a scratch
   reload inside an MFMA loop would drain the LDS-DMA queue (vmcnt) — none anywhere; the builds without dropout keep their SGPR lane
   spills out of the MFMA loops (a handful at D = 512 in the additive-bias build, whose scalar row tables do not fit)."""
   import re
-  lines = [l for l in _stats(monkeypatch, capsys, 192, 256, 320, 384, 448, 512, 640, 1024) if " m16 " in l]
-  assert len(lines) == 8 * 6 * 2, len(lines)  # {MK0, MK2, MK3, MK1, MK0+DROP, MK1+DROP} x {bf16, fp16} per head dim
+  lines = [l for l in _stats(monkeypatch, capsys, 128, 192, 256, 320, 384, 448, 512, 640, 1024) if " m16 " in l]
+  assert len(lines) == 9 * 6 * 2, len(lines)  # {MK0, MK2, MK3, MK1, MK0+DROP, MK1+DROP} x {bf16, fp16} per head dim
   for l in lines:
     m = re.search(r"inside MFMA loops: scratch (\d+), lane spills (\d+)", l)
     hot_scratch, hot_lane = int(m.group(1)), int(m.group(2))
@@ -66,8 +66,8 @@ def test_prefill_builds_have_no_scratch_inside_their_mfma_loops(capsys, monkeypa
       assert hot_lane <= (8 if bias_build else 0), l
       if not bias_build:  # (the bias builds keep a few bytes of scratch for their prologue and their rare ragged-tail / diagonal branch)
         assert "scratch    0 B" in l and "first..last MFMA: scratch ops 0" in l, l
-  # the 32x32x16 prefill kernels of the small head dims (what D = 64 / 128 launch): no spill code inside their MFMA loops either
-  small = [l for l in _stats(monkeypatch, capsys, 128) if "bf16  128 1 b0 b0 b0" in l]
+  # the 32x32x16 prefill kernels that are left (D = 64): no spill code inside their MFMA loops either
+  small = [l for l in _stats(monkeypatch, capsys, 64) if "bf16  64 1 b0 b0 b0" in l]
   assert len(small) == 3, small  # mask kinds 0 / 2 / 1
   for l in small:
     assert "inside MFMA loops: scratch 0, lane spills 0" in l, l

@@ -1,9 +1,9 @@
 """The prefill kernel on the 16x16x32 MFMA shape (csrc/ffpa_fwd_m16_kernel.h; `pytest -m gpu`).
 
-EVERY prefill launch at head dims >= 192 runs this kernel (unmasked, boolean masks, additive biases, dropout, any softmax scale).
+EVERY prefill launch at head dims >= 128 runs this kernel (unmasked, boolean masks, additive biases, dropout, any softmax scale).
 Pinned here: the oracle (the reference's recurrence restated on the CPU), the register-staged 32x32x16 twin of the test library
 (another mapping of the same tiles onto the matrix core: same recurrence, another summation order) within output rounding where
-that twin exists (bf16; head dims 320 / 512 / 640 / 1024), exact NaN / -inf patterns, and the properties that must hold to the bit
+that twin exists (bf16; head dims 128 / 320 / 512 / 640 / 1024), exact NaN / -inf patterns, and the properties that must hold to the bit
 inside one build (determinism, head independence, KV splits merge, strided views, every bias source giving the same bits).
 """
 
@@ -17,10 +17,10 @@ from test_fwd_gpu import _check_vs_oracle, _close, _f32, _rand, hip  # noqa: F40
 pytestmark = pytest.mark.gpu
 
 D = 512  # the headline head dim; DIMS: head dims this build is launched for (128-key tiles at 320, 64-key tiles to 512, split-D tiles above)
-DIMS = [192, 256, 320, 384, 448, 512, 576, 640, 960, 1024]
+DIMS = [128, 192, 256, 320, 384, 448, 512, 576, 640, 960, 1024]
 
 
-TWIN_DIMS = (320, 512, 640, 1024)  # head dims whose register-staged 32x32x16 twin is built into libffpa_attn_hip_test.so (bf16 only)
+TWIN_DIMS = (128, 320, 512, 640, 1024)  # head dims whose register-staged 32x32x16 twin is built into libffpa_attn_hip_test.so (bf16 only)
 
 
 def _has_twin(q):
@@ -70,7 +70,7 @@ def test_matches_the_oracle_and_the_twin_build(hip, dtype, D, case):
 
 
 def test_the_launch_plan_names_this_build(hip):
-  """The C-ABI says which kernel a launch runs (ffpa_attn_fwd_kernel): every prefill launch at D >= 192 names ffpa_fwd_m16_kernel with
+  """The C-ABI says which kernel a launch runs (ffpa_attn_fwd_kernel): every prefill launch at D >= 128 names ffpa_fwd_m16_kernel with
   the mask kind of its build; the two mappings sum in different orders, so on random data the twin cannot agree in every bit."""
   q, k, v = _rand((1, 4, 512, D), seed=1), _rand((1, 4, 2048, D), seed=2), _rand((1, 4, 2048, D), seed=3)
   plan = {}
@@ -94,8 +94,8 @@ def test_the_launch_plan_names_this_build(hip):
   assert plan["kernel"] == "ffpa_fwd_m16_kernel<bf16, 512, MK=1, DROP=1>", plan
   hip.forward(q[..., :256].contiguous(), k[..., :256].contiguous(), v[..., :256].contiguous(), None, False, 256 ** -0.5, plan_out=plan, num_splits=1)
   assert plan["kernel"] == "ffpa_fwd_m16_kernel<bf16, 256, MK=0, DROP=0>", plan
-  hip.forward(q[..., :128].contiguous(), k[..., :128].contiguous(), v[..., :128].contiguous(), None, False, 128 ** -0.5, plan_out=plan, num_splits=1)
-  assert plan["kernel"].startswith("ffpa_fwd_split_d_kernel<bf16, 128, ND=1"), plan  # (D = 64 / 128: the 32x32x16 kernel)
+  hip.forward(q[..., :64].contiguous(), k[..., :64].contiguous(), v[..., :64].contiguous(), None, False, 64 ** -0.5, plan_out=plan, num_splits=1)
+  assert plan["kernel"].startswith("ffpa_fwd_split_d_kernel<bf16, 64, ND=1"), plan  # (D = 64: the 32x32x16 kernel)
   hip.forward(q[:, :, :1], k, v, None, False, D ** -0.5, plan_out=plan)
   assert plan["kernel"].startswith("ffpa_fwd_split_d_kernel<bf16, 512, ND=4") and plan["kernel"].endswith("+ ffpa_fwd_merge_kernel"), plan
   hip.forward(q[:, :, :1], k, v, None, False, D ** -0.5, plan_out=plan, merge_in_launch=True)
@@ -338,7 +338,7 @@ def _bias_cases(B, Hq, Nq, Nkv, dtype, gen):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("D", [192, 256, 320, 384, 512, 640, 1024])
+@pytest.mark.parametrize("D", [128, 192, 256, 320, 384, 512, 640, 1024])
 def test_additive_biases_from_every_source(hip, dtype, D):
   """Additive biases enter this kernel through the S^T accumulators (bias / scale) from three sources — the fp32 row cache in LDS, the
   LDS-DMA staged tiles, element loads; FFPA_FLAG_NO_BIAS_LDS forces the last one.  All three must give the SAME bits (the same

@@ -49,6 +49,8 @@ CASES = {
   "n1024": _c(1, 32, 1024, 512), "n2048": _c(1, 32, 2048, 512), "causal4k": _c(1, 32, 4096, 512, causal=True),
   "d320": _c(1, 32, 8192, 320), "d384": _c(1, 32, 8192, 384), "d448": _c(1, 32, 8192, 448), "d640": _c(1, 32, 8192, 640), "d768": _c(1, 32, 8192, 768),
   "d1024_causal": _c(1, 32, 8192, 1024, causal=True),
+  "d64": _c(1, 32, 8192, 64), "d64_causal": _c(1, 32, 8192, 64, causal=True), "d64_n2048": _c(4, 32, 2048, 64), "key_bias_d128": _c(1, 32, 8192, 128, bias="key"),
+  "dense_bias_d128": _c(1, 32, 8192, 128, bias="dense"), "dropout_d128": _c(1, 32, 8192, 128, dropout=0.1), "mask_d128": _c(2, 32, 8192, 128, hkv=8, nkv=2048, bias="tril_bool"),
   "d128": _c(1, 32, 8192, 128), "d192": _c(1, 32, 8192, 192), "d256": _c(1, 32, 8192, 256), "d128_causal": _c(1, 32, 8192, 128, causal=True),
   "d256_causal": _c(1, 32, 8192, 256, causal=True), "d256_n2048": _c(4, 32, 2048, 256), "key_bias_d256": _c(1, 32, 8192, 256, bias="key"),
   "dense_bias_d256": _c(1, 32, 8192, 256, bias="dense"), "dropout_d256": _c(1, 32, 8192, 256, dropout=0.1), "d128_n2048": _c(4, 32, 2048, 128),
