@@ -202,3 +202,17 @@ def test_no_gfx950_device_is_a_status_not_a_launch(lib):
   assert lib.ffpa_attn_fwd(ctypes.byref(q), None) == 9
   q = _params(bias=ctypes.addressof(buf), bias_dtype=5)
   assert lib.ffpa_attn_fwd(ctypes.byref(q), None) == 2
+
+
+def test_integration_md_binding_mirrors_the_header():
+  """INTEGRATION.md shows the ctypes stub a maintainer of the reference would add: its struct must be the header's (same fields, same order, same size
+  as the ctypes mirror the tests validate against gcc above), and it must pass the ABI version the header defines."""
+  text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+  m = re.search(r"class _Params\(ctypes\.Structure\):.*?\n(\s+_fields_ = \[.*?\])\s*(#[^\n]*)?\n\n", text, flags=re.S)
+  assert m, "the _Params struct of the binding was not found in INTEGRATION.md"
+  ns = {"ctypes": ctypes}
+  exec("class _Params(ctypes.Structure):\n" + m.group(1), ns)
+  doc = ns["_Params"]
+  assert [f[0] for f in doc._fields_] == [f[0] for f in hip.FfpaFwdParams._fields_]
+  assert ctypes.sizeof(doc) == ctypes.sizeof(hip.FfpaFwdParams)
+  assert f"abi_version={hip.ABI_VERSION}," in text
