@@ -549,97 +549,6 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 
     // ================= S^T = K.Q^T =================
     f32x4 sacc[NKB][2];
-    if constexpr (kBias) {
-      // the accumulators start from bias / softmax_scale (zeros where there is no bias): see the header
-      // (mask_free, wave-uniform: this step lies in the neutral interior of the caller's mask (kv_bounds): nothing to read, nothing to add)
-      const bool mask_free = MK == 1 && k0 >= free_lo && k0 + BC <= free_hi;
-      if (bias_owner && !mask_free) {
-        if ((MK == 3 || a.bias_lds > 0) && a.bias_cache_raw) {  // key bias, 16-bit row cache: 4 keys = one ds_read_b64, converted here
-          typedef __attribute__((ext_vector_type(4))) __bf16 b4;
-          typedef __attribute__((ext_vector_type(4))) _Float16 h4;
-          FFPA_LDS const char* bp = Bl + 8 * c + 2 * k0;
-#pragma unroll
-          for (int kb = 0; kb < NKB; ++kb) {
-            f32x4 w;
-            if (a.bias_dtype == 2) {
-              const b4 t = *(FFPA_LDS const b4*)(bp + 32 * kb);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) w[r] = (float)t[r] * a.inv_scale;
-            } else {
-              const h4 t = *(FFPA_LDS const h4*)(bp + 32 * kb);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) w[r] = (float)t[r] * a.inv_scale;
-            }
-            sacc[kb][0] = w;
-            sacc[kb][1] = w;
-          }
-        } else if (MK == 3 || a.bias_lds > 0) {  // key bias: fp32 / scale from the LDS row cache, the same 4 keys for both of the lane's rows
-          FFPA_LDS const char* bp = bl_lane + 4 * k0;
-          FFPA_LDS const char* bp2 = bp;
-          asm volatile("" : "+v"(bp2));  // (two reads, no register copies: the LDS has the bandwidth, the VALU slots are what the softmax needs)
-#pragma unroll
-          for (int kb = 0; kb < NKB; ++kb) {
-            sacc[kb][0] = *(FFPA_LDS const f32x4*)(bp + 64 * kb);
-            sacc[kb][1] = *(FFPA_LDS const f32x4*)(bp2 + 64 * kb);
-          }
-        } else if (MK == 1 && a.bias_tile) {  // the tile this wave staged during the previous step's PV loop (drained at barrier B)
-          typedef __attribute__((ext_vector_type(4))) __bf16 b4;
-          typedef __attribute__((ext_vector_type(4))) _Float16 h4;
-          const int half_rows = 16 * b_rowb;
-          if (a.bias_dtype == 3) {
-#pragma unroll
-            for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-              for (int rh = 0; rh < 2; ++rh) sacc[kb][rh] = *(FFPA_LDS const f32x4*)(baddr[kb] + rh * half_rows) * a.inv_scale;
-          } else if (a.bias_dtype == 2) {
-#pragma unroll
-            for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-              for (int rh = 0; rh < 2; ++rh) {
-                const b4 w = *(FFPA_LDS const b4*)(baddr[kb] + rh * half_rows);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sacc[kb][rh][r] = (float)w[r] * a.inv_scale;
-              }
-          } else {
-#pragma unroll
-            for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-              for (int rh = 0; rh < 2; ++rh) {
-                const h4 w = *(FFPA_LDS const h4*)(baddr[kb] + rh * half_rows);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sacc[kb][rh][r] = (float)w[r] * a.inv_scale;
-              }
-          }
-        } else if constexpr (MK == 1) {  // element-wise from global memory: any strides, any dtype (boolean: 0 / -inf)
-#pragma unroll
-          for (int rh = 0; rh < 2; ++rh) {
-            const int64_t brow = b * a.sbias[0] + hq * a.sbias[1] + (int64_t)qrow_c[rh] * a.sbias[2];
-#pragma unroll
-            for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                int key = k0 + kb * 16 + 4 * c + r;
-                key = key < a.Nkv ? key : a.Nkv - 1;
-                const int64_t e = brow + key * a.sbias[3];
-                float w;
-                if (a.bias_dtype == 4) w = ((const uint8_t*)a.bias)[e] != 0 ? 0.f : -INFINITY;
-                else w = (a.bias_dtype == 3 ? ((const float*)a.bias)[e] : a.bias_dtype == 2 ? (float)((const __bf16*)a.bias)[e] : (float)((const _Float16*)a.bias)[e]) * a.inv_scale;
-                sacc[kb][rh][r] = w;
-              }
-          }
-        }
-      } else {
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-          sacc[kb][0] = (f32x4)(0.f);
-          sacc[kb][1] = (f32x4)(0.f);
-        }
-      }
-      // VALU write -> MFMA SrcC read wait states (the MFMAs are inline asm); every accumulator is named so that all writes precede the pad
-      static_assert(NKB == 2 || NKB == 4, "additive-bias build: 32- or 64-key tiles");
-      if constexpr (NKB == 4) asm volatile("" : "+v"(sacc[2][0]), "+v"(sacc[2][1]), "+v"(sacc[3][0]), "+v"(sacc[3][1]));
-      asm volatile("s_nop 1" : "+v"(sacc[0][0]), "+v"(sacc[0][1]), "+v"(sacc[1][0]), "+v"(sacc[1][1]));
-    }
     {
       v8 kf[N1];
       auto k_frag = [&](int n) -> v8 {
@@ -649,6 +558,100 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int n = 0; n < PF1 && n < N1; ++n) kf[n] = k_frag(n);
+      __builtin_amdgcn_sched_barrier(0);  // (the first K fragments are on their way while the bias tile below is read and converted)
+      if constexpr (kBias) {
+        // the accumulators start from bias / softmax_scale (zeros where there is no bias): see the header
+        // (mask_free, wave-uniform: this step lies in the neutral interior of the caller's mask (kv_bounds): nothing to read, nothing to add)
+        const bool mask_free = MK == 1 && k0 >= free_lo && k0 + BC <= free_hi;
+        if (bias_owner && !mask_free) {
+          if ((MK == 3 || a.bias_lds > 0) && a.bias_cache_raw) {  // key bias, 16-bit row cache: 4 keys = one ds_read_b64, converted here
+            typedef __attribute__((ext_vector_type(4))) __bf16 b4;
+            typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+            FFPA_LDS const char* bp = Bl + 8 * c + 2 * k0;
+  #pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+              f32x4 w;
+              if (a.bias_dtype == 2) {
+                const b4 t = *(FFPA_LDS const b4*)(bp + 32 * kb);
+  #pragma unroll
+                for (int r = 0; r < 4; ++r) w[r] = (float)t[r] * a.inv_scale;
+              } else {
+                const h4 t = *(FFPA_LDS const h4*)(bp + 32 * kb);
+  #pragma unroll
+                for (int r = 0; r < 4; ++r) w[r] = (float)t[r] * a.inv_scale;
+              }
+              sacc[kb][0] = w;
+              sacc[kb][1] = w;
+            }
+          } else if (MK == 3 || a.bias_lds > 0) {  // key bias: fp32 / scale from the LDS row cache, the same 4 keys for both of the lane's rows
+            FFPA_LDS const char* bp = bl_lane + 4 * k0;
+            FFPA_LDS const char* bp2 = bp;
+            asm volatile("" : "+v"(bp2));  // (two reads, no register copies: the LDS has the bandwidth, the VALU slots are what the softmax needs)
+  #pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+              sacc[kb][0] = *(FFPA_LDS const f32x4*)(bp + 64 * kb);
+              sacc[kb][1] = *(FFPA_LDS const f32x4*)(bp2 + 64 * kb);
+            }
+          } else if (MK == 1 && a.bias_tile) {  // the tile this wave staged during the previous step's PV loop (drained at barrier B)
+            typedef __attribute__((ext_vector_type(4))) __bf16 b4;
+            typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+            const int half_rows = 16 * b_rowb;
+            if (a.bias_dtype == 3) {
+  #pragma unroll
+              for (int kb = 0; kb < NKB; ++kb)
+  #pragma unroll
+                for (int rh = 0; rh < 2; ++rh) sacc[kb][rh] = *(FFPA_LDS const f32x4*)(baddr[kb] + rh * half_rows) * a.inv_scale;
+            } else if (a.bias_dtype == 2) {
+  #pragma unroll
+              for (int kb = 0; kb < NKB; ++kb)
+  #pragma unroll
+                for (int rh = 0; rh < 2; ++rh) {
+                  const b4 w = *(FFPA_LDS const b4*)(baddr[kb] + rh * half_rows);
+  #pragma unroll
+                  for (int r = 0; r < 4; ++r) sacc[kb][rh][r] = (float)w[r] * a.inv_scale;
+                }
+            } else {
+  #pragma unroll
+              for (int kb = 0; kb < NKB; ++kb)
+  #pragma unroll
+                for (int rh = 0; rh < 2; ++rh) {
+                  const h4 w = *(FFPA_LDS const h4*)(baddr[kb] + rh * half_rows);
+  #pragma unroll
+                  for (int r = 0; r < 4; ++r) sacc[kb][rh][r] = (float)w[r] * a.inv_scale;
+                }
+            }
+          } else if constexpr (MK == 1) {  // element-wise from global memory: any strides, any dtype (boolean: 0 / -inf)
+  #pragma unroll
+            for (int rh = 0; rh < 2; ++rh) {
+              const int64_t brow = b * a.sbias[0] + hq * a.sbias[1] + (int64_t)qrow_c[rh] * a.sbias[2];
+  #pragma unroll
+              for (int kb = 0; kb < NKB; ++kb)
+  #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  int key = k0 + kb * 16 + 4 * c + r;
+                  key = key < a.Nkv ? key : a.Nkv - 1;
+                  const int64_t e = brow + key * a.sbias[3];
+                  float w;
+                  if (a.bias_dtype == 4) w = ((const uint8_t*)a.bias)[e] != 0 ? 0.f : -INFINITY;
+                  else w = (a.bias_dtype == 3 ? ((const float*)a.bias)[e] : a.bias_dtype == 2 ? (float)((const __bf16*)a.bias)[e] : (float)((const _Float16*)a.bias)[e]) * a.inv_scale;
+                  sacc[kb][rh][r] = w;
+                }
+            }
+          }
+        } else {
+          // (asm: left to the compiler, these 8 NKB moves are hoisted in front of the branch and paid by the biased steps as well)
+  #pragma unroll
+          for (int kb = 0; kb < NKB; ++kb)
+  #pragma unroll
+            for (int rh = 0; rh < 2; ++rh)
+              asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0"
+                           : "=v"(sacc[kb][rh][0]), "=v"(sacc[kb][rh][1]), "=v"(sacc[kb][rh][2]), "=v"(sacc[kb][rh][3]));
+        }
+        // VALU write -> MFMA SrcC read wait states (the MFMAs are inline asm); every accumulator is named so that all writes precede the pad
+        static_assert(NKB == 2 || NKB == 4, "additive-bias build: 32- or 64-key tiles");
+        if constexpr (NKB == 4) asm volatile("" : "+v"(sacc[2][0]), "+v"(sacc[2][1]), "+v"(sacc[3][0]), "+v"(sacc[3][1]));
+        asm volatile("s_nop 1" : "+v"(sacc[0][0]), "+v"(sacc[0][1]), "+v"(sacc[1][0]), "+v"(sacc[1][1]));
+      }
       static_for<N1>([&](auto ic) {
         constexpr int n = decltype(ic)::value;
         __builtin_amdgcn_sched_barrier(0);
