@@ -210,6 +210,20 @@ int check_basic(const ffpa_fwd_params* p, const DimEntry** de_out) {
   return FFPA_OK;
 }
 
+// Dropout keeps the element of Philox word w when u(w) = ((float)w + 1.0f) * 2^-32 > p (prefill.cuh:437-440).  u is monotone in w
+// (int -> float conversion and the add both round monotonically), so the decision is w >= T for the smallest kept word T — found here by
+// bisection with the very float expression, once per call; the kernels compare integers.  p < 1 (checked) keeps w = 2^32 - 1 (u = 1).
+uint32_t dropout_keep_threshold(float p) {
+  if (!(p > 0.f)) return 0u;
+  auto kept = [p](uint32_t w) { return ((float)w + 1.0f) * 2.3283064365386963e-10f > p; };
+  uint32_t lo = 0u, hi = 0xFFFFFFFFu;  // kept(hi) holds; the answer is in [lo, hi]
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2u;
+    if (kept(mid)) hi = mid; else lo = mid + 1u;
+  }
+  return lo;
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 int check_strides(const char* name, const int64_t s[3]) {
@@ -369,6 +383,7 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   }
   a.dropout_p = p->dropout_p;
   a.keep_scale = p->dropout_p > 0.f ? 1.f / (1.f - p->dropout_p) : 1.f;
+  a.keep_threshold = dropout_keep_threshold(p->dropout_p);
   a.philox_seed = p->philox_seed;
   a.philox_offset = p->philox_offset;
   if (pl.splits > 1) {

@@ -194,6 +194,7 @@ struct FwdArgs {
   // dropout (prefill.cuh:398-546): keep iff u > p, u from Philox4x32-10 at the logical element offset
   float dropout_p;          // 0 = off
   float keep_scale;         // 1 / (1 - p)
+  uint32_t keep_threshold;  // smallest Philox word whose element is kept: word >= keep_threshold <=> ((float)word + 1.0f) * 2^-32 > dropout_p
   unsigned long long philox_seed;
   unsigned long long philox_offset;
 };
@@ -450,8 +451,11 @@ __device__ __forceinline__ void philox4x32_10(unsigned long long seed, unsigned 
   out[3] = c3;
 }
 
+// Element kept <=> u = ((float)word + 1.0f) * 2^-32 > p (prefill.cuh:437-440).  u is a monotone function of the 32-bit word, so the host
+// resolves the float comparison ONCE per call into the smallest kept word (FwdArgs::keep_threshold, ffpa_capi.hip: dropout_keep_threshold) and
+// the kernels compare integers: the same decision for every word, without a convert and a multiply-add per score.
 // keep-scale (1/(1-p) or 0) for the 4 consecutive elements e0 .. e0+3 of one score row
-__device__ __forceinline__ void dropout_keep4(unsigned long long seed, unsigned long long e0, float p, float keep_scale,
+__device__ __forceinline__ void dropout_keep4(unsigned long long seed, unsigned long long e0, uint32_t threshold, float keep_scale,
                                               float (&keep)[4]) {
   uint32_t blk[4];
   const unsigned a = (unsigned)(e0 & 3ull);
@@ -460,10 +464,7 @@ __device__ __forceinline__ void dropout_keep4(unsigned long long seed, unsigned 
     // every lane's group is one whole Philox block (philox_offset and Nkv multiples of 4: the usual case): no second block,
     // no word selection
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const float u = ((float)blk[t] + 1.0f) * 2.3283064365386963e-10f;  // (0, 1]  (prefill.cuh:437-440)
-      keep[t] = (u > p) ? keep_scale : 0.f;
-    }
+    for (int t = 0; t < 4; ++t) keep[t] = (blk[t] >= threshold) ? keep_scale : 0.f;
     return;
   }
   uint32_t w[8] = {blk[0], blk[1], blk[2], blk[3], 0, 0, 0, 0};
@@ -476,40 +477,76 @@ __device__ __forceinline__ void dropout_keep4(unsigned long long seed, unsigned 
   for (int t = 0; t < 4; ++t) {
     // word a + t of the 8-word window, selected without run-time indexing (that would go to scratch)
     const uint32_t word = a == 0 ? w[t] : a == 1 ? w[t + 1] : a == 2 ? w[t + 2] : w[t + 3];
-    const float u = ((float)word + 1.0f) * 2.3283064365386963e-10f;  // (0, 1]  (prefill.cuh:437-440)
-    keep[t] = (u > p) ? keep_scale : 0.f;
+    keep[t] = (word >= threshold) ? keep_scale : 0.f;
   }
 }
 
 // The same decision as 4 bits (bit t <-> element e0 + t is kept): the 16x16x32 build draws the bits of a whole KV step before its
-// exponentials and applies them when it packs P (the Philox temporaries are dead by then).  u = (word + 1) * 2^-32 as one FMA: the
-// scaling by a power of two is exact, so fl(word * 2^-32 + 2^-32) is the reference's ((float)word + 1.0f) * 2^-32 bit for bit.
-__device__ __forceinline__ uint32_t dropout_keep_bits4(unsigned long long seed, unsigned long long e0, float p) {
+// exponentials and applies them when it packs P (the Philox temporaries are dead by then).  This form takes any element offset (a group that
+// straddles two Philox blocks draws both): the rare case — philox_offset or Nkv not a multiple of 4.
+__device__ __forceinline__ uint32_t dropout_keep_bits4(unsigned long long seed, unsigned long long e0, uint32_t threshold) {
   uint32_t blk[4];
   const unsigned a = (unsigned)(e0 & 3ull);
   philox4x32_10(seed, e0 >> 2, blk);
-  uint32_t bits = 0u;
-  if (__builtin_amdgcn_ballot_w64(a != 0) == 0ull) {  // every lane's group is one whole Philox block (the usual case)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const float u = __builtin_fmaf((float)blk[t], 2.3283064365386963e-10f, 2.3283064365386963e-10f);  // (0, 1]  (prefill.cuh:437-440)
-      bits |= (u > p ? 1u : 0u) << t;
-    }
-    return bits;
-  }
   uint32_t w[8] = {blk[0], blk[1], blk[2], blk[3], 0, 0, 0, 0};
   if (a != 0) {  // the group straddles two Philox blocks
     philox4x32_10(seed, (e0 >> 2) + 1, blk);
 #pragma unroll
     for (int i = 0; i < 4; ++i) w[4 + i] = blk[i];
   }
+  uint32_t bits = 0u;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const uint32_t word = a == 0 ? w[t] : a == 1 ? w[t + 1] : a == 2 ? w[t + 2] : w[t + 3];
-    const float u = __builtin_fmaf((float)word, 2.3283064365386963e-10f, 2.3283064365386963e-10f);
-    bits |= (u > p ? 1u : 0u) << t;
+    bits |= (word >= threshold ? 1u : 0u) << t;
   }
   return bits;
+}
+
+// ... and the usual case, groups that are whole Philox blocks (element offset a multiple of 4), branch-free: N independent blocks advanced in
+// lockstep, round by round (written out in the source because hipcc, at the register limit, keeps the source order).  Measured on the dropout
+// workloads (profiles/r03_philox.txt): the branch-free form is + 3 ... 5 % over a wave-uniform branch per group; N = 2 / 4 add nothing — the
+// cost is the VALU instruction count, not the latency of the multiply chain — so the kernels use N = 1.
+template <int N>
+__device__ __forceinline__ void dropout_keep_bits4_aligned_n(unsigned long long seed, const unsigned long long (&quad)[N], uint32_t threshold, uint32_t (&bits)[N]) {
+  uint32_t c0[N], c1[N], c2[N], c3[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    c0[i] = (uint32_t)quad[i];
+    c1[i] = (uint32_t)(quad[i] >> 32);
+    c2[i] = 0u;
+    c3[i] = 0u;
+  }
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int round = 0; round < 10; ++round) {
+    uint32_t hi0[N], lo0[N], hi1[N], lo1[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0[i], p1 = (unsigned long long)0xCD9E8D57u * c2[i];
+      hi0[i] = (uint32_t)(p0 >> 32);
+      lo0[i] = (uint32_t)p0;
+      hi1[i] = (uint32_t)(p1 >> 32);
+      lo1[i] = (uint32_t)p1;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      c0[i] = hi1[i] ^ c1[i] ^ k0;
+      c2[i] = hi0[i] ^ c3[i] ^ k1;
+      c1[i] = lo1[i];
+      c3[i] = lo0[i];
+    }
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const uint32_t w[4] = {c0[i], c1[i], c2[i], c3[i]};
+    uint32_t b = 0u;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b |= (w[t] >= threshold ? 1u : 0u) << t;
+    bits[i] = b;
+  }
 }
 
 // Additive bias for the 16 scores one lane holds of a 32-key block:
@@ -1368,7 +1405,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
         for (int i = 0; i < 4; ++i) {
           __builtin_amdgcn_sched_barrier(0);  // one Philox group at a time: bounded register pressure
           float keep[4];
-          dropout_keep4(a.philox_seed, erow + (unsigned long long)(k0 + kb * 32 + 16 * h + 4 * i), a.dropout_p, a.keep_scale, keep);
+          dropout_keep4(a.philox_seed, erow + (unsigned long long)(k0 + kb * 32 + 16 * h + 4 * i), a.keep_threshold, a.keep_scale, keep);
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const int r = 4 * i + t;

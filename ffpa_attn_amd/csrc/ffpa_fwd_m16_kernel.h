@@ -164,7 +164,8 @@ __device__ __forceinline__ int m16_v_swizzle(int key) {
 // are built without the define, get another file name and say so in ffpa_attn_version().
 #ifdef FFPA_PRODUCT_BUILD
 #if FFPA_ABL != 0 || defined(FFPA_M16_TIMING) || FFPA_PERSISTENT != 0 || FFPA_M16_ROWDMA != 1 || FFPA_M16_PF1 != 6 || FFPA_M16_PF2 != 4 || \
-    FFPA_M16_K_PRE != 8 || FFPA_M16_K_PRE_ND2 != 64 || FFPA_M16_ROW_TABLES != 1 || FFPA_DMA_M0_CLOBBER != 1 || FFPA_M16_SWAP_REDUCE != 1 || FFPA_M16_MIN_D != 128 || FFPA_M16_BC128_MIN_D != 256
+    FFPA_M16_K_PRE != 8 || FFPA_M16_K_PRE_ND2 != 64 || FFPA_M16_ROW_TABLES != 1 || FFPA_DMA_M0_CLOBBER != 1 || FFPA_M16_SWAP_REDUCE != 1 || FFPA_M16_MIN_D != 128 || FFPA_M16_BC128_MIN_D != 256 || \
+    (defined(FFPA_M16_PHILOX_ILP) && FFPA_M16_PHILOX_ILP != 1)
 #error "FFPA_PRODUCT_BUILD: a developer switch is not at its shipped default"
 #endif
 #endif
@@ -824,14 +825,35 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     // counter stream (element offset = ((b Hq + hq) Nq + row) Nkv + key).
     uint32_t keep_bits[2][NKB > 8 ? NKB / 8 : 1] = {};
     if constexpr (DROP) {
+#ifndef FFPA_M16_PHILOX_ILP
+#define FFPA_M16_PHILOX_ILP 1  // Philox groups advanced in lockstep between two scheduling fences (2 / 4 measured: nothing, profiles/r03_philox.txt)
+#endif
+      unsigned long long erow[2];
 #pragma unroll
-      for (int rh = 0; rh < 2; ++rh) {
-        const unsigned long long erow =
-            a.philox_offset + (((unsigned long long)b * a.Hq + hq) * a.Nq + (unsigned long long)qrow_c[rh]) * (unsigned long long)a.Nkv;
+      for (int rh = 0; rh < 2; ++rh)
+        erow[rh] = a.philox_offset + (((unsigned long long)b * a.Hq + hq) * a.Nq + (unsigned long long)qrow_c[rh]) * (unsigned long long)a.Nkv;
+      // every lane's 4-key group a whole Philox block (philox_offset and Nkv multiples of 4: the usual case; the key part 16 kb + 4 c always is)?
+      // Then the groups of the step are branch-free and sit in ONE basic block.
+      if (__builtin_amdgcn_ballot_w64(((erow[0] | erow[1]) & 3ull) != 0) == 0ull) {
+        constexpr int kIlp = FFPA_M16_PHILOX_ILP;
+        static_assert(kIlp >= 1 && (2 * NKB) % kIlp == 0, "Philox groups per batch");
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-          __builtin_amdgcn_sched_barrier(0);  // one Philox group at a time: bounded register pressure
-          keep_bits[rh][kb >> 3] |= dropout_keep_bits4(a.philox_seed, erow + (unsigned long long)(k0 + kb * 16 + 4 * c), a.dropout_p) << (4 * (kb & 7));
+        for (int g0 = 0; g0 < 2 * NKB; g0 += kIlp) {
+          __builtin_amdgcn_sched_barrier(0);
+          unsigned long long quad[kIlp];
+          uint32_t bits[kIlp];
+#pragma unroll
+          for (int i = 0; i < kIlp; ++i) quad[i] = (erow[(g0 + i) & 1] + (unsigned long long)(k0 + ((g0 + i) >> 1) * 16 + 4 * c)) >> 2;
+          dropout_keep_bits4_aligned_n<kIlp>(a.philox_seed, quad, a.keep_threshold, bits);
+#pragma unroll
+          for (int i = 0; i < kIlp; ++i) keep_bits[(g0 + i) & 1][((g0 + i) >> 1) >> 3] |= bits[i] << (4 * (((g0 + i) >> 1) & 7));
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 2 * NKB; ++g) {
+          const int kb = g >> 1, rh = g & 1;
+          __builtin_amdgcn_sched_barrier(0);
+          keep_bits[rh][kb >> 3] |= dropout_keep_bits4(a.philox_seed, erow[rh] + (unsigned long long)(k0 + kb * 16 + 4 * c), a.keep_threshold) << (4 * (kb & 7));
         }
       }
       __builtin_amdgcn_sched_barrier(0);
