@@ -384,6 +384,10 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   a.dropout_p = p->dropout_p;
   a.keep_scale = p->dropout_p > 0.f ? 1.f / (1.f - p->dropout_p) : 1.f;
   a.keep_threshold = dropout_keep_threshold(p->dropout_p);
+  // The split-D tiles (D > 512) give a DMA piece less than a microsecond to land (32-key steps, single K / V buffers): their launches touch the
+  // tile two steps ahead (ffpa_fwd_m16_kernel.h, "L2 prefetch").  Measured, same library with and without (profiles/r03_l2_prefetch.txt):
+  // D = 576 ... 1024: + 3 ... 9 % (D = 768: +- 0), every shape tried (self, cross, GQA, batch 4, causal, key bias); D <= 512: - 1 ... 2 %, off.
+  a.l2_prefetch = (p->flags & FFPA_FLAG_NO_L2_PREFETCH) ? 0 : ((p->flags & FFPA_FLAG_L2_PREFETCH) || (pl.m16 && kernel_head_dim(p->head_dim) > 512)) ? 1 : 0;
   a.philox_seed = p->philox_seed;
   a.philox_offset = p->philox_offset;
   if (pl.splits > 1) {

@@ -194,6 +194,7 @@ struct FwdArgs {
   // dropout (prefill.cuh:398-546): keep iff u > p, u from Philox4x32-10 at the logical element offset
   float dropout_p;          // 0 = off
   float keep_scale;         // 1 / (1 - p)
+  int l2_prefetch;          // 16x16x32 prefill builds: touch the K/V tile two steps ahead (ffpa_fwd_m16_kernel.h; ffpa_capi.hip decides)
   uint32_t keep_threshold;  // smallest Philox word whose element is kept: word >= keep_threshold <=> ((float)word + 1.0f) * 2^-32 > dropout_p
   unsigned long long philox_seed;
   unsigned long long philox_offset;

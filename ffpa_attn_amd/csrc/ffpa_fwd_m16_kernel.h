@@ -67,6 +67,24 @@
 #ifndef FFPA_M16_ROW_TABLES
 #define FFPA_M16_ROW_TABLES 1  // scalar row form: 1 = a table of one scalar register per staged row, 0 = row offsets computed per piece (2 SALU)
 #endif
+#ifndef FFPA_M16_PF_WAVES
+#define FFPA_M16_PF_WAVES 2  // L2 prefetch: waves of a workgroup that touch (2: one K and one V slice per step; 4: two of each)
+#endif
+#ifndef FFPA_M16_PF_WHICH
+#define FFPA_M16_PF_WHICH 3  // L2 prefetch: bit 0 = K, bit 1 = V
+#endif
+#ifndef FFPA_M16_PF_DIST
+#define FFPA_M16_PF_DIST 2  // L2 prefetch: steps ahead of the step being computed (the DMA queue itself covers 1)
+#endif
+#ifndef FFPA_M16_DEPHASE
+#define FFPA_M16_DEPHASE 0  // (experiment) behind the barriers of FFPA_M16_DEPHASE_AT, wave w idles w x this many x 16 cycles: the four waves leave a barrier in
+#endif                      //   the same cycle, their MFMA streams then tick in lockstep and they offer their DMA pieces to the one texture addresser together
+#ifndef FFPA_M16_DEPHASE_AT
+#define FFPA_M16_DEPHASE_AT 7  // bit 0: behind barrier A1, bit 1: A2, bit 2: B
+#endif
+#ifndef FFPA_M16_DEPHASE_ND
+#define FFPA_M16_DEPHASE_ND 2  // which tiles: 2 = the split-D tiles (D > 512) only, 1 = D <= 512 only, 3 = both
+#endif
 #ifndef FFPA_M16_K_PRE_ND2
 #define FFPA_M16_K_PRE_ND2 64  // ditto for the split-D tiles (D > 512; clamped to the tile's pieces: all of K(j+1) goes out between the softmax stages)
 #endif
@@ -164,7 +182,7 @@ __device__ __forceinline__ int m16_v_swizzle(int key) {
 // are built without the define, get another file name and say so in ffpa_attn_version().
 #ifdef FFPA_PRODUCT_BUILD
 #if FFPA_ABL != 0 || defined(FFPA_M16_TIMING) || FFPA_PERSISTENT != 0 || FFPA_M16_ROWDMA != 1 || FFPA_M16_PF1 != 6 || FFPA_M16_PF2 != 4 || \
-    FFPA_M16_K_PRE != 8 || FFPA_M16_K_PRE_ND2 != 64 || FFPA_M16_ROW_TABLES != 1 || FFPA_DMA_M0_CLOBBER != 1 || FFPA_M16_SWAP_REDUCE != 1 || FFPA_M16_MIN_D != 128 || FFPA_M16_BC128_MIN_D != 256 || \
+    FFPA_M16_K_PRE != 8 || FFPA_M16_K_PRE_ND2 != 64 || FFPA_M16_DEPHASE != 0 || FFPA_M16_PF_DIST != 2 || FFPA_M16_PF_WAVES != 2 || FFPA_M16_PF_WHICH != 3 || defined(FFPA_M16_PF_DUMMY) || (defined(FFPA_M16_PF_ALL_D) && FFPA_M16_PF_ALL_D != 0) || FFPA_M16_ROW_TABLES != 1 || FFPA_DMA_M0_CLOBBER != 1 || FFPA_M16_SWAP_REDUCE != 1 || FFPA_M16_MIN_D != 128 || FFPA_M16_BC128_MIN_D != 256 || \
     (defined(FFPA_M16_PHILOX_ILP) && FFPA_M16_PHILOX_ILP != 1)
 #error "FFPA_PRODUCT_BUILD: a developer switch is not at its shipped default"
 #endif
@@ -336,6 +354,46 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     } else {
       lds_dma_16_at<i * 1024>(ts.rsrc, v_lds, vrel[i], 0u);
     }
+  };
+
+  // ---- L2 prefetch (FwdArgs::l2_prefetch, set by the launch side for streams that come from HBM): the tile two steps ahead is touched —
+  // one dword per 128-byte line — so that the LDS-DMA pieces of the step after next find their lines in the XCD's L2.  The DMA queue covers one
+  // step of latency (K(j+1) goes out in step j's softmax phase); a first touch that misses L2 AND the Infinity Cache takes longer than that,
+  // and the workgroups that share a K/V stream through one L2 all queue behind the same in-flight lines (measured: 3.4 us per 64-key step at
+  // D = 512 while K/V sit in the Infinity Cache, 4.3 us once all of K/V come from HBM).  The workgroups of a head walk K/V together, so each
+  // one touches only 1/kPfSlices of a tile: the keys [slice kPfKeys, slice kPfKeys + kPfKeys) with slice = (row tile + head) mod kPfSlices,
+  // one 64-lane load for K (wave 0) and one for V (wave 1), issued behind the step's last DMA piece (loads retire in order: the wait at
+  // barrier B then leaves exactly this one outstanding, and it has a whole step to land before the next counted wait).
+  constexpr int kPfLines = (RB + 127) / 128;                                                            // lines per row
+  constexpr int kPfLinesP2 = kPfLines <= 1 ? 1 : kPfLines <= 2 ? 2 : kPfLines <= 4 ? 4 : kPfLines <= 8 ? 8 : 16;
+  static_assert(kPfLines <= 16, "head dims up to 1024");
+  constexpr int kPfKeys = 64 / kPfLinesP2;                                                              // keys one load covers
+  constexpr int kPfSlices = BC / kPfKeys > 0 ? BC / kPfKeys : 1;
+  // (built into the split-D tiles only: at D <= 512 a DMA piece has a whole step to land, the touches cost 1 ... 2 %, and the dropout +
+  // bias builds there have no register to spare)
+#ifndef FFPA_M16_PF_ALL_D
+#define FFPA_M16_PF_ALL_D 0  // (experiment) 1: the D <= 512 builds carry the touches as well (FFPA_FLAG_L2_PREFETCH turns them on)
+#endif
+  constexpr bool kPf = ND == 2 || FFPA_M16_PF_ALL_D != 0;
+  const bool pf_on = kPf && a.l2_prefetch != 0 && wave < FFPA_M16_PF_WAVES && ((FFPA_M16_PF_WHICH >> (wave & 1)) & 1);
+  const bool pf_k = (wave & 1) == 0;  // even waves touch K, odd waves V
+  uint32_t pf_off = kDmaOob;
+  uint32_t pf_junk = 0u;  // (the loads' destination: never read, but live through the loop so that nothing else is allocated to it)
+  if (pf_on) {
+    constexpr int kPer = FFPA_M16_PF_WAVES / 2;  // slices one workgroup touches per step
+    constexpr int kGroups = kPfSlices / kPer > 0 ? kPfSlices / kPer : 1;
+    const int slice = (((qt + hq) % kGroups) * kPer + (wave >> 1)) % kPfSlices;
+    const uint32_t key = (uint32_t)(slice * kPfKeys + lane / kPfLinesP2), line = (uint32_t)(lane % kPfLinesP2);
+    if (line * 128u < rb_valid && key < (uint32_t)BC) pf_off = key * (pf_k ? k_row_bytes : v_row_bytes) + line * 128u;
+  }
+  // (scalar by construction — wave is — and pinned: they feed the descriptor of the asm below)
+  const uint64_t pf_base64 = (uint64_t)(pf_k ? (const void*)Kg : (const void*)Vg);
+  const void* const pf_base = (const void*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pf_base64 >> 32)) << 32) |
+                                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pf_base64));
+  const uint32_t pf_row_bytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pf_k ? k_row_bytes : v_row_bytes));
+  auto issue_prefetch = [&](int key0) {
+    const TileSrc ts = tile_src<BC>(pf_base, pf_row_bytes, key0, a.Nkv, rb_valid);
+    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(pf_junk) : "v"(pf_off), "s"(ts.rsrc) : "memory");
   };
 
   // ---- KV tile range
@@ -539,6 +597,15 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     __syncthreads();
   }
 
+  auto dephase = [&](auto bitc) __attribute__((always_inline)) {
+    if constexpr (FFPA_M16_DEPHASE > 0 && ((FFPA_M16_DEPHASE_AT >> decltype(bitc)::value) & 1) && ((FFPA_M16_DEPHASE_ND >> (ND - 1)) & 1)) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (wave >= 1) static_for<FFPA_M16_DEPHASE>([&](auto) { asm volatile("s_nop 15"); });
+      if (wave >= 2) static_for<FFPA_M16_DEPHASE>([&](auto) { asm volatile("s_nop 15"); });
+      if (wave >= 3) static_for<FFPA_M16_DEPHASE>([&](auto) { asm volatile("s_nop 15"); });
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
 #ifdef FFPA_M16_TIMING
   unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
   unsigned long long tprev = __builtin_amdgcn_s_memtime();
@@ -705,6 +772,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     // barrier A1: every wave is done reading K(j) (ND == 2: and the partial S^T tiles are visible)
     __syncthreads();
     FFPA_TSTAMP(1);  // wait at barrier A1
+    dephase(std::integral_constant<int, 0>{});
     __builtin_amdgcn_sched_barrier(0);
     pre_k_group(std::integral_constant<int, 0>{});
 
@@ -893,6 +961,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       dma_wait_except<kPre>();
       __syncthreads();
       FFPA_TSTAMP(3);  // V(j) drain + wait at barrier A2
+      dephase(std::integral_constant<int, 1>{});
       // pieces of the next step's bias tile to stage (none when that step lies in the mask's neutral interior or past the last tile)
       const int b_next = (MK == 1 && j + 1 < nt && !(k0 + BC >= free_lo && k0 + 2 * BC <= free_hi)) ? b_pieces : 0;
       const u32x4 brs = bias_rsrc();
@@ -940,11 +1009,25 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 
     FFPA_TSTAMP(4);  // PV loop
     // barrier B: every wave is done reading V(j); K(j+1) has landed and is visible
-    dma_wait_all();
+    if (pf_on) {  // (wave-uniform)
+#ifdef FFPA_M16_PF_DUMMY
+      issue_prefetch(0);  // (experiment: the same instruction on lines that are always cached)
+#else
+      issue_prefetch(k0 + FFPA_M16_PF_DIST * BC);
+#endif
+      dma_wait_except<1>();
+    } else {
+      dma_wait_all();
+    }
     __syncthreads();
     FFPA_TSTAMP(5);  // K(j+1) drain + wait at barrier B
+    dephase(std::integral_constant<int, 2>{});
   }
 
+  if (pf_on) {  // the last touches land before their destination register is given to anything else
+    dma_wait_all();
+    asm volatile("" : : "v"(pf_junk));
+  }
   // ================= epilogue (prefill.cuh:1018-1093) =================
   asm volatile("s_nop 15\n\ts_nop 3");  // last PV MFMA (inline asm) -> accumulator reads below: wait states the compiler cannot see
   float l_tot[2], inv[2];

@@ -50,6 +50,8 @@ _STATUS_EXC = {
 FLAG_DEBUG_SAFE_PATH = 0x1
 FLAG_NO_XCD_REMAP = 0x2
 FLAG_NO_BIAS_LDS = 0x8
+FLAG_L2_PREFETCH = 0x10  # bench-only: touch the K/V tile two steps ahead in every prefill launch (default: the library decides; D > 512)
+FLAG_NO_L2_PREFETCH = 0x20  # bench-only: never
 
 # enum ffpa_bias_dtype: additive fp16 / bf16 / fp32, or a boolean mask read as bytes (non-zero = visible)
 # (torch.uint8 is NOT accepted: the public API and the reference take bool / float masks only, functional.py:860-898)

@@ -396,3 +396,41 @@ def test_additive_mask_ranges_and_long_key_biases(hip):
     assert "MK=3" in plan["kernel"], plan
     b, lb = hip.forward(q.to(dt), k.to(dt), v.to(dt), kb, False, D2 ** -0.5, num_splits=1, flags=hip.FLAG_NO_BIAS_LDS, plan_out=plan)
     assert "MK=1" in plan["kernel"] and torch.equal(a, b) and torch.equal(la, lb), dt
+
+
+@pytest.mark.parametrize("D", [128, 320, 512, 576, 640, 768, 1024])
+@pytest.mark.parametrize("case", ["plain", "ragged", "causal_gqa", "bool_mask", "key_bias", "dense_bias", "dropout", "token_major", "split_kv"])
+def test_l2_prefetch_changes_no_bit(hip, D, case):
+  """The launches of the split-D tiles (D > 512) touch the K/V tile two steps ahead (FwdArgs.l2_prefetch: one dword per line, loaded into
+  a register nobody reads): with the touches forced on, forced off and left to the library, every build gives the same bits — outputs
+  and LSE — including the steps whose look-ahead tile starts past the last key or past the caller's head dim.  (The D <= 512 builds do
+  not carry the touches: there the flags must change nothing either.)"""
+  B, Hq, Hkv, Nq, Nkv, causal, kw = 1, 4, 4, 300, 1100, False, {}
+  bias = None
+  if case == "ragged":
+    Nq, Nkv = 129, 97 + 64 * 5
+  elif case == "causal_gqa":
+    Hkv, causal, Nq, Nkv = 2, True, 512, 777
+  elif case == "bool_mask":
+    bias = (torch.rand(1, 1, Nq, Nkv, device="cuda") > 0.3)
+  elif case == "key_bias":
+    bias = (torch.randn(1, 1, 1, Nkv, device="cuda") * 0.5).to(torch.bfloat16)
+  elif case == "dense_bias":
+    bias = (torch.randn(1, Hq, Nq, Nkv, device="cuda") * 0.5).to(torch.bfloat16)
+  elif case == "dropout":
+    kw = dict(dropout_p=0.2, philox_seed=11)
+  elif case == "split_kv":
+    Nq, Nkv, kw = 128, 4096, dict(num_splits=4)
+  q, k, v = _rand((B, Hq, Nq, D), seed=5), _rand((B, Hkv, Nkv, D), seed=6), _rand((B, Hkv, Nkv, D), seed=7)
+  if case == "token_major":  # [B, N, H, D] storage seen as [B, H, N, D]: rows of one head are H * D elements apart
+    k = _rand((B, Nkv, Hkv, D), seed=6).transpose(1, 2)
+    v = _rand((B, Nkv, Hkv, D), seed=7).transpose(1, 2)
+  if case == "ragged" and D > 8:  # a caller's head dim below the built one: the look-ahead touches stay inside the valid bytes of a row
+    q, k, v = q[..., : D - 8], k[..., : D - 8], v[..., : D - 8]
+  scale = q.size(-1) ** -0.5
+  o_on, l_on = hip.forward(q, k, v, bias, causal, scale, flags=hip.FLAG_L2_PREFETCH, **kw)
+  o_off, l_off = hip.forward(q, k, v, bias, causal, scale, flags=hip.FLAG_NO_L2_PREFETCH, **kw)
+  o_def, l_def = hip.forward(q, k, v, bias, causal, scale, **kw)
+  for o, l in ((o_off, l_off), (o_def, l_def)):
+    assert torch.equal(o_on.view(torch.int16), o.view(torch.int16)), f"D={D} {case}: outputs differ"
+    assert torch.equal(torch.nan_to_num(l_on, nan=-7.0), torch.nan_to_num(l, nan=-7.0)), f"D={D} {case}: LSE differs"

@@ -12,7 +12,7 @@ pairs), and max |O - O_first arm| (ablation builds change results by design; A/B
 Cases (`--case`, default cfg2; `--shape` / `--hkv` / `--nkv` / `--causal` / `--dropout` override the "custom" case):
   cfg2 cfg3 cfg4_mask cfg4_offset0 cfg4_nomask causal cross gqa non_aligned dropout   (bench.py's workloads)
   key_bias dense_bias dense_bias_f32 dense_bias_heads key_bias_d320 dense_bias_d320 key_bias_d1024 dense_bias_d1024
-  dropout_d320 dropout_d1024 n1024 n2048 causal4k d320 d384 d448 d640 d768 d1024_causal decode decode_b8
+  dropout_d320 dropout_d1024 n1024 n2048 causal4k d320 d384 d448 d576 ... d960 d1024_causal cross_d1024 n2048_d1024 gqa_d1024 b4_d1024 decode decode_b8
 """
 import argparse
 import os
@@ -54,6 +54,8 @@ CASES = {
   "d128": _c(1, 32, 8192, 128), "d192": _c(1, 32, 8192, 192), "d256": _c(1, 32, 8192, 256), "d128_causal": _c(1, 32, 8192, 128, causal=True),
   "d256_causal": _c(1, 32, 8192, 256, causal=True), "d256_n2048": _c(4, 32, 2048, 256), "key_bias_d256": _c(1, 32, 8192, 256, bias="key"),
   "dense_bias_d256": _c(1, 32, 8192, 256, bias="dense"), "dropout_d256": _c(1, 32, 8192, 256, dropout=0.1), "d128_n2048": _c(4, 32, 2048, 128),
+  "d576": _c(1, 32, 8192, 576), "d704": _c(1, 32, 8192, 704), "d832": _c(1, 32, 8192, 832), "d896": _c(1, 32, 8192, 896), "d960": _c(1, 32, 8192, 960),
+  "cross_d1024": _c(1, 32, 1024, 1024, nkv=8192), "n2048_d1024": _c(1, 32, 2048, 1024), "gqa_d1024": _c(1, 32, 8192, 1024, hkv=8), "b4_d1024": _c(4, 8, 8192, 1024),
   "decode": _c(1, 32, 1, 512, nkv=8192), "decode_b8": _c(8, 32, 1, 512, hkv=8, nkv=8192),
 }
 
