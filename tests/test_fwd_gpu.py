@@ -747,6 +747,24 @@ def test_dropout_mask_matches_the_oracle_bit_for_bit(hip, D, Nq, Nkv, Hq, Hkv, c
     assert (o.float() - o_nodrop.float()).abs().max().item() > 0.02            # dropout really happened
 
 
+@pytest.mark.parametrize("D,Nq", [(64, 96), (128, 96), (512, 1)])
+@pytest.mark.parametrize("p", [2.0 ** -24, 1e-9, 0.25, 0.75, 0.999, float(np.nextafter(np.float32(0.5), np.float32(1.0)))])
+def test_dropout_keep_threshold_is_the_float_comparison(hip, D, Nq, p):
+  """The kernels compare the Philox word with an integer threshold the launch side derives from `((float)word + 1) * 2^-32 > p`
+  (prefill.cuh:437-440; ffpa_capi.hip dropout_keep_threshold): at probabilities that sit on or next to a rounding boundary of that
+  expression the mask is still the oracle's, in the 32x32x16 build (D = 64), the 16x16x32 build and the split-KV tiles (Nq = 1)."""
+  Nkv = 320
+  q, k, v = _rand((1, 2, Nq, D), seed=181), _rand((1, 2, Nkv, D), seed=182), _rand((1, 2, Nkv, D), seed=183)
+  o, _ = hip.forward(q, k, v, None, False, D ** -0.5, dropout_p=p, philox_seed=0x1234567890ABCDEF, philox_offset=4)
+  qb, dt = fo.torch_to_bits(q)
+  kb, _ = fo.torch_to_bits(k)
+  vb, _ = fo.torch_to_bits(v)
+  _, o32, _ = fo.oracle_forward(qb, kb, vb, dt, causal=False, block_keys=32 if Nq <= 32 else 64, dropout_p=p, philox_seed=0x1234567890ABCDEF, philox_offset=4)
+  err = np.abs(_f32(o) - o32)
+  # one flipped keep bit moves a row by about |v| / Nkv / (1 - p): far outside this bound at every p above
+  assert err.max() <= (2.0 ** -7 * np.abs(o32).max() + 2e-3), (p, err.max(), np.abs(o32).max())
+
+
 def test_dropout_public_api_reserves_generator_offsets(hip):
   from ffpa_attn_amd import ffpa_attn_func
 
