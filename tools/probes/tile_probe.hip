@@ -56,7 +56,7 @@ __device__ __forceinline__ void nops16() {
 
 // P0 / PS / P1: pieces per wave in the QK / softmax / PV phase (P0 + PS + P1 = 32 at D = 1024); NV: VALU instructions of the softmax
 // stand-in; DEPH: see the header; XCH: the partial-S exchange (4 ds_write_b128 + 4 ds_read_b128 per lane around barrier A1)
-template <int P0, int PS, int P1, int NV, int DEPH, bool XCH, bool TIMED>
+template <int P0, int PS, int P1, int NV, int DEPH, bool XCH, bool TIMED, int RD = 1>
 __global__ __launch_bounds__(256) void probe_tile(const Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void probe_tile(const Args a) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       __builtin_amdgcn_sched_barrier(0);
-      fr[(f + PF) & 3] = frag_read((h * NF + f + PF) % (2 * NF));
+      if constexpr (RD == 1) fr[(f + PF) & 3] = frag_read((h * NF + f + PF) % (2 * NF));
+      if constexpr (RD == 2) { if (f % 8 == 0) { for (int q = 0; q < 4; ++q) fr[q] = frag_read((h * NF + f + q) % (2 * NF)); } }  // reads in bursts of 4, none in flight at the pieces
       const int ai = (2 * (h * NF + f)) & (NACC - 1);
       acc[ai] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[f & 3], b0, acc[ai], 0, 0, 0);
       if (NPH > 0 && f % STEP == 0 && f / STEP < NPH) piece(first + f / STEP);  // between the pair (the kernel's FFPA_M16_DMA_POS 1)
@@ -191,13 +192,13 @@ __global__ __launch_bounds__(256) void probe_tile(const Args a) {
   }
 }
 
-template <int P0, int PS, int P1, int NV, int DEPH, bool XCH = true>
+template <int P0, int PS, int P1, int NV, int DEPH, bool XCH = true, int RD = 1>
 static void run_tile(const char* name, Args a, int tiles) {
   const int lds = 144 * 1024;
   a.tiles = tiles;
   float ms = 0;
   {
-    auto k = probe_tile<P0, PS, P1, NV, DEPH, XCH, false>;
+    auto k = probe_tile<P0, PS, P1, NV, DEPH, XCH, false, RD>;
     CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(k, dim3(256), dim3(256), lds, 0, a);
     CHECK(hipDeviceSynchronize());
@@ -213,7 +214,7 @@ static void run_tile(const char* name, Args a, int tiles) {
   }
   double ph[6] = {0, 0, 0, 0, 0, 0};
   {
-    auto k = probe_tile<P0, PS, P1, NV, DEPH, XCH, true>;
+    auto k = probe_tile<P0, PS, P1, NV, DEPH, XCH, true, RD>;
     CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(k, dim3(256), dim3(256), lds, 0, a);
     CHECK(hipDeviceSynchronize());
@@ -279,6 +280,10 @@ int main(int argc, char** argv) {
     run_tile<0, 0, 0, 160, 0>("no DMA", a, T);
     run_tile<16, 16, 0, 0, 0>("shipped, no VALU", a, T);
     run_tile<16, 16, 0, 160, 0, false>("shipped, no exchange", a, T);
+    // do the fragment reads make the pieces expensive?  RD 0: MFMA operands stay in registers (no ds_read at all)
+    run_tile<16, 16, 0, 160, 0, true, 0>("shipped, no fragment reads", a, T);
+    run_tile<0, 0, 0, 160, 0, true, 0>("no DMA, no fragment reads", a, T);
+    run_tile<16, 16, 0, 160, 0, true, 2>("shipped, reads in bursts of 4", a, T);
   }
   return 0;
 }
