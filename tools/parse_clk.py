@@ -4,7 +4,7 @@ tags = sys.argv[2:]
 rows = list(csv.DictReader(open(sys.argv[1])))
 disp = collections.OrderedDict()
 for r in rows:
-  if "ffpa_fwd_split" not in r["Kernel_Name"]:
+  if "ffpa_fwd_" not in r["Kernel_Name"] or "merge" in r["Kernel_Name"]:
     continue
   d = disp.setdefault(int(r["Dispatch_Id"]), {"dur": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6})
   d[r["Counter_Name"]] = float(r["Counter_Value"])
