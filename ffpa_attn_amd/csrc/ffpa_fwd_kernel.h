@@ -815,7 +815,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
   vid /= a.nsplit;
   const int bh = vid / a.nqt;
   int qt = vid - bh * a.nqt;
-  if (a.causal) qt = a.nqt - 1 - qt;  // longest rows first
+  if (a.causal || (MASK && a.kv_bounds != nullptr)) qt = a.nqt - 1 - qt;  // longest rows first (mask ranges: their usual source is a causal-like mask)
   const int b = bh / a.Hq;
   const int hq = bh - b * a.Hq;
   const int hkv = hq / a.group;

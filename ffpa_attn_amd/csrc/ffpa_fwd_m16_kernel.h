@@ -270,7 +270,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   vid /= a.nsplit;
   const int bh = vid / a.nqt;
   int qt = vid - bh * a.nqt;
-  if (a.causal) qt = a.nqt - 1 - qt;
+  // longest rows first: with the causal flag — and with mask ranges, whose usual source is a causal-like boolean mask (later rows see
+  // more keys; for any other mask the order of a head's row tiles does not matter) — so that the launch ends on its short workgroups
+  if (a.causal || (MASK && a.kv_bounds != nullptr)) qt = a.nqt - 1 - qt;
   const int b = bh / a.Hq;
   const int hq = bh - b * a.Hq;
   const int hkv = hq / a.group;
