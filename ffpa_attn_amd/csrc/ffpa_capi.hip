@@ -118,14 +118,19 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
   pl.nt = (p->seqlen_kv + pl.bc - 1) / pl.bc;
   pl.splits = 1;
   // KV-split launches (partials + LSE merge).  Short-query tiles: occupancy heuristic cf. select_decode_num_splits
-  // (native/launch.cuh:17-67) — aim at two workgroups per CU, at least 4 KV tiles per split so the merge stays
+  // (native/launch.cuh:17-67) — aim at one (head dims >= 320) or two workgroups per CU, at least 4 KV tiles per split so the merge stays
   // cheap.  Prefill tiles split too when the launch would leave more than half of the chip idle (chunked prefill
   // against a long context with few heads per GPU): one workgroup per CU, at least 8 KV tiles per split.
   const int64_t base = (int64_t)p->batch * p->heads_q * pl.nqt;
   const int64_t cus = device_cu_count();
   const bool underfilled = pl.variant == 0 && !(p->flags & FFPA_FLAG_DEBUG_SAFE_PATH) && base * 2 <= cus;
   if ((pl.variant == 1 || underfilled) && p->num_splits != 1) {
-    int64_t want = pl.variant == 1 ? (2 * cus + base - 1) / base : cus / base;
+    // short-query tiles, measured (tools/gpu_decode_splits.py, profiles/r03_decode_splits.txt): head dims >= 320 want ONE workgroup per CU — their tiles are
+    // 20 KiB and up, one workgroup keeps enough bytes in flight, and half the splits are half the partials to write and merge (- 3 ... 14 % per step
+    // against two per CU; rounded DOWN: at most two of these workgroups fit a CU, above D = 512 one, and a launch a little over one per CU takes twice
+    // as long as one a little under) — the small head dims two (8 KiB tiles at D = 128: one per CU is 40 ... 60 % slower, three or four 10 ... 25 %)
+    const bool sq_one_per_cu = kernel_head_dim(p->head_dim) >= 320;
+    int64_t want = pl.variant == 1 ? (sq_one_per_cu ? cus / base : (2 * cus + base - 1) / base) : cus / base;
     const int min_tiles = pl.variant == 1 ? 4 : 8;
     const int64_t cap = pl.nt / min_tiles > 0 ? pl.nt / min_tiles : 1;
     if (want > cap) want = cap;
