@@ -389,6 +389,21 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   a.dropout_p = p->dropout_p;
   a.keep_scale = p->dropout_p > 0.f ? 1.f / (1.f - p->dropout_p) : 1.f;
   a.keep_threshold = dropout_keep_threshold(p->dropout_p);
+  // XCDs per head (xcd_logical_id, ffpa_fwd_kernel.h).  One XCD per head keeps a head's K/V stream in one L2; but then eight heads are in flight chip-wide,
+  // and once their K + V no longer fit the Infinity Cache the second and later rounds of a head's row tiles come from HBM instead (config 3: eight heads x
+  // 32 MiB = the whole 256 MiB).  Prefill launches with at least two rounds of row tiles per head and XCD therefore share a head between the smallest
+  // power-of-two number of XCDs that brings the K + V in flight under 200 MiB (measured, profiles/r03_xcd_group.txt).
+  {
+    int g = 1;
+    const unsigned forced = (p->flags >> 8) & 7u;
+    if (forced != 0) {
+      g = 1 << (forced - 1 > 3 ? 3 : forced - 1);
+    } else if (pl.m16 && pl.splits == 1 && (int64_t)pl.nqt * (p->heads_q / p->heads_kv) >= 64) {
+      const double kv_mib = 2.0 * (double)p->seqlen_kv * (double)p->head_dim * 2.0 / 1048576.0;  // K + V of one (batch, kv head)
+      while (g < 8 && (8 / g) * kv_mib > 200.0) g *= 2;
+    }
+    a.xcd_group = g;
+  }
   // The split-D tiles (D > 512) give a DMA piece less than a microsecond to land (32-key steps, single K / V buffers): their launches touch the
   // tile two steps ahead (ffpa_fwd_m16_kernel.h, "L2 prefetch").  Measured, same library with and without (profiles/r03_l2_prefetch.txt):
   // D = 576 ... 1024: + 3 ... 9 % (D = 768: +- 0), every shape tried (self, cross, GQA, batch 4, causal, key bias); D <= 512: - 1 ... 2 %, off.

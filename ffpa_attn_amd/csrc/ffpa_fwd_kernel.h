@@ -147,6 +147,21 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 constexpr unsigned kFlagNoXcdRemap = 0x2u;
 
+// Workgroup id -> position in the launch's logical order (batch-major, head, row tile, split).  The hardware deals workgroup ids round-robin
+// to the 8 XCDs (id & 7); each XCD has its own L2.  `group` (FwdArgs::xcd_group: 1, 2, 4 or 8) XCDs share a contiguous range of the logical
+// order and take its workgroups in turn:
+//   group 1: an XCD walks a contiguous range — all row tiles of a head stream K/V through ONE L2 (the default);
+//   group 8: the logical order is the id order — every head is spread over all eight XCDs;
+//   in between: `group` XCDs work on the same head, 8 / group heads are in flight chip-wide.
+// Why it is a launch-side choice: 8 / group heads' K + V are what the 256 MiB Infinity Cache has to hold for the second and later rounds of
+// row tiles to be served from it instead of HBM (ffpa_capi.hip picks the smallest group that fits).  Handles totals that are not multiples of 8.
+__device__ __forceinline__ int xcd_logical_id(int id, int total, int group) {
+  const int xcd = id & 7, j = id >> 3, per = total >> 3, rem = total & 7;
+  const int first = xcd & ~(group - 1);                       // first XCD of this XCD's group
+  const int gstart = first * per + (first < rem ? first : rem);  // ids owned by the XCDs in front of the group
+  return gstart + j * group + (xcd - first);
+}
+
 // Kernel argument block (host fills it from ffpa_fwd_params).
 struct FwdArgs {
   const void* q;
@@ -194,6 +209,7 @@ struct FwdArgs {
   // dropout (prefill.cuh:398-546): keep iff u > p, u from Philox4x32-10 at the logical element offset
   float dropout_p;          // 0 = off
   float keep_scale;         // 1 / (1 - p)
+  int xcd_group;            // XCDs that share a contiguous range of the launch's logical workgroup order: 1 (default), 2, 4 or 8 (xcd_logical_id)
   int l2_prefetch;          // 16x16x32 prefill builds: touch the K/V tile two steps ahead (ffpa_fwd_m16_kernel.h; ffpa_capi.hip decides)
   uint32_t keep_threshold;  // smallest Philox word whose element is kept: word >= keep_threshold <=> ((float)word + 1.0f) * 2^-32 > dropout_p
   unsigned long long philox_seed;
@@ -802,14 +818,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
 #else
   const FwdArgs& a = a_in;
   int vid = blockIdx.x;
-  if (!(a.flags & kFlagNoXcdRemap)) {
-    const int total = gridDim.x;
-    const int xcd = vid & 7;
-    const int idx = vid >> 3;
-    const int per = total >> 3;
-    const int rem = total & 7;
-    vid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
-  }
+  if (!(a.flags & kFlagNoXcdRemap)) vid = xcd_logical_id(vid, gridDim.x, a.xcd_group);
 #endif
   const int split = vid % a.nsplit;
   vid /= a.nsplit;

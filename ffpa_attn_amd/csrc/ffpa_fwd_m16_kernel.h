@@ -261,11 +261,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 
   // workgroup -> (batch, head, row tile, split): as ffpa_fwd_split_d_kernel (all row tiles of a head on one XCD)
   int vid = blockIdx.x;
-  if (!(a.flags & kFlagNoXcdRemap)) {
-    const int total = gridDim.x;
-    const int xcd = vid & 7, idx = vid >> 3, per = total >> 3, rem = total & 7;
-    vid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
-  }
+  if (!(a.flags & kFlagNoXcdRemap)) vid = xcd_logical_id(vid, gridDim.x, a.xcd_group);
   const int split = vid % a.nsplit;
   vid /= a.nsplit;
   const int bh = vid / a.nqt;

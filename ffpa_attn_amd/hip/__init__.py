@@ -53,6 +53,11 @@ FLAG_NO_BIAS_LDS = 0x8
 FLAG_L2_PREFETCH = 0x10  # bench-only: touch the K/V tile two steps ahead in every prefill launch (default: the library decides; D > 512)
 FLAG_NO_L2_PREFETCH = 0x20  # bench-only: never
 
+
+def FLAG_XCD_GROUP(n: int) -> int:
+  """bench-only: force the number of XCDs (1, 2, 4 or 8) that share a head's row tiles (default: the library decides from the K/V footprint)"""
+  return {1: 0x100, 2: 0x200, 4: 0x300, 8: 0x400}[n]
+
 # enum ffpa_bias_dtype: additive fp16 / bf16 / fp32, or a boolean mask read as bytes (non-zero = visible)
 # (torch.uint8 is NOT accepted: the public API and the reference take bool / float masks only, functional.py:860-898)
 _BIAS_DTYPE = {torch.float16: 1, torch.bfloat16: 2, torch.float32: 3, torch.bool: 4}

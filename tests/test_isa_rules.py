@@ -67,7 +67,11 @@ def test_prefill_builds_have_no_scratch_inside_their_mfma_loops(capsys, monkeypa
       bias_build = mk1 or " 3 b0" in l
       assert hot_lane <= (8 if bias_build else 0), l
       if not bias_build:  # (the bias builds keep a few bytes of scratch for their prologue and their rare ragged-tail / diagonal branch)
-        assert "scratch    0 B" in l and "first..last MFMA: scratch ops 0" in l, l
+        # no scratch access between the first and the last MFMA; the unmasked builds reserve no scratch at all (the boolean-mask builds at
+        # D = 256 / 320 reserve a 68-byte frame that no instruction touches: hipcc keeps the slots of SGPR spills it later placed in VGPR lanes)
+        assert "first..last MFMA: scratch ops 0" in l, l
+        size = int(re.search(r"scratch\s+(\d+) B", l).group(1))
+        assert size == 0 or (" 2 b0" in l and size <= 128), l
   # the 32x32x16 prefill kernels that are left (D = 64): no spill code inside their MFMA loops either
   small = [l for l in _stats(monkeypatch, capsys, 64) if "bf16  64 1 b0 b0 b0" in l]
   assert len(small) == 3, small  # mask kinds 0 / 2 / 1

@@ -434,3 +434,18 @@ def test_l2_prefetch_changes_no_bit(hip, D, case):
   for o, l in ((o_off, l_off), (o_def, l_def)):
     assert torch.equal(o_on.view(torch.int16), o.view(torch.int16)), f"D={D} {case}: outputs differ"
     assert torch.equal(torch.nan_to_num(l_on, nan=-7.0), torch.nan_to_num(l, nan=-7.0)), f"D={D} {case}: LSE differs"
+
+
+@pytest.mark.parametrize("case", [(1, 3, 3, 1000, 700, 512, False), (2, 5, 5, 333, 2049, 320, True), (1, 4, 2, 640, 900, 1024, False), (1, 7, 7, 129, 300, 128, True),
+                                  (1, 2, 2, 64, 4096, 512, False), (1, 9, 3, 4100, 260, 64, False)])
+def test_the_xcd_grouping_of_workgroups_changes_no_bit(hip, case):
+  """Which XCD runs which (head, row tile, split) is a launch-side choice (FwdArgs.xcd_group: 1, 2, 4 or 8 XCDs share a head's row tiles, or no
+  remapping at all): every choice walks every workgroup of the launch exactly once — workgroup counts that are not multiples of 8, causal
+  launches (reversed row tiles), KV-split launches, both kernels — so outputs and LSE agree to the bit."""
+  B, Hq, Hkv, Nq, Nkv, D, causal = case
+  q, k, v = _rand((B, Hq, Nq, D), seed=21), _rand((B, Hkv, Nkv, D), seed=22), _rand((B, Hkv, Nkv, D), seed=23)
+  ref_o, ref_l = hip.forward(q, k, v, None, causal, D ** -0.5, flags=hip.FLAG_NO_XCD_REMAP)
+  for flags in [hip.FLAG_XCD_GROUP(g) for g in (1, 2, 4, 8)] + [0]:
+    o, l = hip.forward(q, k, v, None, causal, D ** -0.5, flags=flags)
+    assert torch.equal(o.view(torch.int16), ref_o.view(torch.int16)), f"{case} flags {flags:#x}: outputs differ"
+    assert torch.equal(torch.nan_to_num(l, nan=-7.0), torch.nan_to_num(ref_l, nan=-7.0)), f"{case} flags {flags:#x}: LSE differs"
