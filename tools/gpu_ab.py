@@ -58,6 +58,7 @@ CASES = {
   "cross_d1024": _c(1, 32, 1024, 1024, nkv=8192), "n2048_d1024": _c(1, 32, 2048, 1024), "gqa_d1024": _c(1, 32, 8192, 1024, hkv=8), "b4_d1024": _c(4, 8, 8192, 1024),
   "decode_d1024": _c(1, 32, 1, 1024, nkv=8192), "decode_d128": _c(4, 32, 1, 128, nkv=8192), "decode_long": _c(1, 8, 1, 512, nkv=65536), "decode_q16": _c(1, 32, 16, 512, nkv=8192),
   "n32k_h8": _c(1, 8, 32768, 512), "n32k_h8_d1024": _c(1, 8, 32768, 1024), "n16k": _c(1, 32, 16384, 512), "n16k_causal": _c(1, 32, 16384, 512, causal=True),
+  "n4k_d1024": _c(1, 32, 4096, 1024), "n6k_d1024": _c(1, 32, 6144, 1024), "n12k_d512": _c(1, 32, 12288, 512), "n12k_d1024": _c(1, 16, 12288, 1024),
   "decode": _c(1, 32, 1, 512, nkv=8192), "decode_b8": _c(8, 32, 1, 512, hkv=8, nkv=8192),
 }
 
