@@ -129,7 +129,7 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
     // 20 KiB and up, one workgroup keeps enough bytes in flight, and half the splits are half the partials to write and merge (- 3 ... 14 % per step
     // against two per CU; rounded DOWN: at most two of these workgroups fit a CU, above D = 512 one, and a launch a little over one per CU takes twice
     // as long as one a little under) — the small head dims two (8 KiB tiles at D = 128: one per CU is 40 ... 60 % slower, three or four 10 ... 25 %)
-    const bool sq_one_per_cu = kernel_head_dim(p->head_dim) >= 320;
+    const bool sq_one_per_cu = kernel_head_dim(p->head_dim) >= 320 || pl.lds > 80 * 1024;  // (or tiles of which only one workgroup fits a CU)
     int64_t want = pl.variant == 1 ? (sq_one_per_cu ? cus / base : (2 * cus + base - 1) / base) : cus / base;
     const int min_tiles = pl.variant == 1 ? 4 : 8;
     const int64_t cap = pl.nt / min_tiles > 0 ? pl.nt / min_tiles : 1;

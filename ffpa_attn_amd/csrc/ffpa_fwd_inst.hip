@@ -16,8 +16,8 @@ namespace ffpa {
 
 template <typename T, int D, int ND, bool SAFE, bool DROP = false, bool BTILE = false, int MK = 1>
 static int launch_one(const FwdArgs& a, hipStream_t stream) {
-  constexpr int BC = (ND == 1) ? ((D <= FFPA_BC128_MAX_D && !BTILE) ? 128 : 64) : 32;
-  constexpr int LDS_BASE = 2 * BC * D * 2 + (ND > 1 ? 4 * 4096 : 0);
+  constexpr int BC = (ND == 1) ? ((D <= FFPA_BC128_MAX_D && !BTILE) ? 128 : 64) : splitd_block_keys(D, ND);
+  constexpr int LDS_BASE = 2 * BC * D * 2 + splitd_exchange_bytes(D, ND);
   const int LDS = LDS_BASE + (a.bias_lds > 0 ? a.bias_lds : -a.bias_lds);  // + the key-bias row cache or the bias-tile staging area, sized by the C-ABI layer (<= 160 KiB in total)
   constexpr int kMaxLds = 160 * 1024;
   auto kern = ffpa_fwd_split_d_kernel<T, D, ND, SAFE, DROP, BTILE, MK>;
@@ -169,11 +169,11 @@ void FFPA_CAT(tile_config_d, FFPA_INST_D)(int variant, int* br, int* bc, int* ld
   // variant 0: prefill tiles, 1: short-query tiles, 2: prefill tiles of the additive-bias builds (64 keys at every head dim <= 512:
   // the 16x16x32 build with any additive bias, the 32x32x16 build with LDS-staged bias tiles)
   const int ND = variant == 1 ? ((D % 128 == 0) ? 4 : 2) : ((D <= 512) ? 1 : 2);
-  int BC = (ND == 1) ? ((D <= FFPA_BC128_MAX_D && variant != 2) ? 128 : 64) : 32;
+  int BC = (ND == 1) ? ((D <= FFPA_BC128_MAX_D && variant != 2) ? 128 : 64) : splitd_block_keys(D, ND);
   if (variant != 1 && D >= FFPA_M16_MIN_D) BC = m16_block_keys(D, variant == 2);  // (the 16x16x32 kernel's own rule)
   *br = 32 * (4 / ND);
   *bc = BC;
-  *lds = 2 * BC * D * 2 + (ND > 1 ? 4 * 4096 : 0);
+  *lds = 2 * BC * D * 2 + (variant == 1 ? splitd_exchange_bytes(D, ND) : (ND > 1 ? 4 * 4096 : 0));
 }
 
 }  // namespace ffpa

@@ -147,6 +147,17 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 constexpr unsigned kFlagNoXcdRemap = 0x2u;
 
+// Keys per tile of the tiles whose head dim is split over waves (ND > 1): 32 — except the short-query tiles (ND = 4) of head dims 128, 384 and 512,
+// which take 64: they are HBM-bound and what they stream per request burst is one tile (D = 512: 32 KiB at 32 keys reached 5.5 TB/s where the
+// 64 KiB tiles of D = 1024 reach 6.1).  D = 384 / 512 run ONE workgroup per CU (the split rule for these head dims, ffpa_capi.hip), so the LDS has
+// the room; D = 128 still fits two.  D = 256 does not (96 KiB per workgroup: one per CU, + 6 % time: measured, profiles/r03_decode_splits.txt).
+// The partial-S exchange area grows with the tile: 4 KiB per wave and 32-key block.
+#ifndef FFPA_SQ_BC64
+#define FFPA_SQ_BC64 1
+#endif
+constexpr int splitd_block_keys(int D, int ND) { return (FFPA_SQ_BC64 != 0 && ND == 4 && (D == 128 || D == 384 || D == 512)) ? 64 : 32; }
+constexpr int splitd_exchange_bytes(int D, int ND) { return ND > 1 ? 4 * 4096 * (splitd_block_keys(D, ND) / 32) : 0; }
+
 // Workgroup id -> position in the launch's logical order (batch-major, head, row tile, split).  The hardware deals workgroup ids round-robin
 // to the 8 XCDs (id & 7); each XCD has its own L2.  `group` (FwdArgs::xcd_group: 1, 2, 4 or 8) XCDs share a contiguous range of the logical
 // order and take its workgroups in turn:
@@ -733,7 +744,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
   constexpr int KS = DW / 16;      // QK contraction steps per wave
   // keys per tile: 128 for small head dims (fewer barriers / phase fills per key), 64 up to D = 512, 32 when D
   // is split over waves (ND == 4, short-query launches: small tiles, 2 workgroups / CU)
-  constexpr int BC = (ND == 1) ? ((D <= FFPA_BC128_MAX_D && !BTILE) ? 128 : 64) : 32;  // (bias-tile builds: 64 keys, the LDS must hold the bias tiles too)
+  constexpr int BC = (ND == 1) ? ((D <= FFPA_BC128_MAX_D && !BTILE) ? 128 : 64) : splitd_block_keys(D, ND);  // (bias-tile builds: 64 keys, the LDS must hold the bias tiles too)
   constexpr int NKB = BC / 32;     // 32-key S^T blocks per tile
   constexpr int NKS = BC / 16;     // PV contraction steps per tile
   constexpr int NQB = 4 / ND;      // 32-row blocks per workgroup
@@ -768,7 +779,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
   FFPA_LDS char* const Kt = (FFPA_LDS char*)smem;
   FFPA_LDS char* const Vt = Kt + TILE;
   FFPA_LDS char* const Xb = Kt + 2 * TILE;  // ND == 2: partial-S exchange, 4 KiB per wave
-  FFPA_LDS char* const Bl = Kt + 2 * TILE + (ND > 1 ? 4 * 4096 : 0);  // key-bias row cache (FwdArgs.bias_lds bytes, when enabled)
+  FFPA_LDS char* const Bl = Kt + 2 * TILE + splitd_exchange_bytes(D, ND);  // key-bias row cache (FwdArgs.bias_lds bytes, when enabled)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1137,12 +1148,14 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
       }
     };
     if constexpr (ND > 1) {  // publish this wave's partial S^T (lane-linear, conflict free)
-      FFPA_LDS char* xw = Xb + wave * 4096 + lane * 16;
+      FFPA_LDS char* xw = Xb + wave * (NKB * 4096) + lane * 16;
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        f32x4 t = {sacc[0][4 * r4], sacc[0][4 * r4 + 1], sacc[0][4 * r4 + 2], sacc[0][4 * r4 + 3]};
-        *(FFPA_LDS f32x4*)(xw + r4 * 1024) = t;
-      }
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          f32x4 t = {sacc[kb][4 * r4], sacc[kb][4 * r4 + 1], sacc[kb][4 * r4 + 2], sacc[kb][4 * r4 + 3]};
+          *(FFPA_LDS f32x4*)(xw + kb * 4096 + r4 * 1024) = t;
+        }
     }
 
     // barrier A: every wave is done reading K(j); V(j) has landed; partials visible
@@ -1198,6 +1211,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
     // lane holds x[kb][r] = score(row qrow, key k0 + 32 kb + 16 h + r)
     float x[NKB][16];
     if constexpr (ND == 2) {
+      static_assert(ND != 2 || NKB == 1, "the two-wave exchange moves one 32-key block");
       FFPA_LDS const char* xr = Xb + (wave ^ 1) * 4096 + lane * 16;
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
@@ -1208,19 +1222,21 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
     } else if constexpr (ND == 4) {
       // sum the four D-quarter partials in a fixed order so that all four waves of the row block see
       // bit-identical scores (their softmax state must agree: each owns a different slice of O^T)
-      FFPA_LDS const char* xr = Xb + (wave & ~3) * 4096 + lane * 16;
+      FFPA_LDS const char* xr = Xb + (wave & ~3) * (NKB * 4096) + lane * 16;
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        f32x4 acc4 = *(FFPA_LDS const f32x4*)(xr + r4 * 1024);
+      for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
-          const f32x4 t = *(FFPA_LDS const f32x4*)(xr + w * 4096 + r4 * 1024);
+        for (int r4 = 0; r4 < 4; ++r4) {
+          f32x4 acc4 = *(FFPA_LDS const f32x4*)(xr + kb * 4096 + r4 * 1024);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc4[e] += t[e];
+          for (int w = 1; w < 4; ++w) {
+            const f32x4 t = *(FFPA_LDS const f32x4*)(xr + w * (NKB * 4096) + kb * 4096 + r4 * 1024);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc4[e] += t[e];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[kb][4 * r4 + e] = acc4[e] * a.scale_log2;
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) x[0][4 * r4 + e] = acc4[e] * a.scale_log2;
-      }
     } else {
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb)

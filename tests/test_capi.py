@@ -77,14 +77,14 @@ def test_short_query_plan_and_workspace(lib):
   plan = (ctypes.c_int * 4)()
   p = _params(seqlen_q=1, seqlen_kv=8192, heads_q=4, heads_kv=4)
   assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0
-  assert list(plan) == [1, 32, 32, 1]  # no workspace -> no split
+  assert list(plan) == [1, 32, 64, 1]  # no workspace -> no split (D = 512: 64-key short-query tiles)
   need = lib.ffpa_attn_fwd_workspace_bytes(ctypes.byref(p))
   assert need > 0 and need % (4 * 1 * 4 * 1 * (512 + 1)) == 0
   p.workspace, p.workspace_bytes = 16, need
   assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0
   splits = plan[3]
   assert splits > 1 and need == splits * 4 * 1 * 4 * 1 * (512 + 1)
-  assert -(-8192 // 32) // splits >= 4  # at least 4 KV tiles per split
+  assert -(-8192 // 64) // splits >= 4  # at least 4 KV tiles per split
   p.num_splits = 1
   assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0 and plan[3] == 1
   p.num_splits = 3

@@ -54,6 +54,15 @@ def _f32(t):
   return t.detach().float().cpu().numpy()
 
 
+def _short_query_keys(hip, D):
+  """Keys per tile of the short-query (Nq <= 32) launches: what the oracle's recurrence has to be blocked by to follow the kernel."""
+  plan = {}
+  q = torch.zeros(1, 1, 1, D, dtype=torch.bfloat16, device="cuda")
+  k = torch.zeros(1, 1, 256, D, dtype=torch.bfloat16, device="cuda")
+  hip.forward(q, k, k, None, False, 1.0, plan_out=plan, num_splits=1)
+  return plan["block_keys"]
+
+
 def _check_vs_oracle(o_gpu, lse_gpu, q, k, v, *, causal=False, causal_offset=None, bias=None, rows=None,
                      block_keys=64, threshold=8.0, name=""):
   """o_gpu within one storage-dtype rounding of the oracle's unrounded result, LSE to fp32 noise."""
@@ -553,7 +562,7 @@ def test_short_query_split_kv(hip, D, Nq, Hq, Hkv):
   o, lse = hip.forward(q, k, v, None, False, D ** -0.5, plan_out=plan)
   assert plan["variant"] == 1 and plan["splits"] > 1
   assert plan["packed"] == (Hq != Hkv and Nq <= 7 and (Hq // Hkv) * Nq <= 32)
-  _check_vs_oracle(o, lse, q, k, v, block_keys=32, name=f"short {Nq}x{Hq}/{Hkv} D{D}")
+  _check_vs_oracle(o, lse, q, k, v, block_keys=_short_query_keys(hip, D), name=f"short {Nq}x{Hq}/{Hkv} D{D}")
   o1, lse1 = hip.forward(q, k, v, None, False, D ** -0.5, num_splits=1)  # unsplit: same answer up to rounding
   assert (o.float() - o1.float()).abs().max().item() <= 4e-3
   assert (lse - lse1).abs().max().item() <= 1e-4
@@ -598,9 +607,9 @@ def test_short_query_causal_and_tails(hip, Nq, Hq, Hkv):
   D, Nkv = 512, 1111
   q, k, v = _rand((1, Hq, Nq, D), seed=141), _rand((1, Hkv, Nkv, D), seed=142), _rand((1, Hkv, Nkv, D), seed=143)
   o, lse = hip.forward(q, k, v, None, True, D ** -0.5)                       # tail aligned
-  _check_vs_oracle(o, lse, q, k, v, causal=True, block_keys=32, name="short causal tail")
+  _check_vs_oracle(o, lse, q, k, v, causal=True, block_keys=_short_query_keys(hip, q.size(-1)), name="short causal tail")
   o0, lse0 = hip.forward(q, k, v, None, True, D ** -0.5, causal_offset=0)    # top-left: row i sees keys 0..i
-  _check_vs_oracle(o0, lse0, q, k, v, causal=True, causal_offset=0, block_keys=32, name="short causal topleft")
+  _check_vs_oracle(o0, lse0, q, k, v, causal=True, causal_offset=0, block_keys=_short_query_keys(hip, q.size(-1)), name="short causal topleft")
   assert torch.equal(o0[:, :, 0], v[:, :, 0].repeat_interleave(Hq // Hkv, 1))  # row 0 sees only key 0
 
 
@@ -713,7 +722,7 @@ def test_short_query_bias_is_not_packed(hip):
   plan = {}
   o, lse = hip.forward(q, k, v, bias, False, 512 ** -0.5, plan_out=plan)
   assert plan["variant"] == 1 and not plan["packed"]
-  _check_vs_oracle(o, lse, q, k, v, bias=_f32(bias), block_keys=32, name="short bias")
+  _check_vs_oracle(o, lse, q, k, v, bias=_f32(bias), block_keys=_short_query_keys(hip, q.size(-1)), name="short bias")
 
 
 def test_decode_through_public_api(hip):
@@ -737,7 +746,7 @@ def test_dropout_mask_matches_the_oracle_bit_for_bit(hip, D, Nq, Nkv, Hq, Hkv, c
     qb, dt = fo.torch_to_bits(q)
     kb, _ = fo.torch_to_bits(k)
     vb, _ = fo.torch_to_bits(v)
-    bc = 32 if (Nq <= 32 or D > 512) else 64
+    bc = _short_query_keys(hip, D) if Nq <= 32 else (32 if D > 512 else 64)
     _, o32, lse_ref = fo.oracle_forward(qb, kb, vb, dt, causal=causal, block_keys=bc, dropout_p=p, philox_seed=seed,
                                         philox_offset=off)
     err = np.abs(_f32(o) - o32)
@@ -759,7 +768,7 @@ def test_dropout_keep_threshold_is_the_float_comparison(hip, D, Nq, p):
   qb, dt = fo.torch_to_bits(q)
   kb, _ = fo.torch_to_bits(k)
   vb, _ = fo.torch_to_bits(v)
-  _, o32, _ = fo.oracle_forward(qb, kb, vb, dt, causal=False, block_keys=32 if Nq <= 32 else 64, dropout_p=p, philox_seed=0x1234567890ABCDEF, philox_offset=4)
+  _, o32, _ = fo.oracle_forward(qb, kb, vb, dt, causal=False, block_keys=_short_query_keys(hip, D) if Nq <= 32 else 64, dropout_p=p, philox_seed=0x1234567890ABCDEF, philox_offset=4)
   err = np.abs(_f32(o) - o32)
   # one flipped keep bit moves a row by about |v| / Nkv / (1 - p): far outside this bound at every p above
   assert err.max() <= (2.0 ** -7 * np.abs(o32).max() + 2e-3), (p, err.max(), np.abs(o32).max())
