@@ -96,6 +96,27 @@ def test_short_query_plan_and_workspace(lib):
   assert lib.ffpa_attn_fwd_plan(ctypes.byref(d1024), plan) == 0 and list(plan) == [0, 64, 32, 1]
 
 
+@pytest.mark.parametrize("over, want", [
+  (dict(batch=1, heads_q=32, heads_kv=32, seqlen_kv=8192, head_dim=512), (64, 8)),     # 32 row tiles: 256 CUs / 32 = 8 splits (one workgroup per CU), 64-key tiles
+  (dict(batch=1, heads_q=32, heads_kv=32, seqlen_kv=8192, head_dim=1024), (32, 8)),    # above D = 512 only one workgroup fits a CU: 32-key tiles, 8 splits
+  (dict(batch=3, heads_q=20, heads_kv=20, seqlen_kv=10000, head_dim=512), (64, 4)),    # 60 row tiles: rounded DOWN (5 splits = 300 workgroups would take two rounds)
+  (dict(batch=8, heads_q=8, heads_kv=8, seqlen_kv=8192, head_dim=512), (64, 4)),       # 64 row tiles
+  (dict(batch=4, heads_q=32, heads_kv=32, seqlen_kv=8192, head_dim=128), (64, 4)),     # small head dims: two workgroups per CU (128 row tiles x 4 = 512), 64-key tiles
+  (dict(batch=1, heads_q=64, heads_kv=64, seqlen_kv=8192, head_dim=256), (32, 8)),     # D = 256 keeps 32-key tiles (two workgroups per CU)
+  (dict(batch=1, heads_q=32, heads_kv=32, seqlen_kv=8192, head_dim=320), (32, 8)),     # two-wave split (D % 128 != 0): 32-key tiles, one workgroup per CU
+  (dict(batch=16, heads_q=32, heads_kv=32, seqlen_kv=4096, head_dim=512), (64, 1)),    # 512 row tiles fill the chip: no split
+])
+def test_short_query_split_rule(lib, over, want):
+  """The KV-split count of short-query launches on a 256-CU device (the plan needs no GPU: the CU count falls back to 256): one workgroup per CU
+  for head dims >= 320 — rounded down —, two below; tile sizes by head dim (profiles/r03_decode_splits.txt)."""
+  plan = (ctypes.c_int * 4)()
+  p = _params(seqlen_q=1, **over)
+  p.workspace, p.workspace_bytes = 16, 1 << 40
+  assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0
+  rows = 32 if over["head_dim"] % 128 == 0 else 64  # (head dims that are not multiples of 128: two row blocks x two D-halves)
+  assert (plan[0], plan[1]) == (1, rows) and (plan[2], plan[3]) == want, list(plan)
+
+
 def test_underfilled_prefill_plan_splits_the_kv_axis(lib):
   """Prefill tiles whose launch would leave more than half of the CUs idle (chunked prefill against a long
   context with few heads) split the KV axis too: >= 8 KV tiles per split, one workgroup per CU in total
