@@ -9,10 +9,11 @@ keep the separate merge kernel instead of merging inside the launch).  Arms are 
 rounds inside ONE process (cdna guide section 5.4 rule 24) with HIP events; per case and arm: median / best ms, TFLOPS (valid
 pairs), and max |O - O_first arm| (ablation builds change results by design; A/B arms of one kernel must not).
 
-Cases (`--case`, default cfg2; `--shape` / `--hkv` / `--nkv` / `--causal` / `--dropout` override the "custom" case):
-  cfg2 cfg3 cfg4_mask cfg4_offset0 cfg4_nomask causal cross gqa non_aligned dropout   (bench.py's workloads)
-  key_bias dense_bias dense_bias_f32 dense_bias_heads key_bias_d320 dense_bias_d320 key_bias_d1024 dense_bias_d1024
-  dropout_d320 dropout_d1024 n1024 n2048 causal4k d320 d384 d448 d576 ... d960 d1024_causal cross_d1024 n2048_d1024 gqa_d1024 b4_d1024 decode decode_b8
+Cases (`--case`, default cfg2; `--shape` / `--hkv` / `--nkv` / `--causal` / `--dropout` override the "custom" case): the keys of CASES below —
+bench.py's workloads (cfg2 cfg3 cfg4_* causal cross gqa non_aligned dropout), additive biases (key_bias dense_bias[_f32|_heads], ..._d128 / _d256 / _d320 / _d1024),
+head-dim sweeps (d64 ... d1024, with _causal / _n2048 forms), sequence-length sweeps (n1024 n2048 n16k[_causal] n32k_h8[_d1024] n4k_d1024 n6k_d1024 n12k_d512 n12k_d1024),
+other shapes at D = 1024 (cross_d1024 n2048_d1024 gqa_d1024 b4_d1024 d1024_causal) and the short-query launches (decode decode_b8 decode_d128 decode_d1024 decode_long decode_q16).
+Launch flags of include/ffpa_attn.h worth an arm of their own: 0x2 no XCD remapping, 0x10 / 0x20 look-ahead touches forced on / off, 0x100 ... 0x400 = 1 / 2 / 4 / 8 XCDs per head.
 """
 import argparse
 import os
