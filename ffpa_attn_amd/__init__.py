@@ -10,7 +10,7 @@ from .flops import attention_fwd_flops, attention_valid_pairs
 from .functional import FFPAAttnMeta
 from .interface import ffpa_attn_func
 
-__version__ = "0.1.0"
+__version__ = "0.4.0"  # = the library's ffpa_attn_version() ("ffpa-attn-amd 0.4.0 gfx950"; tests/test_capi.py pins the pair)
 
 __all__ = [
   "ffpa_attn_func",

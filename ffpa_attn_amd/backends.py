@@ -89,6 +89,9 @@ class CUDABackend(HIPBackend):
 
   def __post_init__(self) -> None:
     super().__post_init__()
+    # the reference's CUDA backend is forward-only: CUDABackend(), backend="cuda" and backward_backend="cuda" trip this very assertion
+    # (functional.py:266-268 after Backend.__post_init__ :189-196); callers spell it forward_backend="cuda" / CUDABackend(forward=True)
+    assert not self.backward, "cuda backend does not support backward"
     if self.enable_fp8 or self.enable_fp4:
       raise NotImplementedError("FP8 / FP4 attention is out of scope for the MI355X build (bf16/fp16 only)")
 

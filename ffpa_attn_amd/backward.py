@@ -125,7 +125,11 @@ def _chunked_recompute_backward(grad_out, q, k, v, o, lse, causal, scale, attn_b
 _aten_unsupported: dict = {}
 # (generic words such as "not supported" / "unsupported" are NOT markers: aten uses them for per-call refusals too — a bias stride, an
 # alignment — and remembering one of those would send every later backward of that (dtype, D) down the slower recompute path)
-_CAPABILITY_MARKERS = ("head_dim", "head dim", "headdim", "head size", "last dimension", "dtype", "data type", "no available kernel", "no kernel")
+# Bare "dtype" / "data type" are not markers either (round-3 advisor finding): aten words per-call refusals of a BIAS dtype that way; a dtype
+# message counts only when it names query / key / value.
+_CAPABILITY_MARKERS = ("head_dim", "head dim", "headdim", "head size", "last dimension", "no available kernel", "no kernel")
+_DTYPE_WORDS = ("dtype", "data type")
+_QKV_WORDS = ("query", "key", "value")
 
 
 def _is_capability_error(exc: Exception) -> bool:
@@ -134,7 +138,9 @@ def _is_capability_error(exc: Exception) -> bool:
   msg = str(exc).lower()
   if "out of memory" in msg:
     return False
-  return isinstance(exc, NotImplementedError) or any(m in msg for m in _CAPABILITY_MARKERS)
+  if isinstance(exc, NotImplementedError) or any(m in msg for m in _CAPABILITY_MARKERS):
+    return True
+  return any(w in msg for w in _DTYPE_WORDS) and any(w in msg for w in _QKV_WORDS) and "bias" not in msg and "mask" not in msg
 
 
 def _additive_bias(attn_bias, dtype):

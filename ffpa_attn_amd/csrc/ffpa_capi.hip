@@ -562,9 +562,9 @@ int ffpa_attn_fwd_tile_config(int head_dim, int* block_rows, int* block_keys, in
 const char* ffpa_attn_last_error(void) { return g_err; }
 
 #ifdef FFPA_PRODUCT_BUILD
-const char* ffpa_attn_version(void) { return "ffpa-attn-amd 0.3.0 gfx950"; }
+const char* ffpa_attn_version(void) { return "ffpa-attn-amd 0.4.0 gfx950"; }
 #else
-const char* ffpa_attn_version(void) { return "ffpa-attn-amd 0.3.0 gfx950 (developer variant: NOT a product build)"; }
+const char* ffpa_attn_version(void) { return "ffpa-attn-amd 0.4.0 gfx950 (developer variant: NOT a product build)"; }
 #endif
 
 }  // extern "C"

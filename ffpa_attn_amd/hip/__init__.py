@@ -258,31 +258,57 @@ def mask_kv_bounds(attn_bias: torch.Tensor, nq: int, nkv: int) -> torch.Tensor:
   return torch.stack((first, end, ff, fe), dim=-1).to(torch.int32).contiguous()
 
 
-# One scan per mask, not per call: a static mask (the usual case: the same causal / padding / sliding-window tensor for every layer
-# and step) is scanned once.  An entry is valid only while the very tensor object it was computed from (the view's base: the public
-# API re-views the caller's mask on every call) is still alive — so its memory cannot have been recycled for another mask — and torch's
-# in-place version counter (shared by all views of a storage, bumped by every in-place write) has not moved.  Holds the small int32
-# result only.
+# One scan per mask instead of one per call — OPT-IN (FFPA_HIP_MASK_BOUNDS_CACHE=1): a static mask (the same causal / padding /
+# sliding-window tensor for every layer and step) is then scanned once.  An entry is valid only while the very tensor object it was
+# computed from (the view's base: the public API re-views the caller's mask on every call) is still alive — so its memory cannot have
+# been recycled for another mask — and torch's in-place version counter (shared by all views of a storage, bumped by every in-place
+# write torch knows of) has not moved.  What the counter does NOT see leaves stale ranges behind, and stale ranges make the kernel skip
+# visible keys silently: `mask.data.fill_()`, a Triton / custom kernel writing through the raw pointer, a graph replay refreshing a
+# static mask buffer.  Hence off unless the caller asks for it and knows its masks are written through torch ops only.  Tensors
+# without a version counter (created under torch.inference_mode()) are never cached.  An entry remembers the stream its scan ran
+# on and an event behind it: a consumer on another stream waits for that event first.  Holds the small int32 result only.
 _BOUNDS_CACHE: "dict[tuple, tuple]" = {}
 _BOUNDS_CACHE_MAX = 16
+
+
+def _mask_bounds_cache_enabled() -> bool:
+  return os.environ.get("FFPA_HIP_MASK_BOUNDS_CACHE", "0") not in ("0", "")
+
+
+def _tensor_version(t: torch.Tensor):
+  """torch's in-place version counter of ``t``, or None for tensors that do not track one (inference tensors raise on access)."""
+  try:
+    if t.is_inference():
+      return None
+    return t._version
+  except RuntimeError:
+    return None
 
 
 def cached_mask_kv_bounds(attn_bias: torch.Tensor, nq: int, nkv: int) -> torch.Tensor:
   import weakref
 
+  version = _tensor_version(attn_bias)
+  if version is None:  # no version counter: nothing would ever invalidate the entry
+    return mask_kv_bounds(attn_bias, nq, nkv)
   owner = attn_bias._base if attn_bias._base is not None else attn_bias
   key = (id(owner), attn_bias.data_ptr(), attn_bias.dtype, tuple(attn_bias.shape), tuple(attn_bias.stride()), nq, nkv)
+  stream = torch.cuda.current_stream(attn_bias.device)
   hit = _BOUNDS_CACHE.get(key)
   if hit is not None:
-    ref, version, out = hit
-    if ref() is owner and version == attn_bias._version:
+    ref, ver, out, src_stream, event = hit
+    if ref() is owner and ver == version:
+      if src_stream != stream.cuda_stream:
+        stream.wait_event(event)  # the scan ran on another stream: order this stream's launch behind it
       return out
   out = mask_kv_bounds(attn_bias, nq, nkv)
-  for k_ in [k_ for k_, (r, _, _) in _BOUNDS_CACHE.items() if r() is None]:  # owners that died
+  event = torch.cuda.Event()
+  event.record(stream)
+  for k_ in [k_ for k_, ent in _BOUNDS_CACHE.items() if ent[0]() is None]:  # owners that died
     del _BOUNDS_CACHE[k_]
   if len(_BOUNDS_CACHE) >= _BOUNDS_CACHE_MAX:
     _BOUNDS_CACHE.pop(next(iter(_BOUNDS_CACHE)))
-  _BOUNDS_CACHE[key] = (weakref.ref(owner), attn_bias._version, out)
+  _BOUNDS_CACHE[key] = (weakref.ref(owner), version, out, stream.cuda_stream, event)
   return out
 
 
@@ -357,7 +383,10 @@ def forward(
   ``kv_bounds``: key ranges of the mask (``mask_kv_bounds``) — the kernel then skips the KV tiles the mask hides
   entirely and does not read the mask for the tiles it leaves untouched (an explicit causal mask costs what ``is_causal``
   costs); ``None`` derives them from ``attn_bias``
-  when that is worth a scan of the mask, ``False`` never, ``True`` always, or pass a precomputed tensor.
+  when that is worth a scan of the mask, ``False`` never, ``True`` always, or pass a precomputed tensor.  The scan runs on
+  every call; ``FFPA_HIP_MASK_BOUNDS_CACHE=1`` keeps the ranges per (mask tensor, torch version counter) instead — only safe when
+  the mask is written through torch ops alone (``mask.data`` writes, raw-pointer kernels and graph replays do not move the counter and
+  would leave stale ranges, i.e. silently skipped keys); masks created under ``torch.inference_mode()`` are never cached.
   """
   if not q.is_cuda:
     raise NotImplementedError(
@@ -432,7 +461,7 @@ def forward(
       # (the scan is skipped under stream capture / compile tracing only in the sense that the cache is not consulted there: a
       # captured graph must contain the scan kernel it depends on)
       capturing = torch.cuda.is_current_stream_capturing()
-      kv_bounds = mask_kv_bounds(attn_bias, Nq, Nkv) if (capturing or os.environ.get("FFPA_HIP_MASK_BOUNDS_CACHE") == "0") else cached_mask_kv_bounds(attn_bias, Nq, Nkv)
+      kv_bounds = cached_mask_kv_bounds(attn_bias, Nq, Nkv) if (_mask_bounds_cache_enabled() and not capturing) else mask_kv_bounds(attn_bias, Nq, Nkv)
     if isinstance(kv_bounds, torch.Tensor):
       nblk = (Nq + 31) // 32
       if kv_bounds.dtype != torch.int32 or kv_bounds.dim() != 4 or kv_bounds.shape[2:] != (nblk, 4) or not kv_bounds.is_contiguous():
@@ -456,6 +485,7 @@ def forward(
   p.philox_seed = int(philox_seed) & 0xFFFFFFFFFFFFFFFF
   p.philox_offset = int(philox_offset) & 0xFFFFFFFFFFFFFFFF
 
+  tickets = None
   with torch.cuda.device(q.device):
     ws_bytes = lib.ffpa_attn_fwd_workspace_bytes(ctypes.byref(p)) if num_splits != 1 else 0
     workspace = None
@@ -468,7 +498,9 @@ def forward(
       if merge_in_launch and hasattr(lib, "ffpa_attn_fwd_split_tickets"):
         n_tickets = lib.ffpa_attn_fwd_split_tickets(ctypes.byref(p))
         if n_tickets:
-          p.split_tickets = _split_tickets(q.device, torch.cuda.current_stream(q.device).cuda_stream, n_tickets).data_ptr()
+          # (held in a local until the launch below has been enqueued: under stream capture this is a fresh tensor of the graph's pool)
+          tickets = _split_tickets(q.device, torch.cuda.current_stream(q.device).cuda_stream, n_tickets)
+          p.split_tickets = tickets.data_ptr()
     if plan_out is not None:
       plan = (ctypes.c_int * 4)()
       if lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0:
@@ -479,7 +511,10 @@ def forward(
     stream = torch.cuda.current_stream(q.device).cuda_stream
     rc = lib.ffpa_attn_fwd(ctypes.byref(p), ctypes.c_void_p(stream))
   if rc != 0:
+    if tickets is not None:
+      tickets.zero_()  # a launch that did not complete may have left counters behind: the next call must start from zeros
     raise _STATUS_EXC.get(rc, RuntimeError)(f"ffpa_attn_fwd: {lib.ffpa_attn_last_error().decode()} (status {rc})")
+  del tickets
   if packed:
     o = o.view(*out_shape, Dp)
     lse = lse.view(out_shape) if lse is not None else None

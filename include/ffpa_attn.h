@@ -180,8 +180,10 @@ int ffpa_attn_fwd(const ffpa_fwd_params* params, void* stream);
 size_t ffpa_attn_fwd_workspace_bytes(const ffpa_fwd_params* params);
 
 /*
- * Number of int32 counters ffpa_fwd_params.split_tickets must hold for this call (one per (batch, head); 0 when the
- * call is not a KV-split short-query launch).
+ * Number of int32 counters ffpa_fwd_params.split_tickets must hold for this call (one per (batch, query head, row
+ * tile): batch * heads_q * ceil(seqlen_q / block rows) — a short-query launch has one row tile per head today, the count does not
+ * rely on it; 0 when the call is not a KV-split short-query launch).  The kernel leaves every counter at zero when the launch
+ * completes; after a launch that failed or faulted the caller must zero the buffer again before reusing it.
  */
 size_t ffpa_attn_fwd_split_tickets(const ffpa_fwd_params* params);
 

@@ -78,6 +78,15 @@ case("bad_backend_str", (1, 8, 1024, 512), (1, 8, 1024, 512), backend="nope")
 case("bad_backend_type", (1, 8, 1024, 512), (1, 8, 1024, 512), forward_backend=3)
 case("sdpa_backend", (1, 8, 1024, 512), (1, 8, 1024, 512), backend="sdpa")
 case("fwd_sdpa_backend", (1, 8, 1024, 512), (1, 8, 1024, 512), forward_backend="sdpa")
+# backend-name contracts: the reference's CUDABackend is forward-only — CUDABackend() / backend="cuda" / backward_backend="cuda" trip its
+# assertion (functional.py:266-268 with Backend.__post_init__ :189-196); forward_backend="cuda" is the supported spelling (:501-502)
+case("backend_cuda_str", (1, 8, 1024, 512), (1, 8, 1024, 512), backend="cuda")
+case("fwd_backend_cuda_str", (1, 8, 1024, 512), (1, 8, 1024, 512), forward_backend="cuda")
+case("bwd_backend_cuda_str", (1, 8, 1024, 512), (1, 8, 1024, 512), backward_backend="cuda")
+case("fwd_cuda_bwd_sdpa", (1, 8, 1024, 512), (1, 8, 1024, 512), forward_backend="cuda", backward_backend="sdpa")
+case("backend_triton_str", (1, 8, 1024, 512), (1, 8, 1024, 512), backend="triton")
+case("fwd_backend_triton_str", (1, 8, 1024, 512), (1, 8, 1024, 512), forward_backend="triton")
+case("bwd_backend_sdpa_str", (1, 8, 1024, 512), (1, 8, 1024, 512), backward_backend="sdpa")
 case("batch_mismatch", (2, 8, 1024, 512), (1, 8, 1024, 512))
 case("headdim_mismatch", (1, 8, 1024, 512), (1, 8, 1024, 512), v=(1, 8, 1024, 256))
 

@@ -326,3 +326,56 @@ def test_bool_and_key_bias_masks_on_the_short_query_path(hip):
     ob2, _ = hip.forward(q, k, v, full, False, D ** -0.5)
     oa2, _ = hip.forward(q, k, v, _additive(full, q.dtype), False, D ** -0.5, flags=hip.FLAG_NO_BIAS_LDS)
     assert _same_bits(ob2, oa2)
+
+
+def test_mask_created_under_inference_mode(hip, monkeypatch):
+  """Masks built inside torch.inference_mode() (the usual serving path) have no version counter: reading `_version` raises.  The range
+  scan must serve them with the cache on as well as off (round-3 advisor finding: the default-on cache crashed here)."""
+  from ffpa_attn_amd import ffpa_attn_func
+
+  B, H, N, D = 1, 4, 1024, 512
+  q, k, v = _rand((B, H, N, D), seed=81), _rand((B, H, N, D), seed=82), _rand((B, H, N, D), seed=83)
+  ref = F.scaled_dot_product_attention(q, k, v, is_causal=True)
+  for cache in ("0", "1"):
+    monkeypatch.setenv("FFPA_HIP_MASK_BOUNDS_CACHE", cache)
+    with torch.inference_mode():
+      mask = torch.ones(N, N, dtype=torch.bool, device="cuda").tril()
+      out = ffpa_attn_func(q, k, v, attn_mask=mask)
+      out2 = ffpa_attn_func(q, k, v, attn_mask=mask)
+    assert torch.equal(out, out2)
+    _within_north_star(out, ref)
+
+
+def test_mask_range_cache_is_opt_in_and_follows_the_version_counter(hip, monkeypatch):
+  """Default: every call scans the mask, so a write torch's version counter does not see (`mask.data`) is honoured.  Opt-in cache
+  (FFPA_HIP_MASK_BOUNDS_CACHE=1): one scan per (tensor, version); an in-place torch write invalidates the entry; a consumer on
+  another stream is ordered behind the scan's event."""
+  B, H, N, D = 1, 2, 1024, 512
+  q, k, v = _rand((B, H, N, D), seed=84), _rand((B, H, N, D), seed=85), _rand((B, H, N, D), seed=86)
+  half = torch.zeros(1, 1, N, N, dtype=torch.bool, device="cuda")
+  half[..., : N // 2] = True
+  full = torch.ones(1, 1, N, N, dtype=torch.bool, device="cuda")
+  o_half, _ = hip.forward(q, k, v, half, False, D ** -0.5, kv_bounds=False)
+  o_full, _ = hip.forward(q, k, v, full, False, D ** -0.5, kv_bounds=False)
+
+  monkeypatch.delenv("FFPA_HIP_MASK_BOUNDS_CACHE", raising=False)
+  m = half.clone()
+  assert torch.equal(hip.forward(q, k, v, m, False, D ** -0.5, kv_bounds=True)[0], o_half)
+  m.data.fill_(True)  # invisible to the version counter
+  assert torch.equal(hip.forward(q, k, v, m, False, D ** -0.5, kv_bounds=True)[0], o_full)
+
+  monkeypatch.setenv("FFPA_HIP_MASK_BOUNDS_CACHE", "1")
+  hip._BOUNDS_CACHE.clear()
+  m = half.clone()
+  assert torch.equal(hip.forward(q, k, v, m, False, D ** -0.5, kv_bounds=True)[0], o_half)
+  assert len(hip._BOUNDS_CACHE) == 1
+  first = next(iter(hip._BOUNDS_CACHE.values()))[2]
+  assert hip.cached_mask_kv_bounds(m, N, N) is first  # served from the cache
+  side = torch.cuda.Stream()
+  with torch.cuda.stream(side):  # another stream: waits for the producer's event, same numbers
+    o_side, _ = hip.forward(q, k, v, m, False, D ** -0.5, kv_bounds=True)
+  side.synchronize()
+  assert torch.equal(o_side, o_half)
+  m.fill_(True)  # a torch in-place write: the counter moves, the entry is dropped
+  assert torch.equal(hip.forward(q, k, v, m, False, D ** -0.5, kv_bounds=True)[0], o_full)
+  hip._BOUNDS_CACHE.clear()

@@ -76,6 +76,12 @@ def test_backend_objects_and_aliases():
   with pytest.raises(NotImplementedError):
     CUDABackend(forward=True, enable_fp8=True)
   assert TritonBackend(forward=True).backward is False
+  # the reference's CUDA backend is forward-only (functional.py:266-268): its default construction asserts
+  with pytest.raises(AssertionError, match="cuda backend does not support backward"):
+    CUDABackend()
+  with pytest.raises(AssertionError, match="cuda backend does not support backward"):
+    CUDABackend(backward=True)
+  assert CUDABackend(forward=True).backward is False and CUDABackend(backward=False).forward is True
 
 
 def test_small_d_opt_in_env(monkeypatch):

@@ -118,3 +118,27 @@ def test_bench_takes_the_kernel_name_from_the_library_not_from_a_copy_of_the_dis
   assert not hasattr(bench, "dominant_kernel")
   src = open(os.path.join(root, "bench.py")).read()
   assert 'plan.get("kernel")' in src and "ffpa_fwd_m16_kernel" not in src and "ffpa_fwd_split_d_kernel" not in src
+
+
+def test_tensor_version_probe_handles_inference_tensors():
+  """hip._tensor_version: torch's in-place counter, None for tensors that do not track one (reading `_version` of an inference
+  tensor raises) — the mask-range cache never keys on those."""
+  import torch
+  from ffpa_attn_amd import hip
+
+  t = torch.ones(4, dtype=torch.bool)
+  v0 = hip._tensor_version(t)
+  t.fill_(False)
+  assert hip._tensor_version(t) == v0 + 1
+  with torch.inference_mode():
+    m = torch.ones(4, dtype=torch.bool)
+  assert hip._tensor_version(m) is None
+  assert not hip._mask_bounds_cache_enabled() or True  # (env-dependent: only the call must not raise)
+
+
+def test_package_version_matches_the_library():
+  import ffpa_attn_amd
+  from ffpa_attn_amd import hip
+
+  lib = hip.load_library()
+  assert lib.ffpa_attn_version().decode().split()[1] == ffpa_attn_amd.__version__
