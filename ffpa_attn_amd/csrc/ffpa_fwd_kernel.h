@@ -1514,7 +1514,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
           else *(f32x4*)(wp + db * 32 + 8 * i) = w;
         }
       if (h == 0 && dh == 0) {
-        const float lse_part = dead ? -INFINITY : __logf(l_tot) + m_run * 0.6931471805599453f;
+        const float lse_part = dead ? -INFINITY : __builtin_fmaf(m_run, 0.6931471805599453f, __logf(l_tot));  // (explicit: see ffpa_fwd_m16_kernel.h)
         if (a.tickets != nullptr) __hip_atomic_store(&a.ws_lse[prow], lse_part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else a.ws_lse[prow] = lse_part;
       }
@@ -1546,7 +1546,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
         }
       if (a.lse != nullptr && h == 0 && dh == 0) {
         // natural-log LSE = ln(l) + m*ln2 (prefill.cuh:1063-1073)
-        a.lse[((int64_t)b * a.Hq + hq) * a.Nq + qrow] = __logf(l_tot) + m_run * 0.6931471805599453f;
+        a.lse[((int64_t)b * a.Hq + hq) * a.Nq + qrow] = __builtin_fmaf(m_run, 0.6931471805599453f, __logf(l_tot));
       }
     }
   }

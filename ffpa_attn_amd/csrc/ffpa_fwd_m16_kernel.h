@@ -88,6 +88,83 @@
 #ifndef FFPA_M16_K_PRE_ND2
 #define FFPA_M16_K_PRE_ND2 64  // ditto for the split-D tiles (D > 512; clamped to the tile's pieces: all of K(j+1) goes out between the softmax stages)
 #endif
+// ---- split-D tiles (D > 512), round 4: the K tile in two 16-key halves.  QK^T walks key block 0 over all of its D-half first, then key
+// block 1, with a fourth workgroup barrier (M) in between: barrier B then only needs K1(j+1) = keys 0 .. 15 of the next tile, K2(j+1) may
+// still be in flight until barrier M of step j + 1 — so K pieces can be issued under the PV MFMAs (the one phase whose texture addresser
+// sat idle) and K1(j+1) already under the second half of QK^T(j), whose K1(j) rows are free behind barrier M.  The schedule is a table of
+// piece counts per phase, in sixteenths of a wave's pieces per tile image (PPW; the last entry of each stream takes the remainder):
+//   V(j):    FFPA_M16_KS_VA in QK^T half 1, _VB in half 2, rest between the softmax stages (first there: it is awaited at barrier A2)
+//   K1(j+1): FFPA_M16_KS_K1B in QK^T half 2, _K1C between the softmax stages, rest at the front of the PV loop (awaited at barrier B)
+//   K2(j+1): FFPA_M16_KS_K2C between the softmax stages (last there), rest in the PV loop behind K1's (awaited at barrier M of step j + 1)
+// Every counted wait is derived from the table (loads retire in order: the wait at a barrier leaves exactly the pieces issued behind the
+// last one it needs).  0 = the round-3 schedule (three barriers, all of K(j+1) between the softmax stages).
+#ifndef FFPA_M16_KSPLIT
+#define FFPA_M16_KSPLIT 0
+#endif
+#ifndef FFPA_M16_KS_VA
+#define FFPA_M16_KS_VA 8
+#endif
+#ifndef FFPA_M16_KS_VB
+#define FFPA_M16_KS_VB 8
+#endif
+#ifndef FFPA_M16_KS_K1B
+#define FFPA_M16_KS_K1B 0
+#endif
+#ifndef FFPA_M16_KS_K1C
+#define FFPA_M16_KS_K1C 8
+#endif
+#ifndef FFPA_M16_KS_K2C
+#define FFPA_M16_KS_K2C 0
+#endif
+// ---- split-D tiles (D > 512), round 4, second step: the SOFTMAX PIPELINE.  With the K tile in two 16-key halves (above), key block 0 of tile
+// j + 1 can be contracted while the softmax of tile j runs: the step becomes
+//     Q: QK^T(j) key block 1                         | DMA: K1(j+2) rest, V(j) first part
+//     barrier A1 (partial S^T of block 1 visible, K2(j) rows free, K1(j+1) landed)
+//     S: softmax(j), one small group of VALU instructions in every gap of the 32 MFMAs of QK^T(j+1) key block 0   | DMA: V(j) rest, K2(j+1) first part
+//     barrier A2 (V(j) landed, K1(j+1) rows free)
+//     P: PV(j)                                       | DMA: K2(j+1) rest, K1(j+2) first part
+//     barrier B (V(j) rows free, K2(j+1) landed)
+// — three barriers again, the latency chain of the softmax (partial-S exchange, row max over four lanes, exponentials: ~ 800 cycles during
+// which the matrix core idled) covered by 512 cycles of MFMA work, and every DMA stream has two phases to be issued in.  The partial S^T of
+// block 0 is published one step early, so its exchange area is double-buffered (6 KiB per wave instead of 4).  Piece counts per phase in
+// sixteenths of a wave's pieces per tile image: FFPA_M16_PP_VQ (V pieces in Q; the rest in S), _K1Q (K1 pieces in Q; the rest in the P phase
+// before), _K2S (K2 pieces in S; the rest in P).  Builds: no additive bias, no dropout (MK 0); D % 128 == 0.
+// Measured (config 3, B1 H32 N8192 D1024, interleaved A/B on one box, outputs bit-identical; profiles/r04_pipe.txt): round-3 loop 945 ... 975 TFLOPS,
+// two-half K alone (FFPA_M16_KSPLIT, best table) + 3.9 %, the pipeline + 6.2 ... 6.6 % (VQ / K1Q / K2S = 6 / 2 / 2, three K fragments ahead in S;
+// 7 / 1 / 1: + 5 %, 8 / 0 / 0: + 4.2 %, 10 / 1 / 1: + 1.8 %); D = 640 / 768 / 896: + 4.4 / + 7.6 / + 3.4 %, causal + 4.7 %, Nq 1024 + 9.9 %, 32k keys + 3.5 %.
+#ifndef FFPA_M16_PIPE
+#define FFPA_M16_PIPE 1
+#endif
+#ifndef FFPA_M16_PP_VQ
+#define FFPA_M16_PP_VQ 6
+#endif
+#ifndef FFPA_M16_PP_K1Q
+#define FFPA_M16_PP_K1Q 2
+#endif
+#ifndef FFPA_M16_PP_K2S
+#define FFPA_M16_PP_K2S 2
+#endif
+#ifndef FFPA_M16_PP_QSTEP
+#define FFPA_M16_PP_QSTEP 1  // one piece every this many fragments from the phase's start (0: spread evenly over the phase)
+#endif
+#ifndef FFPA_M16_PP_SSTEP
+#define FFPA_M16_PP_SSTEP 1
+#endif
+#ifndef FFPA_M16_PP_PSTEP
+#define FFPA_M16_PP_PSTEP 2
+#endif
+#ifndef FFPA_M16_PP_PF
+#define FFPA_M16_PP_PF 3  // K fragments requested ahead of their MFMAs in the S phase (the softmax's registers are live next to them)
+#endif
+#ifndef FFPA_M16_PIECE_IL
+// which 1 KiB pieces of a tile image a wave stages (the per-lane-offset form: every build but D = 512 with a mask path):
+// 0 = a contiguous quarter of the image (wave w: pieces w PPW .. + PPW; the four waves' simultaneous requests lie a quarter image apart),
+// 1 = interleaved (wave w: pieces w, w + 4, w + 8, ..: the four waves' simultaneous requests are 4 KiB of consecutive image bytes)
+#define FFPA_M16_PIECE_IL 0
+#endif
+#ifndef FFPA_M16_KS_PVSTEP
+#define FFPA_M16_KS_PVSTEP 0  // PV loop: one K piece every this many V^T fragments from the loop's start (0: spread evenly over the loop)
+#endif
 
 
 // Developer instrumentation (-DFFPA_M16_TIMING, tools/gpu_phase_times.py; never in the shipped build): every wave accumulates the shader
@@ -115,6 +192,19 @@ constexpr int m16_block_keys(int D, bool bias_build) {
   return D > 512 ? 32 : ((!bias_build && D >= FFPA_M16_BC128_MIN_D && D <= FFPA_BC128_MAX_D) ? 128 : 64);
 }
 
+// Bytes of the partial-S^T exchange area behind the two tile images of the split-D tiles (D > 512): 4 KiB per wave; 6 KiB in the builds without
+// an additive bias, whose softmax pipeline publishes key block 0 one step early into a double-buffered half (FFPA_M16_PIPE; reserved whether or
+// not the build is pipelined, so that the launch side needs to know the mask kind only).
+constexpr int m16_exchange_bytes(int D, bool bias_build) { return D > 512 ? (bias_build ? 4 * 4096 : 4 * 6144) : 0; }
+
+// Two-half K schedule (FFPA_M16_KSPLIT): which of `cnt` pieces, if any, rides on fragment n of a loop of N fragments — piece t sits on
+// fragment t * step (step > 0: front-loaded) or floor(t N / cnt) (step == 0: spread evenly); -1 = none.
+constexpr int m16_piece_at(int n, int N, int cnt, int step) {
+  for (int t = 0; t < cnt; ++t)
+    if ((step > 0 ? t * step : (t * N) / cnt) == n) return t;
+  return -1;
+}
+
 // The MFMAs are inline asm: the S^T accumulators must be VGPRs and the O^T tiles exactly the 256 AGPRs, in place (left to hipcc,
 // parts of O^T end up in VGPRs and the Q fragments in scratch); first / acc: S^T (VGPR form), acc_a: O^T (AGPR form).  The
 // operands come from ds_read / global loads / v_cvt long before: tools/check_mfma_hazards.py checks the generated ISA.
@@ -126,6 +216,12 @@ struct Mfma16<__bf16> {
   static __device__ __forceinline__ void first(f32x4& d, v8 a, v8 b) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b)); }
   static __device__ __forceinline__ void acc(f32x4& d, v8 a, v8 b) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b)); }
   static __device__ __forceinline__ void acc_a(f32x4& d, v8 a, v8 b) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b)); }
+  // the LAST MFMA of a pair of accumulator chains, with the MFMA-result -> VALU-reader wait states in the same statement: `other` (the chain
+  // that ended one MFMA earlier) is an operand too, so nothing the compiler emits — a register copy for a loop-carried value included — can read
+  // either accumulator before the pad (a separate pad statement does not bind the copies hipcc places in front of it)
+  static __device__ __forceinline__ void acc_last(f32x4& d, f32x4& other, v8 a, v8 b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n\ts_nop 15\n\ts_nop 3" : "+v"(d), "+v"(other) : "v"(a), "v"(b));
+  }
 };
 template <>
 struct Mfma16<_Float16> {
@@ -133,6 +229,9 @@ struct Mfma16<_Float16> {
   static __device__ __forceinline__ void first(f32x4& d, v8 a, v8 b) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b)); }
   static __device__ __forceinline__ void acc(f32x4& d, v8 a, v8 b) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b)); }
   static __device__ __forceinline__ void acc_a(f32x4& d, v8 a, v8 b) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b)); }
+  static __device__ __forceinline__ void acc_last(f32x4& d, f32x4& other, v8 a, v8 b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %2, %3, %0\n\ts_nop 15\n\ts_nop 3" : "+v"(d), "+v"(other) : "v"(a), "v"(b));
+  }
 };
 
 // A query row lives in the 4 lanes n, n + 16, n + 32, n + 48, and every lane carries a value for two rows (n and 16 + n).
@@ -183,7 +282,8 @@ __device__ __forceinline__ int m16_v_swizzle(int key) {
 #ifdef FFPA_PRODUCT_BUILD
 #if FFPA_ABL != 0 || FFPA_SQ_BC64 != 1 || defined(FFPA_M16_TIMING) || FFPA_PERSISTENT != 0 || FFPA_M16_ROWDMA != 1 || FFPA_M16_PF1 != 6 || FFPA_M16_PF2 != 4 || \
     FFPA_M16_K_PRE != 8 || FFPA_M16_K_PRE_ND2 != 64 || FFPA_M16_DEPHASE != 0 || FFPA_M16_PF_DIST != 2 || FFPA_M16_PF_WAVES != 2 || FFPA_M16_PF_WHICH != 3 || (defined(FFPA_M16_PF_ALL_D) && FFPA_M16_PF_ALL_D != 0) || FFPA_M16_ROW_TABLES != 1 || FFPA_DMA_M0_CLOBBER != 1 || FFPA_M16_SWAP_REDUCE != 1 || FFPA_M16_MIN_D != 128 || FFPA_M16_BC128_MIN_D != 256 || \
-    (defined(FFPA_M16_PHILOX_ILP) && FFPA_M16_PHILOX_ILP != 1)
+    (defined(FFPA_M16_PHILOX_ILP) && FFPA_M16_PHILOX_ILP != 1) || FFPA_M16_KSPLIT != 0 || FFPA_M16_PIPE != 1 || FFPA_M16_PP_VQ != 6 || FFPA_M16_PP_K1Q != 2 || FFPA_M16_PP_K2S != 2 || \
+    FFPA_M16_PP_QSTEP != 1 || FFPA_M16_PP_SSTEP != 1 || FFPA_M16_PP_PSTEP != 2 || FFPA_M16_PP_PF != 3 || FFPA_M16_PIECE_IL != 0 || FFPA_M16_KS_PVSTEP != 0
 #error "FFPA_PRODUCT_BUILD: a developer switch is not at its shipped default"
 #endif
 #endif
@@ -227,6 +327,33 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   constexpr int kPre = ((kPreReq < PPW ? kPreReq : PPW) / 4) * 4;
   constexpr int N1 = KS * NKB;   // K fragments per tile
   constexpr int N2 = NDB * NKS;  // V^T fragments per tile
+  // the two-half K schedule of the split-D tiles (see FFPA_M16_KSPLIT above): needs an even number of pieces per wave (D % 128 == 0)
+  constexpr bool kKS = ND == 2 && (FFPA_M16_KSPLIT != 0 || (FFPA_M16_PIPE != 0 && MK == 0 && !DROP)) && PPW % 2 == 0 && NKB == 2;
+  constexpr int kH = PPW / 2;  // K1 / K2 pieces per wave
+  constexpr int ksVA = PPW * FFPA_M16_KS_VA / 16, ksVB = PPW * FFPA_M16_KS_VB / 16, ksVC = PPW - ksVA - ksVB;
+  constexpr int ksK1B = PPW * FFPA_M16_KS_K1B / 16, ksK1C = PPW * FFPA_M16_KS_K1C / 16, ksK1D = kH - ksK1B - ksK1C;
+  constexpr int ksK2C = PPW * FFPA_M16_KS_K2C / 16, ksK2D = kH - ksK2C;
+  static_assert(!kKS || (ksVA >= 0 && ksVB >= 0 && ksVC >= 0 && ksK1B >= 0 && ksK1C >= 0 && ksK1D >= 0 && ksK2C >= 0 && ksK2D >= 0), "piece counts per phase");
+  static_assert(!kKS || (ksVA <= KS && ksVB + ksK1B <= KS && ksK1D + ksK2D <= N2), "at most one piece per fragment");
+  // the softmax pipeline of the split-D tiles (see FFPA_M16_PIPE above); it uses the two-half K piece map
+  constexpr bool kPipe = ND == 2 && FFPA_M16_PIPE != 0 && PPW % 2 == 0 && NKB == 2 && MK == 0 && !DROP;
+  constexpr int ppVQ = PPW * FFPA_M16_PP_VQ / 16, ppVS = PPW - ppVQ;     // V(j): in Q(j), in S(j)
+  constexpr int ppK1Q = PPW * FFPA_M16_PP_K1Q / 16, ppK1P = kH - ppK1Q;  // K1(j+1): in P(j-1) (first), in Q(j) (rest)
+  constexpr int ppK2S = PPW * FFPA_M16_PP_K2S / 16, ppK2P = kH - ppK2S;  // K2(j+1): in S(j) (first), in P(j) (rest)
+  static_assert(!kPipe || (ppVQ >= 0 && ppVS >= 0 && ppK1Q >= 0 && ppK1P >= 0 && ppK2S >= 0 && ppK2P >= 0), "piece counts per phase");
+  static_assert(!kPipe || (ppVQ + ppK1Q <= KS && ppVS + ppK2S <= KS && ppK2P + ppK1P <= N2), "at most one piece per fragment");
+  // counted waits: order of issue inside a step — Q: K1 rest, V first; S: V rest, K2 first; P: K2 rest, K1 first (of the tile after next), touch
+  constexpr int ppWaitA1 = ppVQ + (ppK1Q > 0 ? 0 : 0);  // K1(j+1) has landed: the V pieces of Q(j) stay in flight (+ the touch when K1Q == 0)
+  constexpr int ppWaitA2 = ppK2S;                       // V(j) has landed
+  constexpr int ppWaitB = ppK1P;                        // K2(j+1) has landed (+ the touch)
+  constexpr bool kIL = FFPA_M16_PIECE_IL != 0;  // interleaved piece -> wave map (per-lane-offset form)
+  constexpr int kPStride = kIL ? 4 : 1;         // KiB between two consecutive pieces of one wave in the LDS image
+  constexpr int ksNC = ksVC + ksK1C + ksK2C;  // pieces between the softmax stages
+  constexpr int ksND = ksK1D + ksK2D;         // pieces in the PV loop
+  // counted waits (pieces issued behind the last one the barrier needs; + 1 when the wave also carries a look-ahead touch)
+  constexpr int ksWaitA2 = (ksVC > 0 ? 0 : ksK1B) + ksK1C + ksK2C;                                              // V(j) has landed
+  constexpr int ksWaitB = ksK1D > 0 ? ksK2D : (ksK1C > 0 ? ksK2C + ksK2D : ksVC + ksK2C + ksK2D);             // K1(j+1) has landed (+ touch)
+  constexpr int ksWaitM = (ksK2D > 0 ? 0 : ksK1D) + ksVA;                                                      // K2(j) has landed (+ touch)
 #ifndef FFPA_M16_STEP1_DIV
 #define FFPA_M16_STEP1_DIV 1  // (experiments) > 1: the V pieces go out that much denser, in the front part of the QK^T loop
 #endif
@@ -248,8 +375,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   FFPA_LDS char* const Kt = (FFPA_LDS char*)smem;
   FFPA_LDS char* const Vt = Kt + TILE;
-  FFPA_LDS char* const Xb = Kt + 2 * TILE;  // ND == 2: partial-S exchange, 4 KiB per wave
-  FFPA_LDS char* const Bl = Kt + 2 * TILE + (ND > 1 ? 4 * 4096 : 0);  // key-bias row cache (FwdArgs.bias_lds bytes, when enabled)
+  FFPA_LDS char* const Xb = Kt + 2 * TILE;  // ND == 2: partial-S exchange, 4 KiB per wave (6 KiB in the builds without an additive bias)
+  FFPA_LDS char* const Bl = Kt + 2 * TILE + m16_exchange_bytes(D, kBias);  // key-bias row cache (FwdArgs.bias_lds bytes, when enabled)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -320,18 +447,24 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     constexpr int SPR = D / 8;  // 16-byte slots per row
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-      const int g = (wave * PPW + i) * 64 + lane;
+      const int g = (kIL ? i * 4 + wave : wave * PPW + i) * 64 + lane;
       const int key = g / SPR;
       const int slot = g - key * SPR;
-      const int ks = slot ^ m16_k_swizzle<D>(key), vs = slot ^ m16_v_swizzle<D>(key);
-      krel[i] = (uint32_t)key * k_row_bytes + (uint32_t)(ks << 4);
-      if (ks >= slots_valid) krel[i] = kDmaOob;
+      const int vs = slot ^ m16_v_swizzle<D>(key);
       vrel[i] = (uint32_t)key * v_row_bytes + (uint32_t)(vs << 4);
       if (vs >= slots_valid) vrel[i] = kDmaOob;  // (V too: O^T columns past the head dim stay exact zeros)
+      // K: the same pieces, or (two-half schedule) this wave's pieces i < PPW / 2 from the first 16 keys and the rest from the last 16:
+      // piece i of wave w is piece w PPW/2 + i of K1 (the image's first 2 PPW KiB), resp. w PPW/2 + i - PPW/2 of K2
+      const int gk = kKS ? ((i < kH ? (kIL ? i * 4 + wave : wave * kH + i) : 2 * PPW + (kIL ? (i - kH) * 4 + wave : wave * kH + (i - kH))) * 64 + lane) : g;
+      const int kkey = gk / SPR;
+      const int kslot = gk - kkey * SPR;
+      const int ks = kslot ^ m16_k_swizzle<D>(kkey);
+      krel[i] = (uint32_t)kkey * k_row_bytes + (uint32_t)(ks << 4);
+      if (ks >= slots_valid) krel[i] = kDmaOob;
     }
     // this wave's pieces land at base + i KiB: one scalar base per tile image, the piece index is an immediate of the DMA asm
-    k_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(uintptr_t)Kt + (uint32_t)(wave * PPW * 1024)));
-    v_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(uintptr_t)Vt + (uint32_t)(wave * PPW * 1024)));
+    k_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(uintptr_t)Kt + (uint32_t)(wave * (kIL ? 1 : (kKS ? kH : PPW)) * 1024)));
+    v_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(uintptr_t)Vt + (uint32_t)(wave * (kIL ? 1 : PPW) * 1024)));
   }
   auto issue_k = [&](auto ic, int key0) {
     constexpr int i = decltype(ic)::value;
@@ -340,7 +473,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       if constexpr (FFPA_M16_ROW_TABLES != 0) lds_dma_row<(16 * (i >> 2) + (i & 3)) * RB, 0>(ts.rsrc, k_lds, kvo[i & 3], kro[i]);
       else lds_dma_row_at<(16 * (i >> 2) + (i & 3)) * RB, 16 * (i >> 2) + (i & 3)>(ts.rsrc, k_lds, kvo[i & 3], k_row_bytes, k_wave_off);
     } else {
-      lds_dma_16_at<i * 1024>(ts.rsrc, k_lds, krel[i], 0u);
+      lds_dma_16_at<(kKS && i >= kH ? 2 * PPW + (i - kH) * kPStride : i * kPStride) * 1024>(ts.rsrc, k_lds, krel[i], 0u);
     }
   };
   auto issue_v = [&](auto ic, int key0) {
@@ -350,7 +483,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       if constexpr (FFPA_M16_ROW_TABLES != 0) lds_dma_row<(16 * (i >> 2) + (i & 3)) * RB, 0>(ts.rsrc, v_lds, vvo[i & 3], vro[i]);
       else lds_dma_row_at<(16 * (i >> 2) + (i & 3)) * RB, 16 * (i >> 2) + (i & 3)>(ts.rsrc, v_lds, vvo[i & 3], v_row_bytes, v_wave_off);
     } else {
-      lds_dma_16_at<i * 1024>(ts.rsrc, v_lds, vrel[i], 0u);
+      lds_dma_16_at<i * kPStride * 1024>(ts.rsrc, v_lds, vrel[i], 0u);
     }
   };
 
@@ -605,10 +738,253 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     }
   };
 #ifdef FFPA_M16_TIMING
-  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (6, 7: two-half K schedule — QK^T key block 0, wait at barrier M)
   unsigned long long tprev = __builtin_amdgcn_s_memtime();
   const unsigned long long tstart = tprev;
 #endif
+  if constexpr (kPipe) {
+    // =====================================================================================================================================
+    // The softmax pipeline of the split-D tiles (FFPA_M16_PIPE; header comment at the macro).  Same arithmetic as the loop below, instruction
+    // for instruction per score — only WHEN each part runs differs: bit-identical outputs (tests/test_m16_gpu.py).
+    // =====================================================================================================================================
+    constexpr int kXW = 6144;  // exchange bytes per wave: block 0 of even tiles, block 0 of odd tiles, block 1
+    constexpr int PFS = FFPA_M16_PP_PF;
+    auto k_frag_sk = [&](int s_, int kb_) -> v8 { return *(FFPA_LDS const v8*)(kaddr[kb_ / 4][s_ % KV] + (s_ / KV) * KVB + (kb_ % 4) * 16 * RB); };
+    FFPA_LDS char* const xw = Xb + wave * kXW + lane * 16;        // this wave's partials
+    FFPA_LDS const char* const xr = Xb + (wave ^ 1) * kXW + lane * 16;  // the other D-half's
+    if (nt > t0) {
+      f32x4 s0[2];  // partial S^T of key block 0 of the first tile (this wave's D-half); in the loop it is contracted one step early
+      // prologue: key block 0 of the first tile (K(t0) has landed and is visible: the barrier above)
+      v8 kf[KS];
+#pragma unroll
+      for (int n = 0; n < PF1 && n < KS; ++n) kf[n] = k_frag_sk(n, 0);
+      static_for<KS>([&](auto sc) {
+        constexpr int s_ = decltype(sc)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (s_ + PF1 < KS) kf[s_ + PF1] = k_frag_sk(s_ + PF1, 0);
+        static_assert(KS >= 2, "the last MFMA of a chain carries the wait states");
+        if constexpr (s_ == 0) {
+          M::first(s0[0], kf[s_], qf[s_][0]);
+          M::first(s0[1], kf[s_], qf[s_][1]);
+        } else {
+          M::acc(s0[0], kf[s_], qf[s_][0]);
+          if constexpr (s_ == KS - 1) M::acc_last(s0[1], s0[0], kf[s_], qf[s_][1]);
+          else M::acc(s0[1], kf[s_], qf[s_][1]);
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      *(FFPA_LDS f32x4*)(xw + (t0 & 1) * 2048) = s0[0];
+      *(FFPA_LDS f32x4*)(xw + (t0 & 1) * 2048 + 1024) = s0[1];
+      __syncthreads();  // every wave is done reading keys 0 .. 15 of K(t0): their rows take K1(t0 + 1)
+      static_for<ppK1P>([&](auto ic) { issue_k(ic, (t0 + 1) * BC); });
+      dma_wait_all();  // (once per workgroup: the counted waits of the loop assume a whole step's pieces behind these)
+    }
+    for (int j = t0; j < nt; ++j) {
+      const int k0 = j * BC;
+      // ================= Q: S^T key block 1 of tile j =================
+      f32x4 s1[2];
+      {
+        v8 kf[KS];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < PF1 && n < KS; ++n) kf[n] = k_frag_sk(n, 1);
+        static_for<KS>([&](auto sc) {
+          constexpr int s_ = decltype(sc)::value;
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (s_ + PF1 < KS) kf[s_ + PF1] = k_frag_sk(s_ + PF1, 1);
+          constexpr int t = m16_piece_at(s_, KS, ppK1Q + ppVQ, FFPA_M16_PP_QSTEP);
+          if constexpr (s_ == 0) M::first(s1[0], kf[s_], qf[s_][0]);
+          else M::acc(s1[0], kf[s_], qf[s_][0]);
+          if constexpr (t >= 0) {
+            if constexpr (t < ppK1Q) issue_k(std::integral_constant<int, ppK1P + t>{}, k0 + BC);  // K1(j+1), rest
+            else issue_v(std::integral_constant<int, t - ppK1Q>{}, k0);                           // V(j), first part
+          }
+          if constexpr (s_ == 0) M::first(s1[1], kf[s_], qf[s_][1]);
+          else if constexpr (s_ == KS - 1) M::acc_last(s1[1], s1[0], kf[s_], qf[s_][1]);
+          else M::acc(s1[1], kf[s_], qf[s_][1]);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        *(FFPA_LDS f32x4*)(xw + 4096) = s1[0];
+        *(FFPA_LDS f32x4*)(xw + 4096 + 1024) = s1[1];
+      }
+      FFPA_TSTAMP(0);  // QK^T key block 1 (+ partial S^T stores)
+      // barrier A1: partial S^T of block 1 visible; every wave done reading K2(j); K1(j+1) has landed everywhere
+      if constexpr (ppK1Q > 0) {
+        dma_wait_except<ppVQ>();
+      } else {
+        if (pf_on) dma_wait_except<ppVQ + 1>();
+        else dma_wait_except<ppVQ>();
+      }
+      __syncthreads();
+      FFPA_TSTAMP(1);  // K1(j+1) drain + wait at barrier A1
+
+      // ================= S: softmax of tile j in the gaps of S^T key block 0 of tile j + 1 =================
+      // (this wave's own block-0 partial of tile j comes back from LDS like the other D-half's: carried in registers across the step, hipcc
+      // keeps two sets and copies one into the other at the loop's end — a VALU read of an MFMA result placed inside its wait states)
+      f32x4 s0[2];  // partial S^T of key block 0 of tile j + 1
+      float x[NKB][2][4];
+      float tmax[2] = {0.f, 0.f};
+      float m_use[2] = {0.f, 0.f}, psum[2] = {0.f, 0.f};
+      v8 pf[NKS][2];
+      {
+        f32x4 tp[NKB][2], xc[2];
+        __builtin_amdgcn_sched_barrier(0);
+        xc[0] = *(FFPA_LDS const f32x4*)(xw + (j & 1) * 2048);
+        xc[1] = *(FFPA_LDS const f32x4*)(xw + (j & 1) * 2048 + 1024);
+        tp[0][0] = *(FFPA_LDS const f32x4*)(xr + (j & 1) * 2048);
+        tp[0][1] = *(FFPA_LDS const f32x4*)(xr + (j & 1) * 2048 + 1024);
+        tp[1][0] = *(FFPA_LDS const f32x4*)(xr + 4096);
+        tp[1][1] = *(FFPA_LDS const f32x4*)(xr + 4096 + 1024);
+        v8 kf[KS];
+#pragma unroll
+        for (int n = 0; n < PFS && n < KS; ++n) kf[n] = k_frag_sk(n, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool tail = k0 + BC > a.Nkv;
+        const bool diag = a.causal && ((int64_t)k0 + BC - 1 > (int64_t)(a.causal_row_mod ? 0 : wq0) + a.causal_offset);
+        // one group of the softmax's instructions per MFMA gap: g = 2 * fragment + (0: behind the first, 1: behind the second MFMA)
+        auto softmax_gap = [&](auto gc) __attribute__((always_inline)) {
+          constexpr int g = decltype(gc)::value;
+          if constexpr (g >= 3 && g <= 6) {  // + the other D-half's partial (a + b == b + a: both waves of a row block see bit-identical scores)
+            constexpr int kb = (g - 3) >> 1, rh = (g - 3) & 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[kb][rh][r] = (kb == 0 ? xc[rh][r] : s1[rh][r]) + tp[kb][rh][r];
+          } else if constexpr (g == 7) {
+            if (tail || diag) {
+#pragma unroll
+              for (int rh = 0; rh < 2; ++rh) {
+                const int crow = a.causal_row_mod ? qrow[rh] % a.causal_row_mod : qrow[rh];
+                const int64_t lim = a.causal ? (int64_t)crow + a.causal_offset : (int64_t)a.Nkv;
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + kb * 16 + 4 * c + r;
+                    if (key >= a.Nkv || key > lim) x[kb][rh][r] = -INFINITY;
+                  }
+              }
+            }
+          } else if constexpr (g == 8 || g == 9) {  // row max, this lane's 8 keys of row half g - 8 (same order as the loop below)
+            constexpr int rh = g - 8;
+            float t = x[0][rh][0];
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) t = fmaxf(t, x[kb][rh][r]);
+            tmax[rh] = t;
+          } else if constexpr (g == 10) {
+            row4_reduce2<true>(tmax[0], tmax[1]);
+            tmax[0] *= a.scale_log2;
+            tmax[1] *= a.scale_log2;
+          } else if constexpr (g == 12) {
+            const float m_new0 = fmaxf(m_run[0], tmax[0]), m_new1 = fmaxf(m_run[1], tmax[1]);
+            const bool grow0 = m_new0 > m_run[0] + a.thr, grow1 = m_new1 > m_run[1] + a.thr;
+            if (__any(grow0 || grow1)) {
+              const float alpha0 = grow0 ? __builtin_amdgcn_exp2f(m_run[0] - m_new0) : 1.f;
+              const float alpha1 = grow1 ? __builtin_amdgcn_exp2f(m_run[1] - m_new1) : 1.f;
+              if (j > t0) {
+#pragma unroll
+                for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                  for (int rh = 0; rh < 2; ++rh) {
+                    f32x4 t = oacc[i][rh];
+                    asm volatile("" : "+a"(t));
+                    t *= (rh ? alpha1 : alpha0);
+                    asm volatile("" : "+a"(t));
+                    oacc[i][rh] = t;
+                    __builtin_amdgcn_sched_barrier(0);
+                  }
+              }
+              l_run[0] *= alpha0;
+              l_run[1] *= alpha1;
+              m_run[0] = grow0 ? m_new0 : m_run[0];
+              m_run[1] = grow1 ? m_new1 : m_run[1];
+            }
+            m_use[0] = (m_run[0] == -INFINITY) ? 0.f : m_run[0];
+            m_use[1] = (m_run[1] == -INFINITY) ? 0.f : m_run[1];
+          } else if constexpr (g >= 14 && g <= 29) {  // one exponential per gap, row half by row half in the loop's order (the row sum adds up in that order)
+            constexpr int i = g - 14, rh = i >> 3, kb = (i >> 2) & 1, r = i & 3;
+            const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(x[kb][rh][r], a.scale_log2, -m_use[rh]));
+            psum[rh] += pv;
+            pf[kb >> 1][rh][4 * (kb & 1) + r] = (T)pv;
+          } else if constexpr (g == 30) {
+            l_run[0] += psum[0];
+            l_run[1] += psum[1];
+          }
+        };
+        // the 32 groups are written for the 32 MFMA gaps of D = 1024; a smaller head dim has 2 KS < 32 gaps and takes several groups per gap
+        auto softmax_gaps = [&](auto gc) __attribute__((always_inline)) {
+          constexpr int g = decltype(gc)::value;
+          constexpr int lo = (g * 32 + 2 * KS - 1) / (2 * KS), hi = ((g + 1) * 32 + 2 * KS - 1) / (2 * KS);
+          static_for<hi - lo>([&](auto uc) { softmax_gap(std::integral_constant<int, lo + decltype(uc)::value>{}); });
+        };
+        static_for<KS>([&](auto sc) {
+          constexpr int s_ = decltype(sc)::value;
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (s_ + PFS < KS) kf[s_ + PFS] = k_frag_sk(s_ + PFS, 0);
+          constexpr int t = m16_piece_at(s_, KS, ppVS + ppK2S, FFPA_M16_PP_SSTEP);
+          if constexpr (s_ == 0) M::first(s0[0], kf[s_], qf[s_][0]);
+          else M::acc(s0[0], kf[s_], qf[s_][0]);
+          if constexpr (t >= 0) {
+            if constexpr (t < ppVS) issue_v(std::integral_constant<int, ppVQ + t>{}, k0);  // V(j), rest
+            else issue_k(std::integral_constant<int, kH + (t - ppVS)>{}, k0 + BC);        // K2(j+1), first part
+          }
+          softmax_gaps(std::integral_constant<int, 2 * s_>{});
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (s_ == 0) M::first(s0[1], kf[s_], qf[s_][1]);
+          else if constexpr (s_ == KS - 1) M::acc_last(s0[1], s0[0], kf[s_], qf[s_][1]);
+          else M::acc(s0[1], kf[s_], qf[s_][1]);
+          softmax_gaps(std::integral_constant<int, 2 * s_ + 1>{});
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        *(FFPA_LDS f32x4*)(xw + ((j + 1) & 1) * 2048) = s0[0];
+        *(FFPA_LDS f32x4*)(xw + ((j + 1) & 1) * 2048 + 1024) = s0[1];
+      }
+
+      // ================= P: O^T += V^T.P^T =================
+      {
+        __builtin_amdgcn_sched_barrier(0);
+        FFPA_TSTAMP(2);  // softmax(j) + QK^T(j+1) key block 0
+        // barrier A2: V(j) has landed on every wave; every wave is done reading K1(j+1)'s rows ... no: done CONTRACTING them — they take K1(j+2)
+        dma_wait_except<ppWaitA2>();
+        __syncthreads();
+        FFPA_TSTAMP(3);  // V(j) drain + wait at barrier A2
+        v8 vf[N2];
+        auto v_frag = [&](int n) -> v8 {
+          const int db = n % NDB, ks = n / NDB;
+          FFPA_LDS const char* vp = vaddr[ks / 2][db % VV] + (db / VV) * VVB + (ks % 2) * 32 * RB;
+          const v4 lo = E::tr_read(vp);
+          const v4 hi = E::tr_read(vp + 16 * RB);
+          return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+#pragma unroll
+        for (int n = 0; n < PF2 && n < N2; ++n) vf[n] = v_frag(n);
+        static_for<N2>([&](auto ic) {
+          constexpr int n = decltype(ic)::value;
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (n + PF2 < N2) vf[n + PF2] = v_frag(n + PF2);
+          constexpr int t = m16_piece_at(n, N2, ppK2P + ppK1P, FFPA_M16_PP_PSTEP);
+          constexpr int db = n % NDB, ks = n / NDB;
+          M::acc_a(oacc[db][0], vf[n], pf[ks][0]);
+          if constexpr (t >= 0) {
+            if constexpr (t < ppK2P) issue_k(std::integral_constant<int, kH + ppK2S + t>{}, k0 + BC);  // K2(j+1), rest
+            else issue_k(std::integral_constant<int, t - ppK2P>{}, k0 + 2 * BC);                       // K1(j+2), first part
+          }
+          M::acc_a(oacc[db][1], vf[n], pf[ks][1]);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      FFPA_TSTAMP(4);  // PV loop
+      // barrier B: every wave is done reading V(j); K2(j+1) has landed and is visible (the K1(j+2) pieces behind it stay in flight)
+      if (pf_on) {  // (wave-uniform)
+        issue_prefetch(k0 + FFPA_M16_PF_DIST * BC);
+        dma_wait_except<ppWaitB + 1>();
+      } else {
+        dma_wait_except<ppWaitB>();
+      }
+      __syncthreads();
+      FFPA_TSTAMP(5);  // K2(j+1) drain + wait at barrier B
+    }
+  } else
   for (int j = t0; j < nt; ++j) {
     const int k0 = j * BC;
 
@@ -621,9 +997,16 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         const int s = n / NKB, kb = n % NKB;
         return *(FFPA_LDS const v8*)(kaddr[kb / 4][s % KV] + (s / KV) * KVB + (kb % 4) * 16 * RB);
       };
+      // (two-half K schedule: fragment index n = kb KS + s — key block 0 over the wave's whole D-half, barrier M, key block 1)
+      auto k_frag_sk = [&](int s, int kb) -> v8 { return *(FFPA_LDS const v8*)(kaddr[kb / 4][s % KV] + (s / KV) * KVB + (kb % 4) * 16 * RB); };
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (kKS) {
 #pragma unroll
-      for (int n = 0; n < PF1 && n < N1; ++n) kf[n] = k_frag(n);
+        for (int n = 0; n < PF1 && n < KS; ++n) kf[n] = k_frag_sk(n, 0);
+      } else {
+#pragma unroll
+        for (int n = 0; n < PF1 && n < N1; ++n) kf[n] = k_frag(n);
+      }
       __builtin_amdgcn_sched_barrier(0);  // (the first K fragments are on their way while the bias tile below is read and converted)
       if constexpr (kBias) {
         // the accumulators start from bias / softmax_scale (zeros where there is no bias): see the header
@@ -718,6 +1101,40 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         if constexpr (NKB == 4) asm volatile("" : "+v"(sacc[2][0]), "+v"(sacc[2][1]), "+v"(sacc[3][0]), "+v"(sacc[3][1]));
         asm volatile("s_nop 1" : "+v"(sacc[0][0]), "+v"(sacc[0][1]), "+v"(sacc[1][0]), "+v"(sacc[1][1]));
       }
+      if constexpr (kKS) {
+        static_for<2>([&](auto kbc) {
+          constexpr int kb = decltype(kbc)::value;
+          if constexpr (kb == 1) {
+            // barrier M: every wave is done reading keys 0 .. 15 of K(j) — their rows may take K1(j+1) — and K2(j) (issued during step
+            // j - 1's softmax / PV phases) has landed everywhere
+            __builtin_amdgcn_sched_barrier(0);
+            FFPA_TSTAMP(6);  // QK^T, key block 0
+            if (pf_on) dma_wait_except<ksWaitM + 1>();
+            else dma_wait_except<ksWaitM>();
+            __syncthreads();
+            FFPA_TSTAMP(7);  // K2(j) drain + wait at barrier M
+#pragma unroll
+            for (int n = 0; n < PF1 && n < KS; ++n) kf[KS + n] = k_frag_sk(n, 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          static_for<KS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            constexpr int n = kb * KS + s;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (s + PF1 < KS) kf[n + PF1] = k_frag_sk(s + PF1, kb);
+            constexpr int t = m16_piece_at(s, KS, kb == 0 ? ksVA : ksVB + ksK1B, 0);
+            if constexpr (s == 0 && !kBias) M::first(sacc[kb][0], kf[n], qf[s][0]);
+            else M::acc(sacc[kb][0], kf[n], qf[s][0]);
+            if constexpr (t >= 0) {
+              if constexpr (kb == 0) issue_v(std::integral_constant<int, t>{}, k0);
+              else if constexpr (t < ksVB) issue_v(std::integral_constant<int, ksVA + t>{}, k0);
+              else issue_k(std::integral_constant<int, t - ksVB>{}, k0 + BC);
+            }
+            if constexpr (s == 0 && !kBias) M::first(sacc[kb][1], kf[n], qf[s][1]);
+            else M::acc(sacc[kb][1], kf[n], qf[s][1]);
+          });
+        });
+      } else
       static_for<N1>([&](auto ic) {
         constexpr int n = decltype(ic)::value;
         __builtin_amdgcn_sched_barrier(0);
@@ -752,7 +1169,20 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 
     auto pre_k_group = [&](auto gc) __attribute__((always_inline)) {
       constexpr int g = decltype(gc)::value;
-      if constexpr (kPre >= 4) {
+      if constexpr (kKS) {
+        // group g of the ksNC pieces that go out between the softmax stages, in the order V(j) rest, K1(j+1), K2(j+1)
+        constexpr int lo = g * ksNC / 4, hi = (g + 1) * ksNC / 4;
+        if constexpr (hi > lo) {
+          __builtin_amdgcn_sched_barrier(0);
+          static_for<hi - lo>([&](auto ic) {
+            constexpr int t = lo + decltype(ic)::value;
+            if constexpr (t < ksVC) issue_v(std::integral_constant<int, ksVA + ksVB + t>{}, k0);
+            else if constexpr (t < ksVC + ksK1C) issue_k(std::integral_constant<int, ksK1B + (t - ksVC)>{}, k0 + BC);
+            else issue_k(std::integral_constant<int, kH + (t - ksVC - ksK1C)>{}, k0 + BC);
+          });
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else if constexpr (kPre >= 4) {
         __builtin_amdgcn_sched_barrier(0);
         static_for<kPre / 4>([&](auto ic) { issue_k(std::integral_constant<int, g * (kPre / 4) + decltype(ic)::value>{}, k0 + BC); });
         __builtin_amdgcn_sched_barrier(0);
@@ -956,7 +1386,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       FFPA_TSTAMP(2);  // softmax + the K(j+1) pieces issued inside it
       // barrier A2: V(j) has landed on every wave (all but the kPre younger K pieces have retired)
-      dma_wait_except<kPre>();
+      dma_wait_except<kKS ? ksWaitA2 : kPre>();
       __syncthreads();
       FFPA_TSTAMP(3);  // V(j) drain + wait at barrier A2
       dephase(std::integral_constant<int, 1>{});
@@ -977,13 +1407,16 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         constexpr int n = decltype(ic)::value;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (n + PF2 < N2) vf[n + PF2] = v_frag(n + PF2);
-        constexpr bool kPiece = n % kStep2 == 0 && n / kStep2 + kPre < PPW;
+        // (two-half K schedule: the ksND pieces of the PV loop — K1(j+1) rest first, then K2(j+1) rest — by m16_piece_at)
+        constexpr int tks = kKS ? m16_piece_at(n, N2, ksND, FFPA_M16_KS_PVSTEP) : -1;
+        constexpr bool kPiece = kKS ? tks >= 0 : (n % kStep2 == 0 && n / kStep2 + kPre < PPW);
+        constexpr int kIdx = !kKS ? n / kStep2 + kPre : (tks < 0 ? 0 : (tks < ksK1D ? ksK1B + ksK1C + tks : kH + ksK2C + (tks - ksK1D)));
         constexpr int db = n % NDB, ks = n / NDB;
-        if constexpr (kPiece && FFPA_M16_DMA_POS == 0) issue_k(std::integral_constant<int, n / kStep2 + kPre>{}, k0 + BC);
+        if constexpr (kPiece && FFPA_M16_DMA_POS == 0) issue_k(std::integral_constant<int, kIdx>{}, k0 + BC);
         M::acc_a(oacc[db][0], vf[n], pf[ks][0]);
-        if constexpr (kPiece && FFPA_M16_DMA_POS == 1) issue_k(std::integral_constant<int, n / kStep2 + kPre>{}, k0 + BC);
+        if constexpr (kPiece && FFPA_M16_DMA_POS == 1) issue_k(std::integral_constant<int, kIdx>{}, k0 + BC);
         M::acc_a(oacc[db][1], vf[n], pf[ks][1]);
-        if constexpr (kPiece && FFPA_M16_DMA_POS == 2) issue_k(std::integral_constant<int, n / kStep2 + kPre>{}, k0 + BC);
+        if constexpr (kPiece && FFPA_M16_DMA_POS == 2) issue_k(std::integral_constant<int, kIdx>{}, k0 + BC);
         if constexpr (MK == 1) {
           // the bias tile of step j + 1 (this wave's rows, its private staging area) in the slots the K pieces leave free
           constexpr int kBStep = kStep2 >= 2 ? kStep2 : 2;
@@ -1007,19 +1440,22 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 
     FFPA_TSTAMP(4);  // PV loop
     // barrier B: every wave is done reading V(j); K(j+1) has landed and is visible
+    // (two-half K schedule: K1(j+1) must have landed, the K2(j+1) pieces behind it stay in flight until barrier M of the next step;
+    // the additive-bias build stages a run-time number of bias pieces among them and keeps the full drain)
+    constexpr int kWaitB = (kKS && MK != 1) ? ksWaitB : 0;
     if (pf_on) {  // (wave-uniform)
       issue_prefetch(k0 + FFPA_M16_PF_DIST * BC);
-      dma_wait_except<1>();
+      dma_wait_except<kWaitB + 1>();
     } else {
-      dma_wait_all();
+      dma_wait_except<kWaitB>();
     }
     __syncthreads();
     FFPA_TSTAMP(5);  // K(j+1) drain + wait at barrier B
     dephase(std::integral_constant<int, 2>{});
   }
 
-  if (pf_on) {  // the last touches land before their destination register is given to anything else
-    dma_wait_all();
+  if (pf_on || kKS) {  // the last touches land before their destination register is given to anything else (two-half K schedule: and the
+    dma_wait_all();    // zero-filled K2 pieces of the tile past the last one before the workgroup's LDS is)
     asm volatile("" : : "v"(pf_junk));
   }
   // ================= epilogue (prefill.cuh:1018-1093) =================
@@ -1045,7 +1481,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         for (int t = 0; t < 4; ++t) w[t] = dead ? 0.f : oacc[db][rh][t] * inv[rh];
         *(f32x4*)(wp + db * 16) = w;
       }
-      if (c == 0 && dh == 0) a.ws_lse[prow] = dead ? -INFINITY : __logf(l_tot[rh]) + m_run[rh] * 0.6931471805599453f;
+      // (one explicit FMA: left to -ffp-contract, builds of this kernel differed in whether they fused it — 1 ulp of the partial's LSE, which the merge
+      // turns into an output ulp here and there; every build must produce the same bits for the same scores)
+      if (c == 0 && dh == 0) a.ws_lse[prow] = dead ? -INFINITY : __builtin_fmaf(m_run[rh], 0.6931471805599453f, __logf(l_tot[rh]));
     }
     return;
   }
@@ -1076,17 +1514,19 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       if (ok && dh * DW + db * 16 + 4 * (c & ~1) < a.d_valid) *(u32x4*)(op + db * 16) = run;
     }
 #ifdef FFPA_M16_TIMING
-    if (a.lse != nullptr && lane == 0) {  // 8 floats per wave at LSE row q0 + 8 * wave: six phase totals, whole kernel, KV tiles
-      float* tp = a.lse + ((int64_t)b * a.Hq + hq) * a.Nq + q0 + 8 * wave;
+    if (a.lse != nullptr && lane == 0) {  // 16 floats per wave at LSE row q0 + 16 * wave: six phase totals, whole kernel, KV tiles, two more phases
+      float* tp = a.lse + ((int64_t)b * a.Hq + hq) * a.Nq + q0 + 16 * wave;
       for (int i = 0; i < 6; ++i) tp[i] = (float)tacc[i];
       tp[6] = (float)(__builtin_amdgcn_s_memtime() - tstart);
       tp[7] = (float)(nt - t0);
+      tp[8] = (float)tacc[6];
+      tp[9] = (float)tacc[7];
     }
 #else
     if (a.lse != nullptr && c == 0 && dh == 0) {
 #pragma unroll
       for (int rh = 0; rh < 2; ++rh)
-        if (qrow[rh] < a.Nq) a.lse[((int64_t)b * a.Hq + hq) * a.Nq + qrow[rh]] = __logf(l_tot[rh]) + m_run[rh] * 0.6931471805599453f;
+        if (qrow[rh] < a.Nq) a.lse[((int64_t)b * a.Hq + hq) * a.Nq + qrow[rh]] = __builtin_fmaf(m_run[rh], 0.6931471805599453f, __logf(l_tot[rh]));
     }
 #endif
   }

@@ -12,6 +12,7 @@ import glob, os, re, sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ffpa_attn_amd", "csrc", "build")
 WINDOW = 2  # the hazard needs 2 wait states; every instruction in between provides at least one
+READ_WAIT = 18  # wait states between an MFMA and a non-accumulator reader of its result (the kernels pad s_nop 15 + s_nop 3 = 20)
 REG = re.compile(r"v\[(\d+):(\d+)\]|v(\d+)")
 
 
@@ -59,6 +60,47 @@ def main():
               bad += 1
               print(f"HAZARD D={d} line {i + 1}: `{p}` writes an operand of `{t}`")
   print(f"{total} asm MFMAs checked over D = {', '.join(dims)}: {bad} preceded by a VALU write to an operand")
+  # The other direction: the result registers of an asm MFMA must not be READ by anything but a dependent MFMA's accumulator operand until
+  # READ_WAIT wait states have passed (MFMA result -> VALU / LDS / VMEM reader; an MFMA taking them as A / B needs them too).  The compiler
+  # does not know these registers are MFMA results: a register copy it places for a loop-carried value is enough to break the rule (round 4).
+  raw_bad = 0
+  for d in dims:
+    for path in glob.glob(os.path.join(ROOT, f"temps_d{d}", "*gfx950.s")):
+      lines = open(path).read().split("\n")
+      in_asm = False
+      for i, l in enumerate(lines):
+        t = l.strip()
+        if t.startswith(";;#ASMSTART"):
+          in_asm = True
+        elif t.startswith(";;#ASMEND"):
+          in_asm = False
+        if not (in_asm and t.startswith("v_mfma")):
+          continue
+        dst = regs(t.split(None, 1)[1].split(",")[0])
+        if dst is None:  # AGPR accumulators (O^T): read by the epilogue / the rescale asm only, behind their own pads
+          continue
+        states, j = 0, i + 1
+        while j < len(lines) and states < READ_WAIT:
+          p = lines[j].strip()
+          j += 1
+          if not p or p.startswith((";", ".", "//")) or p.endswith(":"):
+            continue
+          if p.startswith("s_nop"):
+            states += int(p.split()[1]) + 1
+            continue
+          toks = [x.strip() for x in p.split(None, 1)[1].split(",")] if len(p.split(None, 1)) > 1 else []
+          if p.startswith("v_mfma"):
+            used = [regs(x.split()[0]) for x in toks[1:3]]  # A and B; the accumulator operand may be the same registers (back-to-back chain)
+            states += 4
+          else:
+            used = [regs(x.split()[0]) if x else None for x in toks]
+            states += 1
+          if any(overlap(dst, u) for u in used):
+            raw_bad += 1
+            print(f"READ-AFTER-MFMA D={d} line {j}: `{p}` touches the result of `{t}` (line {i + 1}) after {states - 1} wait states")
+            break
+  print(f"asm MFMA results read inside {READ_WAIT} wait states: {raw_bad}")
+  bad += raw_bad
   # M0 is carried from one LDS-DMA asm statement to the next: nothing outside the asm blocks may write it
   m0_bad = 0
   for d in dims:
