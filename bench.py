@@ -156,20 +156,126 @@ def make_mask(w: dict, dtype, device, seed: int = 0):
   return None
 
 
-def measured_traffic(workload: str):
-  """(bytes, source): HBM bytes per launch from the committed rocprofv3 PMC pass of this workload's bench command
+def measured_traffic(workload: str, lib_sha16: str | None):
+  """(bytes, source, stale): HBM bytes per launch from the committed rocprofv3 PMC pass of this workload's bench command
   (`rocprofv3 --pmc FETCH_SIZE` x2 — gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md §HBM — plus
   `--pmc WRITE_SIZE`; tools/gpu_round.sh stage wprof, summarised by tools/pmc_summary.py).  bench.py cannot profile
-  itself, so this is a profile artefact named by `traffic_source`, or (None, None) when none is committed."""
-  for rnd in ("r03", "r02", "r01"):
+  itself, so this is a profile artefact named by `traffic_source` — and it is only quoted when the profile's
+  `provenance.lib_sha16` IS the library this run loaded: a profile of another binary gives (None, its path, True) and the line
+  says `traffic_stale`.  (None, None, False) when no profile is committed."""
+  for rnd in ("r04", "r03", "r02", "r01"):
     path = os.path.join(ROOT, "profiles", f"{rnd}_bench_{workload}_pmc.json")
     if os.path.exists(path):
       try:
-        d = json.load(open(path))["derived"]
-        return int(d["hbm_read_bytes_corrected_x2"] + d.get("hbm_write_bytes", 0)), os.path.relpath(path, ROOT)
+        doc = json.load(open(path))
+        d = doc["derived"]
+        if lib_sha16 is None or doc.get("provenance", {}).get("lib_sha16") != lib_sha16:
+          return None, os.path.relpath(path, ROOT), True
+        return int(d["hbm_read_bytes_corrected_x2"] + d.get("hbm_write_bytes", 0)), os.path.relpath(path, ROOT), False
       except (KeyError, ValueError):
         pass
-  return None, None
+  return None, None, False
+
+
+class DeviceTelemetry:
+  """Shader clock and socket power of the benchmarked GPU, sampled from its sysfs hwmon node by a thread while the timed region runs,
+  plus what the device says about itself (CU count, maximum shader clock): the numbers that explain why two boxes of a pool give one
+  binary +- 5 % (SURVEY.md section 8d asks for them next to every figure).  Everything is best effort: a box without the nodes gives
+  nulls, never an error."""
+
+  def __init__(self, index: int):
+    import glob
+    import threading
+
+    self._threading = threading
+    self.samples: list[tuple[float, float]] = []
+    self.props = torch.cuda.get_device_properties(index)
+    self.node = None
+    cands = []
+    for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+      try:
+        if open(os.path.join(dev, "vendor")).read().strip() != "0x1002":
+          continue
+        hw = sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*")))
+        if hw and os.path.exists(os.path.join(hw[0], "freq1_input")):
+          slot = ""
+          for ln in open(os.path.join(dev, "uevent")):
+            if ln.startswith("PCI_SLOT_NAME="):
+              slot = ln.split("=", 1)[1].strip().lower()
+          cands.append((slot, hw[0]))
+      except OSError:
+        continue
+    want = ""
+    try:
+      want = f"{self.props.pci_domain_id:04x}:{self.props.pci_bus_id:02x}:{self.props.pci_device_id:02x}.0"
+    except AttributeError:
+      pass
+    for slot, hw in cands:
+      if slot == want:
+        self.node = hw
+    if self.node is None and len(cands) == 1:
+      self.node = cands[0][1]
+    self._power = None
+    if self.node:
+      for f in ("power1_average", "power1_input"):
+        if os.path.exists(os.path.join(self.node, f)):
+          self._power = os.path.join(self.node, f)
+          break
+    self._stop = None
+    self._thread = None
+
+  def _read(self):
+    try:
+      mhz = int(open(os.path.join(self.node, "freq1_input")).read()) / 1e6
+      watts = int(open(self._power).read()) / 1e6 if self._power else float("nan")
+      return mhz, watts
+    except (OSError, ValueError):
+      return None
+
+  def start(self, period_s: float = 0.004) -> None:
+    if not self.node:
+      return
+    self.samples = []
+    self._stop = self._threading.Event()
+
+    def loop():
+      while not self._stop.is_set():
+        r = self._read()
+        if r:
+          self.samples.append(r)
+        self._stop.wait(period_s)
+
+    self._thread = self._threading.Thread(target=loop, daemon=True)
+    self._thread.start()
+
+  def stop(self) -> None:
+    if self._thread is not None:
+      self._stop.set()
+      self._thread.join()
+      self._thread = None
+
+  def summary(self) -> dict:
+    cus = self.props.multi_processor_count
+    fmax = getattr(self.props, "clock_rate", 0) / 1e6  # kHz -> GHz (torch 2.10 + ROCm 7 does not fill it in: then the top DPM level of sysfs)
+    if not fmax and self.node:
+      try:
+        import re
+
+        levels = [int(m.group(1)) for m in re.finditer(r"(\d+)\s*[Mm][Hh]z", open(os.path.join(os.path.dirname(os.path.dirname(self.node)), "pp_dpm_sclk")).read())]
+        fmax = max(levels) / 1e3 if levels else 0.0
+      except OSError:
+        fmax = 0.0
+    out = {"name": self.props.name, "cus": cus, "max_sclk_mhz": round(fmax * 1e3, 1) if fmax else None,
+           # the formula of SURVEY.md section 8d: CUs x 4 SIMDs x 1024 bf16 MFMA FLOP / clk x f_max
+           "peak_tflops_from_device": round(cus * 4 * 1024 * fmax / 1e3, 1) if fmax else None,
+           "telemetry_source": os.path.relpath(self.node, "/sys/class/drm") if self.node else None}
+    if self.samples:
+      f = [x[0] for x in self.samples]
+      p = [x[1] for x in self.samples if x[1] == x[1]]
+      out.update(sclk_mhz_avg=round(sum(f) / len(f), 1), sclk_mhz_min=round(min(f), 1), sclk_mhz_max=round(max(f), 1),
+                 power_w_avg=round(sum(p) / len(p), 1) if p else None, power_w_max=round(max(p), 1) if p else None, samples=len(f),
+                 sampled="freq1_input / power1_* of the GPU's hwmon node, every 4 ms over the timed region")
+    return out
 
 
 def cpu_baseline(w: dict, seconds_budget: float = 25.0) -> dict:
@@ -537,6 +643,7 @@ def main() -> None:
     if dist is not None:
       dist.barrier()
     torch.cuda.synchronize()
+    telemetry.start()
     t0 = time.perf_counter()
     for i in range(args.steps):
       starts[i].record()  # the kernel is launched on torch's current stream; so are these events
@@ -544,6 +651,7 @@ def main() -> None:
       ends[i].record()
     torch.cuda.synchronize()
     local = time.perf_counter() - t0
+    telemetry.stop()
     if dist is not None:
       dist.barrier()
     total = time.perf_counter() - t0
@@ -558,7 +666,9 @@ def main() -> None:
       per_rank = [round(float(x.item()), 2) for x in every]
     return total, per_rank, sorted(a.elapsed_time(b) for a, b in zip(starts, ends))
 
+  telemetry = DeviceTelemetry(local_rank)
   elapsed, per_rank_tflops, kernel_ms = timed(step)
+  device = telemetry.summary()  # (of the first timed region: the bench line's own)
   kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
   value = flops_global * args.steps / elapsed / 1e12
   gather_extra = None
@@ -569,7 +679,8 @@ def main() -> None:
   plan = planned_kernel(w, q[:1], k[:1], v[:1], mask, scale) if rank == 0 else {}
 
   if rank == 0:
-    traffic, traffic_src = measured_traffic(name) if world == 1 else (None, None)
+    build = build_identity()
+    traffic, traffic_src, traffic_stale = measured_traffic(name, build.get("lib_sha16")) if world == 1 else (None, None, False)
     if w["bound"] == "hbm":
       bytes_launch = algorithmic_bytes(w, global_B)
       achieved = bytes_launch / (kernel_ms_avg * 1e-3) / 1e9
@@ -583,6 +694,14 @@ def main() -> None:
               "kernel": plan.get("kernel"), "kernel_ms_avg": round(kernel_ms_avg, 4),
               "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 4), "flops_per_launch": flops_local,
               "algorithmic_bytes_per_launch": algorithmic_bytes(w, max(1, (u1 - u0) // Hkv) if sharded else B)}
+      # the same figure against what THIS device says it is, and per clock at the clock it actually ran: two boxes of a pool differ by
+      # their clock under load, not by the kernel (4096 = 4 SIMDs x 1024 bf16 MFMA FLOP per CU and clock)
+      if device.get("peak_tflops_from_device"):
+        roof["frac_of_device_peak"] = round(achieved / device["peak_tflops_from_device"], 4)
+      if device.get("sclk_mhz_avg"):
+        roof["flop_per_clk_per_cu"] = round(achieved * 1e12 / (device["cus"] * device["sclk_mhz_avg"] * 1e6), 1)
+        roof["frac_of_mfma_rate_at_measured_clock"] = round(roof["flop_per_clk_per_cu"] / 4096.0, 4)
+    roof["traffic_stale"] = bool(traffic_stale)
     shape = f"B={global_B} Hq={Hq} Hkv={Hkv} Nq={Nq} Nkv={Nkv} D={D}"
     line = {
       "metric": metric_name(name, w),
@@ -608,7 +727,8 @@ def main() -> None:
                 ("sharding.attend_units -> ffpa_attn_func" if sharded else "ffpa_attn_func"),
       },
       "roofline": roof,
-      "build": build_identity(),
+      "device": device,
+      "build": build,
       "plan": {k_: plan.get(k_) for k_ in ("variant", "block_rows", "block_keys", "splits")},
     }
     if per_rank_tflops is not None:

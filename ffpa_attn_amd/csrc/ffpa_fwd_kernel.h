@@ -799,7 +799,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
   // The next id's Q fragments and first K tile are requested right behind this id's O stores: the store drain, the
   // workgroup teardown / launch gap and part of the fetch latency overlap.  The kernel arguments are re-read through a
   // laundered pointer every round: nothing derived from them may be hoisted out of (and kept live across) the outer loop
-  // — that is what made two earlier persistent attempts lose to scalar-register pressure.
+  // — that is what made two earlier persistent attempts lose to scalar-register pressure (profiles/NOTES.md section 6).
   for (int round = 0;; ++round) {
   typedef const __attribute__((address_space(4))) FwdArgs CArgs;
   auto kargs = (CArgs*)__builtin_amdgcn_kernarg_segment_ptr();

@@ -5,7 +5,7 @@
 // reference's split_d_fwd_sm80: csrc/cuffpa/native/sm_80/split_d.cuh:96-777); only the mapping of the two products onto the
 // matrix core differs.  Why a second mapping: v_mfma_f32_16x16x32 sustains a 14 - 21 % higher power-capped rate than
 // v_mfma_f32_32x32x16 on random operands, and the D = 512 instruction mix built on it has a 9 % higher ceiling
-// (tools/probes/stream_probe.hip, profiles/r02_stream_probe.txt).
+// (tools/probes/stream_probe.hip, profiles/r02_stream_probe.txt, profiles/NOTES.md section 3).
 //
 // Mapping (one wave = 32 query rows as two 16-row halves rh; D <= 512: all of D per wave, 4 waves = 128 rows):
 //   * S^T = K.Q^T per 16-key block kb and row half rh: A = K[16 keys][32 d] (one ds_read_b128 per lane: key lane % 16, d chunk
@@ -156,6 +156,11 @@
 #ifndef FFPA_M16_PP_PF
 #define FFPA_M16_PP_PF 3  // K fragments requested ahead of their MFMAs in the S phase (the softmax's registers are live next to them)
 #endif
+#ifndef FFPA_M16_FUSE_DMA
+// 1: a DMA piece and the MFMA in front of it are one asm statement (Mfma16::with_dma): the MFMA is the wait state between the M0 write and the piece,
+// no s_nop.  Interleaved A/B, bit-identical (profiles/r04_pipe.txt): config 2 + 1.0 %, cross + 1.7 %, causal + 1.3 %, D = 320 + 1.4 %, config 4 + 0.9 %, D = 1024 +- 0
+#define FFPA_M16_FUSE_DMA 1
+#endif
 #ifndef FFPA_M16_PIECE_IL
 // which 1 KiB pieces of a tile image a wave stages (the per-lane-offset form: every build but D = 512 with a mask path):
 // 0 = a contiguous quarter of the image (wave w: pieces w PPW .. + PPW; the four waves' simultaneous requests lie a quarter image apart),
@@ -222,6 +227,21 @@ struct Mfma16<__bf16> {
   static __device__ __forceinline__ void acc_last(f32x4& d, f32x4& other, v8 a, v8 b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n\ts_nop 15\n\ts_nop 3" : "+v"(d), "+v"(other) : "v"(a), "v"(b));
   }
+  // An MFMA with a 1 KiB LDS-DMA piece riding on it (FFPA_M16_FUSE_DMA): M0 is written in FRONT of the MFMA, which then is the wait state an
+  // LDS-DMA needs behind an M0 write — the piece costs the stream two issue slots instead of three (s_add, s_nop, buffer_load).
+  // KIND 0: first MFMA of a chain (C = 0, VGPR), 1: accumulate (VGPR), 2: accumulate (AGPR tile).
+  template <int KIND, int LCONST>
+  static __device__ __forceinline__ void with_dma(f32x4& d, v8 a, v8 b, u32x4 rsrc, uint32_t lds_base, uint32_t voff, uint32_t soff) {
+    if constexpr (KIND == 0)
+      asm volatile("s_add_u32 m0, %3, %7\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0\n\tbuffer_load_dwordx4 %4, %5, %6 offen lds"
+                   : "=&v"(d) : "v"(a), "v"(b), "s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff), "n"(LCONST) : "memory", "scc" FFPA_M0_CLOBBER);
+    else if constexpr (KIND == 1)
+      asm volatile("s_add_u32 m0, %3, %7\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\tbuffer_load_dwordx4 %4, %5, %6 offen lds"
+                   : "+v"(d) : "v"(a), "v"(b), "s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff), "n"(LCONST) : "memory", "scc" FFPA_M0_CLOBBER);
+    else
+      asm volatile("s_add_u32 m0, %3, %7\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\tbuffer_load_dwordx4 %4, %5, %6 offen lds"
+                   : "+a"(d) : "v"(a), "v"(b), "s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff), "n"(LCONST) : "memory", "scc" FFPA_M0_CLOBBER);
+  }
 };
 template <>
 struct Mfma16<_Float16> {
@@ -231,6 +251,21 @@ struct Mfma16<_Float16> {
   static __device__ __forceinline__ void acc_a(f32x4& d, v8 a, v8 b) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b)); }
   static __device__ __forceinline__ void acc_last(f32x4& d, f32x4& other, v8 a, v8 b) {
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %2, %3, %0\n\ts_nop 15\n\ts_nop 3" : "+v"(d), "+v"(other) : "v"(a), "v"(b));
+  }
+  // An MFMA with a 1 KiB LDS-DMA piece riding on it (FFPA_M16_FUSE_DMA): M0 is written in FRONT of the MFMA, which then is the wait state an
+  // LDS-DMA needs behind an M0 write — the piece costs the stream two issue slots instead of three (s_add, s_nop, buffer_load).
+  // KIND 0: first MFMA of a chain (C = 0, VGPR), 1: accumulate (VGPR), 2: accumulate (AGPR tile).
+  template <int KIND, int LCONST>
+  static __device__ __forceinline__ void with_dma(f32x4& d, v8 a, v8 b, u32x4 rsrc, uint32_t lds_base, uint32_t voff, uint32_t soff) {
+    if constexpr (KIND == 0)
+      asm volatile("s_add_u32 m0, %3, %7\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0\n\tbuffer_load_dwordx4 %4, %5, %6 offen lds"
+                   : "=&v"(d) : "v"(a), "v"(b), "s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff), "n"(LCONST) : "memory", "scc" FFPA_M0_CLOBBER);
+    else if constexpr (KIND == 1)
+      asm volatile("s_add_u32 m0, %3, %7\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\tbuffer_load_dwordx4 %4, %5, %6 offen lds"
+                   : "+v"(d) : "v"(a), "v"(b), "s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff), "n"(LCONST) : "memory", "scc" FFPA_M0_CLOBBER);
+    else
+      asm volatile("s_add_u32 m0, %3, %7\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\tbuffer_load_dwordx4 %4, %5, %6 offen lds"
+                   : "+a"(d) : "v"(a), "v"(b), "s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff), "n"(LCONST) : "memory", "scc" FFPA_M0_CLOBBER);
   }
 };
 
@@ -283,7 +318,7 @@ __device__ __forceinline__ int m16_v_swizzle(int key) {
 #if FFPA_ABL != 0 || FFPA_SQ_BC64 != 1 || defined(FFPA_M16_TIMING) || FFPA_PERSISTENT != 0 || FFPA_M16_ROWDMA != 1 || FFPA_M16_PF1 != 6 || FFPA_M16_PF2 != 4 || \
     FFPA_M16_K_PRE != 8 || FFPA_M16_K_PRE_ND2 != 64 || FFPA_M16_DEPHASE != 0 || FFPA_M16_PF_DIST != 2 || FFPA_M16_PF_WAVES != 2 || FFPA_M16_PF_WHICH != 3 || (defined(FFPA_M16_PF_ALL_D) && FFPA_M16_PF_ALL_D != 0) || FFPA_M16_ROW_TABLES != 1 || FFPA_DMA_M0_CLOBBER != 1 || FFPA_M16_SWAP_REDUCE != 1 || FFPA_M16_MIN_D != 128 || FFPA_M16_BC128_MIN_D != 256 || \
     (defined(FFPA_M16_PHILOX_ILP) && FFPA_M16_PHILOX_ILP != 1) || FFPA_M16_KSPLIT != 0 || FFPA_M16_PIPE != 1 || FFPA_M16_PP_VQ != 6 || FFPA_M16_PP_K1Q != 2 || FFPA_M16_PP_K2S != 2 || \
-    FFPA_M16_PP_QSTEP != 1 || FFPA_M16_PP_SSTEP != 1 || FFPA_M16_PP_PSTEP != 2 || FFPA_M16_PP_PF != 3 || FFPA_M16_PIECE_IL != 0 || FFPA_M16_KS_PVSTEP != 0
+    FFPA_M16_PP_QSTEP != 1 || FFPA_M16_PP_SSTEP != 1 || FFPA_M16_PP_PSTEP != 2 || FFPA_M16_PP_PF != 3 || FFPA_M16_PIECE_IL != 0 || FFPA_M16_KS_PVSTEP != 0 || FFPA_M16_FUSE_DMA != 1
 #error "FFPA_PRODUCT_BUILD: a developer switch is not at its shipped default"
 #endif
 #endif
@@ -485,6 +520,20 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     } else {
       lds_dma_16_at<i * kPStride * 1024>(ts.rsrc, v_lds, vrel[i], 0u);
     }
+  };
+
+  // the same pieces riding on an MFMA (kind: 0 first of a chain, 1 accumulate in VGPRs, 2 accumulate in an AGPR tile); the row-addressed form keeps
+  // its own statement
+  constexpr bool kFuse = FFPA_M16_FUSE_DMA != 0 && !kRowDma;
+  auto issue_k_on = [&](auto ic, int key0, auto kindc, f32x4& d, v8 fa, v8 fb) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    const TileSrc ts = tile_src<BC>(Kg, k_row_bytes, key0, a.Nkv, rb_valid);
+    M::template with_dma<decltype(kindc)::value, (kKS && i >= kH ? 2 * PPW + (i - kH) * kPStride : i * kPStride) * 1024>(d, fa, fb, ts.rsrc, k_lds, krel[kRowDma ? 0 : i], 0u);
+  };
+  auto issue_v_on = [&](auto ic, int key0, auto kindc, f32x4& d, v8 fa, v8 fb) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    const TileSrc ts = tile_src<BC>(Vg, v_row_bytes, key0, a.Nkv, rb_valid);
+    M::template with_dma<decltype(kindc)::value, i * kPStride * 1024>(d, fa, fb, ts.rsrc, v_lds, vrel[kRowDma ? 0 : i], 0u);
   };
 
   // ---- L2 prefetch (FwdArgs::l2_prefetch, set by the launch side for streams that come from HBM): the tile two steps ahead is touched —
@@ -793,11 +842,17 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (s_ + PF1 < KS) kf[s_ + PF1] = k_frag_sk(s_ + PF1, 1);
           constexpr int t = m16_piece_at(s_, KS, ppK1Q + ppVQ, FFPA_M16_PP_QSTEP);
-          if constexpr (s_ == 0) M::first(s1[0], kf[s_], qf[s_][0]);
-          else M::acc(s1[0], kf[s_], qf[s_][0]);
-          if constexpr (t >= 0) {
-            if constexpr (t < ppK1Q) issue_k(std::integral_constant<int, ppK1P + t>{}, k0 + BC);  // K1(j+1), rest
-            else issue_v(std::integral_constant<int, t - ppK1Q>{}, k0);                           // V(j), first part
+          if constexpr (t >= 0 && kFuse) {
+            using kind = std::integral_constant<int, s_ == 0 ? 0 : 1>;
+            if constexpr (t < ppK1Q) issue_k_on(std::integral_constant<int, ppK1P + t>{}, k0 + BC, kind{}, s1[0], kf[s_], qf[s_][0]);
+            else issue_v_on(std::integral_constant<int, t - ppK1Q>{}, k0, kind{}, s1[0], kf[s_], qf[s_][0]);
+          } else {
+            if constexpr (s_ == 0) M::first(s1[0], kf[s_], qf[s_][0]);
+            else M::acc(s1[0], kf[s_], qf[s_][0]);
+            if constexpr (t >= 0) {
+              if constexpr (t < ppK1Q) issue_k(std::integral_constant<int, ppK1P + t>{}, k0 + BC);  // K1(j+1), rest
+              else issue_v(std::integral_constant<int, t - ppK1Q>{}, k0);                           // V(j), first part
+            }
           }
           if constexpr (s_ == 0) M::first(s1[1], kf[s_], qf[s_][1]);
           else if constexpr (s_ == KS - 1) M::acc_last(s1[1], s1[0], kf[s_], qf[s_][1]);
@@ -922,11 +977,17 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (s_ + PFS < KS) kf[s_ + PFS] = k_frag_sk(s_ + PFS, 0);
           constexpr int t = m16_piece_at(s_, KS, ppVS + ppK2S, FFPA_M16_PP_SSTEP);
-          if constexpr (s_ == 0) M::first(s0[0], kf[s_], qf[s_][0]);
-          else M::acc(s0[0], kf[s_], qf[s_][0]);
-          if constexpr (t >= 0) {
-            if constexpr (t < ppVS) issue_v(std::integral_constant<int, ppVQ + t>{}, k0);  // V(j), rest
-            else issue_k(std::integral_constant<int, kH + (t - ppVS)>{}, k0 + BC);        // K2(j+1), first part
+          if constexpr (t >= 0 && kFuse) {
+            using kind = std::integral_constant<int, s_ == 0 ? 0 : 1>;
+            if constexpr (t < ppVS) issue_v_on(std::integral_constant<int, ppVQ + t>{}, k0, kind{}, s0[0], kf[s_], qf[s_][0]);
+            else issue_k_on(std::integral_constant<int, kH + (t - ppVS)>{}, k0 + BC, kind{}, s0[0], kf[s_], qf[s_][0]);
+          } else {
+            if constexpr (s_ == 0) M::first(s0[0], kf[s_], qf[s_][0]);
+            else M::acc(s0[0], kf[s_], qf[s_][0]);
+            if constexpr (t >= 0) {
+              if constexpr (t < ppVS) issue_v(std::integral_constant<int, ppVQ + t>{}, k0);  // V(j), rest
+              else issue_k(std::integral_constant<int, kH + (t - ppVS)>{}, k0 + BC);        // K2(j+1), first part
+            }
           }
           softmax_gaps(std::integral_constant<int, 2 * s_>{});
           __builtin_amdgcn_sched_barrier(0);
@@ -964,10 +1025,16 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
           if constexpr (n + PF2 < N2) vf[n + PF2] = v_frag(n + PF2);
           constexpr int t = m16_piece_at(n, N2, ppK2P + ppK1P, FFPA_M16_PP_PSTEP);
           constexpr int db = n % NDB, ks = n / NDB;
-          M::acc_a(oacc[db][0], vf[n], pf[ks][0]);
-          if constexpr (t >= 0) {
-            if constexpr (t < ppK2P) issue_k(std::integral_constant<int, kH + ppK2S + t>{}, k0 + BC);  // K2(j+1), rest
-            else issue_k(std::integral_constant<int, t - ppK2P>{}, k0 + 2 * BC);                       // K1(j+2), first part
+          if constexpr (t >= 0 && kFuse) {
+            using kind = std::integral_constant<int, 2>;
+            if constexpr (t < ppK2P) issue_k_on(std::integral_constant<int, kH + ppK2S + t>{}, k0 + BC, kind{}, oacc[db][0], vf[n], pf[ks][0]);
+            else issue_k_on(std::integral_constant<int, t - ppK2P>{}, k0 + 2 * BC, kind{}, oacc[db][0], vf[n], pf[ks][0]);
+          } else {
+            M::acc_a(oacc[db][0], vf[n], pf[ks][0]);
+            if constexpr (t >= 0) {
+              if constexpr (t < ppK2P) issue_k(std::integral_constant<int, kH + ppK2S + t>{}, k0 + BC);  // K2(j+1), rest
+              else issue_k(std::integral_constant<int, t - ppK2P>{}, k0 + 2 * BC);                       // K1(j+2), first part
+            }
           }
           M::acc_a(oacc[db][1], vf[n], pf[ks][1]);
         });
@@ -1148,9 +1215,13 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         static_assert(FFPA_M16_DMA_POS == 1, "FFPA_PRODUCT_BUILD: a developer switch is not at its shipped default");
 #endif
         if constexpr (kPiece && FFPA_M16_DMA_POS == 0) issue_v(std::integral_constant<int, n / kStep1>{}, k0);
-        if constexpr (s == 0 && !kBias) M::first(sacc[kb][0], kf[n], qf[s][0]);
-        else M::acc(sacc[kb][0], kf[n], qf[s][0]);
-        if constexpr (kPiece && FFPA_M16_DMA_POS == 1) issue_v(std::integral_constant<int, n / kStep1>{}, k0);
+        if constexpr (kPiece && FFPA_M16_DMA_POS == 1 && kFuse) {
+          issue_v_on(std::integral_constant<int, n / kStep1>{}, k0, std::integral_constant<int, (s == 0 && !kBias) ? 0 : 1>{}, sacc[kb][0], kf[n], qf[s][0]);
+        } else {
+          if constexpr (s == 0 && !kBias) M::first(sacc[kb][0], kf[n], qf[s][0]);
+          else M::acc(sacc[kb][0], kf[n], qf[s][0]);
+        }
+        if constexpr (kPiece && FFPA_M16_DMA_POS == 1 && !kFuse) issue_v(std::integral_constant<int, n / kStep1>{}, k0);
         if constexpr (s == 0 && !kBias) M::first(sacc[kb][1], kf[n], qf[s][1]);
         else M::acc(sacc[kb][1], kf[n], qf[s][1]);
         if constexpr (kPiece && FFPA_M16_DMA_POS == 2) issue_v(std::integral_constant<int, n / kStep1>{}, k0);
@@ -1413,8 +1484,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         constexpr int kIdx = !kKS ? n / kStep2 + kPre : (tks < 0 ? 0 : (tks < ksK1D ? ksK1B + ksK1C + tks : kH + ksK2C + (tks - ksK1D)));
         constexpr int db = n % NDB, ks = n / NDB;
         if constexpr (kPiece && FFPA_M16_DMA_POS == 0) issue_k(std::integral_constant<int, kIdx>{}, k0 + BC);
-        M::acc_a(oacc[db][0], vf[n], pf[ks][0]);
-        if constexpr (kPiece && FFPA_M16_DMA_POS == 1) issue_k(std::integral_constant<int, kIdx>{}, k0 + BC);
+        if constexpr (kPiece && FFPA_M16_DMA_POS == 1 && kFuse) issue_k_on(std::integral_constant<int, kIdx>{}, k0 + BC, std::integral_constant<int, 2>{}, oacc[db][0], vf[n], pf[ks][0]);
+        else M::acc_a(oacc[db][0], vf[n], pf[ks][0]);
+        if constexpr (kPiece && FFPA_M16_DMA_POS == 1 && !kFuse) issue_k(std::integral_constant<int, kIdx>{}, k0 + BC);
         M::acc_a(oacc[db][1], vf[n], pf[ks][1]);
         if constexpr (kPiece && FFPA_M16_DMA_POS == 2) issue_k(std::integral_constant<int, kIdx>{}, k0 + BC);
         if constexpr (MK == 1) {

@@ -141,7 +141,8 @@ def attend_and_gather_units(qu: torch.Tensor, ku: torch.Tensor, vu: torch.Tensor
   and every finished piece is all-gathered asynchronously (RCCL runs the collective on its own stream, ordered behind the
   kernel that produced the piece) while the next piece computes — the gather of a 256 MiB shard costs about as much as the
   kernel (7 x 153 GB/s xGMI links), so hiding it under compute is the difference between ~1x and ~2x the step time.
-  Needs an even split (``n_units % world == 0``); returns ``[n_units, group, Nq, D]`` on every rank."""
+  Needs an even split (``n_units % world == 0``); returns ``[n_units, group, Nq, D]`` on every rank.  ``chunks`` is a request: it
+  is lowered until no piece under-fills the chip (see below), so the result does not depend on it — not even at the rounding level."""
   world = dist.get_world_size(group)
   if n_units % world != 0:
     return gather_units(attend_units(qu, ku, vu, **kwargs), n_units, group, out)
@@ -155,6 +156,18 @@ def attend_and_gather_units(qu: torch.Tensor, ku: torch.Tensor, vu: torch.Tensor
   if per == 0:
     return out
   chunks = max(1, min(chunks, per))
+  if qu.is_cuda:
+    # A piece must not UNDER-FILL the chip: a prefill launch with fewer workgroups than half the CUs splits the KV axis (fp32 partials +
+    # LSE merge — the same values to rounding, not to the bit), so the gathered tensor would depend on `chunks` at the rounding level.
+    # Pieces are therefore kept at more than CUs / 2 workgroups (config 5 on 8 GPUs: 32 units x 64 row tiles per rank, 4 pieces of 512
+    # workgroups); a block that under-fills even as ONE piece is attended as one piece (its plan is then the plan of the plain call).
+    from . import hip
+
+    cus = torch.cuda.get_device_properties(qu.device).multi_processor_count
+    rows = hip.tile_config(hip.padded_head_dim(d))["block_rows"]
+    per_unit = g * ((nq + rows - 1) // rows)
+    min_units = (cus // 2 + per_unit) // per_unit  # smallest unit count with more than cus / 2 workgroups
+    chunks = max(1, min(chunks, per // min_units))
   bounds = [per * c // chunks for c in range(chunks + 1)]
   works = []
   for c0, c1 in zip(bounds, bounds[1:]):

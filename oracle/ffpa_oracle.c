@@ -26,8 +26,12 @@
  * Parity pinning: the reference holds no golden vectors for this path (every forward test is
  * "allclose to PyTorch SDPA on seeded randn", tests/test_ffpa_fwd.py:106-121), so this oracle is
  * pinned (tests/test_oracle.py) against (i) OUTPUTS OF THE REFERENCE'S OWN large-head-dim kernel executed in the authoring
- * container — its Triton forward under TRITON_INTERPRET=1, fp16 and bf16, nine cases incl. late score spikes that walk the
- * lazy-rescale branch (tests/golden/make_triton_golden.py -> ref_triton_cases.npz), (ii) PyTorch CPU SDPA — the reference's own
+ * container — its Triton forward under TRITON_INTERPRET=1, fp16 and bf16, eleven cases incl. late score spikes that walk the
+ * lazy-rescale branch and two 128-row x 8192-key cases at D = 512 (the headline key count) (tests/golden/make_triton_golden.py ->
+ * ref_triton_cases.npz).  Qualification: the fp16 cases run the interpreter unmodified; the bf16 cases depend on two functions of
+ * Triton's INTERPRETER being wrapped in the generator (its dot product multiplies bf16 bit patterns as integers and its fp32 -> bf16
+ * cast truncates: the wrappers widen dot operands to fp32 and round to nearest even — make_triton_golden.py:63-83).  The reference's
+ * kernel source is imported unchanged, but the bf16 pin is only as good as those twenty lines, (ii) PyTorch CPU SDPA — the reference's own
  * test oracle — on the committed fixtures in tests/golden/, (iii) the output of the reference's ffpa_attn_func
  * itself, run in the authoring container on config 1 (tests/golden/make_golden.py), and (iv) an
  * fp64 plain-math evaluation.
@@ -158,10 +162,14 @@ static inline int dropout_keeps(uint64_t seed, uint64_t element, float p) {
  * it only changes fp32 summation order and when the lazy rescale fires.
  * Returns 0, or -1 on bad arguments / allocation failure.
  */
-int ffpa_oracle_fwd_dropout(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* o_f32, float* lse,
-                            const float* bias, const int64_t* bias_stride, int B, int Hq, int Hkv, int Nq, int Nkv, int D,
-                            int dtype, float scale, int causal, int causal_offset, float thr, int block_keys,
-                            int row_begin, int row_end, float dropout_p, uint64_t philox_seed, uint64_t philox_offset) {
+/* pmax [B,Hq,2,Nq] (may be NULL): per row, plane 0 = the largest normalised probability max_k P / l, plane 1 = sum_k (P / l)^2.  Not part of
+ * the reference's outputs — they are what a checker needs to bound (0) how far ONE differently-rounded P entry can move an output element
+ * (2^-8 * pmax * |v| for bf16) and (1) the noise the 16-bit rounding of ALL P entries leaves in it (rms 2^-9 / sqrt 3 * sqrt(sum (P/l)^2) * rms |v|),
+ * which two implementations that round P against different running maxima do not share. */
+int ffpa_oracle_fwd_ex(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* o_f32, float* lse,
+                       const float* bias, const int64_t* bias_stride, int B, int Hq, int Hkv, int Nq, int Nkv, int D,
+                       int dtype, float scale, int causal, int causal_offset, float thr, int block_keys,
+                       int row_begin, int row_end, float dropout_p, uint64_t philox_seed, uint64_t philox_offset, float* pmax) {
   if (!q || !k || !v || !o || B <= 0 || Hq <= 0 || Hkv <= 0 || Nq <= 0 || Nkv <= 0 || D <= 0) return -1;
   if (Hq % Hkv != 0 || block_keys <= 0 || (dtype != 0 && dtype != 1)) return -1;
   if (row_begin < 0) row_begin = 0;
@@ -203,7 +211,8 @@ int ffpa_oracle_fwd_dropout(const uint16_t* q, const uint16_t* k, const uint16_t
           }
           const size_t qoff = (((size_t)b * Hq + hq) * Nq + r) * (size_t)D;
           for (int d = 0; d < D; ++d) qf[d] = load_elem(q + qoff + d, dtype);
-          float m = -INFINITY, l = 0.f;
+          float m = -INFINITY, l = 0.f, xmax_all = -INFINITY;
+          double l2 = 0.0; /* sum of P^2 (checker statistics only) */
           /* visible keys: key <= r + causal_offset (and key < Nkv) */
           long lim = causal ? (long)r + causal_offset : (long)Nkv - 1;
           if (lim > Nkv - 1) lim = Nkv - 1;
@@ -230,6 +239,7 @@ int ffpa_oracle_fwd_dropout(const uint16_t* q, const uint16_t* k, const uint16_t
               x[j] = xv;
               if (xv > tmax) tmax = xv;
             }
+            if (tmax > xmax_all) xmax_all = tmax;
             const float m_new = (tmax > m) ? tmax : m;
             float alpha = 1.f;
             if (m_new > m + thr) { /* lazy rescale (prefill.cuh:684-755); first finite max always rescales */
@@ -240,11 +250,13 @@ int ffpa_oracle_fwd_dropout(const uint16_t* q, const uint16_t* k, const uint16_t
             if (alpha != 1.f) {
               for (int d = 0; d < D; ++d) acc[d] *= alpha;
               l *= alpha;
+              l2 *= (double)alpha * alpha;
             }
             float psum = 0.f;
             for (int j = 0; j < kn; ++j) {
               const float p = exp2f(x[j] - m_use);
               psum += p;
+              l2 += (double)p * p;
               float p16 = round_elem(p, dtype);
               if (dropout_p > 0.f) { /* on the rounded P, after the row sum; rounded again (prefill.cuh:508-546) */
                 const uint64_t e = philox_offset + (((uint64_t)b * Hq + hq) * Nq + (uint64_t)r) * (uint64_t)Nkv + (uint64_t)(k0 + j);
@@ -264,6 +276,10 @@ int ffpa_oracle_fwd_dropout(const uint16_t* q, const uint16_t* k, const uint16_t
             o[qoff + d] = store_elem(val, dtype);
           }
           if (lse) lse[((size_t)b * Hq + hq) * Nq + r] = logf(l) + m * FFPA_LN2;
+          if (pmax) {
+            pmax[(((size_t)b * Hq + hq) * 2 + 0) * Nq + r] = exp2f(xmax_all - ((m == -INFINITY) ? 0.f : m)) * inv;
+            pmax[(((size_t)b * Hq + hq) * 2 + 1) * Nq + r] = (float)(l2 * (double)inv * inv);
+          }
           free(qf);
           free(acc);
           free(x);
@@ -276,6 +292,14 @@ int ffpa_oracle_fwd_dropout(const uint16_t* q, const uint16_t* k, const uint16_t
   return status;
 }
 
+int ffpa_oracle_fwd_dropout(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* o_f32, float* lse,
+                            const float* bias, const int64_t* bias_stride, int B, int Hq, int Hkv, int Nq, int Nkv, int D,
+                            int dtype, float scale, int causal, int causal_offset, float thr, int block_keys,
+                            int row_begin, int row_end, float dropout_p, uint64_t philox_seed, uint64_t philox_offset) {
+  return ffpa_oracle_fwd_ex(q, k, v, o, o_f32, lse, bias, bias_stride, B, Hq, Hkv, Nq, Nkv, D, dtype, scale, causal, causal_offset, thr,
+                            block_keys, row_begin, row_end, dropout_p, philox_seed, philox_offset, NULL);
+}
+
 int ffpa_oracle_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, float* o_f32, float* lse,
                     const float* bias, const int64_t* bias_stride, int B, int Hq, int Hkv, int Nq, int Nkv, int D,
                     int dtype, float scale, int causal, int causal_offset, float thr, int block_keys, int row_begin,
@@ -284,4 +308,4 @@ int ffpa_oracle_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, uin
                                  causal_offset, thr, block_keys, row_begin, row_end, 0.f, 0, 0);
 }
 
-int ffpa_oracle_abi_version(void) { return 2; }
+int ffpa_oracle_abi_version(void) { return 3; }

@@ -58,6 +58,8 @@ def _load() -> ctypes.CDLL:
     ]
     lib.ffpa_oracle_fwd_dropout.restype = ctypes.c_int
     lib.ffpa_oracle_fwd_dropout.argtypes = lib.ffpa_oracle_fwd.argtypes + [ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64]
+    lib.ffpa_oracle_fwd_ex.restype = ctypes.c_int
+    lib.ffpa_oracle_fwd_ex.argtypes = lib.ffpa_oracle_fwd_dropout.argtypes + [ctypes.c_void_p]
     lib.ffpa_oracle_philox.restype = None
     lib.ffpa_oracle_philox.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32)]
     _lib = lib
@@ -135,11 +137,15 @@ def oracle_forward(
   dropout_p: float = 0.0,
   philox_seed: int = 0,
   philox_offset: int = 0,
+  return_pmax: bool = False,
 ):
   """Run the C oracle.  Inputs are uint16 storage bits, dense ``[B,H,N,D]``.
 
   Returns ``(o_bits uint16, o_f32 float32 (unrounded), lse float32)``; with ``rows=(r0, r1)`` only
   those query rows of every (batch, head) are computed (the rest of the outputs is zero).
+  ``return_pmax=True`` appends ``pmax float32 [B,Hq,Nq]`` — each row's largest normalised probability (what bounds the
+  effect of one differently-rounded P entry on an output element); ``return_pmax="both"`` appends ``(pmax, p2sum)`` with
+  ``p2sum = sum_k (P/l)^2`` (what scales the noise the 16-bit rounding of all P entries leaves in an output element).
   """
   lib = _load()
   q_bits = np.ascontiguousarray(q_bits, dtype=np.uint16)
@@ -160,14 +166,19 @@ def oracle_forward(
     bst = _bias_strides(bias, (B, Hq, Nq, Nkv))
     bias_p, bst_p = bias.ctypes.data, bst.ctypes.data
   r0, r1 = (0, Nq) if rows is None else rows
-  rc = lib.ffpa_oracle_fwd_dropout(
+  pmax = np.zeros((B, Hq, 2, Nq), dtype=np.float32)
+  rc = lib.ffpa_oracle_fwd_ex(
     q_bits.ctypes.data, k_bits.ctypes.data, v_bits.ctypes.data, o.ctypes.data, o32.ctypes.data, lse.ctypes.data,
     bias_p, bst_p, B, Hq, Hkv, Nq, Nkv, D, 0 if dtype == "bf16" else 1, float(scale), int(bool(causal)),
     int(causal_offset), float(threshold), int(block_keys), int(r0), int(r1), float(dropout_p), int(philox_seed),
-    int(philox_offset),
+    int(philox_offset), pmax.ctypes.data,
   )
   if rc != 0:
     raise RuntimeError(f"ffpa_oracle_fwd failed ({rc})")
+  if return_pmax == "both":
+    return o, o32, lse, (pmax[:, :, 0], pmax[:, :, 1])
+  if return_pmax:
+    return o, o32, lse, pmax[:, :, 0]
   return o, o32, lse
 
 

@@ -1,6 +1,7 @@
 """Pin the oracle to EXECUTED reference code: run the reference's own Triton forward kernel on the CPU and keep its outputs.
 
-    python tests/golden/make_triton_golden.py          (authoring container only: needs /root/reference and triton)
+    python tests/golden/make_triton_golden.py [--only NAME,NAME]     (authoring container only: needs /root/reference and triton;
+                                                                      --only: run these cases and merge them into the existing fixture)
 
 The reference's large-head-dim arithmetic that can run without an NVIDIA GPU is its Triton statement of the algorithm
 (src/ffpa_attn/triton/_ffpa_fwd.py: kernel `_ffpa_fwd_kernel_impl` :302-495, launcher `_ffpa_attn_forward_generic_impl`
@@ -78,8 +79,16 @@ def main():
   ti.InterpreterBuilder.create_dot = dot
 
   store, meta = {}, []
+  only = None
+  if "--only" in sys.argv:
+    only = set(sys.argv[sys.argv.index("--only") + 1].split(","))
+    old = np.load(os.path.join(HERE, "ref_triton_cases.npz"))
+    store = {k_: old[k_] for k_ in old.files}
+    meta = [m for m in json.load(open(os.path.join(HERE, "ref_triton_cases.json")))["cases"] if m["name"] not in only]
   for case in CASES:
     name, B, Hq, Hkv, Nq, Nkv, D, causal, bshape, dtype, spike = case
+    if only is not None and name not in only:
+      continue
     tdt = torch.float16 if dtype == "fp16" else torch.bfloat16
     arrs = triton_case_inputs(case)
     q, k, v, bias = (None if a is None else (torch.from_numpy(a) if dtype == "fp16" else torch.from_numpy(a.view(np.int16)).view(tdt)) for a in arrs)
@@ -103,6 +112,8 @@ def main():
     store[f"{name}.lse"] = lse[..., :Nq].contiguous().numpy()
     meta.append({"name": name, "B": B, "Hq": Hq, "Hkv": Hkv, "Nq": Nq, "Nkv": Nkv, "D": D, "causal": causal, "bias_shape": bshape, "dtype": dtype,
                  "late_spikes": spike})
+  order = {c[0]: i for i, c in enumerate(CASES)}
+  meta.sort(key=lambda m: order[m["name"]])
   np.savez_compressed(os.path.join(HERE, "ref_triton_cases.npz"), **store)
   with open(os.path.join(HERE, "ref_triton_cases.json"), "w") as f:
     json.dump({"source": f"reference src/ffpa_attn/triton/_ffpa_fwd.py::_ffpa_attn_forward_impl under TRITON_INTERPRET=1, triton {triton.__version__}, "

@@ -18,6 +18,10 @@ CASES = [
   ("bf16_d320_gqa_causal", 1, 4, 2, 192, 320, 320, True, None, "bf16", False),
   ("bf16_d1024_bias", 1, 1, 1, 130, 257, 1024, False, (1, 1, 130, 257), "bf16", False),
   ("bf16_d512_keybias_spike", 2, 2, 2, 72, 1100, 512, False, (2, 1, 1, 1100), "bf16", True),
+  # the BASELINE key count (round 4): one head, 128 query rows against 8192 keys at D = 512 — the reference's own arithmetic at the headline's
+  # row length (its suite goes to 8191 / 8192-key tails: tests/test_ffpa_fwd.py:1110-1143); non-causal and tail-aligned causal
+  ("bf16_d512_n8192", 1, 1, 1, 128, 8192, 512, False, None, "bf16", False),
+  ("bf16_d512_n8192_causal", 1, 1, 1, 128, 8192, 512, True, None, "bf16", False),
 ]
 
 

@@ -46,7 +46,7 @@ def test_bool_mask_is_bit_identical_to_its_additive_form(hip, shape, D):
     else:
       assert torch.equal(ob, oa) and torch.equal(lb, la), f"{shape} D={D} flags={flags}"
   if shape[3] == 1:
-    # a [B, 1, Nq, 1] mask (no key axis): PyTorch-ROCm's fused SDPA is not a usable reference for it (it moves the
+    # a [B, 1, Nq, 1] mask (no key axis): PyTorch-ROCm's fused SDPA is not a usable reference for it (profiles/NOTES.md section 4: it moves the
     # result for the additive form of such a mask, and for the boolean form it returned NaN rows under an all-True mask on this pool) —
     # fp32 math instead
     s_ = (q.float() @ k.float().transpose(-1, -2)) * D ** -0.5

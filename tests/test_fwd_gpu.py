@@ -17,7 +17,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import case_bias
+from conftest import GOLDEN, case_bias
 from oracle import ffpa_oracle as fo
 
 pytestmark = pytest.mark.gpu
@@ -64,28 +64,43 @@ def _short_query_keys(hip, D):
 
 
 def _check_vs_oracle(o_gpu, lse_gpu, q, k, v, *, causal=False, causal_offset=None, bias=None, rows=None,
-                     block_keys=64, threshold=8.0, name=""):
-  """o_gpu within one storage-dtype rounding of the oracle's unrounded result, LSE to fp32 noise."""
+                     block_keys=64, threshold=8.0, name="", split=False):
+  """o_gpu within one storage-dtype rounding of the oracle's unrounded result, LSE to fp32 noise.  ``split``: the launch splits the KV
+  axis over workgroups (fp32 partials + LSE merge) — every split rounds its P entries against its OWN running max, so the 16-bit
+  rounding noise of P is not shared with the oracle's single walk and enters the allowance (five sigma of both sides)."""
   qb, dt = fo.torch_to_bits(q)
   kb, _ = fo.torch_to_bits(k)
   vb, _ = fo.torch_to_bits(v)
-  _, o32, lse = fo.oracle_forward(qb, kb, vb, dt, causal=causal, causal_offset=causal_offset, bias=bias, rows=rows,
-                                  block_keys=block_keys, threshold=threshold)
+  _, o32, lse, (pmax, p2sum) = fo.oracle_forward(qb, kb, vb, dt, causal=causal, causal_offset=causal_offset, bias=bias, rows=rows,
+                                                 block_keys=block_keys, threshold=threshold, return_pmax="both")
   got = _f32(o_gpu)
   r0, r1 = (0, got.shape[2]) if rows is None else rows
-  got, want = got[:, :, r0:r1], o32[:, :, r0:r1]
+  got, want, pmax, p2sum = got[:, :, r0:r1], o32[:, :, r0:r1], pmax[:, :, r0:r1], p2sum[:, :, r0:r1]
   finite = np.isfinite(want)
   assert np.array_equal(np.isnan(got), np.isnan(want)), f"{name}: NaN pattern differs"
   # |round(kernel_f32) - oracle_f32| <= half a storage ulp of the result + the effect of P entries whose
   # fp32 value sits on a rounding boundary and rounds the other way in the kernel (v_exp_f32 / MFMA summation
-  # order vs libm / sequential): one flip moves O by 2^-8 * p/l * |v| — visible at short Nkv where p/l ~ 0.1.
+  # order vs libm / sequential): one flip moves O by ulp * p/l * |v|.  The allowance is that expression with the ROW's largest p/l (the
+  # oracle returns it) and the largest |v| — 2.5e-3 at 32 keys (p/l ~ 0.1 ... 1: the constant earlier rounds used everywhere, still the cap),
+  # ~ 1e-4 at 8192 keys (p/l ~ 5e-3), where a constant 2.5e-3 would be a quarter of an output's standard deviation and could not see a
+  # dropped KV tile (round-3 review; test_oracle_check_catches_a_dropped_kv_tile).
   ulp = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
-  flip = 2.5e-3 if dt == "bf16" else 4e-4
+  vmax = float(v.detach().float().abs().max().item())
+  flip_cap = 2.5e-3 if dt == "bf16" else 4e-4
+  noise = 0.0
+  if split:
+    vrms = float(v.detach().float().pow(2).mean().sqrt().item())
+    noise = 5.0 * (0.5 * ulp / np.sqrt(3.0)) * np.sqrt(2.0 * np.nan_to_num(p2sum, nan=1.0)) * vrms
+  # (3 x: the kernel's scores differ from the oracle's by the fp32 summation order of the MFMA — ~ 1e-5 in the log2 domain, i.e. about one P
+  # entry in 500 lands on the other side of a 16-bit rounding boundary: rows of a few hundred keys see a handful of flips among their larger
+  # entries; 1.5 x failed 64 of the suite's 1447 cases by up to 3e-4, all at 250 ... 3000 keys)
+  flip = np.minimum(flip_cap, np.maximum(3.0 * ulp * np.nan_to_num(pmax, nan=1.0) * vmax, 2e-5) + noise)[..., None] * np.ones_like(want)
   err = np.abs(got - want)[finite]
   half_ulp = (ulp * np.maximum(np.abs(want), 2.0 ** -6))[finite]
+  flip = flip[finite]
   assert (err <= half_ulp + flip).all(), f"{name}: max err {err.max():.3e} (worst excess {(err - half_ulp - flip).max():.3e})"
   # flips are rare: the MEAN error must stay at pure output-rounding level
-  assert err.mean() <= 0.5 * (half_ulp + 3e-4).mean(), f"{name}: mean err {err.mean():.3e}"
+  assert err.mean() <= 0.5 * (half_ulp + np.minimum(3e-4, 2e-5 + flip / 3)).mean(), f"{name}: mean err {err.mean():.3e}"
   if lse_gpu is not None:
     lg, lw = _f32(lse_gpu)[:, :, r0:r1], lse[:, :, r0:r1]
     fin = np.isfinite(lw)
@@ -133,19 +148,27 @@ def test_kernel_matches_the_executed_reference_triton_kernel(hip):
   """fp16 and bf16 outputs of the reference's own Triton forward (tests/golden/make_triton_golden.py, run under TRITON_INTERPRET=1
   in the authoring container) vs the HIP kernel on the re-created inputs: tails, tail-aligned causal + GQA, additive
   biases with -inf entries, late score spikes (the lazy-rescale branch), D = 320 / 512 / 1024."""
-  from test_oracle import _bits_to_f32, _triton_cases
+  import sys
+
+  from test_oracle import _bits_to_f32, _triton_cases, triton_fixture_limits
+
+  sys.path.insert(0, GOLDEN)
+  import triton_cases as mt
 
   for case, (q, k, v, bias), o_ref_bits, lse_ref in _triton_cases():
-    name, D, causal, dtype = case[0], case[6], case[7], case[9]
+    name, Nkv, D, causal, dtype = case[0], case[5], case[6], case[7], case[9]
     tdt = torch.float16 if dtype == "fp16" else torch.bfloat16
     qt, kt, vt = (torch.from_numpy(a.view(np.int16).copy()).view(tdt).cuda() for a in (q, k, v))
     bt = None if bias is None else torch.from_numpy(bias.view(np.int16).copy()).view(tdt).cuda()
-    o, lse = hip.forward(qt, kt, vt, bt, causal, D ** -0.5)
-    want = torch.from_numpy(_bits_to_f32(o_ref_bits, dtype)).cuda()
-    d = (o.float() - want).abs()
-    ulp = 2.0 ** -11 if dtype == "fp16" else 2.0 ** -8
-    lim = 2.0 * ulp * torch.clamp(want.abs(), min=0.5 * max(1.0, want.abs().max().item())) + 1e-4  # one output ulp of the binade above (row scale for the spike cases)
-    assert bool((d <= lim).all()) and d.mean().item() <= (5e-5 if dtype == "fp16" else 4e-4), (name, d.max().item(), d.mean().item())
+    o, lse = hip.forward(qt, kt, vt, bt, causal, D ** -0.5, num_splits=1 if Nkv >= 4096 else 0)
+    want = _bits_to_f32(o_ref_bits, dtype)
+    # (the rows' largest p / l for the long cases' allowance comes from the oracle: test infrastructure, like the limits themselves)
+    pmax = fo.oracle_forward(q.view(np.uint16), k.view(np.uint16), v.view(np.uint16), dtype, causal=causal, bias=mt.to_f32(bias, dtype),
+                             return_pmax="both")[3] if Nkv >= 4096 else None
+    lim, mean_lim = triton_fixture_limits(want, dtype, Nkv, pmax, float(np.abs(mt.to_f32(v, dtype)).max()))
+    d = np.abs(_f32(o) - want)
+    # (short rows: one output ulp of the binade above, row scale for the spike cases; BASELINE-length rows: one spacing of the element's own binade)
+    assert bool((d <= lim).all()) and d.mean() <= mean_lim * (1.25 if dtype == "fp16" and Nkv < 4096 else 1.0), (name, d.max(), d.mean())
     assert (lse.cpu() - torch.from_numpy(lse_ref)).abs().max().item() <= 3e-5, name
 
 
@@ -368,13 +391,30 @@ def test_baseline_config_2_and_3_full_size(hip, D):
   assert err.max().item() <= NORTH_STAR_MAX_ABS, err.max().item()
   _close(o, ref, q.dtype)
   bc = hip.tile_config(D)["block_keys"]
-  for head, rows in ((0, (0, 48)), (17, (4090, 4130)), (31, (8150, 8192))):
+  # 8 heads x 64 rows = 512 rows against the oracle, the per-element allowance scaled by each row's largest p/l (~ 1e-4 here)
+  for i, head in enumerate((0, 5, 9, 14, 17, 22, 27, 31)):
+    r0 = (0, 1000, 2040, 3333, 4090, 5555, 7000, 8128)[i]
     sl = slice(head, head + 1)
-    _check_vs_oracle(o[:, sl], lse[:, sl], q[:, sl], k[:, sl], v[:, sl], rows=rows, block_keys=bc, name=f"h{head}")
+    _check_vs_oracle(o[:, sl], lse[:, sl], q[:, sl], k[:, sl], v[:, sl], rows=(r0, r0 + 64), block_keys=bc, name=f"h{head}")
   o2, lse2 = hip.forward(q, k, v, None, False, scale)
   assert torch.equal(o, o2) and torch.equal(lse, lse2)          # run-to-run deterministic
   o4, _ = hip.forward(q, k, v * 4, None, False, scale)           # P unchanged, V scaled by 2^2: exact
   assert torch.equal(o4, o * 4)
+
+
+def test_oracle_check_catches_a_dropped_kv_tile(hip):
+  """The oracle comparison must bite at the BASELINE key count: an output computed WITHOUT the last KV tile (32 or 64 of 8192 keys: what a
+  wrong tile bound would produce) has to fail it — per element AND in the mean — while the true output passes (round-3 review: with the
+  constant 2.5e-3 allowance the element bound could not see this)."""
+  for D in (512, 1024):
+    q, k, v = _baseline_inputs(1, 2, 2, 256, 8192, D)
+    bc = hip.tile_config(D)["block_keys"]
+    scale = D ** -0.5
+    o, lse = hip.forward(q, k, v, None, False, scale, num_splits=1)
+    _check_vs_oracle(o[:, :1], lse[:, :1], q[:, :1], k[:, :1], v[:, :1], rows=(64, 128), block_keys=bc, name="intact")
+    o_bad, lse_bad = hip.forward(q, k[:, :, : 8192 - bc].contiguous(), v[:, :, : 8192 - bc].contiguous(), None, False, scale, num_splits=1)
+    with pytest.raises(AssertionError, match="max err"):
+      _check_vs_oracle(o_bad[:, :1], None, q[:, :1], k[:, :1], v[:, :1], rows=(64, 128), block_keys=bc, name="dropped tile")
 
 
 def test_baseline_config_4_gqa_cross_causal_mask(hip):
@@ -392,10 +432,12 @@ def test_baseline_config_4_gqa_cross_causal_mask(hip):
   om, _ = hip.forward(q, k, v, bias, False, scale)
   _within_north_star(om, ref)
   assert (om.float() - o.float()).abs().max().item() <= 8e-3  # (the 16-bit mask runs the 64-key bias-tile build: one bf16 ulp at |O| in [1, 2))
-  for head, rows in ((0, (0, 40)), (13, (2040, 2080)), (31, (8160, 8192))):
-    sl, kv = slice(head, head + 1), slice(head // 4, head // 4 + 1)
-    _check_vs_oracle(o[:1, sl], lse[:1, sl], q[:1, sl], k[:1, kv], v[:1, kv], causal=True, causal_offset=0, rows=rows,
-                     name=f"cfg4 h{head}")
+  bc4 = hip.tile_config(320)["block_keys"]
+  for i, head in enumerate((0, 3, 8, 13, 18, 23, 28, 31)):  # 8 heads x 64 rows, both batch elements
+    r0 = (0, 500, 1100, 2040, 3000, 4500, 6000, 8128)[i]
+    sl, kv, bb = slice(head, head + 1), slice(head // 4, head // 4 + 1), slice(i % 2, i % 2 + 1)
+    _check_vs_oracle(o[bb, sl], lse[bb, sl], q[bb, sl], k[bb, kv], v[bb, kv], causal=True, causal_offset=0, rows=(r0, r0 + 64),
+                     block_keys=bc4, name=f"cfg4 h{head}")
 
 
 def test_baseline_config_5_unsharded_on_one_gpu(hip):
@@ -562,7 +604,7 @@ def test_short_query_split_kv(hip, D, Nq, Hq, Hkv):
   o, lse = hip.forward(q, k, v, None, False, D ** -0.5, plan_out=plan)
   assert plan["variant"] == 1 and plan["splits"] > 1
   assert plan["packed"] == (Hq != Hkv and Nq <= 7 and (Hq // Hkv) * Nq <= 32)
-  _check_vs_oracle(o, lse, q, k, v, block_keys=_short_query_keys(hip, D), name=f"short {Nq}x{Hq}/{Hkv} D{D}")
+  _check_vs_oracle(o, lse, q, k, v, block_keys=_short_query_keys(hip, D), name=f"short {Nq}x{Hq}/{Hkv} D{D}", split=True)
   o1, lse1 = hip.forward(q, k, v, None, False, D ** -0.5, num_splits=1)  # unsplit: same answer up to rounding
   assert (o.float() - o1.float()).abs().max().item() <= 4e-3
   assert (lse - lse1).abs().max().item() <= 1e-4
@@ -607,9 +649,9 @@ def test_short_query_causal_and_tails(hip, Nq, Hq, Hkv):
   D, Nkv = 512, 1111
   q, k, v = _rand((1, Hq, Nq, D), seed=141), _rand((1, Hkv, Nkv, D), seed=142), _rand((1, Hkv, Nkv, D), seed=143)
   o, lse = hip.forward(q, k, v, None, True, D ** -0.5)                       # tail aligned
-  _check_vs_oracle(o, lse, q, k, v, causal=True, block_keys=_short_query_keys(hip, q.size(-1)), name="short causal tail")
+  _check_vs_oracle(o, lse, q, k, v, causal=True, block_keys=_short_query_keys(hip, q.size(-1)), name="short causal tail", split=True)
   o0, lse0 = hip.forward(q, k, v, None, True, D ** -0.5, causal_offset=0)    # top-left: row i sees keys 0..i
-  _check_vs_oracle(o0, lse0, q, k, v, causal=True, causal_offset=0, block_keys=_short_query_keys(hip, q.size(-1)), name="short causal topleft")
+  _check_vs_oracle(o0, lse0, q, k, v, causal=True, causal_offset=0, block_keys=_short_query_keys(hip, q.size(-1)), name="short causal topleft", split=True)
   assert torch.equal(o0[:, :, 0], v[:, :, 0].repeat_interleave(Hq // Hkv, 1))  # row 0 sees only key 0
 
 

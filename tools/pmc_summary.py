@@ -6,7 +6,7 @@ Per counter: mean over the dispatches of the dominant kernel (default: the prefi
 Derived values follow /opt/skills/guides/MI355X_MICROARCH.md: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count
 quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES counts cycles (32 per 32x32x16 MFMA, 16 per 16x16x32), GRBM_GUI_ACTIVE is summed over the 8 XCDs,
 FETCH_SIZE is KiB and reads half of a wide coalesced stream on gfx950 (corrected x2 here).  The workload's algorithmic
-bytes / FLOPs and the kernel's L2->LDS operand stream are taken from the bench line in
+bytes / FLOPs and the kernel's L2->LDS operand stream (profiles/NOTES.md section 3) are taken from the bench line in
 <dir>/*.log when one is found, so that request counters can be read as bytes per request.
 """
 import collections, csv, glob, json, os, re, sys
