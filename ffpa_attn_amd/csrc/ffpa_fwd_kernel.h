@@ -155,7 +155,15 @@ constexpr unsigned kFlagNoXcdRemap = 0x2u;
 #ifndef FFPA_SQ_BC64
 #define FFPA_SQ_BC64 1
 #endif
-constexpr int splitd_block_keys(int D, int ND) { return (FFPA_SQ_BC64 != 0 && ND == 4 && (D == 128 || D == 384 || D == 512)) ? 64 : 32; }
+// Round 4: the two-wave split (ND = 2: head dims that are not multiples of 128) takes 64-key tiles too where the LDS has the room — D = 320 (112 KiB)
+// and D = 448 (144 KiB); 576 and up would need 176 KiB.  Interleaved A/B on one box (profiles/r04_decode_nd2.txt): D = 320 B1 H32 Nkv 8192 75.9 -> 66.9 us
+// (4.4 -> 5.0 TB/s of K / V), B8 GQA 144 -> 123 us (5.45 TB/s), 64k keys 144 -> 124 us, 16 query rows - 11 %; D = 448 - 2 % / +- 0.
+#ifndef FFPA_SQ_BC64_ND2
+#define FFPA_SQ_BC64_ND2 1
+#endif
+constexpr int splitd_block_keys(int D, int ND) {
+  return ((FFPA_SQ_BC64 != 0 && ND == 4 && (D == 128 || D == 384 || D == 512)) || (FFPA_SQ_BC64_ND2 != 0 && ND == 2 && (D == 320 || D == 448))) ? 64 : 32;
+}
 constexpr int splitd_exchange_bytes(int D, int ND) { return ND > 1 ? 4 * 4096 * (splitd_block_keys(D, ND) / 32) : 0; }
 
 // Workgroup id -> position in the launch's logical order (batch-major, head, row tile, split).  The hardware deals workgroup ids round-robin
@@ -1211,14 +1219,15 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
     // lane holds x[kb][r] = score(row qrow, key k0 + 32 kb + 16 h + r)
     float x[NKB][16];
     if constexpr (ND == 2) {
-      static_assert(ND != 2 || NKB == 1, "the two-wave exchange moves one 32-key block");
-      FFPA_LDS const char* xr = Xb + (wave ^ 1) * 4096 + lane * 16;
+      FFPA_LDS const char* xr = Xb + (wave ^ 1) * (NKB * 4096) + lane * 16;  // (4 KiB per wave and 32-key block, as the four-wave form)
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const f32x4 t = *(FFPA_LDS const f32x4*)(xr + r4 * 1024);
+      for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) x[0][4 * r4 + e] = (sacc[0][4 * r4 + e] + t[e]) * a.scale_log2;
-      }
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const f32x4 t = *(FFPA_LDS const f32x4*)(xr + kb * 4096 + r4 * 1024);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[kb][4 * r4 + e] = (sacc[kb][4 * r4 + e] + t[e]) * a.scale_log2;
+        }
     } else if constexpr (ND == 4) {
       // sum the four D-quarter partials in a fixed order so that all four waves of the row block see
       // bit-identical scores (their softmax state must agree: each owns a different slice of O^T)

@@ -145,7 +145,7 @@
 #define FFPA_M16_PP_K2S 2
 #endif
 #ifndef FFPA_M16_PP_QSTEP
-#define FFPA_M16_PP_QSTEP 1  // one piece every this many fragments from the phase's start (0: spread evenly over the phase)
+#define FFPA_M16_PP_QSTEP 2  // one piece every this many fragments from the phase's start (0: spread evenly over the phase); Q: 2 vs 1 + 1.6 % on config 3
 #endif
 #ifndef FFPA_M16_PP_SSTEP
 #define FFPA_M16_PP_SSTEP 1
@@ -315,10 +315,10 @@ __device__ __forceinline__ int m16_v_swizzle(int key) {
 // overwrites LSE rows, experimental schedules — may be anything but its shipped default there.  Variant libraries (build.py --variant)
 // are built without the define, get another file name and say so in ffpa_attn_version().
 #ifdef FFPA_PRODUCT_BUILD
-#if FFPA_ABL != 0 || FFPA_SQ_BC64 != 1 || defined(FFPA_M16_TIMING) || FFPA_PERSISTENT != 0 || FFPA_M16_ROWDMA != 1 || FFPA_M16_PF1 != 6 || FFPA_M16_PF2 != 4 || \
+#if FFPA_ABL != 0 || FFPA_SQ_BC64 != 1 || FFPA_SQ_BC64_ND2 != 1 || defined(FFPA_M16_TIMING) || FFPA_PERSISTENT != 0 || FFPA_M16_ROWDMA != 1 || FFPA_M16_PF1 != 6 || FFPA_M16_PF2 != 4 || \
     FFPA_M16_K_PRE != 8 || FFPA_M16_K_PRE_ND2 != 64 || FFPA_M16_DEPHASE != 0 || FFPA_M16_PF_DIST != 2 || FFPA_M16_PF_WAVES != 2 || FFPA_M16_PF_WHICH != 3 || (defined(FFPA_M16_PF_ALL_D) && FFPA_M16_PF_ALL_D != 0) || FFPA_M16_ROW_TABLES != 1 || FFPA_DMA_M0_CLOBBER != 1 || FFPA_M16_SWAP_REDUCE != 1 || FFPA_M16_MIN_D != 128 || FFPA_M16_BC128_MIN_D != 256 || \
     (defined(FFPA_M16_PHILOX_ILP) && FFPA_M16_PHILOX_ILP != 1) || FFPA_M16_KSPLIT != 0 || FFPA_M16_PIPE != 1 || FFPA_M16_PP_VQ != 6 || FFPA_M16_PP_K1Q != 2 || FFPA_M16_PP_K2S != 2 || \
-    FFPA_M16_PP_QSTEP != 1 || FFPA_M16_PP_SSTEP != 1 || FFPA_M16_PP_PSTEP != 2 || FFPA_M16_PP_PF != 3 || FFPA_M16_PIECE_IL != 0 || FFPA_M16_KS_PVSTEP != 0 || FFPA_M16_FUSE_DMA != 1
+    FFPA_M16_PP_QSTEP != 2 || FFPA_M16_PP_SSTEP != 1 || FFPA_M16_PP_PSTEP != 2 || FFPA_M16_PP_PF != 3 || FFPA_M16_PIECE_IL != 0 || FFPA_M16_KS_PVSTEP != 0 || FFPA_M16_FUSE_DMA != 1
 #error "FFPA_PRODUCT_BUILD: a developer switch is not at its shipped default"
 #endif
 #endif
@@ -377,6 +377,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   constexpr int ppK2S = PPW * FFPA_M16_PP_K2S / 16, ppK2P = kH - ppK2S;  // K2(j+1): in S(j) (first), in P(j) (rest)
   static_assert(!kPipe || (ppVQ >= 0 && ppVS >= 0 && ppK1Q >= 0 && ppK1P >= 0 && ppK2S >= 0 && ppK2P >= 0), "piece counts per phase");
   static_assert(!kPipe || (ppVQ + ppK1Q <= KS && ppVS + ppK2S <= KS && ppK2P + ppK1P <= N2), "at most one piece per fragment");
+  // (a step that walks past the phase's last fragment would silently drop the pieces behind it: a tile image with stale rows)
+  static_assert(!kPipe || ((ppVQ + ppK1Q - 1) * FFPA_M16_PP_QSTEP < KS && (ppVS + ppK2S - 1) * FFPA_M16_PP_SSTEP < KS && (ppK2P + ppK1P - 1) * FFPA_M16_PP_PSTEP < N2),
+                "every piece of a phase must ride on one of its fragments");
   // counted waits: order of issue inside a step — Q: K1 rest, V first; S: V rest, K2 first; P: K2 rest, K1 first (of the tile after next), touch
   constexpr int ppWaitA1 = ppVQ + (ppK1Q > 0 ? 0 : 0);  // K1(j+1) has landed: the V pieces of Q(j) stay in flight (+ the touch when K1Q == 0)
   constexpr int ppWaitA2 = ppK2S;                       // V(j) has landed

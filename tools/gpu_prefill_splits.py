@@ -1,0 +1,36 @@
+"""KV-split count of exactly-filled / under-filled PREFILL launches (developer tool): time hip.forward with num_splits forced to 1 .. 4 next to
+the library's own rule (0), interleaved, HIP events.  Cases: `cross` (Nq 1024: 256 workgroups = one per CU), config 4 shapes, a few more."""
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ffpa_attn_amd import hip
+
+CASES = {
+  "cross": (1, 32, 32, 1024, 8192, 512, False), "cross_d320": (1, 32, 32, 1024, 8192, 320, False), "cross_d1024": (1, 32, 32, 1024, 8192, 1024, False),
+  "cfg4_nomask": (2, 32, 8, 8192, 2048, 320, False), "n1024": (1, 32, 32, 1024, 1024, 512, False), "n2048": (1, 32, 32, 2048, 2048, 512, False),
+  "h8_n4096": (1, 8, 8, 4096, 4096, 512, False), "h12_n4096": (1, 12, 12, 4096, 8192, 512, False),
+}
+hip.load_library()
+for name, (B, Hq, Hkv, Nq, Nkv, D, causal) in CASES.items():
+  torch.manual_seed(0)
+  q = torch.randn(B, Hq, Nq, D, dtype=torch.bfloat16, device="cuda")
+  k = torch.randn(B, Hkv, Nkv, D, dtype=torch.bfloat16, device="cuda")
+  v = torch.randn(B, Hkv, Nkv, D, dtype=torch.bfloat16, device="cuda")
+  flops = 4 * B * Hq * D * Nq * Nkv
+  arms = [0, 1, 2, 3, 4]
+  times = {a: [] for a in arms}
+  plans = {}
+  for a in arms:
+    p = {}
+    hip.forward(q, k, v, None, causal, D ** -0.5, num_splits=a, return_lse=False, plan_out=p)
+    plans[a] = p.get("splits")
+  for _ in range(7):
+    for a in arms:
+      s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      s.record()
+      for _ in range(5):
+        hip.forward(q, k, v, None, causal, D ** -0.5, num_splits=a, return_lse=False)
+      e.record()
+      torch.cuda.synchronize()
+      times[a].append(s.elapsed_time(e) / 5)
+  print(f"SPLITS {name:12s} B{B} H{Hq}/{Hkv} Nq{Nq} Nkv{Nkv} D{D}: " + "  ".join(f"req {a} (plan {plans[a]}): {sorted(times[a])[3]:.4f} ms {flops / sorted(times[a])[3] / 1e9:7.1f} TF" for a in arms), flush=True)
