@@ -103,7 +103,8 @@ def test_short_query_plan_and_workspace(lib):
   (dict(batch=8, heads_q=8, heads_kv=8, seqlen_kv=8192, head_dim=512), (64, 4)),       # 64 row tiles
   (dict(batch=4, heads_q=32, heads_kv=32, seqlen_kv=8192, head_dim=128), (64, 4)),     # small head dims: two workgroups per CU (128 row tiles x 4 = 512), 64-key tiles
   (dict(batch=1, heads_q=64, heads_kv=64, seqlen_kv=8192, head_dim=256), (32, 8)),     # D = 256 keeps 32-key tiles (two workgroups per CU)
-  (dict(batch=1, heads_q=32, heads_kv=32, seqlen_kv=8192, head_dim=320), (32, 8)),     # two-wave split (D % 128 != 0): 32-key tiles, one workgroup per CU
+      (dict(batch=1, heads_q=32, heads_kv=32, seqlen_kv=8192, head_dim=320), (64, 8)),     # two-wave split (D % 128 != 0): 64-key tiles since round 4 (D = 320 / 448), one workgroup per CU
+      (dict(batch=1, heads_q=32, heads_kv=32, seqlen_kv=8192, head_dim=576), (32, 8)),     # ... 32-key tiles where the LDS has no room for 64 (D >= 576)
   (dict(batch=16, heads_q=32, heads_kv=32, seqlen_kv=4096, head_dim=512), (64, 1)),    # 512 row tiles fill the chip: no split
 ])
 def test_short_query_split_rule(lib, over, want):
