@@ -123,7 +123,8 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
   // against a long context with few heads per GPU): one workgroup per CU, at least 8 KV tiles per split.
   const int64_t base = (int64_t)p->batch * p->heads_q * pl.nqt;
   const int64_t cus = device_cu_count();
-  const bool underfilled = pl.variant == 0 && !(p->flags & FFPA_FLAG_DEBUG_SAFE_PATH) && base * 2 <= cus;
+  const bool underfilled = pl.variant == 0 && !(p->flags & FFPA_FLAG_DEBUG_SAFE_PATH) &&
+                           (base * 2 <= cus || ((p->flags & FFPA_FLAG_FORCE_SPLITS) && p->num_splits > 1));  // (the flag: sweeps of the rule, tools/gpu_prefill_splits.py)
   if ((pl.variant == 1 || underfilled) && p->num_splits != 1) {
     // short-query tiles, measured (tools/gpu_decode_splits.py, profiles/r03_decode_splits.txt): head dims >= 320 want ONE workgroup per CU — their tiles are
     // 20 KiB and up, one workgroup keeps enough bytes in flight, and half the splits are half the partials to write and merge (- 3 ... 14 % per step
@@ -131,6 +132,7 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
     // as long as one a little under) — the small head dims two (8 KiB tiles at D = 128: one per CU is 40 ... 60 % slower, three or four 10 ... 25 %)
     const bool sq_one_per_cu = kernel_head_dim(p->head_dim) >= 320 || pl.lds > 80 * 1024;  // (or tiles of which only one workgroup fits a CU)
     int64_t want = pl.variant == 1 ? (sq_one_per_cu ? cus / base : (2 * cus + base - 1) / base) : cus / base;
+    if (pl.variant == 0 && (p->flags & FFPA_FLAG_FORCE_SPLITS) && p->num_splits > 1) want = p->num_splits;
     const int min_tiles = pl.variant == 1 ? 4 : 8;
     const int64_t cap = pl.nt / min_tiles > 0 ? pl.nt / min_tiles : 1;
     if (want > cap) want = cap;

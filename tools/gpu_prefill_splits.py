@@ -22,14 +22,14 @@ for name, (B, Hq, Hkv, Nq, Nkv, D, causal) in CASES.items():
   plans = {}
   for a in arms:
     p = {}
-    hip.forward(q, k, v, None, causal, D ** -0.5, num_splits=a, return_lse=False, plan_out=p)
+    hip.forward(q, k, v, None, causal, D ** -0.5, num_splits=a, return_lse=False, plan_out=p, flags=hip.FLAG_FORCE_SPLITS if a > 1 else 0)
     plans[a] = p.get("splits")
   for _ in range(7):
     for a in arms:
       s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
       s.record()
       for _ in range(5):
-        hip.forward(q, k, v, None, causal, D ** -0.5, num_splits=a, return_lse=False)
+        hip.forward(q, k, v, None, causal, D ** -0.5, num_splits=a, return_lse=False, flags=hip.FLAG_FORCE_SPLITS if a > 1 else 0)
       e.record()
       torch.cuda.synchronize()
       times[a].append(s.elapsed_time(e) / 5)
