@@ -318,7 +318,7 @@ __device__ __forceinline__ int m16_v_swizzle(int key) {
 #if FFPA_ABL != 0 || FFPA_SQ_BC64 != 1 || FFPA_SQ_BC64_ND2 != 1 || defined(FFPA_M16_TIMING) || FFPA_PERSISTENT != 0 || FFPA_M16_ROWDMA != 1 || FFPA_M16_PF1 != 6 || FFPA_M16_PF2 != 4 || \
     FFPA_M16_K_PRE != 8 || FFPA_M16_K_PRE_ND2 != 64 || FFPA_M16_DEPHASE != 0 || FFPA_M16_PF_DIST != 2 || FFPA_M16_PF_WAVES != 2 || FFPA_M16_PF_WHICH != 3 || (defined(FFPA_M16_PF_ALL_D) && FFPA_M16_PF_ALL_D != 0) || FFPA_M16_ROW_TABLES != 1 || FFPA_DMA_M0_CLOBBER != 1 || FFPA_M16_SWAP_REDUCE != 1 || FFPA_M16_MIN_D != 128 || FFPA_M16_BC128_MIN_D != 256 || \
     (defined(FFPA_M16_PHILOX_ILP) && FFPA_M16_PHILOX_ILP != 1) || FFPA_M16_KSPLIT != 0 || FFPA_M16_PIPE != 1 || FFPA_M16_PP_VQ != 6 || FFPA_M16_PP_K1Q != 2 || FFPA_M16_PP_K2S != 2 || \
-    FFPA_M16_PP_QSTEP != 2 || FFPA_M16_PP_SSTEP != 1 || FFPA_M16_PP_PSTEP != 2 || FFPA_M16_PP_PF != 3 || FFPA_M16_PIECE_IL != 0 || FFPA_M16_KS_PVSTEP != 0 || FFPA_M16_FUSE_DMA != 1
+    FFPA_M16_PP_QSTEP != 2 || FFPA_M16_PP_SSTEP != 1 || FFPA_M16_PP_PSTEP != 2 || FFPA_M16_PP_PF != 3 || FFPA_M16_PIECE_IL != 0 || FFPA_M16_KS_PVSTEP != 0 || FFPA_M16_FUSE_DMA != 1 || (defined(FFPA_M16_PF_SLICE_BY_XCD_SEQ) && FFPA_M16_PF_SLICE_BY_XCD_SEQ != 1) || (defined(FFPA_M16_PK_FMA) && FFPA_M16_PK_FMA != 1)
 #error "FFPA_PRODUCT_BUILD: a developer switch is not at its shipped default"
 #endif
 #endif
@@ -565,7 +565,15 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   if (pf_on) {
     constexpr int kPer = FFPA_M16_PF_WAVES / 2;  // slices one workgroup touches per step
     constexpr int kGroups = kPfSlices / kPer > 0 ? kPfSlices / kPer : 1;
-    const int slice = (((qt + hq) % kGroups) * kPer + (wave >> 1)) % kPfSlices;
+#ifndef FFPA_M16_PF_SLICE_BY_XCD_SEQ
+#define FFPA_M16_PF_SLICE_BY_XCD_SEQ 1
+#endif
+    // which slice: by the workgroup's sequence number ON ITS XCD (the hardware deals workgroup ids round-robin to the 8 XCDs: id >> 3) — the ~32
+    // workgroups resident on an XCD have consecutive numbers, so together they touch every slice of the tile in that XCD's L2.  (Round 3 used
+    // (row tile + head) mod slices: with two XCDs per head — config 3 — an XCD holds only the even or only the odd row tiles of a head, i.e. four
+    // of the eight slices: half of every tile's lines were never touched in its L2.)
+    const int slice_seq = FFPA_M16_PF_SLICE_BY_XCD_SEQ ? (int)(blockIdx.x >> 3) : qt + hq;
+    const int slice = ((slice_seq % kGroups) * kPer + (wave >> 1)) % kPfSlices;
     const uint32_t key = (uint32_t)(slice * kPfKeys + lane / kPfLinesP2), line = (uint32_t)(lane % kPfLinesP2);
     if (line * 128u < rb_valid && key < (uint32_t)BC) pf_off = key * (pf_k ? k_row_bytes : v_row_bytes) + line * 128u;
   }
@@ -882,7 +890,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       f32x4 s0[2];  // partial S^T of key block 0 of tile j + 1
       float x[NKB][2][4];
       float tmax[2] = {0.f, 0.f};
-      float m_use[2] = {0.f, 0.f}, psum[2] = {0.f, 0.f};
+      float m_use[2] = {0.f, 0.f}, psum[2] = {0.f, 0.f}, earg[2] = {0.f, 0.f};
       v8 pf[NKS][2];
       {
         f32x4 tp[NKB][2], xc[2];
@@ -961,7 +969,14 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
             m_use[1] = (m_run[1] == -INFINITY) ? 0.f : m_run[1];
           } else if constexpr (g >= 14 && g <= 29) {  // one exponential per gap, row half by row half in the loop's order (the row sum adds up in that order)
             constexpr int i = g - 14, rh = i >> 3, kb = (i >> 2) & 1, r = i & 3;
-            const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(x[kb][rh][r], a.scale_log2, -m_use[rh]));
+            if constexpr ((r & 1) == 0) {  // (the pair's two exponents in one packed FMA: the same roundings)
+              typedef __attribute__((ext_vector_type(2))) float f32x2;
+              const f32x2 xv = {x[kb][rh][r], x[kb][rh][r + 1]};
+              const f32x2 av = __builtin_elementwise_fma(xv, (f32x2)(a.scale_log2), (f32x2)(-m_use[rh]));
+              earg[0] = av[0];
+              earg[1] = av[1];
+            }
+            const float pv = __builtin_amdgcn_exp2f(earg[r & 1]);
             psum[rh] += pv;
             pf[kb >> 1][rh][4 * (kb & 1) + r] = (T)pv;
           } else if constexpr (g == 30) {
@@ -1439,7 +1454,21 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(x[kb][rh][r], a.scale_log2, -m_use));
+#ifndef FFPA_M16_PK_FMA
+// the exponents' x * scale - m as packed FMAs (v_pk_fma_f32: two scores per instruction, the same roundings — bit-identical): config 2 + 0.6 %, causal + 2.0 %,
+// cross + 1.2 %, config 4 + 2.2 %, D = 320 + 0.7 % (interleaved A/B, profiles/r04_pipe.txt)
+#define FFPA_M16_PK_FMA 1
+#endif
+          float arg;
+          if constexpr (FFPA_M16_PK_FMA != 0) {
+            typedef __attribute__((ext_vector_type(2))) float f32x2;
+            const f32x2 xv = {x[kb][rh][r & ~1], x[kb][rh][r | 1]};
+            const f32x2 av = __builtin_elementwise_fma(xv, (f32x2)(a.scale_log2), (f32x2)(-m_use));
+            arg = av[r & 1];
+          } else {
+            arg = __builtin_fmaf(x[kb][rh][r], a.scale_log2, -m_use);
+          }
+          const float p = __builtin_amdgcn_exp2f(arg);
           psum += p;  // row sum from the unrounded P (prefill.cuh:755-756)
           if constexpr (DROP) {
             // dropout: applied to the ROUNDED P, after the row sum (LSE is undropped), scaled by 1 / (1 - p) and rounded again
