@@ -1460,7 +1460,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 #define FFPA_M16_PK_FMA 1
 #endif
           float arg;
-          if constexpr (FFPA_M16_PK_FMA != 0) {
+          // (not in the boolean-mask build of D = 512: there the packed form costs the allocator one scalar lane spill inside the MFMA loops)
+          if constexpr (FFPA_M16_PK_FMA != 0 && !(D == 512 && MK == 2)) {
             typedef __attribute__((ext_vector_type(2))) float f32x2;
             const f32x2 xv = {x[kb][rh][r & ~1], x[kb][rh][r | 1]};
             const f32x2 av = __builtin_elementwise_fma(xv, (f32x2)(a.scale_log2), (f32x2)(-m_use));
