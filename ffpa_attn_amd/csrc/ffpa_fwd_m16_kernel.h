@@ -153,6 +153,11 @@
 #ifndef FFPA_M16_PP_PSTEP
 #define FFPA_M16_PP_PSTEP 2
 #endif
+// (measured, profiles/r04_pipe.txt: at D = 1024 "one per gap" and "all behind the MFMAs" run equally fast — VALU between a wave's own MFMAs is paid in full either way —,
+// at D = 640 behind is + 1.9 %, in front - 3 ... 4 % everywhere; -1 = behind for D < 1024, per gap at D = 1024)
+#ifndef FFPA_M16_PP_SMPOS
+#define FFPA_M16_PP_SMPOS -1  // where the softmax's instruction groups sit in the S phase: 0 = one per MFMA gap, 1 = all behind the phase's MFMAs, 2 = all in front, 4 / 8 = clustered in every 4th / 8th gap
+#endif
 #ifndef FFPA_M16_PP_PF
 #define FFPA_M16_PP_PF 3  // K fragments requested ahead of their MFMAs in the S phase (the softmax's registers are live next to them)
 #endif
@@ -318,7 +323,7 @@ __device__ __forceinline__ int m16_v_swizzle(int key) {
 #if FFPA_ABL != 0 || FFPA_SQ_BC64 != 1 || FFPA_SQ_BC64_ND2 != 1 || defined(FFPA_M16_TIMING) || FFPA_PERSISTENT != 0 || FFPA_M16_ROWDMA != 1 || FFPA_M16_PF1 != 6 || FFPA_M16_PF2 != 4 || \
     FFPA_M16_K_PRE != 8 || FFPA_M16_K_PRE_ND2 != 64 || FFPA_M16_DEPHASE != 0 || FFPA_M16_PF_DIST != 2 || FFPA_M16_PF_WAVES != 2 || FFPA_M16_PF_WHICH != 3 || (defined(FFPA_M16_PF_ALL_D) && FFPA_M16_PF_ALL_D != 0) || FFPA_M16_ROW_TABLES != 1 || FFPA_DMA_M0_CLOBBER != 1 || FFPA_M16_SWAP_REDUCE != 1 || FFPA_M16_MIN_D != 128 || FFPA_M16_BC128_MIN_D != 256 || \
     (defined(FFPA_M16_PHILOX_ILP) && FFPA_M16_PHILOX_ILP != 1) || FFPA_M16_KSPLIT != 0 || FFPA_M16_PIPE != 1 || FFPA_M16_PP_VQ != 6 || FFPA_M16_PP_K1Q != 2 || FFPA_M16_PP_K2S != 2 || \
-    FFPA_M16_PP_QSTEP != 2 || FFPA_M16_PP_SSTEP != 1 || FFPA_M16_PP_PSTEP != 2 || FFPA_M16_PP_PF != 3 || FFPA_M16_PIECE_IL != 0 || FFPA_M16_KS_PVSTEP != 0 || FFPA_M16_FUSE_DMA != 1 || (defined(FFPA_M16_PF_SLICE_BY_XCD_SEQ) && FFPA_M16_PF_SLICE_BY_XCD_SEQ != 1) || (defined(FFPA_M16_PK_FMA) && FFPA_M16_PK_FMA != 1)
+    FFPA_M16_PP_QSTEP != 2 || FFPA_M16_PP_SSTEP != 1 || FFPA_M16_PP_PSTEP != 2 || FFPA_M16_PP_PF != 3 || FFPA_M16_PIECE_IL != 0 || FFPA_M16_KS_PVSTEP != 0 || FFPA_M16_FUSE_DMA != 1 || (defined(FFPA_M16_PF_SLICE_BY_XCD_SEQ) && FFPA_M16_PF_SLICE_BY_XCD_SEQ != 1) || (defined(FFPA_M16_PK_FMA) && FFPA_M16_PK_FMA != 1) || FFPA_M16_PP_SMPOS != -1
 #error "FFPA_PRODUCT_BUILD: a developer switch is not at its shipped default"
 #endif
 #endif
@@ -990,6 +995,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
           constexpr int lo = (g * 32 + 2 * KS - 1) / (2 * KS), hi = ((g + 1) * 32 + 2 * KS - 1) / (2 * KS);
           static_for<hi - lo>([&](auto uc) { softmax_gap(std::integral_constant<int, lo + decltype(uc)::value>{}); });
         };
+        if constexpr (FFPA_M16_PP_SMPOS == 2) static_for<2 * KS>([&](auto gc) { softmax_gaps(gc); });
         static_for<KS>([&](auto sc) {
           constexpr int s_ = decltype(sc)::value;
           __builtin_amdgcn_sched_barrier(0);
@@ -1007,13 +1013,16 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
               else issue_k(std::integral_constant<int, kH + (t - ppVS)>{}, k0 + BC);        // K2(j+1), first part
             }
           }
-          softmax_gaps(std::integral_constant<int, 2 * s_>{});
+          constexpr int kSmPos = FFPA_M16_PP_SMPOS < 0 ? (KS < 16 ? 1 : 0) : FFPA_M16_PP_SMPOS;
+          if constexpr (kSmPos == 0) softmax_gaps(std::integral_constant<int, 2 * s_>{});
+          else if constexpr (kSmPos >= 4 && (2 * s_) % kSmPos == 0) static_for<kSmPos>([&](auto uc) { if constexpr (2 * s_ + decltype(uc)::value < 2 * KS) softmax_gaps(std::integral_constant<int, 2 * s_ + decltype(uc)::value>{}); });
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (s_ == 0) M::first(s0[1], kf[s_], qf[s_][1]);
           else if constexpr (s_ == KS - 1) M::acc_last(s0[1], s0[0], kf[s_], qf[s_][1]);
           else M::acc(s0[1], kf[s_], qf[s_][1]);
-          softmax_gaps(std::integral_constant<int, 2 * s_ + 1>{});
+          if constexpr (kSmPos == 0) softmax_gaps(std::integral_constant<int, 2 * s_ + 1>{});
         });
+        if constexpr (FFPA_M16_PP_SMPOS == 1 || (FFPA_M16_PP_SMPOS < 0 && KS < 16)) static_for<2 * KS>([&](auto gc) { softmax_gaps(gc); });
         __builtin_amdgcn_sched_barrier(0);
         *(FFPA_LDS f32x4*)(xw + ((j + 1) & 1) * 2048) = s0[0];
         *(FFPA_LDS f32x4*)(xw + ((j + 1) & 1) * 2048 + 1024) = s0[1];
