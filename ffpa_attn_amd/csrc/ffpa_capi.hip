@@ -123,8 +123,33 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
   // against a long context with few heads per GPU): one workgroup per CU, at least 8 KV tiles per split.
   const int64_t base = (int64_t)p->batch * p->heads_q * pl.nqt;
   const int64_t cus = device_cu_count();
+  // Ragged rounds (round 4, profiles/r04_launch_side.txt): a prefill launch of a little over one round of workgroups — 288 ... 384 on 256 CUs — takes two
+  // rounds' time.  Split over 2 or 3 KV ranges it fills whole rounds (9 heads x 32 row tiles x 3 = 864 = 3.4 rounds), and on a long context the partials
+  // and their merge cost little next to that: B1 H9 / H10 / H11 / H12 x Nq 4096 x Nkv 8192 D512 + 18 / + 15 / + 10 / + 5 %, H40 x Nq 1024 + 14 %,
+  // D = 1024 H5 + 19 %; against 2048 keys or under the causal flag the same splits LOSE 18 ... 37 % — the rule prices both sides and splits only for a
+  // predicted gain of 10 % (the model errs on the launch's side: it over-prices the splits by ~ 10 % on every measured shape):
+  //   time(s) = rounds(s) x (tiles per split + 4 tiles of per-workgroup fixed cost) x tile time  +  (8 s + 2) bytes per output element / 5 TB/s
+  int ragged_splits = 1;
+  if (pl.variant == 0 && !(p->flags & (FFPA_FLAG_DEBUG_SAFE_PATH | FFPA_FLAG_FORCE_SPLITS)) && p->num_splits == 0 && base > cus && 2 * base <= 3 * cus &&
+      p->bias == nullptr && p->kv_bounds == nullptr && !(p->dropout_p > 0.f) && p->workspace != nullptr) {
+    const int dk = kernel_head_dim(p->head_dim);
+    const double nt_eff = p->causal ? 0.5 * pl.nt : (double)pl.nt;  // (a causal row tile walks about half of the keys)
+    const double tile_s = 4.0 * pl.br * pl.bc * dk / (dk > 512 ? 4.0e12 : 5.0e12);  // one KV tile of one workgroup at the rate one CU sustains
+    const double elems = (double)p->batch * p->heads_q * p->seqlen_q * dk;
+    auto predicted = [&](int s) {
+      const double rounds = (double)((base * s + cus - 1) / cus);
+      return rounds * (nt_eff / s + 4.0) * tile_s + (s > 1 ? elems * (8.0 * s + 2.0) / 5.0e12 : 0.0);
+    };
+    const double t1 = predicted(1);
+    double best = t1;
+    for (int s = 2; s <= 3; ++s) {
+      if (pl.nt / s < 8) break;  // (>= 8 KV tiles per split, as the under-filled rule)
+      const double t = predicted(s);
+      if (t < 0.9 * t1 && t < best) best = t, ragged_splits = s;
+    }
+  }
   const bool underfilled = pl.variant == 0 && !(p->flags & FFPA_FLAG_DEBUG_SAFE_PATH) &&
-                           (base * 2 <= cus || ((p->flags & FFPA_FLAG_FORCE_SPLITS) && p->num_splits > 1));  // (the flag: sweeps of the rule, tools/gpu_prefill_splits.py)
+                           (base * 2 <= cus || ragged_splits > 1 || ((p->flags & FFPA_FLAG_FORCE_SPLITS) && p->num_splits > 1));  // (the flag: sweeps of the rule, tools/gpu_prefill_splits.py)
   if ((pl.variant == 1 || underfilled) && p->num_splits != 1) {
     // short-query tiles, measured (tools/gpu_decode_splits.py, profiles/r03_decode_splits.txt): head dims >= 320 want ONE workgroup per CU — their tiles are
     // 20 KiB and up, one workgroup keeps enough bytes in flight, and half the splits are half the partials to write and merge (- 3 ... 14 % per step
@@ -133,6 +158,7 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
     const bool sq_one_per_cu = kernel_head_dim(p->head_dim) >= 320 || pl.lds > 80 * 1024;  // (or tiles of which only one workgroup fits a CU)
     int64_t want = pl.variant == 1 ? (sq_one_per_cu ? cus / base : (2 * cus + base - 1) / base) : cus / base;
     if (pl.variant == 0 && (p->flags & FFPA_FLAG_FORCE_SPLITS) && p->num_splits > 1) want = p->num_splits;
+    if (ragged_splits > 1) want = ragged_splits;
     const int min_tiles = pl.variant == 1 ? 4 : 8;
     const int64_t cap = pl.nt / min_tiles > 0 ? pl.nt / min_tiles : 1;
     if (want > cap) want = cap;

@@ -142,6 +142,36 @@ def test_underfilled_prefill_plan_splits_the_kv_axis(lib):
   assert lib.ffpa_attn_fwd_plan(ctypes.byref(full), plan) == 0 and plan[3] == 1
 
 
+@pytest.mark.parametrize("over, want", [
+  (dict(heads_q=9, heads_kv=9, seqlen_q=4096, seqlen_kv=8192), 3),      # 288 workgroups = 1.125 rounds of 256 CUs -> 864 = 3.4 rounds (measured + 18 %)
+  (dict(heads_q=10, heads_kv=10, seqlen_q=4096, seqlen_kv=8192), 3),    # 320 -> + 15 %
+  (dict(heads_q=11, heads_kv=11, seqlen_q=4096, seqlen_kv=8192), 2),    # 352 -> 704 = 2.75 rounds (+ 10 %; three splits measured slower)
+  (dict(heads_q=12, heads_kv=12, seqlen_q=4096, seqlen_kv=8192), 2),    # 384 -> three whole rounds (+ 5 %)
+  (dict(heads_q=40, heads_kv=40, seqlen_q=1024, seqlen_kv=8192), 3),    # 320 workgroups of a short-query-axis launch (+ 14 %)
+  (dict(heads_q=5, heads_kv=5, seqlen_q=4096, seqlen_kv=8192, head_dim=1024), 3),  # D = 1024: 64-row tiles, 320 workgroups (+ 19 %)
+  (dict(heads_q=12, heads_kv=12, seqlen_q=4096, seqlen_kv=2048), 1),    # short context: the partials and their merge would cost more than the ragged round (measured - 18 %)
+  (dict(heads_q=12, heads_kv=12, seqlen_q=4096, seqlen_kv=4096, causal=1), 1),  # causal: half the keys per row tile (measured - 37 %)
+  (dict(heads_q=17, heads_kv=17, seqlen_q=4096, seqlen_kv=8192), 1),    # 2.1 rounds: a predicted 4 % is under the rule's 10 %
+  (dict(heads_q=20, heads_kv=20, seqlen_q=4096, seqlen_kv=8192), 1),    # 2.5 rounds
+  (dict(heads_q=32, heads_kv=32, seqlen_q=1024, seqlen_kv=8192), 1),    # exactly one round (`cross`): splits measured - 14 %
+  (dict(heads_q=32, heads_kv=32, seqlen_q=8192, seqlen_kv=8192), 1),    # the headline shape: 8 whole rounds
+])
+def test_ragged_round_split_rule(lib, over, want):
+  """Prefill launches of a little over one round of workgroups (1 < workgroups / CUs <= 1.5) split the KV axis in 2 or 3 when the cost model of
+  ffpa_capi.hip predicts >= 10 % (profiles/r04_launch_side.txt); nothing else that fills the chip splits.  256-CU fallback: no GPU needed."""
+  plan = (ctypes.c_int * 4)()
+  p = _params(**over)
+  p.workspace, p.workspace_bytes = 16, 1 << 40
+  assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0
+  assert plan[0] == 0 and plan[3] == want, list(plan)
+  if want > 1:
+    p.workspace, p.workspace_bytes = None, 0  # a caller without scratch: the plain launch
+    assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0 and plan[3] == 1
+    p.workspace, p.workspace_bytes = 16, 1 << 40
+    p.num_splits = 1                           # ... or one that forbids splits
+    assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0 and plan[3] == 1
+
+
 def test_tile_configs():
   for d in range(64, 1025, 64):
     c = hip.tile_config(d)

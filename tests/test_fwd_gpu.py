@@ -681,6 +681,28 @@ def test_underfilled_prefill_splits_the_kv_axis(hip, D, Hq, Hkv, Nq, Nkv, causal
   assert (ob.float() - ob1.float()).abs().max().item() <= 4e-3
 
 
+@pytest.mark.parametrize("D,H,Nq,Nkv", [(512, 9, 4096, 8192), (512, 11, 4096, 8190), (1024, 5, 4096, 8192), (320, 10, 4096, 8192)])
+def test_ragged_round_prefill_splits_the_kv_axis(hip, D, H, Nq, Nkv):
+  """A launch of a little over one round of workgroups (1 < workgroups / CUs <= 1.5) on a long context: the plan splits the KV axis in 2
+  or 3 (ffpa_capi.hip make_plan; profiles/r04_launch_side.txt).  Same answer as the unsplit launch to rounding, the oracle's bound on a
+  row subset, and one split on request."""
+  cus = torch.cuda.get_device_properties(0).multi_processor_count
+  q, k, v = _rand((1, H, Nq, D), seed=411), _rand((1, H, Nkv, D), seed=412), _rand((1, H, Nkv, D), seed=413)
+  scale = D ** -0.5
+  plan = {}
+  o, lse = hip.forward(q, k, v, None, False, scale, plan_out=plan)
+  wgs = H * (Nq // plan["block_rows"])
+  if not (cus < wgs <= 1.5 * cus):
+    pytest.skip(f"{wgs} workgroups on {cus} CUs is not a ragged round on this device")
+  assert plan["variant"] == 0 and plan["splits"] in (2, 3), plan
+  o1, lse1 = hip.forward(q, k, v, None, False, scale, num_splits=1, plan_out=plan)
+  assert plan["splits"] == 1
+  assert (o.float() - o1.float()).abs().max().item() <= 4e-3 and (lse - lse1).abs().max().item() <= 1e-4
+  rows = torch.arange(0, Nq, Nq // 64, device="cuda")  # 64 rows spread over the row tiles, every head
+  _check_vs_oracle(o[:, :, rows].contiguous(), lse[:, :, rows].contiguous(), q[:, :, rows].contiguous(), k, v, block_keys=plan["block_keys"],
+                   name=f"ragged D{D} H{H}", split=True)
+
+
 @pytest.mark.parametrize("D", [512, 320, 1024])
 def test_mask_derived_tile_clipping_changes_nothing_but_the_time(hip, D):
   """kv_bounds (visible-key range per 32-row block, derived from the mask): tiles the mask hides entirely are

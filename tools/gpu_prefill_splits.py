@@ -9,14 +9,21 @@ CASES = {
   "cross": (1, 32, 32, 1024, 8192, 512, False), "cross_d320": (1, 32, 32, 1024, 8192, 320, False), "cross_d1024": (1, 32, 32, 1024, 8192, 1024, False),
   "cfg4_nomask": (2, 32, 8, 8192, 2048, 320, False), "n1024": (1, 32, 32, 1024, 1024, 512, False), "n2048": (1, 32, 32, 2048, 2048, 512, False),
   "h8_n4096": (1, 8, 8, 4096, 4096, 512, False), "h12_n4096": (1, 12, 12, 4096, 8192, 512, False),
+  # ragged rounds: 1 < workgroups / CUs <= 1.5 (256 CUs, 128-row tiles: 32 row tiles per head at Nq 4096)
+  "h9_n4096": (1, 9, 9, 4096, 8192, 512, False), "h10_n4096": (1, 10, 10, 4096, 8192, 512, False), "h11_n4096": (1, 11, 11, 4096, 8192, 512, False),
+  "h12_n4096_short": (1, 12, 12, 4096, 2048, 512, False), "h12_n4096_causal": (1, 12, 12, 4096, 4096, 512, True), "h10_d320": (1, 10, 10, 4096, 8192, 320, False),
+  "h20_n4096_d1024": (1, 5, 5, 4096, 8192, 1024, False), "h6_d1024": (1, 6, 6, 4096, 8192, 1024, False), "h40_n1024": (1, 40, 40, 1024, 8192, 512, False),
+  "h17": (1, 17, 17, 4096, 8192, 512, False), "h20": (1, 20, 20, 4096, 8192, 512, False),
 }
+if os.environ.get("ONLY"):
+  CASES = {k_: v_ for k_, v_ in CASES.items() if k_ in os.environ["ONLY"].split(",")}
 hip.load_library()
 for name, (B, Hq, Hkv, Nq, Nkv, D, causal) in CASES.items():
   torch.manual_seed(0)
   q = torch.randn(B, Hq, Nq, D, dtype=torch.bfloat16, device="cuda")
   k = torch.randn(B, Hkv, Nkv, D, dtype=torch.bfloat16, device="cuda")
   v = torch.randn(B, Hkv, Nkv, D, dtype=torch.bfloat16, device="cuda")
-  flops = 4 * B * Hq * D * Nq * Nkv
+  flops = 4 * B * Hq * D * Nq * Nkv // (2 if causal else 1)
   arms = [0, 1, 2, 3, 4]
   times = {a: [] for a in arms}
   plans = {}
