@@ -547,6 +547,7 @@ def main() -> None:
   ap.add_argument("--no-sdpa", action="store_true", help="skip the SDPA-on-GPU accuracy / speed comparison")
   ap.add_argument("--no-ref-protocol", action="store_true", help="skip the reference bench's own timing protocol (2 warm-ups + 10 iterations)")
   ap.add_argument("--no-gather-extra", action="store_true", help="N > 1: skip the second timed region that adds the all_gather of O")
+  ap.add_argument("--no-steady", action="store_true", help="N = 1: skip the steady-state leg (the step again after >= 150 ms of continuous load, outside the timed region)")
   ap.add_argument("--sweep", action="store_true", help="the reference bench's case table for --sweep-dims in one process (python -m ffpa_attn.bench)")
   ap.add_argument("--sweep-dims", default="320,512,1024")
   ap.add_argument("--stub-backend", default="", help="(tests) run the launch / barrier / reduction plumbing on CPU over this torch.distributed "
@@ -676,6 +677,32 @@ def main() -> None:
     g_elapsed, g_per_rank, _ = timed(step_gather)
     gather_extra = {"value": round(flops_global * args.steps / g_elapsed / 1e12, 2), "unit": "TFLOPS", "ms_per_step": round(g_elapsed / args.steps * 1e3, 4),
                     "per_rank_tflops": g_per_rank, "what": f"the step + RCCL all_gather_into_tensor of O ({args.gather_chunks} pieces overlapped with compute)"}
+  steady = None
+  if world == 1 and not args.no_steady and not args.stub_backend:
+    # Context for `value`, never `value` itself: a GPU coming out of idle runs its first ~ 10 - 25 ms of work slower than it does under
+    # continuous load (profiles/r04_clock_ramp.txt: the first 25 launches of a 0.44 ms kernel take 0.53 ms at a REPORTED 2.4 GHz, a 3.2 ms
+    # kernel's first five 3.7 ms), and socket power takes ~ 200 ms to reach its cap, pulling the clock from 2.4 to ~ 2.0 GHz.  W = 5 + K = 20
+    # steps of a short kernel live inside that transient.  This leg repeats the step back to back until >= 150 ms of load have passed and
+    # times the launches after that with one event pair.
+    est_ms = max(kernel_ms_avg, 1e-3)
+    n_pre, n_timed = max(20, int(150.0 / est_ms)), max(20, min(400, int(60.0 / est_ms)))
+    for _ in range(n_pre):
+      step()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    telemetry.start()
+    ev0.record()
+    for _ in range(n_timed):
+      step()
+    ev1.record()
+    torch.cuda.synchronize()
+    telemetry.stop()
+    tel2 = telemetry.summary()
+    ss_ms = ev0.elapsed_time(ev1) / n_timed
+    steady = {"ms_per_step": round(ss_ms, 4), "tflops": round(flops_local / ss_ms / 1e9, 2), "launches": n_timed, "after_launches": n_pre,
+              "sclk_mhz_avg": tel2.get("sclk_mhz_avg"), "power_w_avg": tel2.get("power_w_avg"),
+              "what": "the same step back to back after >= 150 ms of continuous load, one HIP event pair around the launches; outside the timed region"}
+    if w["bound"] == "hbm":
+      steady["gbps"] = round(algorithmic_bytes(w, global_B) / (ss_ms * 1e-3) / 1e9, 1)
   plan = planned_kernel(w, q[:1], k[:1], v[:1], mask, scale) if rank == 0 else {}
 
   if rank == 0:
@@ -728,6 +755,7 @@ def main() -> None:
       },
       "roofline": roof,
       "device": device,
+      "steady_state": steady,
       "build": build,
       "plan": {k_: plan.get(k_) for k_ in ("variant", "block_rows", "block_keys", "splits")},
     }

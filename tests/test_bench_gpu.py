@@ -1,0 +1,49 @@
+"""bench.py as the driver runs it, on one GPU: one JSON line with the contract's keys, the roofline and CPU-baseline objects, what the device
+said about itself, and the steady-state leg.  No throughput is asserted — only that the line is whole and self-consistent."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _bench(*flags):
+  env = dict(os.environ)
+  for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+    env.pop(k_, None)
+  out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=600, env=env)
+  assert out.returncode == 0, out.stderr[-2000:]
+  lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+  assert len(lines) == 1, out.stdout[-2000:]
+  return json.loads(lines[0])
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_bench_line_of_a_short_workload_is_whole():
+  line = _bench("--gpus", "1", "--workload", "cross", "--steps", "4", "--warmup", "2", "--no-sdpa")
+  for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "device", "steady_state", "build", "plan"):
+    assert key in line, key
+  assert line["n_gpus"] == 1 and line["steps"] == 4 and line["warmup"] == 2 and line["dtype"] == "bf16" and line["vs_baseline"] is None
+  assert "model" not in line["config"] and line["config"]["workload"].startswith("cross")
+  roof = line["roofline"]
+  assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 2500.0 and "traffic" in roof
+  assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and 0.0 < roof["frac"] < 1.0
+  assert roof["kernel"].startswith("ffpa_fwd_m16_kernel<bf16, 512")
+  # the step cannot be shorter than its kernel, and the value follows from the step time
+  assert roof["kernel_ms_avg"] <= line["ms_per_step"] * 1.02
+  assert abs(line["value"] - roof["flops_per_launch"] / line["ms_per_step"] / 1e9) / line["value"] < 0.01
+  cpu = line["cpu_baseline"]
+  assert cpu["kind"] in ("reference", "port") and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
+  assert line["device"]["cus"] == torch.cuda.get_device_properties(0).multi_processor_count
+  steady = line["steady_state"]
+  assert steady["launches"] >= 20 and steady["after_launches"] >= 20 and steady["ms_per_step"] > 0
+  assert abs(steady["tflops"] - roof["flops_per_launch"] / steady["ms_per_step"] / 1e9) / steady["tflops"] < 0.01
+  assert line["build"]["lib"].endswith("libffpa_attn_hip.so") and len(line["build"]["lib_sha16"]) == 16

@@ -1,6 +1,11 @@
 #!/bin/bash
-mkdir -p gpurun_out/v23
-timeout 200 tools/probes/bin/share_probe > gpurun_out/v23/share_probe.txt 2>&1
-cat gpurun_out/v23/share_probe.txt
-timeout 300 python bench.py > gpurun_out/v23/bench_default.json 2> gpurun_out/v23/bench_default.err
-tail -c 3000 gpurun_out/v23/bench_default.json
+mkdir -p gpurun_out/v25
+timeout 600 python -m pytest tests/test_bench_gpu.py -m gpu -q > gpurun_out/v25/pytest_bench.txt 2>&1; tail -5 gpurun_out/v25/pytest_bench.txt
+for w in cross cfg4_mask decode; do
+  timeout 300 python bench.py --workload $w --no-cpu-baseline > gpurun_out/v25/bench_$w.json 2> gpurun_out/v25/bench_$w.err
+  python - <<PY
+import json
+d=json.loads(open('gpurun_out/v25/bench_$w.json').read().strip().splitlines()[-1])
+print('$w', d['value'], d['ms_per_step'], d['roofline']['frac'], d['steady_state'])
+PY
+done
