@@ -129,8 +129,11 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
   // D = 1024 H5 + 19 %; against 2048 keys or under the causal flag the same splits LOSE 18 ... 37 % — the rule prices both sides and splits only for a
   // predicted gain of 10 % (the model errs on the launch's side: it over-prices the splits by ~ 10 % on every measured shape):
   //   time(s) = rounds(s) x (tiles per split + 4 tiles of per-workgroup fixed cost) x tile time  +  (8 s + 2) bytes per output element / 5 TB/s
+  // The same pricing serves a launch of PART of a round (CUs / 2 < workgroups < CUs; at most half of the chip is the under-filled rule below): 160 workgroups
+  // in three KV ranges are 480 = two rounds of a third of the length — B1 H5 x Nq 4096 D512 + 10 % at 8192 keys, + 19 % at 16384, D = 320 + 7 %, H20 x Nq 1024
+  // + 8 %; 192 and 224 workgroups (H6, H7, D = 1024 H3) gain from no split count, and the model picks none.
   int ragged_splits = 1;
-  if (pl.variant == 0 && !(p->flags & (FFPA_FLAG_DEBUG_SAFE_PATH | FFPA_FLAG_FORCE_SPLITS)) && p->num_splits == 0 && base > cus && 2 * base <= 3 * cus &&
+  if (pl.variant == 0 && !(p->flags & (FFPA_FLAG_DEBUG_SAFE_PATH | FFPA_FLAG_FORCE_SPLITS)) && p->num_splits == 0 && 2 * base > cus && 2 * base <= 3 * cus &&
       p->bias == nullptr && p->kv_bounds == nullptr && !(p->dropout_p > 0.f) && p->workspace != nullptr) {
     const int dk = kernel_head_dim(p->head_dim);
     const double nt_eff = p->causal ? 0.5 * pl.nt : (double)pl.nt;  // (a causal row tile walks about half of the keys)

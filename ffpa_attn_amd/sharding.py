@@ -157,16 +157,17 @@ def attend_and_gather_units(qu: torch.Tensor, ku: torch.Tensor, vu: torch.Tensor
     return out
   chunks = max(1, min(chunks, per))
   if qu.is_cuda:
-    # A piece must not UNDER-FILL the chip: a prefill launch with fewer workgroups than half the CUs splits the KV axis (fp32 partials +
-    # LSE merge — the same values to rounding, not to the bit), so the gathered tensor would depend on `chunks` at the rounding level.
-    # Pieces are therefore kept at more than CUs / 2 workgroups (config 5 on 8 GPUs: 32 units x 64 row tiles per rank, 4 pieces of 512
-    # workgroups); a block that under-fills even as ONE piece is attended as one piece (its plan is then the plan of the plain call).
+    # A piece must stay out of the launch plan's KV-split rules: a prefill launch of at most 1.5 rounds of workgroups (under-filled, part of a round, a
+    # ragged round: ffpa_capi.hip make_plan) may split the KV axis (fp32 partials + LSE merge — the same values to rounding, not to the bit), so the
+    # gathered tensor would depend on `chunks` at the rounding level.  Pieces are therefore kept at more than 1.5 x CUs workgroups (config 5 on 8 GPUs:
+    # 32 units x 64 row tiles per rank, 4 pieces of 512 workgroups); a block smaller than that is attended as one piece (its plan is then the plan of
+    # the plain call).
     from . import hip
 
     cus = torch.cuda.get_device_properties(qu.device).multi_processor_count
     rows = hip.tile_config(hip.padded_head_dim(d))["block_rows"]
     per_unit = g * ((nq + rows - 1) // rows)
-    min_units = (cus // 2 + per_unit) // per_unit  # smallest unit count with more than cus / 2 workgroups
+    min_units = (3 * cus // 2 + per_unit) // per_unit  # smallest unit count with more than 1.5 x cus workgroups
     chunks = max(1, min(chunks, per // min_units))
   bounds = [per * c // chunks for c in range(chunks + 1)]
   works = []

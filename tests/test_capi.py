@@ -155,9 +155,19 @@ def test_underfilled_prefill_plan_splits_the_kv_axis(lib):
   (dict(heads_q=20, heads_kv=20, seqlen_q=4096, seqlen_kv=8192), 1),    # 2.5 rounds
   (dict(heads_q=32, heads_kv=32, seqlen_q=1024, seqlen_kv=8192), 1),    # exactly one round (`cross`): splits measured - 14 %
   (dict(heads_q=32, heads_kv=32, seqlen_q=8192, seqlen_kv=8192), 1),    # the headline shape: 8 whole rounds
+  # part of one round (CUs / 2 < workgroups < CUs)
+  (dict(heads_q=5, heads_kv=5, seqlen_q=4096, seqlen_kv=8192), 3),      # 160 workgroups -> 480 = two rounds of a third (measured + 10 %)
+  (dict(heads_q=5, heads_kv=5, seqlen_q=4096, seqlen_kv=16384), 3),     # ... + 19 % on 16384 keys
+  (dict(heads_q=20, heads_kv=20, seqlen_q=1024, seqlen_kv=8192), 3),    # 160 workgroups of a short query axis (+ 8 %)
+  (dict(heads_q=5, heads_kv=5, seqlen_q=4096, seqlen_kv=8192, head_dim=320), 3),  # + 7 %
+  (dict(heads_q=6, heads_kv=6, seqlen_q=4096, seqlen_kv=8192), 1),      # 192: no split count fills whole rounds (best measured arm - 9 %)
+  (dict(heads_q=7, heads_kv=7, seqlen_q=4096, seqlen_kv=8192), 1),      # 224
+  (dict(heads_q=3, heads_kv=3, seqlen_q=4096, seqlen_kv=8192, head_dim=1024), 1),  # 192 workgroups of 64 rows
+  (dict(heads_q=5, heads_kv=5, seqlen_q=4096, seqlen_kv=2048), 1),      # short context (measured - 20 %)
+  (dict(heads_q=5, heads_kv=5, seqlen_q=4096, seqlen_kv=4096, causal=1), 1),
 ])
 def test_ragged_round_split_rule(lib, over, want):
-  """Prefill launches of a little over one round of workgroups (1 < workgroups / CUs <= 1.5) split the KV axis in 2 or 3 when the cost model of
+  """Prefill launches of a little over one round of workgroups (1 < workgroups / CUs <= 1.5) or of part of one (0.5 < ... < 1) split the KV axis in 2 or 3 when the cost model of
   ffpa_capi.hip predicts >= 10 % (profiles/r04_launch_side.txt); nothing else that fills the chip splits.  256-CU fallback: no GPU needed."""
   plan = (ctypes.c_int * 4)()
   p = _params(**over)

@@ -681,9 +681,9 @@ def test_underfilled_prefill_splits_the_kv_axis(hip, D, Hq, Hkv, Nq, Nkv, causal
   assert (ob.float() - ob1.float()).abs().max().item() <= 4e-3
 
 
-@pytest.mark.parametrize("D,H,Nq,Nkv", [(512, 9, 4096, 8192), (512, 11, 4096, 8190), (1024, 5, 4096, 8192), (320, 10, 4096, 8192)])
+@pytest.mark.parametrize("D,H,Nq,Nkv", [(512, 9, 4096, 8192), (512, 11, 4096, 8190), (1024, 5, 4096, 8192), (320, 10, 4096, 8192), (512, 5, 4096, 8192)])
 def test_ragged_round_prefill_splits_the_kv_axis(hip, D, H, Nq, Nkv):
-  """A launch of a little over one round of workgroups (1 < workgroups / CUs <= 1.5) on a long context: the plan splits the KV axis in 2
+  """A launch of a little over one round of workgroups (1 < workgroups / CUs <= 1.5), or of part of one, on a long context: the plan splits the KV axis in 2
   or 3 (ffpa_capi.hip make_plan; profiles/r04_launch_side.txt).  Same answer as the unsplit launch to rounding, the oracle's bound on a
   row subset, and one split on request."""
   cus = torch.cuda.get_device_properties(0).multi_processor_count
@@ -692,7 +692,7 @@ def test_ragged_round_prefill_splits_the_kv_axis(hip, D, H, Nq, Nkv):
   plan = {}
   o, lse = hip.forward(q, k, v, None, False, scale, plan_out=plan)
   wgs = H * (Nq // plan["block_rows"])
-  if not (cus < wgs <= 1.5 * cus):
+  if not (0.5 * cus < wgs <= 1.5 * cus) or wgs == cus:
     pytest.skip(f"{wgs} workgroups on {cus} CUs is not a ragged round on this device")
   assert plan["variant"] == 0 and plan["splits"] in (2, 3), plan
   o1, lse1 = hip.forward(q, k, v, None, False, scale, num_splits=1, plan_out=plan)

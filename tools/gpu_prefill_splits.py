@@ -14,6 +14,10 @@ CASES = {
   "h12_n4096_short": (1, 12, 12, 4096, 2048, 512, False), "h12_n4096_causal": (1, 12, 12, 4096, 4096, 512, True), "h10_d320": (1, 10, 10, 4096, 8192, 320, False),
   "h20_n4096_d1024": (1, 5, 5, 4096, 8192, 1024, False), "h6_d1024": (1, 6, 6, 4096, 8192, 1024, False), "h40_n1024": (1, 40, 40, 1024, 8192, 512, False),
   "h17": (1, 17, 17, 4096, 8192, 512, False), "h20": (1, 20, 20, 4096, 8192, 512, False),
+  # part of one round: CUs / 2 < workgroups < CUs
+  "h5_n4096": (1, 5, 5, 4096, 8192, 512, False), "h6_n4096": (1, 6, 6, 4096, 8192, 512, False), "h7_n4096": (1, 7, 7, 4096, 8192, 512, False),
+  "h5_n4096_short": (1, 5, 5, 4096, 2048, 512, False), "h5_n4096_causal": (1, 5, 5, 4096, 4096, 512, True), "h3_d1024": (1, 3, 3, 4096, 8192, 1024, False),
+  "h5_d320": (1, 5, 5, 4096, 8192, 320, False), "h20_n1024": (1, 20, 20, 1024, 8192, 512, False), "h5_n4096_16k": (1, 5, 5, 4096, 16384, 512, False),
 }
 if os.environ.get("ONLY"):
   CASES = {k_: v_ for k_, v_ in CASES.items() if k_ in os.environ["ONLY"].split(",")}
@@ -24,7 +28,7 @@ for name, (B, Hq, Hkv, Nq, Nkv, D, causal) in CASES.items():
   k = torch.randn(B, Hkv, Nkv, D, dtype=torch.bfloat16, device="cuda")
   v = torch.randn(B, Hkv, Nkv, D, dtype=torch.bfloat16, device="cuda")
   flops = 4 * B * Hq * D * Nq * Nkv // (2 if causal else 1)
-  arms = [0, 1, 2, 3, 4]
+  arms = [int(x) for x in os.environ.get('ARMS', '0,1,2,3,4').split(',')]
   times = {a: [] for a in arms}
   plans = {}
   for a in arms:

@@ -1,11 +1,7 @@
 #!/bin/bash
-mkdir -p gpurun_out/v25
-timeout 600 python -m pytest tests/test_bench_gpu.py -m gpu -q > gpurun_out/v25/pytest_bench.txt 2>&1; tail -5 gpurun_out/v25/pytest_bench.txt
-for w in cross cfg4_mask decode; do
-  timeout 300 python bench.py --workload $w --no-cpu-baseline > gpurun_out/v25/bench_$w.json 2> gpurun_out/v25/bench_$w.err
-  python - <<PY
-import json
-d=json.loads(open('gpurun_out/v25/bench_$w.json').read().strip().splitlines()[-1])
-print('$w', d['value'], d['ms_per_step'], d['roofline']['frac'], d['steady_state'])
-PY
-done
+mkdir -p gpurun_out/v27
+rm -f ffpa_attn_amd/variants/*.so
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/v27/pytest.txt 2>&1
+tail -4 gpurun_out/v27/pytest.txt
+ARMS=0,1,3 ONLY=h5_n4096,h6_n4096,h5_n4096_short,h5_d320,h20_n1024,h5_n4096_16k,h3_d1024 timeout 300 python tools/gpu_prefill_splits.py > gpurun_out/v27/partial_rule.txt 2>&1
+grep -h "^SPLITS" gpurun_out/v27/*.txt
