@@ -132,17 +132,17 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
   // The same pricing serves a launch of PART of a round (CUs / 2 < workgroups < CUs; at most half of the chip is the under-filled rule below): 160 workgroups
   // in three KV ranges are 480 = two rounds of a third of the length — B1 H5 x Nq 4096 D512 + 10 % at 8192 keys, + 19 % at 16384, D = 320 + 7 %, H20 x Nq 1024
   // + 8 %; 192 and 224 workgroups (H6, H7, D = 1024 H3) gain from no split count, and the model picks none.
+  const int dk_price = kernel_head_dim(p->head_dim);
+  const double nt_eff = p->causal ? 0.5 * pl.nt : (double)pl.nt;  // (a causal row tile walks about half of the keys)
+  const double tile_s = 4.0 * pl.br * pl.bc * dk_price / (dk_price > 512 ? 4.0e12 : 5.0e12);  // one KV tile of one workgroup at the rate one CU sustains
+  const double out_elems = (double)p->batch * p->heads_q * p->seqlen_q * dk_price;
+  auto predicted = [&](int64_t s) {
+    const double rounds = (double)((base * s + cus - 1) / cus);
+    return rounds * (nt_eff / s + 4.0) * tile_s + (s > 1 ? out_elems * (8.0 * s + 2.0) / 5.0e12 : 0.0);
+  };
+  const bool priced = pl.variant == 0 && !(p->flags & (FFPA_FLAG_DEBUG_SAFE_PATH | FFPA_FLAG_FORCE_SPLITS)) && p->num_splits == 0 && p->workspace != nullptr;
   int ragged_splits = 1;
-  if (pl.variant == 0 && !(p->flags & (FFPA_FLAG_DEBUG_SAFE_PATH | FFPA_FLAG_FORCE_SPLITS)) && p->num_splits == 0 && 2 * base > cus && 2 * base <= 3 * cus &&
-      p->bias == nullptr && p->kv_bounds == nullptr && !(p->dropout_p > 0.f) && p->workspace != nullptr) {
-    const int dk = kernel_head_dim(p->head_dim);
-    const double nt_eff = p->causal ? 0.5 * pl.nt : (double)pl.nt;  // (a causal row tile walks about half of the keys)
-    const double tile_s = 4.0 * pl.br * pl.bc * dk / (dk > 512 ? 4.0e12 : 5.0e12);  // one KV tile of one workgroup at the rate one CU sustains
-    const double elems = (double)p->batch * p->heads_q * p->seqlen_q * dk;
-    auto predicted = [&](int s) {
-      const double rounds = (double)((base * s + cus - 1) / cus);
-      return rounds * (nt_eff / s + 4.0) * tile_s + (s > 1 ? elems * (8.0 * s + 2.0) / 5.0e12 : 0.0);
-    };
+  if (priced && 2 * base > cus && 2 * base <= 3 * cus && p->bias == nullptr && p->kv_bounds == nullptr && !(p->dropout_p > 0.f)) {
     const double t1 = predicted(1);
     double best = t1;
     for (int s = 2; s <= 3; ++s) {
@@ -162,6 +162,19 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
     int64_t want = pl.variant == 1 ? (sq_one_per_cu ? cus / base : (2 * cus + base - 1) / base) : cus / base;
     if (pl.variant == 0 && (p->flags & FFPA_FLAG_FORCE_SPLITS) && p->num_splits > 1) want = p->num_splits;
     if (ragged_splits > 1) want = ragged_splits;
+    if (priced && base * 2 <= cus && want >= 2) {
+      // CUs / workgroups far from a whole number (96 workgroups: two ranges fill 192 of 256 CUs): a count that makes two rounds of shorter workgroups can
+      // beat the one-round count on a long context — 96 workgroups x 5 = 480: + 6 ... 11 % at 16384 keys, + 7 % at D = 1024 / 8192 keys, + 2 % at D = 512 /
+      // 8192 keys (profiles/r04_launch_side.txt); 80 x 3 and 56 x 4 stay.  Both sides pay partials and a merge, so the pricing's margin is 5 % here.
+      const double t0 = predicted(want);
+      double best = t0;
+      const int64_t one_round = want;
+      for (int64_t s = one_round + 1; s <= 3 * one_round && s <= ffpa::kMergeMaxSplits; ++s) {
+        if (pl.nt / s < 8) break;
+        const double t = predicted(s);
+        if (t < 0.95 * t0 && t < best) best = t, want = s;
+      }
+    }
     const int min_tiles = pl.variant == 1 ? 4 : 8;
     const int64_t cap = pl.nt / min_tiles > 0 ? pl.nt / min_tiles : 1;
     if (want > cap) want = cap;

@@ -165,6 +165,14 @@ def test_underfilled_prefill_plan_splits_the_kv_axis(lib):
   (dict(heads_q=3, heads_kv=3, seqlen_q=4096, seqlen_kv=8192, head_dim=1024), 1),  # 192 workgroups of 64 rows
   (dict(heads_q=5, heads_kv=5, seqlen_q=4096, seqlen_kv=2048), 1),      # short context (measured - 20 %)
   (dict(heads_q=5, heads_kv=5, seqlen_q=4096, seqlen_kv=4096, causal=1), 1),
+  # under-filled (workgroups <= CUs / 2): CUs / workgroups splits fill one round; a count that makes two rounds of shorter workgroups is taken at 5 % predicted
+  (dict(heads_q=3, heads_kv=3, seqlen_q=4096, seqlen_kv=8192), 2),      # 96 workgroups: 2 x 96 = 192 of 256 CUs; five ranges measured + 2 % — inside the margin
+  (dict(heads_q=3, heads_kv=3, seqlen_q=4096, seqlen_kv=16384), 5),     # ... on 16384 keys 5 x 96 = 480 = two rounds of a fifth: + 6 ... 8 %
+  (dict(heads_q=12, heads_kv=12, seqlen_q=1024, seqlen_kv=16384), 5),   # + 11 %
+  (dict(heads_q=3, heads_kv=3, seqlen_q=2048, seqlen_kv=8192, head_dim=1024), 5),  # + 7 %
+  (dict(heads_q=5, heads_kv=5, seqlen_q=2048, seqlen_kv=8192), 3),      # 80 x 3 = 240: the one-round count is the fastest measured arm
+  (dict(heads_q=7, heads_kv=7, seqlen_q=1024, seqlen_kv=8192), 4),      # 56 x 4 = 224: likewise
+  (dict(heads_q=4, heads_kv=4, seqlen_q=4096, seqlen_kv=8192), 2),      # 128 x 2 = 256: exact
 ])
 def test_ragged_round_split_rule(lib, over, want):
   """Prefill launches of a little over one round of workgroups (1 < workgroups / CUs <= 1.5) or of part of one (0.5 < ... < 1) split the KV axis in 2 or 3 when the cost model of

@@ -14,6 +14,9 @@ CASES = {
   "h12_n4096_short": (1, 12, 12, 4096, 2048, 512, False), "h12_n4096_causal": (1, 12, 12, 4096, 4096, 512, True), "h10_d320": (1, 10, 10, 4096, 8192, 320, False),
   "h20_n4096_d1024": (1, 5, 5, 4096, 8192, 1024, False), "h6_d1024": (1, 6, 6, 4096, 8192, 1024, False), "h40_n1024": (1, 40, 40, 1024, 8192, 512, False),
   "h17": (1, 17, 17, 4096, 8192, 512, False), "h20": (1, 20, 20, 4096, 8192, 512, False),
+  # under-filled (workgroups <= CUs / 2) with CUs / workgroups far from a whole number
+  "h3_n4096": (1, 3, 3, 4096, 8192, 512, False), "h5_n2048": (1, 5, 5, 2048, 8192, 512, False), "h3_n4096_16k": (1, 3, 3, 4096, 16384, 512, False),
+  "h7_n1024": (1, 7, 7, 1024, 8192, 512, False), "h3_n2048_d1024": (1, 3, 3, 2048, 8192, 1024, False), "h12_n1024": (1, 12, 12, 1024, 16384, 512, False),
   # part of one round: CUs / 2 < workgroups < CUs
   "h5_n4096": (1, 5, 5, 4096, 8192, 512, False), "h6_n4096": (1, 6, 6, 4096, 8192, 512, False), "h7_n4096": (1, 7, 7, 4096, 8192, 512, False),
   "h5_n4096_short": (1, 5, 5, 4096, 2048, 512, False), "h5_n4096_causal": (1, 5, 5, 4096, 4096, 512, True), "h3_d1024": (1, 3, 3, 4096, 8192, 1024, False),
