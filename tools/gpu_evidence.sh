@@ -19,7 +19,8 @@ import json
 try:
   d=json.loads(open('gpurun_out/final/bench_$w.json').read().strip().splitlines()[-1])
   dv=d.get('device',{})
-  print('BENCH %-13s %8.2f TF %8.4f ms frac %.4f @clk %s MHz (rate frac %s) err %s/%s sdpa %s' % ('$w', d['value'], d['ms_per_step'], d['roofline']['frac'], dv.get('sclk_mhz_avg'), d['roofline'].get('frac_of_mfma_rate_at_measured_clock'), d.get('max_abs_err_vs_sdpa'), d.get('max_abs_err_vs_fp32_math'), d.get('sdpa_gpu_tflops')))
+  ss=d.get('steady_state') or {}
+  print('BENCH %-13s %8.2f TF %8.4f ms frac %.4f @clk %s MHz (rate frac %s) | steady %s TF @ %s MHz %s W | err %s/%s sdpa %s' % ('$w', d['value'], d['ms_per_step'], d['roofline']['frac'], dv.get('sclk_mhz_avg'), d['roofline'].get('frac_of_mfma_rate_at_measured_clock'), ss.get('tflops'), ss.get('sclk_mhz_avg'), ss.get('power_w_avg'), d.get('max_abs_err_vs_sdpa'), d.get('max_abs_err_vs_fp32_math'), d.get('sdpa_gpu_tflops')))
 except Exception as e: print('BENCH $w parse fail', e)
 PY
   done

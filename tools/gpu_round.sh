@@ -72,8 +72,8 @@ wprof)
   # rocprofv3 kernel stats + PMC passes for one bench workload ($PMC_WORKLOAD, default cfg3); counters beyond the SQ sets are
   # one pass each, short timeouts: a TCC pass hung on this pool in round 1, so those run last
   W=${PMC_WORKLOAD:-cfg3}; OUT=gpurun_out/wprof_$W; rm -rf $OUT; mkdir -p $OUT
-  BENCH="python $PWD/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-sdpa"
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT -o trace -- python $OLDPWD/bench.py --workload $W --steps 30 --warmup 5 --no-cpu-baseline --no-sdpa) > $OUT/trace.log 2>&1; echo "wprof $W trace exit $?"
+  BENCH="python $PWD/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-sdpa --no-steady"
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT -o trace -- python $OLDPWD/bench.py --workload $W --steps 30 --warmup 5 --no-cpu-baseline --no-sdpa --no-steady) > $OUT/trace.log 2>&1; echo "wprof $W trace exit $?"
   pass() { n=$1; shift; (cd /tmp && timeout -s KILL ${PASS_TIMEOUT:-120} rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $OLDPWD/$OUT -o $n -- $BENCH) > $OUT/$n.log 2>&1; echo "wprof $W $n exit $?"; }
   pass sq1 SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS GRBM_GUI_ACTIVE
   pass sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM SQ_INSTS_VALU
