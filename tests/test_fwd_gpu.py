@@ -966,6 +966,41 @@ def test_randomized_against_oracle(hip, seed):
   np.testing.assert_allclose(_f32(lse)[lfin], lse_ref[lfin], atol=3e-4, rtol=3e-5, err_msg=str(c))
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_randomized_launch_plans_against_oracle(hip, seed):
+  """Long contexts with at most 1.5 rounds of workgroups — where make_plan prices KV splits (under-filled, part of a round, ragged round): whatever count
+  it takes, the result equals the unsplit launch to rounding and the oracle on a row sample, tails and the causal flag included."""
+  rng = np.random.default_rng(7000 + seed)
+  cus = torch.cuda.get_device_properties(0).multi_processor_count
+  D = int(rng.choice([320, 512, 512, 1024, 448, 640]))
+  rows_per_wg = hip.tile_config(hip.padded_head_dim(D))["block_rows"]
+  Nq = int(rng.choice([512, 1024, 2048, 4096])) - int(rng.choice([0, 0, 1, 37]))
+  nqt = (Nq + rows_per_wg - 1) // rows_per_wg
+  want_wgs = int(rng.integers(cus // 8, 3 * cus // 2 + 1))
+  H = max(1, want_wgs // nqt)
+  group = int(rng.choice([1, 1, 2])) if H % 2 == 0 else 1
+  Nkv = int(rng.choice([4096, 8192, 12288, 16384])) - int(rng.choice([0, 0, 5, 100]))
+  causal = bool(rng.random() < 0.3) and Nkv >= Nq
+  dt = torch.float16 if rng.random() < 0.2 else torch.bfloat16
+  q, k, v = _rand((1, H, Nq, D), dt, seed=seed * 3 + 7001), _rand((1, H // group, Nkv, D), dt, seed=seed * 3 + 7002), _rand((1, H // group, Nkv, D), dt, seed=seed * 3 + 7003)
+  scale = D ** -0.5
+  plan, plan1 = {}, {}
+  o, lse = hip.forward(q, k, v, None, causal, scale, plan_out=plan)
+  o1, lse1 = hip.forward(q, k, v, None, causal, scale, num_splits=1, plan_out=plan1)
+  assert plan1["splits"] == 1 and plan["variant"] == 0, (plan, plan1)
+  tag = f"seed {seed}: H{H}/{H // group} Nq{Nq} Nkv{Nkv} D{D} causal {causal} {dt} -> {H * nqt} workgroups, {plan['splits']} splits"
+  if plan["splits"] == 1:
+    assert torch.equal(o, o1) and torch.equal(lse, lse1), tag
+  else:
+    assert (o.float() - o1.float()).abs().max().item() <= 4e-3 and (lse - lse1).abs().max().item() <= 1e-4, tag
+  heads = sorted(set(int(x) for x in rng.integers(0, H, 2)))
+  r0 = int(rng.integers(0, max(1, Nq - 32)))
+  for h in heads:
+    hs, ks = slice(h, h + 1), slice(h // group, h // group + 1)
+    _check_vs_oracle(o[:, hs], lse[:, hs], q[:, hs], k[:, ks], v[:, ks], causal=causal, rows=(r0, min(Nq, r0 + 32)), block_keys=plan["block_keys"],
+                     name=tag + f" head {h}", split=plan["splits"] > 1)
+
+
 # ----------------------------------------------------------------------------- streams and HIP graphs
 def test_runs_on_the_callers_stream_and_in_a_hip_graph(hip):
   """The C-ABI launches on the stream it is given (torch's current stream), never synchronises and allocates
