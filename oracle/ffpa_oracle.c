@@ -31,7 +31,10 @@
  * ref_triton_cases.npz).  Qualification: the fp16 cases run the interpreter unmodified; the bf16 cases depend on two functions of
  * Triton's INTERPRETER being wrapped in the generator (its dot product multiplies bf16 bit patterns as integers and its fp32 -> bf16
  * cast truncates: the wrappers widen dot operands to fp32 and round to nearest even — make_triton_golden.py:63-83).  The reference's
- * kernel source is imported unchanged, but the bf16 pin is only as good as those twenty lines, (ii) PyTorch CPU SDPA — the reference's own
+ * kernel source is imported unchanged, but the bf16 pin is only as good as those twenty lines; (i') the same executed reference WITH
+ * DROPOUT (round 4: its Triton forward carries the CUDA kernels' Philox mapping, triton/_ffpa_fwd.py:80-123) — three cases, fp16 and bf16,
+ * offsets inside a Philox quad, batch / head terms, a 62-bit seed (make_triton_golden.py --dropout -> ref_triton_dropout.npz): the
+ * stream, the element offsets, the keep rule and the 1 / (1 - p) scaling below are the executed reference's, (ii) PyTorch CPU SDPA — the reference's own
  * test oracle — on the committed fixtures in tests/golden/, (iii) the output of the reference's ffpa_attn_func
  * itself, run in the authoring container on config 1 (tests/golden/make_golden.py), and (iv) an
  * fp64 plain-math evaluation.

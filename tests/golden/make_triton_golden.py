@@ -2,6 +2,7 @@
 
     python tests/golden/make_triton_golden.py [--only NAME,NAME]     (authoring container only: needs /root/reference and triton;
                                                                       --only: run these cases and merge them into the existing fixture)
+    python tests/golden/make_triton_golden.py --dropout              (the dropout cases only -> ref_triton_dropout.{npz,json})
 
 The reference's large-head-dim arithmetic that can run without an NVIDIA GPU is its Triton statement of the algorithm
 (src/ffpa_attn/triton/_ffpa_fwd.py: kernel `_ffpa_fwd_kernel_impl` :302-495, launcher `_ffpa_attn_forward_generic_impl`
@@ -39,7 +40,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
-from triton_cases import CASES, bf16_bits_to_f32, f32_to_bf16_bits, triton_case_inputs  # the input recipe shared with the tests
+from triton_cases import CASES, DROPOUT_CASES, bf16_bits_to_f32, f32_to_bf16_bits, triton_case_inputs  # the input recipe shared with the tests
 
 
 def main():
@@ -78,6 +79,8 @@ def main():
   ti._convert_float = convert
   ti.InterpreterBuilder.create_dot = dot
 
+  if "--dropout" in sys.argv:
+    return make_dropout(ref, torch, triton)
   store, meta = {}, []
   only = None
   if "--only" in sys.argv:
@@ -119,6 +122,41 @@ def main():
     json.dump({"source": f"reference src/ffpa_attn/triton/_ffpa_fwd.py::_ffpa_attn_forward_impl under TRITON_INTERPRET=1, triton {triton.__version__}, "
                          f"torch {torch.__version__}; default tile BLOCK_M=128 BLOCK_N=64 head-dim blocks 64", "cases": meta}, f, indent=1)
   print("wrote ref_triton_cases.{npz,json}")
+
+
+def make_dropout(ref, torch, triton):
+  """The reference's Triton forward with dropout_p > 0 (its Philox mapping is the CUDA kernels': triton/_ffpa_fwd.py:80-123).  Sanity: the
+  executed output must differ from plain attention (dropout really happened) and be an unbiased estimate of it (mean over elements)."""
+  store, meta = {}, []
+  for case in DROPOUT_CASES:
+    name, B, Hq, Hkv, Nq, Nkv, D, causal, bshape, dtype, _, p, seed, offset = case
+    tdt = torch.float16 if dtype == "fp16" else torch.bfloat16
+    arrs = triton_case_inputs(case)
+    q, k, v, bias = (None if a is None else (torch.from_numpy(a) if dtype == "fp16" else torch.from_numpy(a.view(np.int16)).view(tdt)) for a in arrs)
+    o = torch.zeros_like(q)
+    lse = torch.zeros(B, Hq, (Nq + 127) // 128 * 128, dtype=torch.float32)
+    ref._ffpa_attn_forward_impl(q, k, v, o, lse, attn_bias=bias, causal=causal, dropout_p=p, philox_seed=seed, philox_offset=offset)
+    g = Hq // Hkv
+    s = (q.float() @ k.float().repeat_interleave(g, 1).transpose(-1, -2)) * D ** -0.5
+    if bias is not None:
+      s = s + bias.float()
+    if causal:
+      r, c = torch.arange(Nq)[:, None], torch.arange(Nkv)[None, :]
+      s = s.masked_fill(c > r + (Nkv - Nq), float("-inf"))
+    plain = torch.softmax(s, -1) @ v.float().repeat_interleave(g, 1)
+    diff = (o.float() - plain)
+    lerr = (lse[..., :Nq] - torch.logsumexp(s, -1)).abs().max().item()
+    print(f"{name} [{dtype}] p={p}: max |O_dropout - O_plain| = {diff.abs().max().item():.2e} (mean {diff.mean().item():+.1e}), max |LSE - ref| = {lerr:.2e}", flush=True)
+    assert diff.abs().max().item() > 0.05 and abs(diff.mean().item()) < 0.02 and lerr < 1e-3, name  # LSE is the undropped one
+    store[f"{name}.o"] = o.contiguous().view(torch.int16).numpy().view(np.uint16).copy()
+    store[f"{name}.lse"] = lse[..., :Nq].contiguous().numpy()
+    meta.append({"name": name, "B": B, "Hq": Hq, "Hkv": Hkv, "Nq": Nq, "Nkv": Nkv, "D": D, "causal": causal, "bias_shape": bshape, "dtype": dtype,
+                 "dropout_p": p, "philox_seed": seed, "philox_offset": offset})
+  np.savez_compressed(os.path.join(HERE, "ref_triton_dropout.npz"), **store)
+  with open(os.path.join(HERE, "ref_triton_dropout.json"), "w") as f:
+    json.dump({"source": f"reference src/ffpa_attn/triton/_ffpa_fwd.py::_ffpa_attn_forward_impl(dropout_p, philox_seed, philox_offset) under TRITON_INTERPRET=1, "
+                         f"triton {triton.__version__}, torch {torch.__version__}", "cases": meta}, f, indent=1)
+  print("wrote ref_triton_dropout.{npz,json}")
 
 
 if __name__ == "__main__":

@@ -24,6 +24,16 @@ CASES = [
   ("bf16_d512_n8192_causal", 1, 1, 1, 128, 8192, 512, True, None, "bf16", False),
 ]
 
+# Dropout (round 4): the reference's Triton forward carries the SAME Philox mapping as its CUDA kernels (triton/_ffpa_fwd.py:80-123: element offset =
+# philox_offset + ((b Hq + h) Nq + r) Nkv + k, keep iff u > p, P scaled by 1 / (1 - p) after the row sum), so its executed outputs pin the oracle's —
+# and through it the HIP kernel's — dropout stream, offsets and scaling.  Same tuple as CASES + (dropout_p, philox_seed, philox_offset); outputs in
+# ref_triton_dropout.npz.  Offsets that are not multiples of 4 start inside a Philox quad; B = 2 / Hq = 2 exercise the (b, h) term.
+DROPOUT_CASES = [
+  ("drop_fp16_d320_gqa", 1, 2, 1, 70, 200, 320, False, None, "fp16", False, 0.3, 0x1234567890ABCDEF & (2 ** 62 - 1), 1003),
+  ("drop_bf16_d512_causal", 1, 2, 2, 130, 257, 512, True, None, "bf16", False, 0.1, 42, 0),
+  ("drop_bf16_d1024_keybias", 2, 1, 1, 40, 300, 1024, False, (2, 1, 1, 300), "bf16", False, 0.5, 2 ** 40 + 7, 4 * 12345 + 2),
+]
+
 
 def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
   """fp32 -> bfloat16 storage bits, round to nearest even (NaN kept quiet): what every bf16 store of the hardware does."""
@@ -42,7 +52,7 @@ def bf16_bits_to_f32(b: np.ndarray) -> np.ndarray:
 def triton_case_inputs(case):
   """q, k, v (and additive bias) of a case as numpy arrays — float16 arrays for fp16 cases, uint16 bfloat16 STORAGE BITS for bf16
   cases.  The ONE recipe shared by the generator and the tests."""
-  name, B, Hq, Hkv, Nq, Nkv, D, causal, bshape, dtype, spike = case
+  name, B, Hq, Hkv, Nq, Nkv, D, causal, bshape, dtype, spike = case[:11]
   rs = np.random.RandomState(abs(hash_name(name)) % (2 ** 31))
   q = rs.standard_normal((B, Hq, Nq, D)).astype(np.float32)
   k = rs.standard_normal((B, Hkv, Nkv, D)).astype(np.float32)

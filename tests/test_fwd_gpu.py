@@ -172,6 +172,35 @@ def test_kernel_matches_the_executed_reference_triton_kernel(hip):
     assert (lse.cpu() - torch.from_numpy(lse_ref)).abs().max().item() <= 3e-5, name
 
 
+def test_kernel_dropout_matches_the_executed_reference_triton_kernel(hip):
+  """Dropout against EXECUTED reference code: the reference's Triton forward run with dropout_p / philox_seed / philox_offset in the authoring container
+  (tests/golden/ref_triton_dropout.npz) vs the HIP kernel on the re-created inputs — the Philox stream, its element offsets (inside a quad, batch / head
+  terms, 62-bit seed), the keep rule and the 1 / (1 - p) scaling are the reference's, not just the oracle's."""
+  import sys
+
+  from test_oracle import _bits_to_f32, _triton_dropout_cases, dropout_fixture_limit
+
+  sys.path.insert(0, GOLDEN)
+  n = 0
+  for case, (q, k, v, bias), o_ref_bits, lse_ref in _triton_dropout_cases():
+    name, D, causal, dtype, p, seed, offset = case[0], case[6], case[7], case[9], case[11], case[12], case[13]
+    tdt = torch.float16 if dtype == "fp16" else torch.bfloat16
+    qt, kt, vt = (torch.from_numpy(a.view(np.int16).copy()).view(tdt).cuda() for a in (q, k, v))
+    bt = None if bias is None else torch.from_numpy(bias.view(np.int16).copy()).view(tdt).cuda()
+    plan = {}
+    o, lse = hip.forward(qt, kt, vt, bt, causal, D ** -0.5, dropout_p=p, philox_seed=seed, philox_offset=offset, plan_out=plan)
+    assert "DROP=1" in plan["kernel"], plan
+    want = _bits_to_f32(o_ref_bits, dtype)
+    d = np.abs(_f32(o) - want)
+    lim = dropout_fixture_limit(want, dtype, p)
+    assert bool((d <= lim).all()) and d.mean() <= (6e-5 if dtype == "fp16" else 5e-4) / (1.0 - p), (name, d.max(), d.mean())
+    assert (lse.cpu() - torch.from_numpy(lse_ref)).abs().max().item() <= 3e-5, name
+    o_shift, _ = hip.forward(qt, kt, vt, bt, causal, D ** -0.5, dropout_p=p, philox_seed=seed, philox_offset=offset + 1)
+    assert (np.abs(_f32(o_shift) - want) > lim).mean() > 0.5, name  # the check can tell another stream
+    n += 1
+  assert n == 3
+
+
 # ----------------------------------------------------------------------------- fast path == safe path
 @pytest.mark.parametrize("D", [64])
 def test_dma_and_transpose_read_path_is_bit_identical_to_register_staged_twin(hip, D):
