@@ -3,6 +3,7 @@
     python tests/golden/make_triton_golden.py [--only NAME,NAME]     (authoring container only: needs /root/reference and triton;
                                                                       --only: run these cases and merge them into the existing fixture)
     python tests/golden/make_triton_golden.py --dropout              (the dropout cases only -> ref_triton_dropout.{npz,json})
+    python tests/golden/make_triton_golden.py --decode               (the split-KV decode cases only -> ref_triton_decode.{npz,json})
 
 The reference's large-head-dim arithmetic that can run without an NVIDIA GPU is its Triton statement of the algorithm
 (src/ffpa_attn/triton/_ffpa_fwd.py: kernel `_ffpa_fwd_kernel_impl` :302-495, launcher `_ffpa_attn_forward_generic_impl`
@@ -40,7 +41,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
-from triton_cases import CASES, DROPOUT_CASES, bf16_bits_to_f32, f32_to_bf16_bits, triton_case_inputs  # the input recipe shared with the tests
+from triton_cases import CASES, DECODE_CASES, DROPOUT_CASES, bf16_bits_to_f32, f32_to_bf16_bits, triton_case_inputs  # the input recipe shared with the tests
 
 
 def main():
@@ -81,6 +82,8 @@ def main():
 
   if "--dropout" in sys.argv:
     return make_dropout(ref, torch, triton)
+  if "--decode" in sys.argv:
+    return make_decode(ref, torch, triton)
   store, meta = {}, []
   only = None
   if "--only" in sys.argv:
@@ -157,6 +160,42 @@ def make_dropout(ref, torch, triton):
     json.dump({"source": f"reference src/ffpa_attn/triton/_ffpa_fwd.py::_ffpa_attn_forward_impl(dropout_p, philox_seed, philox_offset) under TRITON_INTERPRET=1, "
                          f"triton {triton.__version__}, torch {torch.__version__}", "cases": meta}, f, indent=1)
   print("wrote ref_triton_dropout.{npz,json}")
+
+
+def make_decode(ref, torch, triton):
+  """The reference's split-KV decode path (stage 1 per KV chunk + stage 2 LSE merge, triton/_ffpa_fwd.py:497-861) with the split count forced per case:
+  `_get_decode_num_splits` reads the device (:268-273) and is replaced by the case's constant — a launch parameter, not arithmetic."""
+  store, meta = {}, []
+  for case in DECODE_CASES:
+    name, B, Hq, Hkv, Nq, Nkv, D, causal, bshape, dtype, _, splits = case
+    ref._get_decode_num_splits = lambda *a, _n=splits, **k: _n
+    tdt = torch.float16 if dtype == "fp16" else torch.bfloat16
+    arrs = triton_case_inputs(case)
+    q, k, v, bias = (None if a is None else (torch.from_numpy(a) if dtype == "fp16" else torch.from_numpy(a.view(np.int16)).view(tdt)) for a in arrs)
+    o = torch.zeros_like(q)
+    lse = torch.zeros(B, Hq, (Nq + 127) // 128 * 128, dtype=torch.float32)
+    ref._ffpa_attn_forward_impl(q, k, v, o, lse, attn_bias=bias, causal=causal)
+    g = Hq // Hkv
+    s = (q.float() @ k.float().repeat_interleave(g, 1).transpose(-1, -2)) * D ** -0.5
+    if bias is not None:
+      s = s + bias.float()
+    if causal:
+      r, c = torch.arange(Nq)[:, None], torch.arange(Nkv)[None, :]
+      s = s.masked_fill(c > r + (Nkv - Nq), float("-inf"))
+    want = torch.softmax(s, -1) @ v.float().repeat_interleave(g, 1)
+    err = (o.float() - want).abs().max().item()
+    lerr = (lse[..., :Nq] - torch.logsumexp(s, -1)).abs().max().item()
+    print(f"{name} [{dtype}] {splits} splits: max |O_triton - fp32 math| = {err:.2e}, max |LSE - ref| = {lerr:.2e}", flush=True)
+    assert err < (3e-3 if dtype == "fp16" else 2e-2) and lerr < 1e-3, name
+    store[f"{name}.o"] = o.contiguous().view(torch.int16).numpy().view(np.uint16).copy()
+    store[f"{name}.lse"] = lse[..., :Nq].contiguous().numpy()
+    meta.append({"name": name, "B": B, "Hq": Hq, "Hkv": Hkv, "Nq": Nq, "Nkv": Nkv, "D": D, "causal": causal, "bias_shape": bshape, "dtype": dtype,
+                 "num_splits": splits})
+  np.savez_compressed(os.path.join(HERE, "ref_triton_decode.npz"), **store)
+  with open(os.path.join(HERE, "ref_triton_decode.json"), "w") as f:
+    json.dump({"source": f"reference src/ffpa_attn/triton/_ffpa_fwd.py::_ffpa_attn_forward_impl -> _ffpa_attn_forward_decode_impl (split count forced) under "
+                         f"TRITON_INTERPRET=1, triton {triton.__version__}, torch {torch.__version__}", "cases": meta}, f, indent=1)
+  print("wrote ref_triton_decode.{npz,json}")
 
 
 if __name__ == "__main__":

@@ -34,6 +34,18 @@ DROPOUT_CASES = [
   ("drop_bf16_d1024_keybias", 2, 1, 1, 40, 300, 1024, False, (2, 1, 1, 300), "bf16", False, 0.5, 2 ** 40 + 7, 4 * 12345 + 2),
 ]
 
+# Split-KV decode (round 4): the reference's Triton stage-1 (per-chunk online softmax, partial O_c = acc / l_c, LSE_c) + stage-2 (LSE merge) kernels
+# (triton/_ffpa_fwd.py:497-861), executed with the split count forced (its heuristic reads the device): the semantics of SURVEY.md appendix A.7.  Same tuple as
+# CASES + (num_splits,); outputs in ref_triton_decode.npz.  Nq > 1 runs the tl.dot tiles (fp32 products: agreement at output rounding); Nq = 1 runs the
+# reference's GEMV branch, which multiplies q and k in the 16-bit dtype before summing (:613: one rounding per product — a property of that Triton statement,
+# not of the CUDA split_kv.cuh path, which converts to fp32 first), so that case agrees to the product-rounding noise only (fp16; the bound is in the test).
+DECODE_CASES = [
+  ("decode_fp16_d320_nq7_causal_s3", 1, 4, 4, 7, 1111, 320, True, None, "fp16", False, 3),
+  ("decode_bf16_d512_nq4_gqa_s4", 2, 8, 2, 4, 1500, 512, False, None, "bf16", False, 4),
+  ("decode_fp16_d512_nq1_gqa_s4", 2, 8, 2, 1, 1500, 512, False, None, "fp16", False, 4),
+  ("decode_bf16_d1024_nq2_keybias_s5", 1, 2, 1, 2, 700, 1024, False, (1, 1, 1, 700), "bf16", False, 5),
+]
+
 
 def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
   """fp32 -> bfloat16 storage bits, round to nearest even (NaN kept quiet): what every bf16 store of the hardware does."""

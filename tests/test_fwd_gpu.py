@@ -201,6 +201,33 @@ def test_kernel_dropout_matches_the_executed_reference_triton_kernel(hip):
   assert n == 3
 
 
+def test_short_query_kernels_match_the_executed_reference_split_kv_decode_path(hip):
+  """The reference's split-KV decode kernels executed with 3 / 4 / 5 splits (tests/golden/ref_triton_decode.npz) vs the short-query launches of the HIP
+  library (D split over the waves, KV split over workgroups + ffpa_fwd_merge_kernel — whatever count ITS plan takes, and with the reference's count forced)."""
+  import sys
+
+  from test_oracle import _bits_to_f32, _triton_decode_cases, decode_fixture_limits
+
+  sys.path.insert(0, GOLDEN)
+  n = 0
+  for case, (q, k, v, bias), o_ref_bits, lse_ref in _triton_decode_cases():
+    name, D, causal, dtype, splits = case[0], case[6], case[7], case[9], case[11]
+    tdt = torch.float16 if dtype == "fp16" else torch.bfloat16
+    qt, kt, vt = (torch.from_numpy(a.view(np.int16).copy()).view(tdt).cuda() for a in (q, k, v))
+    bt = None if bias is None else torch.from_numpy(bias.view(np.int16).copy()).view(tdt).cuda()
+    want = _bits_to_f32(o_ref_bits, dtype)
+    lim, mean_lim, lse_lim = decode_fixture_limits(want, case)
+    for req in (0, splits):
+      plan = {}
+      o, lse = hip.forward(qt, kt, vt, bt, causal, D ** -0.5, num_splits=req, plan_out=plan)
+      assert plan["variant"] == 1 and (req == 0 or 1 < plan["splits"] <= splits), plan
+      d = np.abs(_f32(o) - want)
+      assert bool((d <= lim).all()) and d.mean() <= mean_lim * 1.25, (name, req, plan, d.max(), d.mean())
+      assert (lse.cpu() - torch.from_numpy(lse_ref)).abs().max().item() <= lse_lim, (name, req)
+    n += 1
+  assert n == 4
+
+
 # ----------------------------------------------------------------------------- fast path == safe path
 @pytest.mark.parametrize("D", [64])
 def test_dma_and_transpose_read_path_is_bit_identical_to_register_staged_twin(hip, D):
