@@ -94,6 +94,9 @@
 #ifndef FFPA_K_PRE_SPREAD_ND2
 #define FFPA_K_PRE_SPREAD_ND2 1  // split-D kernels: all of K(j+1) goes out between the softmax stages, none between the PV MFMAs (D = 1024: +7 %)
 #endif
+#ifndef FFPA_SQ_NT
+#define FFPA_SQ_NT 1  // 1: the short-query (ND >= 2) builds carry a second form of their K / V LDS-DMA with the non-temporal hint; FwdArgs.flags picks per launch
+#endif
 #ifndef FFPA_PERSISTENT
 #define FFPA_PERSISTENT 0  // 1: a workgroup walks several (batch, head, row tile) ids when the host launches fewer workgroups than ids
 #endif
@@ -146,6 +149,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define FFPA_GLB __attribute__((address_space(1)))
 
 constexpr unsigned kFlagNoXcdRemap = 0x2u;
+constexpr unsigned kFlagStreamKV = 0x80000000u;  // set by the launch side only (ffpa_capi.hip): every K / V byte of this launch is read by ONE workgroup and the
+                                                 // K + V of the launch exceed the Infinity Cache — the short-query tiles then fetch them with the non-temporal hint
 
 // Keys per tile of the tiles whose head dim is split over waves (ND > 1): 32 — except the short-query tiles (ND = 4) of head dims 128, 384 and 512,
 // which take 64: they are HBM-bound and what they stream per request burst is one tile (D = 512: 32 KiB at 32 keys reached 5.5 TB/s where the
@@ -313,11 +318,34 @@ __device__ __forceinline__ int v_slot_swizzle(int key) {  // in 16-byte slots
 // vmcnt waits for its own loads stay correct (loads retire in order; hidden younger ops only make a
 // counted wait conservative).  M0 is written in the same statement that consumes it and is declared clobbered (the compiler
 // keeps no value of its own in M0 across the statement; tools/check_mfma_hazards.py still verifies that nothing else writes it).
+// NT: the non-temporal hint (`nt`): a stream that nobody reads twice — the K / V of a short-query launch — goes through L2 / MALL without displacing
+// anything and without the fill traffic of a line that is never hit: LDS-DMA streaming from HBM reaches 5.9 TB/s without the hint and 7.3 TB/s
+// with it (tools/probes/hbm_read_probe.hip, profiles/r04_hbm_read_probe.txt).  Prefill tiles are re-read by the other row tiles of the head: no hint.
+template <bool NT = false>
 __device__ __forceinline__ void lds_dma_16(u32x4 rsrc, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-               :
-               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
-               : "memory" FFPA_M0_CLOBBER);
+  if constexpr (NT) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory" FFPA_M0_CLOBBER);
+  } else {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory" FFPA_M0_CLOBBER);
+  }
+}
+
+// NT_BUILD builds pick the form per launch (`stream`, wave-uniform: one scalar branch per piece in a kernel that waits on HBM).
+template <bool NT_BUILD>
+__device__ __forceinline__ void lds_dma_16_sel(bool stream, u32x4 rsrc, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
+  if constexpr (NT_BUILD) {
+    if (stream) {
+      lds_dma_16<true>(rsrc, lds_addr, voff, soff);
+      return;
+    }
+  }
+  lds_dma_16<false>(rsrc, lds_addr, voff, soff);
 }
 
 // The same with the destination given as scalar base + compile-time constant (nothing to precompute and keep in a register per piece).
@@ -333,15 +361,25 @@ __device__ __forceinline__ void lds_dma_16_at(u32x4 rsrc, uint32_t lds_base, uin
 // column offset `voff` is scalar: destination = lds_base + LCONST (+ IMM), source row offset `row_off` inside
 // the tile, and IMM advances source and destination together for the second KiB of a 2 KiB row.  No VALU;
 // rows past the tile's last key are zero-filled by the descriptor's range check.
-template <int LCONST, int IMM>
+template <int LCONST, int IMM, bool NT = false>
 __device__ __forceinline__ void lds_dma_row(u32x4 rsrc, uint32_t lds_base, uint32_t voff, uint32_t row_off) {
-  asm volatile(
-      "s_add_u32 m0, %0, %4\n\t"
-      "s_nop 0\n\t"
-      "buffer_load_dwordx4 %1, %2, %3 offen offset:%5 lds"
-      :
-      : "s"(lds_base), "v"(voff), "s"(rsrc), "s"(row_off), "n"(LCONST), "n"(IMM)
-      : "memory", "scc" FFPA_M0_CLOBBER);
+  if constexpr (NT) {
+    asm volatile(
+        "s_add_u32 m0, %0, %4\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen offset:%5 nt lds"
+        :
+        : "s"(lds_base), "v"(voff), "s"(rsrc), "s"(row_off), "n"(LCONST), "n"(IMM)
+        : "memory", "scc" FFPA_M0_CLOBBER);
+  } else {
+    asm volatile(
+        "s_add_u32 m0, %0, %4\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen offset:%5 lds"
+        :
+        : "s"(lds_base), "v"(voff), "s"(rsrc), "s"(row_off), "n"(LCONST), "n"(IMM)
+        : "memory", "scc" FFPA_M0_CLOBBER);
+  }
 }
 
 // The same with the source row offset computed in place: row_bytes * KEY + base_off (KEY a compile-time row of the tile, base_off the
@@ -420,9 +458,9 @@ __device__ __forceinline__ TileSrc tile_src(const void* slice, uint32_t row_byte
 // columns past the head dim are not stored — so the hoisted / row-uniform V offsets are left alone (what they fetch there
 // is in range: the descriptor ends with the last valid row's last valid byte); the per-piece form masks both.
 constexpr uint32_t kDmaOob = 0x80000000u;
-template <typename T, int D, int BC, bool IS_V, bool SAFE>
+template <typename T, int D, int BC, bool IS_V, bool SAFE, bool NT_BUILD = false>
 __device__ __forceinline__ void stage_piece(u32x4 rsrc, const char* __restrict__ base, uint32_t row_bytes, int rows,
-                                            FFPA_LDS char* lds_tile, int wave, int lane, int i, int slots_valid) {
+                                            FFPA_LDS char* lds_tile, int wave, int lane, int i, int slots_valid, bool stream = false) {
   constexpr int SPR = D / 8;  // 16-byte slots per row
   constexpr int PPW = BC * D * 2 / 4096;
   const int p = wave * PPW + i;
@@ -446,7 +484,7 @@ __device__ __forceinline__ void stage_piece(u32x4 rsrc, const char* __restrict__
     if (src_slot >= slots_valid) voff = kDmaOob;
   }
   if constexpr (!SAFE) {
-    lds_dma_16(rsrc, (uint32_t)(uintptr_t)(lds_tile + p * 1024), voff, soff);
+    lds_dma_16_sel<NT_BUILD>(stream, rsrc, (uint32_t)(uintptr_t)(lds_tile + p * 1024), voff, soff);
   } else {
     u32x4 x = {0u, 0u, 0u, 0u};
     if (key < rows && voff != kDmaOob) x = *(const u32x4*)(base + (size_t)voff + (size_t)soff);
@@ -928,7 +966,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
   }
   // All three forms address the tile through tile_src(): offsets are relative to the tile's first row and the
   // descriptor zero-fills rows past the last key.
-  auto issue_k = [&](auto ic, int key0, int dlane) {
+  constexpr bool kNt = FFPA_SQ_NT != 0 && ND >= 2;  // the short-query builds can stream K / V past the caches (see lds_dma_16) ...
+  const bool stream_kv = kNt && (a.flags & kFlagStreamKV) != 0;  // ... when the launch side says every byte has one reader and the caches cannot hold them
+  auto issue_k = [&](auto ic, int key0, int dlane) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
     const TileSrc ts = tile_src<BC>(Kg, k_row_bytes, key0, a.Nkv, rb_valid);
     if constexpr (kRowDma) {
@@ -941,30 +981,32 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
           if (half * 64 + (dlane ^ (4 * wave + (jk & 3))) >= slots_valid) kv = kDmaOob;
         }
       }
-      lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(ts.rsrc, k_lds, kv, kro[jk]);
+      if (kNt && stream_kv) lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024, true>(ts.rsrc, k_lds, kv, kro[jk]);
+      else lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024, false>(ts.rsrc, k_lds, kv, kro[jk]);
     } else if constexpr (kHoist) {
-      lds_dma_16(ts.rsrc, (uint32_t)(uintptr_t)(Kt + (wave * PPW + i) * 1024), krel[i], 0u);
+      lds_dma_16_sel<kNt>(stream_kv, ts.rsrc, (uint32_t)(uintptr_t)(Kt + (wave * PPW + i) * 1024), krel[i], 0u);
     } else {
-      stage_piece<T, D, BC, false, SAFE>(ts.rsrc, ts.base, k_row_bytes, ts.rows, Kt, wave, dlane, i, slots_valid);
+      stage_piece<T, D, BC, false, SAFE, kNt>(ts.rsrc, ts.base, k_row_bytes, ts.rows, Kt, wave, dlane, i, slots_valid, stream_kv);
     }
   };
-  auto issue_v = [&](auto ic, int key0, int dlane) {
+  auto issue_v = [&](auto ic, int key0, int dlane) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
     const TileSrc ts = tile_src<BC>(Vg, v_row_bytes, key0, a.Nkv, rb_valid);
     if constexpr (kRowDma) {
       constexpr int jk = i / RPP, half = i % RPP;
-      lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024>(ts.rsrc, v_lds, vvo[jk & 3], vro[jk]);
+      if (kNt && stream_kv) lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024, true>(ts.rsrc, v_lds, vvo[jk & 3], vro[jk]);
+      else lds_dma_row<(16 * (jk >> 2) + (jk & 3)) * RB, half * 1024, false>(ts.rsrc, v_lds, vvo[jk & 3], vro[jk]);
     } else if constexpr (kHoist) {
-      lds_dma_16(ts.rsrc, (uint32_t)(uintptr_t)(Vt + (wave * PPW + i) * 1024), vrel[i], 0u);
+      lds_dma_16_sel<kNt>(stream_kv, ts.rsrc, (uint32_t)(uintptr_t)(Vt + (wave * PPW + i) * 1024), vrel[i], 0u);
     } else {
-      stage_piece<T, D, BC, true, SAFE>(ts.rsrc, ts.base, v_row_bytes, ts.rows, Vt, wave, dlane, i, slots_valid);
+      stage_piece<T, D, BC, true, SAFE, kNt>(ts.rsrc, ts.base, v_row_bytes, ts.rows, Vt, wave, dlane, i, slots_valid, stream_kv);
     }
   };
-  auto issue_k_tile = [&](int key0) {
+  auto issue_k_tile = [&](int key0) __attribute__((always_inline)) {
     const int dl = opaque_lane(lane);
     static_for<PPW>([&](auto ic) { issue_k(ic, key0, dl); });
   };
-  auto issue_v_tile = [&](int key0) {
+  auto issue_v_tile = [&](int key0) __attribute__((always_inline)) {
     const int dl = opaque_lane(lane);
     static_for<PPW>([&](auto ic) { issue_v(ic, key0, dl); });
   };

@@ -53,6 +53,8 @@ FLAG_NO_BIAS_LDS = 0x8
 FLAG_L2_PREFETCH = 0x10  # bench-only: touch the K/V tile two steps ahead in every prefill launch (default: the library decides; D > 512)
 FLAG_NO_L2_PREFETCH = 0x20  # bench-only: never
 FLAG_FORCE_SPLITS = 0x40  # bench-only: honour num_splits > 1 for prefill launches that fill the chip too
+FLAG_KV_STREAM = 0x80      # bench-only: force the non-temporal K / V fetch of short-query launches
+FLAG_NO_KV_STREAM = 0x800  # bench-only: never
 
 
 def FLAG_XCD_GROUP(n: int) -> int:

@@ -669,6 +669,23 @@ def test_short_query_split_kv(hip, D, Nq, Hq, Hkv):
   assert (o3.float() - o1.float()).abs().max().item() <= 4e-3
 
 
+@pytest.mark.parametrize("D", [128, 320, 512, 640, 1024])
+def test_streaming_kv_fetch_changes_no_bit(hip, D):
+  """Short-query launches fetch K / V with the non-temporal hint when every byte has one reader and K + V exceed the Infinity Cache (ffpa_capi.hip;
+  profiles/r04_kv_stream.txt).  A cache hint moves no data differently: forced on, forced off and the launch side's own choice give the same bits —
+  MHA, packed and un-packed GQA, tails, causal, every short-query tile family."""
+  for (B, Hq, Hkv, Nq, Nkv, causal, dt) in [(2, 8, 8, 1, 3001, False, torch.bfloat16), (1, 8, 2, 1, 2048, False, torch.float16), (1, 8, 2, 16, 1500, True, torch.bfloat16),
+                                             (1, 4, 4, 32, 777, False, torch.bfloat16)]:
+    q, k, v = _rand((B, Hq, Nq, D), dt, seed=601), _rand((B, Hkv, Nkv, D), dt, seed=602), _rand((B, Hkv, Nkv, D), dt, seed=603)
+    plan = {}
+    o0, l0 = hip.forward(q, k, v, None, causal, D ** -0.5, plan_out=plan)
+    assert plan["variant"] == 1
+    o1, l1 = hip.forward(q, k, v, None, causal, D ** -0.5, flags=hip.FLAG_KV_STREAM)
+    o2, l2 = hip.forward(q, k, v, None, causal, D ** -0.5, flags=hip.FLAG_NO_KV_STREAM)
+    assert torch.equal(o1, o2) and torch.equal(l1, l2) and torch.equal(o0, o1) and torch.equal(l0, l1), (D, B, Hq, Hkv, Nq, Nkv)
+  _check_vs_oracle(o1, l1, q, k, v, block_keys=_short_query_keys(hip, D), name=f"streamed D{D}", split=True)
+
+
 def test_split_partials_merged_inside_the_launch_equal_the_merge_kernel(hip):
   """Short-query KV-split launches with ffpa_fwd_params.split_tickets: the last split of a row tile to arrive merges the partials itself
   (write-through partial stores, one relaxed agent-scope ticket, agent-scope acquire by the merger: one launch per call).  Same arithmetic
