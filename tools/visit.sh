@@ -1,4 +1,3 @@
 #!/bin/bash
-mkdir -p gpurun_out/v40
-timeout 500 python tools/gpu_ab.py --case cfg2,cfg3,cfg4_nomask,cross,causal --rounds 7 --reps 5 main ntqo > gpurun_out/v40/ab_ntqo.txt 2>&1
-grep "^AB" gpurun_out/v40/ab_ntqo.txt
+rm -f ffpa_attn_amd/variants/*.so
+FFPA_GIT_HEAD=d4e9af7 bash tools/gpu_evidence.sh
