@@ -394,14 +394,14 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   a.flags = p->flags & 0x7fffffffu;  // (bit 31 is the launch side's own: kFlagStreamKV)
   {
     // Short-query launches stream K / V with the non-temporal hint when nothing would hit in a cache anyway: every (batch, kv head) is read by ONE
-    // workgroup per KV range (MHA, or query heads packed into the rows by the caller: heads_q == heads_kv) and K + V are well past the 256 MiB Infinity
+    // workgroup per KV range (MHA, or query heads packed into the rows by the caller: heads_q == heads_kv) and K + V are past the 256 MiB Infinity
     // Cache (a cache of that size read every decode step IS served from it: B4 H32 Nkv 1024 D512 = 256 MiB measured - 5 % with the hint, 128 MiB - 3 %;
-    // 512 MiB + 5 %: the line is drawn at 384 MiB).  LDS-DMA from HBM: 5.9
+    // 288 MiB + 3 %, 320 MiB + 5 ... 7 %, 384 / 512 MiB + 5 ... 8 %: the line is drawn at 272 MiB).  LDS-DMA from HBM: 5.9
     // TB/s without the hint, 7.3 with it (tools/probes/hbm_read_probe.hip); decode B1 H32 Nkv 8192 D512 102.8 -> 95.6 us per step, B8 GQA 180 -> 169,
     // D = 1024 179 -> 170, 131072 keys 356 -> 335; un-packed GQA (several workgroups read the same K / V through L2) LOSES 2 ... 15 % and keeps the
     // plain form (profiles/r04_kv_stream.txt).
     const int64_t kv_bytes = 2LL * p->batch * p->heads_kv * p->seqlen_kv * p->head_dim * 2;
-    bool stream = pl.variant == 1 && p->heads_q == p->heads_kv && kv_bytes >= (384LL << 20);
+    bool stream = pl.variant == 1 && p->heads_q == p->heads_kv && kv_bytes >= (272LL << 20);
     if (p->flags & FFPA_FLAG_KV_STREAM) stream = pl.variant == 1;
     if (p->flags & FFPA_FLAG_NO_KV_STREAM) stream = false;
     if (stream) a.flags |= ffpa::kFlagStreamKV;
