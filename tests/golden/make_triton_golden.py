@@ -4,6 +4,7 @@
                                                                       --only: run these cases and merge them into the existing fixture)
     python tests/golden/make_triton_golden.py --dropout              (the dropout cases only -> ref_triton_dropout.{npz,json})
     python tests/golden/make_triton_golden.py --decode               (the split-KV decode cases only -> ref_triton_decode.{npz,json})
+    python tests/golden/make_triton_golden.py --api                  (the reference's argument handling + its kernel -> ref_triton_api.{npz,json})
 
 The reference's large-head-dim arithmetic that can run without an NVIDIA GPU is its Triton statement of the algorithm
 (src/ffpa_attn/triton/_ffpa_fwd.py: kernel `_ffpa_fwd_kernel_impl` :302-495, launcher `_ffpa_attn_forward_generic_impl`
@@ -41,7 +42,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
-from triton_cases import CASES, DECODE_CASES, DROPOUT_CASES, bf16_bits_to_f32, f32_to_bf16_bits, triton_case_inputs  # the input recipe shared with the tests
+from triton_cases import API_CASES, CASES, DECODE_CASES, DROPOUT_CASES, api_case_inputs, bf16_bits_to_f32, f32_to_bf16_bits, triton_case_inputs  # the input recipe shared with the tests
 
 
 def main():
@@ -84,6 +85,8 @@ def main():
     return make_dropout(ref, torch, triton)
   if "--decode" in sys.argv:
     return make_decode(ref, torch, triton)
+  if "--api" in sys.argv:
+    return make_api(ref, torch, triton)
   store, meta = {}, []
   only = None
   if "--only" in sys.argv:
@@ -196,6 +199,48 @@ def make_decode(ref, torch, triton):
     json.dump({"source": f"reference src/ffpa_attn/triton/_ffpa_fwd.py::_ffpa_attn_forward_impl -> _ffpa_attn_forward_decode_impl (split count forced) under "
                          f"TRITON_INTERPRET=1, triton {triton.__version__}, torch {torch.__version__}", "cases": meta}, f, indent=1)
   print("wrote ref_triton_decode.{npz,json}")
+
+
+def make_api(ref, torch, triton):
+  """The reference's own argument handling in front of its kernel: FFPAAttnMeta.from_kwargs().normalize(...) (functional.py:726-942, imported unchanged, CPU
+  tensors) gives the validated inputs, the additive 4-D bias and the resolved scale; `_ffpa_attn_forward_impl` runs on exactly those."""
+  from ffpa_attn.functional import FFPAAttnMeta
+
+  store, meta_out = {}, []
+  for case in API_CASES:
+    name, B, Hq, Hkv, Nq, Nkv, D, causal, kind, dtype, scale, gqa = case
+    tdt = torch.float16 if dtype == "fp16" else torch.bfloat16
+    qa, ka, va, mask_np = api_case_inputs(case)
+    q, k, v = (torch.from_numpy(a) if dtype == "fp16" else torch.from_numpy(a.view(np.int16)).view(tdt) for a in (qa, ka, va))
+    mask = None if mask_np is None else torch.from_numpy(mask_np)
+    meta = FFPAAttnMeta.from_kwargs()
+    meta, q2, k2, v2, bias = meta.normalize(q, k, v, mask, 0.0, causal, scale, gqa)
+    assert not meta.fallback(q2, k2, mask, 0.0), name  # the shapes are ones the reference serves with its own kernels
+    o = torch.zeros_like(q2)
+    lse = torch.zeros(B, Hq, (Nq + 127) // 128 * 128, dtype=torch.float32)
+    ref._ffpa_attn_forward_impl(q2, k2, v2, o, lse, attn_bias=bias, causal=causal, softmax_scale=meta.attn_meta.scale)
+    g = Hq // Hkv
+    s = (q.float() @ k.float().repeat_interleave(g, 1).transpose(-1, -2)) * meta.attn_meta.scale
+    if mask is not None:
+      m4 = mask if mask.dim() == 4 else (mask.view(1, 1, Nq, Nkv) if mask.dim() == 2 else mask.view(B, 1, Nq, Nkv))
+      s = s.masked_fill(~m4, float("-inf")) if mask.dtype == torch.bool else s + m4
+    if causal:
+      r, c = torch.arange(Nq)[:, None], torch.arange(Nkv)[None, :]
+      s = s.masked_fill(c > r + (Nkv - Nq), float("-inf"))
+    want = torch.softmax(s, -1) @ v.float().repeat_interleave(g, 1)
+    err = (o.float() - want).abs().max().item()
+    lerr = (lse[..., :Nq] - torch.logsumexp(s, -1)).abs().max().item()
+    print(f"{name} [{dtype}] scale {meta.attn_meta.scale:.5f}: max |O - fp32 math| = {err:.2e}, max |LSE - ref| = {lerr:.2e}", flush=True)
+    assert err < (3e-3 if dtype == "fp16" else 2e-2) and lerr < 1e-3, name
+    store[f"{name}.o"] = o.contiguous().view(torch.int16).numpy().view(np.uint16).copy()
+    store[f"{name}.lse"] = lse[..., :Nq].contiguous().numpy()
+    meta_out.append({"name": name, "B": B, "Hq": Hq, "Hkv": Hkv, "Nq": Nq, "Nkv": Nkv, "D": D, "is_causal": causal, "mask": kind, "dtype": dtype, "scale": scale,
+                     "enable_gqa": gqa, "resolved_scale": meta.attn_meta.scale})
+  np.savez_compressed(os.path.join(HERE, "ref_triton_api.npz"), **store)
+  with open(os.path.join(HERE, "ref_triton_api.json"), "w") as f:
+    json.dump({"source": f"reference FFPAAttnMeta.normalize (src/ffpa_attn/functional.py) -> triton/_ffpa_fwd.py::_ffpa_attn_forward_impl under TRITON_INTERPRET=1, "
+                         f"triton {triton.__version__}, torch {torch.__version__}", "cases": meta_out}, f, indent=1)
+  print("wrote ref_triton_api.{npz,json}")
 
 
 if __name__ == "__main__":

@@ -46,6 +46,34 @@ DECODE_CASES = [
   ("decode_bf16_d1024_nq2_keybias_s5", 1, 2, 1, 2, 700, 1024, False, (1, 1, 1, 700), "bf16", False, 5),
 ]
 
+# Through the reference's PUBLIC argument handling (round 4): FFPAAttnMeta.normalize (functional.py:726-942: validation, default scale, enable_gqa,
+# bool mask -> 0 / -inf in q.dtype, 2-D / 3-D masks -> broadcasting 4-D views) feeding its Triton forward — what `ffpa_attn_func(q, k, v, attn_mask=...,
+# scale=..., enable_gqa=...)` computes at head dims > 256 and sequence lengths >= 512 (shorter ones fall back to SDPA: functional.py:717-724).
+# (name, B, Hq, Hkv, Nq, Nkv, D, is_causal, user-mask kind, dtype, scale or None, enable_gqa); outputs in ref_triton_api.npz.
+API_CASES = [
+  ("api_fp16_d320_bool2d_gqa", 1, 4, 2, 512, 640, 320, False, "bool2d", "fp16", None, True),
+  ("api_bf16_d512_bool3d_scale", 2, 2, 2, 520, 777, 512, False, "bool3d", "bf16", 0.05, False),
+  ("api_bf16_d512_f32_keys_heads", 1, 2, 2, 512, 512, 512, False, "f32_heads_keys", "bf16", None, False),
+  ("api_bf16_d1024_causal_gqa", 1, 2, 1, 512, 600, 1024, True, None, "bf16", None, True),
+]
+
+
+def api_case_inputs(case):
+  """q, k, v as triton_case_inputs gives them + the USER's attn_mask (numpy bool / float32, in the shape the user passes) or None."""
+  name, B, Hq, Hkv, Nq, Nkv, D, causal, kind, dtype, scale, gqa = case
+  q, k, v, _ = triton_case_inputs((name, B, Hq, Hkv, Nq, Nkv, D, causal, None, dtype, False))
+  rs = np.random.RandomState((abs(hash_name(name)) + 17) % (2 ** 31))
+  mask = None
+  if kind == "bool2d":
+    mask = rs.random_sample((Nq, Nkv)) < 0.7
+    mask[:, 0] = True  # never a whole row hidden
+  elif kind == "bool3d":
+    mask = rs.random_sample((B, Nq, Nkv)) < 0.5
+    mask[..., 3] = True
+  elif kind == "f32_heads_keys":
+    mask = (rs.standard_normal((1, Hq, 1, Nkv)) * 0.7).astype(np.float32)
+  return q, k, v, mask
+
 
 def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
   """fp32 -> bfloat16 storage bits, round to nearest even (NaN kept quiet): what every bf16 store of the hardware does."""

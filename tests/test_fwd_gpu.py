@@ -228,6 +228,33 @@ def test_short_query_kernels_match_the_executed_reference_split_kv_decode_path(h
   assert n == 4
 
 
+def test_public_api_matches_the_executed_reference_api_path(hip):
+  """`ffpa_attn_func(q, k, v, attn_mask=..., is_causal=..., scale=..., enable_gqa=...)` of this package on the GPU vs the reference's own argument handling +
+  Triton forward executed on the same user-level arguments (tests/golden/ref_triton_api.npz): 2-D / 3-D boolean masks, an fp32 mask broadcasting over rows,
+  default and custom scale, GQA, tail-aligned causal — all at shapes the reference serves with its own kernels (no SDPA fallback on either side)."""
+  import sys
+
+  from ffpa_attn_amd import ffpa_attn_func
+  from ffpa_attn_amd.functional import FFPAAttnMeta
+  from test_oracle import _bits_to_f32, _triton_api_cases, triton_fixture_limits
+
+  sys.path.insert(0, GOLDEN)
+  n = 0
+  for case, (q, k, v, mask_np), o_ref_bits, lse_ref, _ in _triton_api_cases():
+    name, Nkv, causal, dtype, scale, gqa = case[0], case[5], case[7], case[9], case[10], case[11]
+    tdt = torch.float16 if dtype == "fp16" else torch.bfloat16
+    qt, kt, vt = (torch.from_numpy(a.view(np.int16).copy()).view(tdt).cuda() for a in (q, k, v))
+    mask = None if mask_np is None else torch.from_numpy(mask_np).cuda()
+    assert not FFPAAttnMeta.from_kwargs().fallback(qt, kt, mask, 0.0), name  # the HIP kernel serves it, not SDPA
+    o = ffpa_attn_func(qt, kt, vt, attn_mask=mask, is_causal=causal, scale=scale, enable_gqa=gqa)
+    want = _bits_to_f32(o_ref_bits, dtype)
+    lim, mean_lim = triton_fixture_limits(want, dtype, Nkv, None, None)
+    d = np.abs(_f32(o) - want)
+    assert bool((d <= lim).all()) and d.mean() <= mean_lim * (1.25 if dtype == "fp16" else 1.0), (name, d.max(), d.mean())
+    n += 1
+  assert n == 4
+
+
 # ----------------------------------------------------------------------------- fast path == safe path
 @pytest.mark.parametrize("D", [64])
 def test_dma_and_transpose_read_path_is_bit_identical_to_register_staged_twin(hip, D):
