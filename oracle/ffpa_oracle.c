@@ -36,7 +36,8 @@
  * offsets inside a Philox quad, batch / head terms, a 62-bit seed (make_triton_golden.py --dropout -> ref_triton_dropout.npz): the
  * stream, the element offsets, the keep rule and the 1 / (1 - p) scaling below are the executed reference's; (i'') the reference's
  * split-KV decode kernels (stage 1 per KV chunk + stage 2 LSE merge, triton/_ffpa_fwd.py:497-861) executed with 3 / 4 / 5 splits
- * (make_triton_golden.py --decode -> ref_triton_decode.npz): this oracle's single walk lands on the merged O and LSE, (ii) PyTorch CPU SDPA — the reference's own
+ * (make_triton_golden.py --decode -> ref_triton_decode.npz): this oracle's single walk lands on the merged O and LSE; (i''') the reference's
+ * FFPAAttnMeta.normalize in front of that kernel on user-level arguments (--api -> ref_triton_api.npz), (ii) PyTorch CPU SDPA — the reference's own
  * test oracle — on the committed fixtures in tests/golden/, (iii) the output of the reference's ffpa_attn_func
  * itself, run in the authoring container on config 1 (tests/golden/make_golden.py), and (iv) an
  * fp64 plain-math evaluation.
