@@ -1,8 +1,9 @@
 #!/bin/bash
 # One evidence visit: the GPU suite, the bench line of every workload, the sweep, rocprofv3 kernel trace + PMC passes for the profiled
 # workloads — everything under gpurun_out/ in the layout tools/collect_profiles.sh copies into profiles/.
-#   usage: FFPA_GIT_HEAD=<sha> bash tools/gpu_evidence.sh ["pytest bench sweep wprof"] ["cfg2 cfg3 ..."]
-STAGES=${1:-"pytest bench sweep wprof"}
+#   usage: FFPA_GIT_HEAD=<sha> [FFPA_ROUND=r05] bash tools/gpu_evidence.sh ["pytest wprof bench sweep"] ["cfg2 cfg3 ..."]
+STAGES=${1:-"pytest wprof bench sweep"}  # (wprof first: the bench lines then quote roofline.traffic from the PMC summaries of this very visit)
+ROUND=${FFPA_ROUND:-r04}
 WPROF=${2:-"cfg2 cfg3 cfg4_mask attn_mask dropout decode"}
 export TMPDIR=/tmp
 mkdir -p gpurun_out/final
@@ -32,6 +33,8 @@ wprof)
     tcc=1; [ $w = decode ] && tcc=0
     PMC_WORKLOAD=$w PMC_TCC=$tcc bash tools/gpu_round.sh wprof > gpurun_out/wprof_$w.log 2>&1
     grep -E "exit [1-9]" gpurun_out/wprof_$w.log | head -3
+    # (on the box only: the snapshot's profiles/ gets this visit's summary, so that the bench stage below finds a profile of the running library)
+    [ -s gpurun_out/wprof_$w/summary.json ] && cp gpurun_out/wprof_$w/summary.json profiles/${ROUND}_bench_${w}_pmc.json
     python - <<PY
 import json
 try:
