@@ -27,6 +27,18 @@ def test_bench_spawns_its_own_ranks_when_no_launcher_did():
   assert d["per_rank_s"][1] > d["per_rank_s"][0] and d["ms_per_step"] * 4e-3 >= d["per_rank_s"][1] * 0.99
 
 
+def test_bench_plumbing_at_the_scaling_curves_world_sizes():
+  """The driver takes the scaling curve at N = 1, 2, 4, 8: the launch / barrier / max-over-ranks plumbing at 4 and 8 ranks (gloo stand-in; the
+  data path needs GPUs and is covered at world size 2 in tests/test_sharding.py and on the GPU box)."""
+  for n in (4, 8):
+    r = _run(["--gpus", str(n), "--stub-backend", "gloo", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and len(d["per_rank_s"]) == n and d["ms_per_step"] * 2e-3 >= max(d["per_rank_s"]) * 0.99
+
+
 def test_bench_under_a_launcher_does_not_spawn_and_checks_the_world_size():
   port = "29631"
   r = _run(["--gpus", "1", "--stub-backend", "gloo", "--steps", "2", "--warmup", "0"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port})
