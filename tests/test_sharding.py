@@ -98,6 +98,16 @@ def test_two_rank_gloo_born_sharded_blocks_and_gather():
     assert ret[0][1][0] == 0 and ret[0][1][1] == ret[1][1][0] and ret[1][1][1] == n_units
 
 
+def test_four_rank_gloo_born_sharded_blocks_and_gather():
+  """World size 4 (the scaling curve goes to 8): contiguous unit blocks, the overlapped gather in 1 / 2 / 3 pieces, an uneven split (6 units over 4 ranks)."""
+  for n_units, g in ((8, 2), (6, 1)):
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_born_worker, args=(4, port, n_units, g, ret), nprocs=4, join=True)
+    assert all(ret[r][0] and ret[r][2] for r in range(4)), dict(ret)
+    assert ret[0][1][0] == 0 and ret[3][1][1] == n_units and all(ret[r][1][1] == ret[r + 1][1][0] for r in range(3))
+
+
 def test_two_rank_gloo_sharded_attention_matches_unsharded():
   for (B, Hq, Hkv) in ((2, 8, 2), (1, 6, 3)):  # even and uneven (3 units over 2 ranks) splits
     port = _free_port()
