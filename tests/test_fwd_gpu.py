@@ -582,6 +582,24 @@ def test_key_permutation_invariance_at_full_length(hip):
   assert (oc.float() - 1).abs().max().item() <= 2 ** -7
 
 
+@pytest.mark.parametrize("D", [320, 512, 1024])
+def test_a_constant_bias_moves_the_lse_and_nothing_else_at_full_length(hip, D):
+  """softmax(s + c) = softmax(s): a constant additive bias — over the keys ([1,1,1,Nkv], the cached key-bias build), over rows and keys ([1,1,Nq,Nkv], the
+  staged bias-tile build) — must leave O where the unmasked build puts it (to the rounding of P against a shifted running max) and move LSE by exactly c.
+  Three builds of the prefill kernel against each other at the BASELINE key count."""
+  q, k, v = _baseline_inputs(1, 2, 2, 1024, 8192, D)
+  scale = D ** -0.5
+  o, lse = hip.forward(q, k, v, None, False, scale)
+  for c, shape in ((1.5, (1, 1, 1, 8192)), (-2.0, (1, 1, 1024, 8192))):
+    bias = torch.full(shape, c, dtype=q.dtype, device="cuda")
+    plan = {}
+    ob, lseb = hip.forward(q, k, v, bias, False, scale, plan_out=plan)
+    assert "MK=3" in plan["kernel"] or "MK=1" in plan["kernel"], plan
+    d = (o.float() - ob.float()).abs()
+    assert d.max().item() <= 5e-4 and d.mean().item() <= 3e-5, (D, shape, d.max().item(), d.mean().item())
+    assert (lseb - lse - c).abs().max().item() <= 2e-4, (D, shape)
+
+
 # ----------------------------------------------------------------------------- public API on the GPU
 def test_public_api_routes_large_d_to_the_kernel(hip, monkeypatch):
   from ffpa_attn_amd import ffpa_attn_func
