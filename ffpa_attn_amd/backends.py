@@ -3,15 +3,40 @@
 
 Mirrors the reference's user-facing config surface (``src/ffpa_attn/functional.py:176-507``:
 ``Backend``, ``SDPABackend``, ``CUDABackend``, ``TritonBackend``, ``CuTeDSLBackend`` and the
-string coercion rules) so that call sites written against the reference keep working.  On
-MI355X there is exactly one native forward implementation — the hand-written gfx950 kernel —
-so every non-SDPA backend name resolves to it (``HIPBackend``); NVIDIA-only knobs (TMA,
-CuTe, FP8/FP4, Triton autotune) are accepted for source compatibility and ignored.
+string coercion rules) so that call sites written against the reference keep working: every
+field of the reference's dataclasses is accepted under its name, with its default, and checked
+by the reference's own assertions (same message) — ``TritonBackend(autotune_mode="max",
+enable_tma=True)`` and ``CUDABackend(forward=True, fp8_smooth_k=False)`` construct here exactly as
+they do there (pinned against the imported reference: tests/golden/backend_golden.json).  On
+MI355X there is one native forward implementation — the hand-written gfx950 kernel — so every
+non-SDPA backend name resolves to it (``HIPBackend``); the NVIDIA-only knobs (TMA, CuTe, warp
+specialisation, Triton autotune, the backward-only Triton storage options, the FP8 / FP4
+quantisation sub-options) select nothing here and are ignored.  The two switches that would change
+the ARITHMETIC if they were silently ignored — ``enable_fp8`` / ``enable_fp4`` — construct (as in the
+reference) and are refused when a call reaches the kernel with them set.
 """
 
 from __future__ import annotations
 
 from dataclasses import dataclass
+
+import torch
+
+
+def _normalize_grad_storage_dtype(dtype):
+  """``None`` / ``"fp16"`` / ``"fp32"`` / ``torch.float16`` / ``torch.float32`` (functional.py:158-172)."""
+  if dtype is None:
+    return None
+  if dtype == "fp16":
+    return torch.float16
+  if dtype == "fp32":
+    return torch.float32
+  if dtype in (torch.float16, torch.float32):
+    return dtype
+  raise ValueError(
+    "grad_kv_storage_dtype must be None, 'fp16', 'fp32', torch.float16, or torch.float32, "
+    f"got {dtype!r}"
+  )
 
 
 @dataclass
@@ -50,9 +75,6 @@ class HIPBackend(Backend):
   :ivar stages: accepted for compatibility; the LDS pipeline depth is fixed per head dim.
   :ivar rescale_threshold: lazy-rescale threshold in log2 units; ``None`` = the reference's
       ``FFPA_RESCALE_THRESHOLD`` = 8 (csrc/cuffpa/common.cuh:14); ``0`` = exact recurrence.
-  :ivar causal_offset: ``None`` = tail-aligned causal mask (reference semantics,
-      ``key <= row + Nkv - Nq``); ``0`` = SDPA's top-left alignment (only reachable through
-      :func:`ffpa_attn_amd.hip.forward`, the public API keeps the reference's contract).
   """
 
   name: str = "hip"
@@ -62,23 +84,36 @@ class HIPBackend(Backend):
 
   def __post_init__(self) -> None:
     super().__post_init__()
-    if self.acc not in ("f16", "f32"):
-      raise AssertionError(f"acc must be 'f16' or 'f32', got {self.acc!r}")
+    self._check_acc()
+
+  def _check_acc(self) -> None:
+    assert self.acc in ("f16", "f32"), f"acc must be 'f16' or 'f32', got {self.acc!r}"
     if self.acc == "f16":
+      # (the reference raises the same class when its fp16-acc kernels were not compiled: functional.py:274-278)
       raise ValueError(
-        "HIPBackend(acc='f16') is not available: the gfx950 kernel accumulates in fp32 only "
-        "(the reference gates its fp16-acc kernels behind ENABLE_FFPA_F16_ACC as well)."
+        f"{type(self).__name__}(acc='f16') requires the fp16 MMA acc kernels, which do not exist in the gfx950 build "
+        "(the kernel accumulates in fp32 only)."
       )
 
   @property
   def acc_code(self) -> int:
     return 1
 
+  @property
+  def quantized(self) -> str | None:
+    """``"fp8"`` / ``"fp4"`` when the instance asks for a quantised forward (refused at dispatch), else ``None``."""
+    return None
+
+
+_QUANT_METHODS_QK = ("per_block", "per_thread")
+_QUANT_METHODS_V = ("per_block", "per_channel")
+
 
 @dataclass
 class CUDABackend(HIPBackend):
-  """Source-compatible alias: the reference's hand-written native backend
-  (functional.py:218-373).  Runs the gfx950 kernel; NVIDIA-only switches are ignored."""
+  """Source-compatible with the reference's hand-written native backend (functional.py:218-373): the same fields, defaults
+  and assertions.  Runs the gfx950 kernel; ``enable_tma`` / ``enable_cute`` / ``enable_ws`` and the ``fp8_*`` / ``fp4_*``
+  sub-options select nothing here."""
 
   name: str = "cuda"
   enable_tma: bool | None = None
@@ -86,24 +121,86 @@ class CUDABackend(HIPBackend):
   enable_ws: bool = False
   enable_fp8: bool = False
   enable_fp4: bool = False
+  fp8_smooth_k: bool = True
+  fp8_smooth_v: bool = False
+  fp8_q_quant_method: str = "per_block"
+  fp8_k_quant_method: str = "per_block"
+  fp8_v_quant_method: str = "per_block"
+  fp8_pv_acc_type: str = "f32"
+  fp8_qk_mm_type: str = "fp8"
+  fp8_hybrid: bool | None = None
+  fp8_hybrid_n_early: int = 256
+  fp4_hybrid: bool | None = None
+  fp4_hybrid_n_early: int = 256
+  is_causal: bool = False  # runtime: set from ffpa_attn_func(is_causal=...) by normalize_inputs, as in the reference
 
   def __post_init__(self) -> None:
-    super().__post_init__()
+    Backend.__post_init__(self)
     # the reference's CUDA backend is forward-only: CUDABackend(), backend="cuda" and backward_backend="cuda" trip this very assertion
     # (functional.py:266-268 after Backend.__post_init__ :189-196); callers spell it forward_backend="cuda" / CUDABackend(forward=True)
     assert not self.backward, "cuda backend does not support backward"
-    if self.enable_fp8 or self.enable_fp4:
-      raise NotImplementedError("FP8 / FP4 attention is out of scope for the MI355X build (bf16/fp16 only)")
+    self._check_acc()
+    assert not (self.enable_fp8 and self.enable_fp4), ("enable_fp8 and enable_fp4 are mutually exclusive")
+    assert self.fp8_q_quant_method in _QUANT_METHODS_QK, (
+      f"fp8_q_quant_method must be 'per_block' or 'per_thread', "
+      f"got {self.fp8_q_quant_method!r}"
+    )
+    assert self.fp8_k_quant_method in _QUANT_METHODS_QK, (
+      f"fp8_k_quant_method must be 'per_block' or 'per_thread', "
+      f"got {self.fp8_k_quant_method!r}"
+    )
+    assert self.fp8_v_quant_method in _QUANT_METHODS_V, (
+      f"fp8_v_quant_method must be 'per_block' or 'per_channel', "
+      f"got {self.fp8_v_quant_method!r}"
+    )
+    assert self.fp8_pv_acc_type in ("f16", "f32"), (
+      f"fp8_pv_acc_type must be 'f32' or 'f16', got {self.fp8_pv_acc_type!r}"
+    )
+    assert self.fp8_qk_mm_type in ("fp8", "int8"), (
+      f"fp8_qk_mm_type must be 'fp8' or 'int8', got {self.fp8_qk_mm_type!r}"
+    )
+    assert not self.fp8_smooth_v or self.fp8_v_quant_method == "per_channel", (
+      "fp8_smooth_v requires fp8_v_quant_method='per_channel'"
+    )
+    # the reference resolves enable_tma / enable_cute = None to what its build and device offer (functional.py:304-325): neither exists here
+    if self.enable_tma is None:
+      self.enable_tma = False
+    if self.enable_cute is None:
+      self.enable_cute = False
+
+  @property
+  def quantized(self) -> str | None:
+    return "fp4" if self.enable_fp4 else ("fp8" if self.enable_fp8 else None)
 
 
 @dataclass
 class TritonBackend(HIPBackend):
-  """Source-compatible alias for the reference's default backend (functional.py:377-421).
-  No Triton is used here; the call runs the gfx950 kernel."""
+  """Source-compatible with the reference's default backend (functional.py:377-421): the same fields, defaults and assertions.
+  No Triton is used here; a forward call runs the gfx950 kernel, the backward-only options configure a backward this build
+  routes to SDPA's (ffpa_attn_amd/backward.py) and are ignored."""
 
   name: str = "triton"
-  enable_ws: bool = False
   autotune: bool = False
+  autotune_mode: str = "fast"
+  enable_tma: bool = False
+  enable_ws: bool = False
+  persist_dkdv: bool = False
+  split_launch: bool = False
+  preprocess_d_chunk: bool = False
+  grad_kv_storage_dtype: torch.dtype | str | None = None
+  grad_q_storage_dtype: torch.dtype | str | None = None
+
+  def __post_init__(self) -> None:
+    super().__post_init__()
+    assert self.autotune_mode in ("fast", "max"), \
+      f"Unsupported autotune_mode={self.autotune_mode!r}; choose 'fast' or 'max'."
+    self.grad_kv_storage_dtype = _normalize_grad_storage_dtype(self.grad_kv_storage_dtype)
+    self.grad_q_storage_dtype = _normalize_grad_storage_dtype(self.grad_q_storage_dtype)
+    if self.persist_dkdv:
+      assert self.backward, "persist_dkdv is only valid for Triton backward"
+      assert self.enable_tma, "persist_dkdv requires enable_tma=True"
+    if self.split_launch or self.preprocess_d_chunk or self.grad_kv_storage_dtype is not None or self.grad_q_storage_dtype is not None:
+      assert self.backward, "backward-only Triton options require backward=True"
 
 
 @dataclass
@@ -112,6 +209,14 @@ class CuTeDSLBackend(Backend):
   exactly like the reference when ``cute_forward_available()`` is false — it falls back to SDPA."""
 
   name: str = "cutedsl"
+  grad_kv_storage_dtype: torch.dtype | str | None = None
+
+  def __post_init__(self) -> None:
+    super().__post_init__()
+    self.grad_kv_storage_dtype = _normalize_grad_storage_dtype(self.grad_kv_storage_dtype)
+    if self.grad_kv_storage_dtype is not None:
+      assert self.backward, \
+        "grad_kv_storage_dtype is a backward-only option; requires backward=True"
 
 
 _BACKEND_BY_NAME = {

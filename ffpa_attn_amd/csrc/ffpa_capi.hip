@@ -63,6 +63,7 @@ struct Plan {
   int variant, br, bc, lds, nqt, nt, splits, tiles_per_split;
   int btile;  // 1: a bias with a row axis goes through LDS tiles staged one KV step ahead
   int m16;    // 1: the launch runs ffpa_fwd_m16_kernel (prefill tiles, head dim >= FFPA_M16_MIN_D), 0: ffpa_fwd_split_d_kernel
+  int wide;   // 1: ... its wide-row tile, ffpa_fwd_m16w_kernel (launch variant 3)
   int mk;     // m16: the mask kind of the build (0 none, 1 additive bias, 2 boolean mask / ranges)
   int bias_raw;  // FwdArgs.bias_cache_raw
   int bias_lds;  // FwdArgs.bias_lds: > 0 bytes of the key-bias row cache, < 0 -(bytes of the bias-tile staging areas), 0 neither
@@ -108,12 +109,39 @@ int check_device() {
   return FFPA_OK;
 }
 
+// The wide-row prefill tile (ffpa_fwd_m16w_kernel.h: 16 RH rows per wave, RH sized to the accumulator file; 64-key tiles, double-buffered, one barrier
+// per KV step): does this launch take it?  The builds that exist: no additive bias, no dropout.  Measured on D = 320 (profiles/r05_wide_tile.txt, interleaved
+// same-box A/B): a row of the 192-row tile costs 2 ... 7 % less than a row of the 128-row tile, so what decides is how the launch quantises into rounds of
+// workgroups — B2 Hq32 x Nq 8192 (config 4 without its mask): 2752 workgroups = 11 rounds of 192 rows against 16 of 128: + 2.3 %; B1 H32 x Nq 8192: 1376 =
+// 5.4 -> SIX rounds against 8: - 4 %.  Launches whose workgroups differ in length (causal flag, masks, mask ranges: longest first, the last round's tail is short
+// workgroups) have no such quantum but need enough workgroups per CU for the lengths to even out: config 4 (10.75 per CU) + 1.0 ... 1.6 %, B1 H32 causal 8192
+// (5.4 per CU) - 3 %.
+constexpr double kWideGain = 1.04;     // rows per unit time, wide : 32-row tile (the pricing's figure: low end of the measured range)
+constexpr int kWideMinWgPerCu = 8;     // ragged launches: workgroups per CU from which the wide tile is taken
+bool pick_wide_tile(const ffpa_fwd_params* p, const DimEntry* de, const Plan& pl, int64_t cus) {
+  if (pl.variant != 0 || (p->flags & (FFPA_FLAG_DEBUG_SAFE_PATH | FFPA_FLAG_NO_WIDE_TILE))) return false;
+  if (p->dropout_p > 0.f || !(p->bias == nullptr || p->bias_dtype == FFPA_BIAS_BOOL8)) return false;
+  int br = 0, bc = 0, lds = 0;
+  de->config(3, &br, &bc, &lds);
+  if (br <= 0) return false;
+  if (p->flags & FFPA_FLAG_WIDE_TILE) return true;
+  const int64_t wgs_wide = (int64_t)p->batch * p->heads_q * ((p->seqlen_q + br - 1) / br);
+  const int64_t wgs_now = (int64_t)p->batch * p->heads_q * ((p->seqlen_q + pl.br - 1) / pl.br);
+  if (p->causal || p->bias != nullptr || p->kv_bounds != nullptr) return wgs_wide >= kWideMinWgPerCu * cus;
+  if (wgs_wide < 2 * cus) return false;  // (launches of a round or two: the KV-split rules below were measured on the 128-row tile)
+  const double t_wide = (double)((wgs_wide + cus - 1) / cus) * br / kWideGain, t_now = (double)((wgs_now + cus - 1) / cus) * pl.br;
+  return t_wide < t_now;
+}
+
 Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
   Plan pl = {};
   // <= 32 query rows per (batch, head): one 32-row block per workgroup with D split over all four waves;
   // the reference switches to its split-KV decode kernels only for Nq == 1 (native/launch.cuh:306-340)
   pl.variant = (p->seqlen_q <= 32 && !(p->flags & FFPA_FLAG_DEBUG_SAFE_PATH)) ? 1 : 0;
   de->config(pl.variant, &pl.br, &pl.bc, &pl.lds);
+  const int64_t cus = device_cu_count();
+  pl.wide = pick_wide_tile(p, de, pl, cus) ? 1 : 0;
+  if (pl.wide) de->config(3, &pl.br, &pl.bc, &pl.lds);
   pl.nqt = (p->seqlen_q + pl.br - 1) / pl.br;
   pl.nt = (p->seqlen_kv + pl.bc - 1) / pl.bc;
   pl.splits = 1;
@@ -122,7 +150,6 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
   // cheap.  Prefill tiles split too when the launch would leave more than half of the chip idle (chunked prefill
   // against a long context with few heads per GPU): one workgroup per CU, at least 8 KV tiles per split.
   const int64_t base = (int64_t)p->batch * p->heads_q * pl.nqt;
-  const int64_t cus = device_cu_count();
   // Ragged rounds (round 4, profiles/r04_launch_side.txt): a prefill launch of a little over one round of workgroups — 288 ... 384 on 256 CUs — takes two
   // rounds' time.  Split over 2 or 3 KV ranges it fills whole rounds (9 heads x 32 row tiles x 3 = 864 = 3.4 rounds), and on a long context the partials
   // and their merge cost little next to that: B1 H9 / H10 / H11 / H12 x Nq 4096 x Nkv 8192 D512 + 18 / + 15 / + 10 / + 5 %, H40 x Nq 1024 + 14 %,
@@ -477,7 +504,7 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
     a.tickets = pl.variant == 1 ? p->split_tickets : nullptr;
   }
 
-  int st = de->launch(p->dtype, safe, pl.variant, a, static_cast<hipStream_t>(stream));
+  int st = de->launch(p->dtype, safe, pl.wide ? 3 : pl.variant, a, static_cast<hipStream_t>(stream));
   if (st == 0 && pl.splits > 1 && a.tickets == nullptr) {
     const unsigned rows = (unsigned)((int64_t)p->batch * p->heads_q * p->seqlen_q);
     if (p->dtype == FFPA_DTYPE_BF16)
@@ -578,7 +605,9 @@ int ffpa_attn_fwd_kernel(const ffpa_fwd_params* params, char* buf, size_t n) {
   const char* dt = params->dtype == FFPA_DTYPE_FP16 ? "fp16" : "bf16";
   const int drop = params->dropout_p > 0.f ? 1 : 0;
   const char* merge = pl.splits > 1 ? ((params->split_tickets != nullptr && pl.variant == 1) ? " (in-launch split merge)" : " + ffpa_fwd_merge_kernel") : "";
-  if (pl.m16) {
+  if (pl.wide) {
+    snprintf(buf, n, "ffpa_fwd_m16w_kernel<%s, %d, RH=%d, MK=%d>%s", dt, de->d, pl.br / 64, pl.mk, merge);
+  } else if (pl.m16) {
     snprintf(buf, n, "ffpa_fwd_m16_kernel<%s, %d, MK=%d, DROP=%d>%s", dt, de->d, pl.mk, drop, merge);
   } else {
     const int nd = pl.variant == 1 ? ((de->d % 128 == 0) ? 4 : 2) : (de->d <= 512 ? 1 : 2);

@@ -6,6 +6,7 @@
 
 #include "ffpa_fwd_kernel.h"
 #include "ffpa_fwd_m16_kernel.h"
+#include "ffpa_fwd_m16w_kernel.h"
 #include "ffpa_launch.h"
 
 #ifndef FFPA_INST_D
@@ -66,6 +67,29 @@ static int launch_m16(const FwdArgs& a, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
+// The wide-row prefill tile of the head dims whose O^T leaves accumulator registers idle at 32 rows per wave (ffpa_fwd_m16w_kernel.h).
+template <typename T, int D, int MK>
+static int launch_m16w(const FwdArgs& a, hipStream_t stream) {
+  if constexpr (m16w_available(D)) {
+    constexpr int RH = m16w_row_halves(D);
+    auto kern = ffpa_fwd_m16w_kernel<T, D, RH, m16w_block_keys(D), MK>;
+    static std::atomic<bool> attr_done[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (dev < 0 || dev >= 64 || !attr_done[dev].load(std::memory_order_acquire)) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        (void)hipGetLastError();
+        return -2;
+      }
+      if (dev >= 0 && dev < 64) attr_done[dev].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.total_wg), dim3(256), m16w_lds_bytes(D), stream, a);
+    return (int)hipGetLastError();
+  } else {
+    return -3;
+  }
+}
+
 #define FFPA_CAT2(a, b) a##b
 #define FFPA_CAT(a, b) FFPA_CAT2(a, b)
 
@@ -102,6 +126,17 @@ static int launch_fwd_impl(int dtype, int safe, int variant, const FwdArgs& a, h
   if (safe) return -3;
 #endif
   const bool no_bias = a.bias_dtype == 0 && a.kv_bounds == nullptr;  // no attn_bias, no mask ranges: the builds without any bias path
+  if (variant == 3) {  // the wide-row tile (the plan only picks it for the builds that exist: no additive bias, no dropout)
+    if (a.dropout_p > 0.f || !(a.bias_dtype == 0 || a.bias_dtype == 4)) return -3;
+    if (no_bias) {
+      if (dtype == 0) return launch_m16w<__bf16, D, 0>(a, stream);
+      if (dtype == 1) return launch_m16w<_Float16, D, 0>(a, stream);
+      return -4;
+    }
+    if (dtype == 0) return launch_m16w<__bf16, D, 2>(a, stream);
+    if (dtype == 1) return launch_m16w<_Float16, D, 2>(a, stream);
+    return -4;
+  }
   if constexpr (D >= FFPA_M16_MIN_D) {
     if (a.dropout_p > 0.f) {
       if (no_bias) {
@@ -167,7 +202,14 @@ int FFPA_CAT(launch_fwd_d, FFPA_INST_D)(int dtype, int safe, int variant, const 
 void FFPA_CAT(tile_config_d, FFPA_INST_D)(int variant, int* br, int* bc, int* lds) {
   constexpr int D = FFPA_INST_D;
   // variant 0: prefill tiles, 1: short-query tiles, 2: prefill tiles of the additive-bias builds (64 keys at every head dim <= 512:
-  // the 16x16x32 build with any additive bias, the 32x32x16 build with LDS-staged bias tiles)
+  // the 16x16x32 build with any additive bias, the 32x32x16 build with LDS-staged bias tiles), 3: the wide-row prefill tile
+  // (ffpa_fwd_m16w_kernel.h; *br = 0 where the head dim has none)
+  if (variant == 3) {
+    *br = m16w_available(D) ? m16w_block_rows(m16w_row_halves(D)) : 0;
+    *bc = m16w_block_keys(D);
+    *lds = m16w_available(D) ? m16w_lds_bytes(D) : 0;
+    return;
+  }
   const int ND = variant == 1 ? ((D % 128 == 0) ? 4 : 2) : ((D <= 512) ? 1 : 2);
   int BC = (ND == 1) ? ((D <= FFPA_BC128_MAX_D && variant != 2) ? 128 : 64) : splitd_block_keys(D, ND);
   if (variant != 1 && D >= FFPA_M16_MIN_D) BC = m16_block_keys(D, variant == 2);  // (the 16x16x32 kernel's own rule)

@@ -17,7 +17,7 @@ from dataclasses import dataclass, field
 
 import torch
 
-from .backends import Backend, CuTeDSLBackend, HIPBackend, SDPABackend, coerce_backend
+from .backends import Backend, CUDABackend, CuTeDSLBackend, HIPBackend, SDPABackend, coerce_backend
 
 logger = logging.getLogger("FFPA")
 
@@ -112,11 +112,7 @@ class FFPAAttnMeta:
       8 <= Nq < 512,
       Nkv < 512,
     ]
-    if any(reasons):
-      return True
-    if not query.is_cuda:
-      return False  # large-D CPU tensors reach the op and raise NotImplementedError, like the reference
-    return False
+    return any(reasons)  # (large-D CPU tensors reach the op and raise NotImplementedError, like the reference)
 
   # ------------------------------------------------------------------ validation
   def normalize_inputs(self, query, key, value, attn_mask, dropout_p, is_causal, scale, enable_gqa) -> "FFPAAttnMeta":
@@ -129,6 +125,19 @@ class FFPAAttnMeta:
       raise RuntimeError("ffpa_attn_func: explicit attn_mask should not be set when is_causal=True")
     if attn_mask is not None and attn_mask.dtype == torch.bool and attn_mask.requires_grad:
       raise TypeError("ffpa_attn_func: boolean attn_mask cannot require gradients")
+    # (the reference propagates is_causal to its CUDA backend object and resolves the *_hybrid switches here: functional.py:780-795)
+    fwd = self.forward_meta
+    if isinstance(fwd, CUDABackend):
+      fwd.is_causal = bool(is_causal)
+      if fwd.fp8_hybrid is None:
+        fwd.fp8_hybrid = bool(fwd.enable_fp8 and is_causal)
+      if fwd.fp4_hybrid is None:
+        fwd.fp4_hybrid = bool(fwd.enable_fp4 and is_causal)
+    if getattr(fwd, "quantized", None):
+      # the one pair of switches that cannot be "accepted and ignored": they change the arithmetic (sm_120 FP8 / NVFP4 kernels in the reference)
+      raise NotImplementedError(
+        f"ffpa_attn_func: enable_{fwd.quantized}=True selects the reference's sm_120 quantised kernels; the MI355X build computes in bf16 / fp16 only"
+      )
     if query.dtype not in (torch.float16, torch.bfloat16):
       raise TypeError(f"ffpa_attn_func only supports fp16/bf16, got {query.dtype}")
     if query.dim() != 4 or key.dim() != 4 or value.dim() != 4:

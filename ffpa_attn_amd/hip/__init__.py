@@ -55,6 +55,8 @@ FLAG_NO_L2_PREFETCH = 0x20  # bench-only: never
 FLAG_FORCE_SPLITS = 0x40  # bench-only: honour num_splits > 1 for prefill launches that fill the chip too
 FLAG_KV_STREAM = 0x80      # bench-only: force the non-temporal K / V fetch of short-query launches
 FLAG_NO_KV_STREAM = 0x800  # bench-only: never
+FLAG_WIDE_TILE = 0x1000     # bench / test: prefill launches take the wide-row tile wherever one is built (default: the library decides)
+FLAG_NO_WIDE_TILE = 0x2000  # bench / test: never
 
 
 def FLAG_XCD_GROUP(n: int) -> int:
@@ -189,6 +191,34 @@ def load_debug_library() -> ctypes.CDLL:
 
 def library_available() -> bool:
   return os.path.exists(LIB_PATH)
+
+
+# Module-level capability attributes, under the names the reference's CUDA shim exports at import (``src/ffpa_attn/cuda/__init__.py:6-25``:
+# read from its pybind module, ``csrc/cuffpa/ffpa_api.cc:283-305``) — call sites that gate on ``ffpa_attn.cuda.CUDA_FWD_AVAILABLE`` keep working
+# against this module.  Answered lazily from ``ffpa_attn_query()`` (PEP 562: importing the package must not need the built library).  The
+# reference's process-global ``set/get_cuda_backend_impl`` hint (``:38-47``, ``backend.h:16-27``) has NO equivalent on purpose: the C-ABI keeps
+# no mutable global state, every choice travels in ``ffpa_fwd_params`` (SURVEY.md section 8b "Threading").
+_CAPABILITY_QUERIES = {
+  "HIP_FWD_AVAILABLE": 1, "CUDA_FWD_AVAILABLE": 1,  # FFPA_QUERY_FWD_AVAILABLE
+  "FP16_AVAILABLE": 5, "DROPOUT_AVAILABLE": 6,       # FFPA_QUERY_FP16_AVAILABLE / _DROPOUT_AVAILABLE
+}
+_CAPABILITY_CONSTANTS = {
+  "F16_ACC_AVAILABLE": False,        # fp32 accumulation only (the reference builds its fp16-acc kernels behind ENABLE_FFPA_F16_ACC)
+  "CUDA_TMA_AVAILABLE": False,       # sm_90+ hardware feature
+  "CUDA_CUTE_TMA_AVAILABLE": False,  # sm_120 CuTe kernels
+  "CUDA_BWD_AVAILABLE": False,       # as in the reference: the native backend is forward-only
+}
+
+
+def __getattr__(name: str):
+  if name in _CAPABILITY_CONSTANTS:
+    return _CAPABILITY_CONSTANTS[name]
+  if name in _CAPABILITY_QUERIES:
+    try:
+      return load_library().ffpa_attn_query(_CAPABILITY_QUERIES[name]) == 1
+    except (RuntimeError, OSError):
+      return False  # not built: the reference answers False when its extension module is missing, too
+  raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 
 
 def tile_config(head_dim: int) -> dict:

@@ -123,3 +123,30 @@ def ffpa_attn_func(
     query, key, value, attn_mask, dropout_p, is_causal, scale, enable_gqa
   )
   return _ffpa_apply(query, key, value, attn_bias, meta)
+
+
+def ffpa_attn_varlen_func(
+  q: torch.Tensor,
+  k: torch.Tensor,
+  v: torch.Tensor,
+  cu_seqlens_q: torch.Tensor,
+  cu_seqlens_k: torch.Tensor | None,
+  max_seqlen_q: int,
+  max_seqlen_k: int,
+  *,
+  dropout_p: float = 0.0,
+  softmax_scale: float | None = None,
+  causal: bool = False,
+  enable_gqa: bool = False,
+  return_lse: bool = False,
+  **kwargs: object,
+):
+  """The reference's packed-THD entry point (``ffpa_attn_interface.py:192-280``), kept under its name and signature so that
+  ``from ffpa_attn import ffpa_attn_varlen_func`` call sites import.  In the reference it is served by the CuTe-DSL backend ONLY and
+  "any unsupported case raises an actionable error immediately — there is no silent fallback to dense / per-sequence paths";
+  CuTe-DSL is NVIDIA-only, so on MI355X every call is the unsupported case.  Unpack the batch and call :func:`ffpa_attn_func`
+  per sequence (what the reference tells callers of unsupported shapes to do)."""
+  raise NotImplementedError(
+    "ffpa_attn_varlen_func is served by the CuTeDSL backend only (NVIDIA SM8x / SM90); it is not available in the MI355X build. "
+    "Unpack the batch with cu_seqlens and call ffpa_attn_func per sequence."
+  )

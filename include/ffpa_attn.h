@@ -69,6 +69,8 @@ enum ffpa_bias_dtype {
 #define FFPA_FLAG_FORCE_SPLITS    0x40u /* bench-only: honour num_splits > 1 for a prefill launch that fills the chip too (default: only under-filled launches split) */
 #define FFPA_FLAG_KV_STREAM       0x80u /* bench-only: short-query launches fetch K / V with the non-temporal hint (default: the launch side decides — one reader per byte and K + V larger than the Infinity Cache) */
 #define FFPA_FLAG_NO_KV_STREAM    0x800u /* bench-only: never                                          */
+#define FFPA_FLAG_WIDE_TILE       0x1000u /* bench / test: prefill launches take the wide-row tile (ffpa_fwd_m16w_kernel) wherever the head dim and the mask kind have one (default: the launch side decides) */
+#define FFPA_FLAG_NO_WIDE_TILE    0x2000u /* bench / test: never                                       */
 #define FFPA_FLAG_XCD_GROUP(log2p1) ((unsigned)(log2p1) << 8) /* bench-only: bits 8..10 = 1 + log2 of the XCDs that share a head's row tiles (1 -> 1, 2 -> 2, 3 -> 4, 4 -> 8); 0 = the launch side decides */
 
 /*

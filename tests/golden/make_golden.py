@@ -8,6 +8,8 @@ only: it never travels to the GPU box, in any form.  What it produces is data:
   dispatch_golden.json   FFPAAttnMeta.{from_kwargs,fallback,normalize} decisions of the reference on
                          meta tensors: per case either {"fallback": true}, {"raises": {type, match}}
                          or {"ffpa": {"scale": ..}} — pins this repo's host-side dispatch/validation.
+  backend_golden.json    construction of the reference's Backend dataclasses with their full field lists (which kwargs construct, which assertion
+                         trips, the fields afterwards) and where a config-2 call carrying the object is routed.
   flops_golden.json      reference attention_valid_pairs / attention_fwd_flops over a grid
                          (src/ffpa_attn/cli/_flops.py:15-53).
   cfg1_cpu.npz           BASELINE config 1 (B1 H4 N1024 D64 bf16, seed 0): q/k/v bits and the output of
@@ -124,6 +126,72 @@ def run_dispatch():
   return out
 
 
+# ------------------------------------------------------------------------------------ backend objects
+# Construction of the reference's Backend dataclasses (functional.py:176-470) with its full field lists: which kwargs construct, which trip
+# which assertion, what the fields hold afterwards — and where a call carrying the object as forward_backend is routed (config-2 shapes on
+# meta tensors: fused kernel or SDPA fallback).
+BACKEND_CASES = [
+  ("TritonBackend", {}), ("TritonBackend", {"forward": True}), ("TritonBackend", {"backward": True}),
+  ("TritonBackend", {"autotune_mode": "max", "enable_tma": True}), ("TritonBackend", {"autotune": True, "enable_ws": True, "forward": True}),
+  ("TritonBackend", {"autotune_mode": "slow"}), ("TritonBackend", {"persist_dkdv": True}), ("TritonBackend", {"persist_dkdv": True, "enable_tma": True}),
+  ("TritonBackend", {"forward": True, "persist_dkdv": True, "enable_tma": True}), ("TritonBackend", {"forward": True, "split_launch": True}),
+  ("TritonBackend", {"backward": True, "split_launch": True, "preprocess_d_chunk": True}), ("TritonBackend", {"backward": True, "grad_kv_storage_dtype": "fp32"}),
+  ("TritonBackend", {"grad_q_storage_dtype": "fp16"}), ("TritonBackend", {"grad_q_storage_dtype": "bf16"}), ("TritonBackend", {"forward": True, "grad_kv_storage_dtype": "fp16"}),
+  ("TritonBackend", {"foo": 1}),
+  ("CUDABackend", {}), ("CUDABackend", {"forward": True}), ("CUDABackend", {"backward": False}), ("CUDABackend", {"forward": True, "fp8_smooth_k": False}),
+  ("CUDABackend", {"forward": True, "enable_fp8": True}), ("CUDABackend", {"forward": True, "enable_fp4": True, "fp4_hybrid": False}),
+  ("CUDABackend", {"forward": True, "enable_fp8": True, "enable_fp4": True}), ("CUDABackend", {"forward": True, "fp8_q_quant_method": "per_channel"}),
+  ("CUDABackend", {"forward": True, "fp8_k_quant_method": "per_thread"}), ("CUDABackend", {"forward": True, "fp8_v_quant_method": "per_thread"}),
+  ("CUDABackend", {"forward": True, "fp8_v_quant_method": "per_channel", "fp8_smooth_v": True}), ("CUDABackend", {"forward": True, "fp8_smooth_v": True}),
+  ("CUDABackend", {"forward": True, "fp8_pv_acc_type": "bf16"}), ("CUDABackend", {"forward": True, "fp8_pv_acc_type": "f16", "fp8_qk_mm_type": "int8"}),
+  ("CUDABackend", {"forward": True, "fp8_qk_mm_type": "fp4"}), ("CUDABackend", {"forward": True, "acc": "f64"}), ("CUDABackend", {"forward": True, "acc": "f16"}),
+  ("CUDABackend", {"forward": True, "enable_tma": True}), ("CUDABackend", {"forward": True, "enable_cute": True, "stages": 2}),
+  ("CUDABackend", {"forward": True, "enable_tma": True, "enable_cute": True, "enable_ws": True}),
+  ("CUDABackend", {"forward": True, "fp8_hybrid": True, "fp8_hybrid_n_early": 128, "fp4_hybrid_n_early": 64}), ("CUDABackend", {"forward": True, "bar": 2}),
+  ("CuTeDSLBackend", {}), ("CuTeDSLBackend", {"grad_kv_storage_dtype": "fp16"}), ("CuTeDSLBackend", {"forward": True, "grad_kv_storage_dtype": "fp16"}),
+  ("CuTeDSLBackend", {"grad_kv_storage_dtype": "int8"}),
+  ("SDPABackend", {}), ("SDPABackend", {"backward": True, "high_precision_grad": True}), ("SDPABackend", {"forward": True}),
+]
+# fields whose value depends on the reference's build / device (the CUDA backend resolves its pipeline depth from the GPU generation): not compared
+BACKEND_DEVICE_FIELDS = ("stages",)
+
+
+def _plain(v):
+  return str(v) if isinstance(v, torch.dtype) else v
+
+
+def run_backends():
+  import dataclasses
+
+  import ffpa_attn
+  from ffpa_attn.functional import FFPAAttnMeta
+
+  out = []
+  for cls_name, kw in BACKEND_CASES:
+    rec = {"cls": cls_name, "kwargs": kw}
+    try:
+      obj = getattr(ffpa_attn, cls_name)(**kw)
+      rec["expect"] = {"fields": {f.name: _plain(getattr(obj, f.name)) for f in dataclasses.fields(obj) if f.name not in BACKEND_DEVICE_FIELDS}}
+    except Exception as e:  # noqa: BLE001 - recording the contract
+      rec["expect"] = {"raises": {"type": type(e).__name__, "message": str(e)}}
+      out.append(rec)
+      continue
+    # where does a config-2 call carrying this object go?
+    q = torch.empty((1, 32, 8192, 512), dtype=torch.bfloat16, device="meta")
+    try:
+      meta = FFPAAttnMeta.from_kwargs(**({"forward_backend": obj} if obj.forward else {"backward_backend": obj}))
+      rec["route"] = {"fallback": bool(meta.fallback(q, q, None, 0.0))}
+      if not rec["route"]["fallback"]:
+        meta, *_ = meta.normalize(q, q, q, None, 0.0, True, None, False)
+        rec["route"]["scale"] = meta.attn_meta.scale
+        rec["route"]["fields_after"] = {f.name: _plain(getattr(meta.forward_meta, f.name)) for f in dataclasses.fields(meta.forward_meta)
+                                        if f.name in ("is_causal", "fp8_hybrid", "fp4_hybrid")}
+    except Exception as e:  # noqa: BLE001
+      rec["route"] = {"raises": {"type": type(e).__name__, "message": str(e)}}
+    out.append(rec)
+  return out
+
+
 # ------------------------------------------------------------------------------------ flops table
 def run_flops():
   from ffpa_attn.cli._flops import attention_fwd_flops, attention_valid_pairs
@@ -234,10 +302,15 @@ def main():
   except ImportError:
     sys.exit("run with PYTHONPATH=/root/reference/src (the reference is only available in the authoring container)")
   torch.set_num_threads(8)
-  with open(os.path.join(HERE, "dispatch_golden.json"), "w") as f:
-    json.dump(run_dispatch(), f, indent=1)
+  if "--backends-only" not in sys.argv:
+    with open(os.path.join(HERE, "dispatch_golden.json"), "w") as f:
+      json.dump(run_dispatch(), f, indent=1)
   with open(os.path.join(HERE, "flops_golden.json"), "w") as f:
     json.dump(run_flops(), f, indent=1)
+  with open(os.path.join(HERE, "backend_golden.json"), "w") as f:
+    json.dump(run_backends(), f, indent=1)
+  if "--backends-only" in sys.argv:
+    return
   run_cfg1()
   run_small()
   print("golden fixtures written to", HERE)

@@ -190,6 +190,33 @@ def test_ragged_round_split_rule(lib, over, want):
     assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0 and plan[3] == 1
 
 
+@pytest.mark.parametrize("over, rows", [
+  (dict(batch=2, heads_q=32, heads_kv=8, seqlen_q=8192, seqlen_kv=2048, head_dim=320), 192),             # config 4 without its mask: 11 rounds of 192 rows < 16 of 128
+  (dict(batch=2, heads_q=32, heads_kv=8, seqlen_q=8192, seqlen_kv=2048, head_dim=320, causal=1), 192),   # config 4 (causal flag): 10.75 workgroups per CU
+  (dict(batch=2, heads_q=32, heads_kv=8, seqlen_q=8192, seqlen_kv=2048, head_dim=296, causal=1), 192),   # a head dim served by the D = 320 object
+  (dict(batch=1, heads_q=32, heads_kv=32, seqlen_q=8192, seqlen_kv=8192, head_dim=320), 128),            # 1376 workgroups = 5.4 -> six rounds of 192 > 8 of 128
+  (dict(batch=1, heads_q=32, heads_kv=32, seqlen_q=8192, seqlen_kv=8192, head_dim=320, causal=1), 128),  # ragged, but only 5.4 workgroups per CU
+  (dict(batch=2, heads_q=32, heads_kv=8, seqlen_q=8192, seqlen_kv=2048, head_dim=320, dropout_p=0.1), 128),  # no dropout build
+  (dict(batch=2, heads_q=32, heads_kv=8, seqlen_q=8192, seqlen_kv=2048, head_dim=512), 128),             # no wide tile at this head dim
+  (dict(batch=2, heads_q=32, heads_kv=8, seqlen_q=8192, seqlen_kv=2048, head_dim=256), 128),
+])
+def test_wide_tile_rule(lib, over, rows):
+  """Which prefill launches take the wide-row tile (ffpa_fwd_m16w_kernel: D = 320, 192 rows per workgroup, 64-key tiles): the pricing of
+  ffpa_capi.hip::pick_wide_tile (profiles/r05_wide_tile.txt); FFPA_FLAG_WIDE_TILE / _NO_WIDE_TILE override it where a build exists.  256-CU fallback: no GPU needed."""
+  plan = (ctypes.c_int * 4)()
+  name = ctypes.create_string_buffer(160)
+  p = _params(**over)
+  assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0
+  assert plan[1] == rows and plan[2] == (64 if rows == 192 else plan[2]), list(plan)
+  assert lib.ffpa_attn_fwd_kernel(ctypes.byref(p), name, len(name)) == 0
+  assert name.value.decode().startswith("ffpa_fwd_m16w_kernel<bf16, 320, RH=3, MK=0>" if rows == 192 else "ffpa_fwd_m16_kernel<"), name.value
+  p.flags = hip.FLAG_NO_WIDE_TILE
+  assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0 and plan[1] == 128
+  p.flags = hip.FLAG_WIDE_TILE
+  has_build = (over["head_dim"] + 63) // 64 * 64 == 320 and not over.get("dropout_p")
+  assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0 and plan[1] == (192 if has_build else 128)
+
+
 def test_tile_configs():
   for d in range(64, 1025, 64):
     c = hip.tile_config(d)
