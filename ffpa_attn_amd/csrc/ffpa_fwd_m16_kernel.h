@@ -128,7 +128,7 @@
 // which the matrix core idled) covered by 512 cycles of MFMA work, and every DMA stream has two phases to be issued in.  The partial S^T of
 // block 0 is published one step early, so its exchange area is double-buffered (6 KiB per wave instead of 4).  Piece counts per phase in
 // sixteenths of a wave's pieces per tile image: FFPA_M16_PP_VQ (V pieces in Q; the rest in S), _K1Q (K1 pieces in Q; the rest in the P phase
-// before), _K2S (K2 pieces in S; the rest in P).  Builds: no additive bias, no dropout (MK 0); D % 128 == 0.
+// before), _K2S (K2 pieces in S; the rest in P).  Builds: no additive bias, no dropout (MK 0 and, since round 5, the boolean-mask / mask-range build MK 2); D % 128 == 0.
 // Measured (config 3, B1 H32 N8192 D1024, interleaved A/B on one box, outputs bit-identical; profiles/r04_pipe.txt): round-3 loop 945 ... 975 TFLOPS,
 // two-half K alone (FFPA_M16_KSPLIT, best table) + 3.9 %, the pipeline + 6.2 ... 6.6 % (VQ / K1Q / K2S = 6 / 2 / 2, three K fragments ahead in S;
 // 7 / 1 / 1: + 5 %, 8 / 0 / 0: + 4.2 %, 10 / 1 / 1: + 1.8 %); D = 640 / 768 / 896: + 4.4 / + 7.6 / + 3.4 %, causal + 4.7 %, Nq 1024 + 9.9 %, 32k keys + 3.5 %.
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   constexpr int N1 = KS * NKB;   // K fragments per tile
   constexpr int N2 = NDB * NKS;  // V^T fragments per tile
   // the two-half K schedule of the split-D tiles (see FFPA_M16_KSPLIT above): needs an even number of pieces per wave (D % 128 == 0)
-  constexpr bool kKS = ND == 2 && (FFPA_M16_KSPLIT != 0 || (FFPA_M16_PIPE != 0 && MK == 0 && !DROP)) && PPW % 2 == 0 && NKB == 2;
+  constexpr bool kKS = ND == 2 && (FFPA_M16_KSPLIT != 0 || (FFPA_M16_PIPE != 0 && (MK == 0 || MK == 2) && !DROP)) && PPW % 2 == 0 && NKB == 2;
   constexpr int kH = PPW / 2;  // K1 / K2 pieces per wave
   constexpr int ksVA = PPW * FFPA_M16_KS_VA / 16, ksVB = PPW * FFPA_M16_KS_VB / 16, ksVC = PPW - ksVA - ksVB;
   constexpr int ksK1B = PPW * FFPA_M16_KS_K1B / 16, ksK1C = PPW * FFPA_M16_KS_K1C / 16, ksK1D = kH - ksK1B - ksK1C;
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   static_assert(!kKS || (ksVA >= 0 && ksVB >= 0 && ksVC >= 0 && ksK1B >= 0 && ksK1C >= 0 && ksK1D >= 0 && ksK2C >= 0 && ksK2D >= 0), "piece counts per phase");
   static_assert(!kKS || (ksVA <= KS && ksVB + ksK1B <= KS && ksK1D + ksK2D <= N2), "at most one piece per fragment");
   // the softmax pipeline of the split-D tiles (see FFPA_M16_PIPE above); it uses the two-half K piece map
-  constexpr bool kPipe = ND == 2 && FFPA_M16_PIPE != 0 && PPW % 2 == 0 && NKB == 2 && MK == 0 && !DROP;
+  constexpr bool kPipe = ND == 2 && FFPA_M16_PIPE != 0 && PPW % 2 == 0 && NKB == 2 && (MK == 0 || MK == 2) && !DROP;
   constexpr int ppVQ = PPW * FFPA_M16_PP_VQ / 16, ppVS = PPW - ppVQ;     // V(j): in Q(j), in S(j)
   constexpr int ppK1Q = PPW * FFPA_M16_PP_K1Q / 16, ppK1P = kH - ppK1Q;  // K1(j+1): in P(j-1) (first), in Q(j) (rest)
   constexpr int ppK2S = PPW * FFPA_M16_PP_K2S / 16, ppK2P = kH - ppK2S;  // K2(j+1): in S(j) (first), in P(j) (rest)
@@ -920,6 +920,38 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) x[kb][rh][r] = (kb == 0 ? xc[rh][r] : s1[rh][r]) + tp[kb][rh][r];
           } else if constexpr (g == 7) {
+            if constexpr (MK == 2) {
+              // boolean mask bytes (non-zero = visible), straight from the caller's tensor, exactly as the loop below reads them; steps in the mask's
+              // neutral interior (kv_bounds) read nothing.  (The loads are the compiler's: its wait in front of their first use also drains the DMA
+              // pieces issued so far in this phase — only on the steps that read the mask.)
+              const bool mask_free = k0 >= free_lo && k0 + BC <= free_hi;
+              if (a.bias_dtype == 4 && !mask_free) {
+                const uint8_t* mp = (const uint8_t*)a.bias + b * a.sbias[0] + hq * a.sbias[1];
+#pragma unroll
+                for (int rh = 0; rh < 2; ++rh) {
+                  const uint8_t* mr = mp + (int64_t)qrow_c[rh] * a.sbias[2];
+                  if (a.bias_vec == 16 && k0 + BC <= a.Nkv) {
+                    uint32_t raw[NKB];
+#pragma unroll
+                    for (int kb = 0; kb < NKB; ++kb) raw[kb] = *(const uint32_t*)(mr + k0 + kb * 16 + 4 * c);
+#pragma unroll
+                    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                      for (int r = 0; r < 4; ++r)
+                        if (((raw[kb] >> (8 * r)) & 0xffu) == 0u) x[kb][rh][r] = -INFINITY;
+                  } else {
+#pragma unroll
+                    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                      for (int r = 0; r < 4; ++r) {
+                        int key = k0 + kb * 16 + 4 * c + r;
+                        key = key < a.Nkv ? key : a.Nkv - 1;
+                        if (mr[key * a.sbias[3]] == 0) x[kb][rh][r] = -INFINITY;
+                      }
+                  }
+                }
+              }
+            }
             if (tail || diag) {
 #pragma unroll
               for (int rh = 0; rh < 2; ++rh) {
@@ -1013,7 +1045,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
               else issue_k(std::integral_constant<int, kH + (t - ppVS)>{}, k0 + BC);        // K2(j+1), first part
             }
           }
-          constexpr int kSmPos = FFPA_M16_PP_SMPOS < 0 ? (KS < 16 ? 1 : 0) : FFPA_M16_PP_SMPOS;
+          constexpr int kSmPos = FFPA_M16_PP_SMPOS < 0 ? ((KS < 16 || MK == 2) ? 1 : 0) : FFPA_M16_PP_SMPOS;  // (the mask build's softmax carries a branch — the mask read: behind the MFMAs at every head dim)
           if constexpr (kSmPos == 0) softmax_gaps(std::integral_constant<int, 2 * s_>{});
           else if constexpr (kSmPos >= 4 && (2 * s_) % kSmPos == 0) static_for<kSmPos>([&](auto uc) { if constexpr (2 * s_ + decltype(uc)::value < 2 * KS) softmax_gaps(std::integral_constant<int, 2 * s_ + decltype(uc)::value>{}); });
           __builtin_amdgcn_sched_barrier(0);
@@ -1022,7 +1054,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
           else M::acc(s0[1], kf[s_], qf[s_][1]);
           if constexpr (kSmPos == 0) softmax_gaps(std::integral_constant<int, 2 * s_ + 1>{});
         });
-        if constexpr (FFPA_M16_PP_SMPOS == 1 || (FFPA_M16_PP_SMPOS < 0 && KS < 16)) static_for<2 * KS>([&](auto gc) { softmax_gaps(gc); });
+        if constexpr (FFPA_M16_PP_SMPOS == 1 || (FFPA_M16_PP_SMPOS < 0 && (KS < 16 || MK == 2))) static_for<2 * KS>([&](auto gc) { softmax_gaps(gc); });
         __builtin_amdgcn_sched_barrier(0);
         *(FFPA_LDS f32x4*)(xw + ((j + 1) & 1) * 2048) = s0[0];
         *(FFPA_LDS f32x4*)(xw + ((j + 1) & 1) * 2048 + 1024) = s0[1];

@@ -50,7 +50,9 @@ CASES = {
   "n1024": _c(1, 32, 1024, 512), "n2048": _c(1, 32, 2048, 512), "causal4k": _c(1, 32, 4096, 512, causal=True),
   "d320": _c(1, 32, 8192, 320), "d320_causal": _c(1, 32, 8192, 320, causal=True), "d320_n2048": _c(4, 32, 2048, 320), "d320_gqa": _c(2, 32, 8192, 320, hkv=8),
   "d320_b3": _c(3, 32, 8192, 320), "d320_n6k": _c(1, 32, 6144, 320), "d256_b3": _c(3, 32, 8192, 256), "d192_b3": _c(3, 32, 8192, 192), "d128_b3": _c(3, 32, 8192, 128),
-  "d256_mask": _c(2, 32, 8192, 256, hkv=8, nkv=2048, bias="tril_bool"), "d384": _c(1, 32, 8192, 384), "d448": _c(1, 32, 8192, 448), "d640": _c(1, 32, 8192, 640), "d768": _c(1, 32, 8192, 768),
+  "d256_mask": _c(2, 32, 8192, 256, hkv=8, nkv=2048, bias="tril_bool"),
+  "cfg3_mask": _c(1, 32, 8192, 1024, bias="tril_bool"), "mask_d1024": _c(2, 32, 8192, 1024, hkv=8, nkv=2048, bias="tril_bool"), "d640_mask": _c(1, 32, 8192, 640, bias="tril_bool"),
+  "d768_mask": _c(1, 32, 8192, 768, bias="tril_bool"), "d896_mask": _c(1, 32, 8192, 896, bias="tril_bool"), "d384": _c(1, 32, 8192, 384), "d448": _c(1, 32, 8192, 448), "d640": _c(1, 32, 8192, 640), "d768": _c(1, 32, 8192, 768),
   "d1024_causal": _c(1, 32, 8192, 1024, causal=True),
   "d64": _c(1, 32, 8192, 64), "d64_causal": _c(1, 32, 8192, 64, causal=True), "d64_n2048": _c(4, 32, 2048, 64), "key_bias_d128": _c(1, 32, 8192, 128, bias="key"),
   "dense_bias_d128": _c(1, 32, 8192, 128, bias="dense"), "dropout_d128": _c(1, 32, 8192, 128, dropout=0.1), "mask_d128": _c(2, 32, 8192, 128, hkv=8, nkv=2048, bias="tril_bool"),
