@@ -232,18 +232,25 @@ class DeviceTelemetry:
     except (OSError, ValueError):
       return None
 
-  def start(self, period_s: float = 0.001) -> None:
+  def start(self, period_s: float = 0.010) -> None:
+    """One sample now, then one every ``period_s`` (and a last one at stop()).  10 ms: `value` is wall-clock based and includes host launch time, and a
+    Python thread that wakes every millisecond contends for the GIL with the launch loop of a launch-bound workload (decode: ~ 100 us per step) — at
+    10 ms the sampler takes the GIL a handful of times per timed region; the round-4 lines were taken at 1 ms."""
     if not self.node:
       return
     self.samples = []
     self._stop = self._threading.Event()
 
     def loop():
-      while not self._stop.is_set():
+      while True:
         r = self._read()
         if r:
           self.samples.append(r)
-        self._stop.wait(period_s)
+        if self._stop.wait(period_s):
+          break
+      r = self._read()
+      if r:
+        self.samples.append(r)
 
     self._thread = self._threading.Thread(target=loop, daemon=True)
     self._thread.start()

@@ -18,7 +18,7 @@ reference) and are refused when a call reaches the kernel with them set.
 
 from __future__ import annotations
 
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 
 import torch
 
@@ -75,12 +75,21 @@ class HIPBackend(Backend):
   :ivar stages: accepted for compatibility; the LDS pipeline depth is fixed per head dim.
   :ivar rescale_threshold: lazy-rescale threshold in log2 units; ``None`` = the reference's
       ``FFPA_RESCALE_THRESHOLD`` = 8 (csrc/cuffpa/common.cuh:14); ``0`` = exact recurrence.
+  :ivar kv_bounds: precomputed key ranges of THIS call's ``attn_mask`` (``ffpa_attn_amd.hip.mask_kv_bounds(mask, Nq, Nkv)``: int32
+      ``[B|1, Hq|1, ceil(Nq / 32), 4]``) — the kernel skips the KV tiles the mask hides and does not read the mask where it is neutral.  ``None``
+      (default): the ranges are derived from the mask by a scan kernel on EVERY call that is worth one (a full read of the mask per layer and
+      step); a serving loop with a static mask scans once and passes the result here — or opts into the version-counter cache with
+      ``FFPA_HIP_MASK_BOUNDS_CACHE=1`` (see ``hip.forward``).  The ranges must describe the mask they are passed with: stale ranges are silently
+      skipped keys.
+
+  The fields of this class are keyword-only, so that the positional order of ``CUDABackend`` / ``TritonBackend`` stays the reference's.
   """
 
   name: str = "hip"
-  acc: str = "f32"
-  stages: int | None = None
-  rescale_threshold: float | None = None
+  acc: str = field(default="f32", kw_only=True)
+  stages: int | None = field(default=None, kw_only=True)
+  rescale_threshold: float | None = field(default=None, kw_only=True)
+  kv_bounds: "torch.Tensor | None" = field(default=None, kw_only=True, repr=False, compare=False)
 
   def __post_init__(self) -> None:
     super().__post_init__()
@@ -116,6 +125,8 @@ class CUDABackend(HIPBackend):
   sub-options select nothing here."""
 
   name: str = "cuda"
+  acc: str = "f32"          # (positional, in the reference's order: name, forward, backward, acc, stages, enable_tma, ...)
+  stages: int | None = None
   enable_tma: bool | None = None
   enable_cute: bool | None = None
   enable_ws: bool = False

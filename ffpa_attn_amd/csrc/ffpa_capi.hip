@@ -9,6 +9,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -76,7 +77,14 @@ constexpr int kMaxDevices = 64;
 std::atomic<int> g_cu_count[kMaxDevices];  // 0 = not looked up yet
 std::atomic<int> g_arch_ok[kMaxDevices];   // 0 = not looked up yet, 1 = gfx950, 2 = something else
 
+// Test-only: FFPA_HIP_FAKE_CUS=<n> makes the launch plan price a device of n compute units (the plan fuzz of tests/test_fwd_gpu.py and the CPU plan
+// tables of tests/test_capi.py walk 128 / 256 / 304).  Read on every call while set (no cached state to go stale); the kernels never see it — any
+// grid is correct on any device, the plan only decides how fast.
 int device_cu_count() {
+  if (const char* fake = getenv("FFPA_HIP_FAKE_CUS")) {
+    const int n = atoi(fake);
+    if (n > 0) return n;
+  }
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
   int n = g_cu_count[dev].load(std::memory_order_relaxed);
@@ -86,6 +94,48 @@ int device_cu_count() {
   }
   return n;
 }
+
+// What the split pricing needs to know about the device besides its CU count: the matrix rate of ONE compute unit and the HBM bandwidth — both read
+// from the device (engine clock; memory clock x bus width) instead of being MI355X constants, scaled by what this library's kernels were MEASURED to
+// sustain of them on gfx950 (a table next to the tile configuration: the same fractions the bench lines report as roofline.frac).  A part with other
+// clocks or another stack count prices itself; without a device (plan queries on a CPU box) the MI355X figures are the fallback.
+struct DeviceRates {
+  double cu_flops;   // dense bf16 MFMA peak of one CU: 4 SIMDs x 1024 FLOP / clk x engine clock
+  double hbm_bytes;  // HBM peak, bytes / s
+};
+std::atomic<long long> g_clock_khz[kMaxDevices];   // 0 = not looked up yet
+std::atomic<long long> g_hbm_mbps[kMaxDevices];    // MB / s
+
+DeviceRates device_rates() {
+  DeviceRates r = {4.0 * 1024.0 * 2.4e9, 8.0e12};  // MI355X: 2.4 GHz, 8 TB/s (MI355X_MICROARCH.md)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    (void)hipGetLastError();
+    return r;
+  }
+  long long khz = g_clock_khz[dev].load(std::memory_order_relaxed), mbps = g_hbm_mbps[dev].load(std::memory_order_relaxed);
+  if (khz == 0) {
+    int clk = 0, mclk = 0, bus = 0;
+    if (hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, dev) != hipSuccess || clk <= 0) clk = 2400000;
+    khz = clk;
+    // HBM3 / HBM3E (every gfx94x / gfx950 part; this library only loads on gfx950): four transfers per reported memory clock x bus width —
+    // MI355X: 2000 MHz x 8192 bit x 4 / 8 = 8.19 TB/s, MI300X: 1300 MHz -> 5.3 TB/s.  A driver that does not report them leaves the MI355X figure
+    if (hipDeviceGetAttribute(&mclk, hipDeviceAttributeMemoryClockRate, dev) == hipSuccess && mclk > 0 &&
+        hipDeviceGetAttribute(&bus, hipDeviceAttributeMemoryBusWidth, dev) == hipSuccess && bus > 0)
+      mbps = (long long)(4.0 * (double)mclk * 1e3 * (double)bus / 8.0 / 1e6);
+    if (mbps < 500000 || mbps > 20000000) mbps = 8000000;  // (0.5 ... 20 TB/s: anything else is a driver reporting another unit)
+    (void)hipGetLastError();
+    g_clock_khz[dev].store(khz, std::memory_order_relaxed);
+    g_hbm_mbps[dev].store(mbps, std::memory_order_relaxed);
+  }
+  r.cu_flops = 4.0 * 1024.0 * (double)khz * 1e3;
+  r.hbm_bytes = (double)mbps * 1e6;
+  return r;
+}
+// measured on gfx950 (profiles/r04_bench_*.json, r05): fraction of a CU's MFMA peak one workgroup of the prefill tiles sustains while it walks KV tiles, and
+// the fraction of the HBM peak the partial-write + merge traffic of a KV-split launch moves at
+constexpr double kTileRateFracD512 = 5.0e12 / 9.8304e12, kTileRateFracSplitD = 4.0e12 / 9.8304e12, kMergeBwFrac = 5.0e12 / 8.0e12;  // (5.0 / 4.0 TFLOP/s per CU, 5 TB/s on MI355X: what profiles/r04_launch_side.txt was priced with)
+constexpr double kMaxAutoWorkspaceBytes = 1024.0 * 1048576.0;  // the pricing never asks a caller for more scratch than this on its own (a forced num_splits may)
 
 // FFPA_OK iff the current device is a gfx950 (the only target of the embedded code objects)
 int check_device() {
@@ -160,12 +210,30 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
   // in three KV ranges are 480 = two rounds of a third of the length — B1 H5 x Nq 4096 D512 + 10 % at 8192 keys, + 19 % at 16384, D = 320 + 7 %, H20 x Nq 1024
   // + 8 %; 192 and 224 workgroups (H6, H7, D = 1024 H3) gain from no split count, and the model picks none.
   const int dk_price = kernel_head_dim(p->head_dim);
-  const double nt_eff = p->causal ? 0.5 * pl.nt : (double)pl.nt;  // (a causal row tile walks about half of the keys)
-  const double tile_s = 4.0 * pl.br * pl.bc * dk_price / (dk_price > 512 ? 4.0e12 : 5.0e12);  // one KV tile of one workgroup at the rate one CU sustains
+  // KV tiles an average row tile walks: all of them — or, under the causal flag, those up to its diagonal: rows r see keys <= r + causal_offset, the mean
+  // over the rows is causal_offset + Nq / 2, clamped to [0, Nkv] (top-left causal against a long context: Nq / 2 keys, not Nkv / 2; tail-aligned: Nkv - Nq / 2)
+  double nt_eff = (double)pl.nt;
+  int64_t visible_end = p->seqlen_kv;  // keys at and past this index are hidden from EVERY row of the launch
+  if (p->causal) {
+    double mean = (double)p->causal_offset + 0.5 * (double)(p->causal_row_mod ? p->causal_row_mod : p->seqlen_q);
+    mean = mean < 0.0 ? 0.0 : (mean > (double)p->seqlen_kv ? (double)p->seqlen_kv : mean);
+    nt_eff = mean / pl.bc > 1.0 ? mean / pl.bc : 1.0;
+    const int64_t last = (int64_t)(p->causal_row_mod ? p->causal_row_mod : p->seqlen_q) - 1 + p->causal_offset + 1;
+    visible_end = last < 0 ? 0 : (last < p->seqlen_kv ? last : p->seqlen_kv);
+  }
+  const int nt_visible = (int)((visible_end + pl.bc - 1) / pl.bc);  // KV tiles any row can see: a split range past them would be workgroups that do nothing
+  const DeviceRates rates = device_rates();
+  const double tile_s = 4.0 * pl.br * pl.bc * dk_price / ((dk_price > 512 ? kTileRateFracSplitD : kTileRateFracD512) * rates.cu_flops);  // one KV tile of one workgroup
   const double out_elems = (double)p->batch * p->heads_q * p->seqlen_q * dk_price;
+  const double merge_bw = kMergeBwFrac * rates.hbm_bytes;
   auto predicted = [&](int64_t s) {
     const double rounds = (double)((base * s + cus - 1) / cus);
-    return rounds * (nt_eff / s + 4.0) * tile_s + (s > 1 ? out_elems * (8.0 * s + 2.0) / 5.0e12 : 0.0);
+    return rounds * (nt_eff / s + 4.0) * tile_s + (s > 1 ? out_elems * (8.0 * s + 2.0) / merge_bw : 0.0);
+  };
+  // a split count is admissible for the pricing's own rules if its last KV range still holds keys some row can see and its scratch stays under the cap
+  auto admissible = [&](int64_t s) {
+    const int64_t tps = (pl.nt + s - 1) / s;
+    return (s - 1) * tps < nt_visible && (double)s * out_elems / dk_price * (dk_price + 1.0) * 4.0 <= kMaxAutoWorkspaceBytes;
   };
   const bool priced = pl.variant == 0 && !(p->flags & (FFPA_FLAG_DEBUG_SAFE_PATH | FFPA_FLAG_FORCE_SPLITS)) && p->num_splits == 0 && p->workspace != nullptr;
   int ragged_splits = 1;
@@ -174,6 +242,7 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
     double best = t1;
     for (int s = 2; s <= 3; ++s) {
       if (pl.nt / s < 8) break;  // (>= 8 KV tiles per split, as the under-filled rule)
+      if (!admissible(s)) continue;
       const double t = predicted(s);
       if (t < 0.9 * t1 && t < best) best = t, ragged_splits = s;
     }
@@ -198,6 +267,7 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
       const int64_t one_round = want;
       for (int64_t s = one_round + 1; s <= 3 * one_round && s <= ffpa::kMergeMaxSplits; ++s) {
         if (pl.nt / s < 8) break;
+        if (!admissible(s)) continue;
         const double t = predicted(s);
         if (t < 0.95 * t0 && t < best) best = t, want = s;
       }
@@ -205,6 +275,10 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
     const int min_tiles = pl.variant == 1 ? 4 : 8;
     const int64_t cap = pl.nt / min_tiles > 0 ? pl.nt / min_tiles : 1;
     if (want > cap) want = cap;
+    // prefill under the causal flag: no KV range entirely behind every row's diagonal (top-left causal against a long context: rows see at most Nq keys —
+    // ranges past them would be workgroups that do nothing, their partials and the merge pure cost)
+    if (pl.variant == 0 && !(p->flags & FFPA_FLAG_FORCE_SPLITS))
+      while (want > 1 && (want - 1) * ((pl.nt + want - 1) / want) >= nt_visible) --want;
     if (want > ffpa::kMergeMaxSplits) want = ffpa::kMergeMaxSplits;  // the merge kernel keeps the split weights in LDS
     if (p->num_splits > 1 && want > p->num_splits) want = p->num_splits;
     if (want < 1) want = 1;
@@ -631,6 +705,10 @@ int ffpa_attn_query(int what) {
 #else
     case FFPA_QUERY_DEBUG_KERNELS: return 0;
 #endif
+    // what the launch plan's pricing reads from the current device (fallbacks without one): compute units, engine clock, HBM peak
+    case FFPA_QUERY_DEVICE_CUS: return device_cu_count();
+    case FFPA_QUERY_DEVICE_CLOCK_MHZ: return (int)(device_rates().cu_flops / 4096.0 / 1e6);
+    case FFPA_QUERY_DEVICE_HBM_GBPS: return (int)(device_rates().hbm_bytes / 1e9);
     default: return -1;
   }
 }

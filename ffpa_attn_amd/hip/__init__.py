@@ -231,6 +231,53 @@ def tile_config(head_dim: int) -> dict:
   return {"block_rows": br.value, "block_keys": bc.value, "lds_bytes": lds.value}
 
 
+def launch_plan(batch: int, heads_q: int, heads_kv: int, seqlen_q: int, seqlen_kv: int, head_dim: int, *, dtype: torch.dtype = torch.bfloat16,
+                causal: bool = False, bias_dtype: "torch.dtype | None" = None, dropout_p: float = 0.0, flags: int = 0, num_splits: int = 0,
+                device: "torch.device | int | None" = None) -> dict:
+  """The launch plan the library would pick for a call of this shape class — tile (``block_rows`` x ``block_keys``), KV ``splits``, ``variant``
+  (0 prefill, 1 short-query) and the ``kernel`` name — without launching anything (``ffpa_attn_fwd_plan`` / ``_kernel`` on a parameter block with
+  placeholder pointers; with ``device`` the plan is that GPU's: its CU count prices the split rules).  A caller that cuts a batch into pieces and needs the
+  pieces to run the plan of the whole (``sharding.attend_and_gather_units``) asks here."""
+  lib = load_library()
+  d8 = (int(head_dim) + 7) // 8 * 8
+  p = FfpaFwdParams()
+  p.struct_size = ctypes.sizeof(FfpaFwdParams)
+  p.abi_version = ABI_VERSION
+  p.q = p.k = p.v = p.o = 16
+  p.batch, p.heads_q, p.heads_kv, p.seqlen_q, p.seqlen_kv, p.head_dim = int(batch), int(heads_q), int(heads_kv), int(seqlen_q), int(seqlen_kv), d8
+  for name, h, n in (("q_stride", heads_q, seqlen_q), ("k_stride", heads_kv, seqlen_kv), ("v_stride", heads_kv, seqlen_kv), ("o_stride", heads_q, seqlen_q)):
+    getattr(p, name)[:] = [h * n * d8, n * d8, d8]
+  p.dtype = _DTYPE[dtype]
+  p.causal = 1 if causal else 0
+  p.causal_offset = int(seqlen_kv) - int(seqlen_q)
+  p.softmax_scale = float(head_dim) ** -0.5
+  p.rescale_threshold = -1.0
+  p.dropout_p = float(dropout_p)
+  p.flags = int(flags)
+  p.num_splits = int(num_splits)
+  if bias_dtype is not None:
+    p.bias = 16
+    p.bias_dtype = _BIAS_DTYPE[bias_dtype]
+    p.bias_stride[:] = [0, 0, int(seqlen_kv), 1]
+  if num_splits != 1:
+    p.workspace, p.workspace_bytes = 16, (1 << 62)
+  plan = (ctypes.c_int * 4)()
+  name = ctypes.create_string_buffer(160)
+
+  def ask():
+    rc = lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan)
+    if rc != 0:
+      raise _STATUS_EXC.get(rc, RuntimeError)(lib.ffpa_attn_last_error().decode())
+    lib.ffpa_attn_fwd_kernel(ctypes.byref(p), name, len(name))
+
+  if device is not None and torch.cuda.is_available():
+    with torch.cuda.device(device):
+      ask()
+  else:
+    ask()
+  return {"variant": plan[0], "block_rows": plan[1], "block_keys": plan[2], "splits": plan[3], "kernel": name.value.decode()}
+
+
 def padded_head_dim(d: int) -> int:
   """The head dim of the kernel instantiation that serves ``d``: kernels are built per multiple of 64; a head dim in
   between (any multiple of 8) runs on the next one with the missing columns read as zeros and never stored — in the
@@ -357,10 +404,31 @@ def _want_mask_bounds(attn_bias: torch.Tensor, b: int, hq: int, nq: int, nkv: in
   return b * hq >= 2 * attn_bias.size(0) * attn_bias.size(1)
 
 
-# Zeroed int32 counters for the in-launch merge of KV-split launches (ffpa_fwd_params.split_tickets): one buffer per (device, stream),
-# zeroed once — the kernel leaves every counter at zero — and grown on demand.  Launches on one stream are ordered, so they may share
-# it; launches on different streams may overlap and get their own.
+# Per-(device, stream) scratch of the KV-split launches.  Launches on one stream are ordered, so they may share a buffer; launches on different
+# streams may overlap and get their own.  Both tables are small LRU maps (a process that churns through streams does not accumulate buffers).
+#   _TICKETS:    zeroed int32 counters for the in-launch merge (ffpa_fwd_params.split_tickets): zeroed once — the kernel leaves every counter at
+#                zero — and grown on demand;
+#   _WORKSPACES: the fp32 partials + LSE of the short-query (decode) launches — a fresh torch.empty per token was a fifth of the host time of a
+#                decode step.  Only workspaces up to _WORKSPACE_KEEP_BYTES are kept; the transient hundreds of MiB of a split PREFILL launch go
+#                back to the caching allocator as before.
+_SCRATCH_MAX_STREAMS = 32
+_WORKSPACE_KEEP_BYTES = 8 << 20
 _TICKETS: "dict[tuple, torch.Tensor]" = {}
+_WORKSPACES: "dict[tuple, torch.Tensor]" = {}
+
+
+def _lru_get(table: dict, key):
+  t = table.pop(key, None)
+  if t is not None:
+    table[key] = t  # (re-inserted: dicts keep insertion order, the first key is the least recently used)
+  return t
+
+
+def _lru_put(table: dict, key, value) -> None:
+  table.pop(key, None)
+  while len(table) >= _SCRATCH_MAX_STREAMS:
+    table.pop(next(iter(table)))
+  table[key] = value
 
 
 def _split_tickets(device: torch.device, stream: int, n: int) -> torch.Tensor:
@@ -368,11 +436,43 @@ def _split_tickets(device: torch.device, stream: int, n: int) -> torch.Tensor:
     # inside a stream capture: a buffer of the graph's own pool, zeroed by a node of the graph (like the workspace, it is replayed in place)
     return torch.zeros(n, dtype=torch.int32, device=device)
   key = (device.index, stream)
-  t = _TICKETS.get(key)
+  t = _lru_get(_TICKETS, key)
   if t is None or t.numel() < n:
     t = torch.zeros(max(4096, n), dtype=torch.int32, device=device)
-    _TICKETS[key] = t
+    _lru_put(_TICKETS, key, t)
   return t
+
+
+def _workspace(device: torch.device, stream: int, nbytes: int) -> torch.Tensor:
+  words = (nbytes + 3) // 4
+  if nbytes > _WORKSPACE_KEEP_BYTES or torch.cuda.is_current_stream_capturing():
+    return torch.empty(words, dtype=torch.float32, device=device)  # caching allocator (under capture: the graph's pool, replayed in place)
+  key = (device.index, stream)
+  t = _lru_get(_WORKSPACES, key)
+  if t is None or t.numel() < words:
+    t = torch.empty(max(words, 1 << 16), dtype=torch.float32, device=device)
+    _lru_put(_WORKSPACES, key, t)
+  return t
+
+
+# What a launch needs besides its tensors — workspace bytes and ticket count — is a function of the shape class only (ffpa_capi.hip make_plan): asked
+# once per class, not once per call (two ctypes round trips less per decode token).
+_PLAN_SCRATCH: "dict[tuple, tuple[int, int]]" = {}
+
+
+def _plan_scratch(lib, p: "FfpaFwdParams", num_splits: int, want_tickets: bool, device_index: int) -> tuple[int, int]:
+  if num_splits == 1:
+    return 0, 0
+  key = (id(lib), device_index, p.dtype, p.batch, p.heads_q, p.heads_kv, p.seqlen_q, p.seqlen_kv, p.head_dim, p.causal, p.bias is not None,
+         p.kv_bounds is not None, p.dropout_p > 0.0, p.flags, num_splits, p.causal_row_mod, p.causal_offset, want_tickets, os.environ.get("FFPA_HIP_FAKE_CUS"))
+  hit = _PLAN_SCRATCH.get(key)
+  if hit is None:
+    ws = int(lib.ffpa_attn_fwd_workspace_bytes(ctypes.byref(p)))
+    nt = int(lib.ffpa_attn_fwd_split_tickets(ctypes.byref(p))) if (ws and want_tickets and hasattr(lib, "ffpa_attn_fwd_split_tickets")) else 0
+    if len(_PLAN_SCRATCH) >= 512:
+      _PLAN_SCRATCH.clear()
+    hit = _PLAN_SCRATCH[key] = (ws, nt)
+  return hit
 
 
 def forward(
@@ -506,6 +606,11 @@ def forward(
   else:
     p.bias = None
     p.bias_dtype = 0
+  if num_splits == 0 and Nq > 32 and os.environ.get("FFPA_HIP_PREFILL_SPLITS", "1").lower() in ("0", "off", "false", "no"):
+    # opt-out of the KV-split rules for PREFILL launches (under-filled / part of a round / ragged round: ffpa_capi.hip make_plan): they allocate fp32
+    # scratch of splits x B x Hq x Nq x (D + 1) x 4 bytes per call (up to kMaxAutoWorkspaceBytes = 1 GiB) and make the bits of a (batch, head) slice depend on
+    # how many heads share the launch (fp32 partials + LSE merge: equal to rounding, not to the bit).  Short-query (decode) launches keep their rule.
+    num_splits = 1
   p.dtype = _DTYPE[q.dtype]
   p.causal = 1 if causal else 0
   p.causal_offset = int(causal_offset)
@@ -520,20 +625,18 @@ def forward(
 
   tickets = None
   with torch.cuda.device(q.device):
-    ws_bytes = lib.ffpa_attn_fwd_workspace_bytes(ctypes.byref(p)) if num_splits != 1 else 0
+    stream = torch.cuda.current_stream(q.device).cuda_stream
+    if merge_in_launch is None:
+      merge_in_launch = os.environ.get("FFPA_HIP_MERGE_IN_LAUNCH", "0") not in ("0", "")
+    ws_bytes, n_tickets = _plan_scratch(lib, p, num_splits, bool(merge_in_launch), q.device.index or 0)
     workspace = None
     if ws_bytes:
-      workspace = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=q.device)  # caching allocator
+      workspace = _workspace(q.device, stream, ws_bytes)  # (held in a local until the launch below has been enqueued)
       p.workspace = workspace.data_ptr()
       p.workspace_bytes = ws_bytes
-      if merge_in_launch is None:
-        merge_in_launch = os.environ.get("FFPA_HIP_MERGE_IN_LAUNCH", "0") not in ("0", "")
-      if merge_in_launch and hasattr(lib, "ffpa_attn_fwd_split_tickets"):
-        n_tickets = lib.ffpa_attn_fwd_split_tickets(ctypes.byref(p))
-        if n_tickets:
-          # (held in a local until the launch below has been enqueued: under stream capture this is a fresh tensor of the graph's pool)
-          tickets = _split_tickets(q.device, torch.cuda.current_stream(q.device).cuda_stream, n_tickets)
-          p.split_tickets = tickets.data_ptr()
+      if n_tickets:
+        tickets = _split_tickets(q.device, stream, n_tickets)
+        p.split_tickets = tickets.data_ptr()
     if plan_out is not None:
       plan = (ctypes.c_int * 4)()
       if lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0:
@@ -541,7 +644,6 @@ def forward(
       name = ctypes.create_string_buffer(160)
       if hasattr(lib, "ffpa_attn_fwd_kernel") and lib.ffpa_attn_fwd_kernel(ctypes.byref(p), name, len(name)) == 0:
         plan_out["kernel"] = name.value.decode()
-    stream = torch.cuda.current_stream(q.device).cuda_stream
     rc = lib.ffpa_attn_fwd(ctypes.byref(p), ctypes.c_void_p(stream))
   if rc != 0:
     if tickets is not None:
@@ -567,7 +669,7 @@ torch.library.define(
   f"{_OP_NAMESPACE}::_fwd_hip",
   "(Tensor q, Tensor k, Tensor v, Tensor attn_bias, int stages, int acc, int causal, "
   "float softmax_scale, float dropout_p, int philox_seed, int philox_offset, "
-  "int causal_offset=-2147483648, float rescale_threshold=-1.0) -> (Tensor o, Tensor softmax_lse)",
+  "int causal_offset=-2147483648, float rescale_threshold=-1.0, Tensor? kv_bounds=None) -> (Tensor o, Tensor softmax_lse)",
 )
 
 _AUTO_OFFSET = -2147483648
@@ -588,6 +690,7 @@ def _fwd_hip_torch_op(
   philox_offset,
   causal_offset=_AUTO_OFFSET,
   rescale_threshold=-1.0,
+  kv_bounds=None,
 ):
   del stages, acc  # tile/pipeline shape is fixed per head dim; accumulation is always fp32
   o, lse = forward(
@@ -602,6 +705,7 @@ def _fwd_hip_torch_op(
     dropout_p=dropout_p,
     philox_seed=philox_seed,
     philox_offset=philox_offset,
+    kv_bounds=kv_bounds,
   )
   return o, lse
 
@@ -621,6 +725,7 @@ def _fwd_hip_fake(
   philox_offset,
   causal_offset=_AUTO_OFFSET,
   rescale_threshold=-1.0,
+  kv_bounds=None,
 ):
   B, Hq, Nq, D = q.shape
   o = q.new_empty((B, Hq, Nq, D))
@@ -641,9 +746,11 @@ def ffpa_attn_forward_hip(
   philox_offset: int = 0,
   causal_offset: int | None = None,
   rescale_threshold: float = -1.0,
+  kv_bounds: torch.Tensor | None = None,
 ) -> tuple[torch.Tensor, torch.Tensor]:
   """Python-level entry (the analogue of ``_ffpa_attn_forward_cuda``, cuda/_ffpa_fwd.py:6-62):
-  converts ``attn_bias=None`` into the empty tensor the op schema expects and calls the op."""
+  converts ``attn_bias=None`` into the empty tensor the op schema expects and calls the op.  ``kv_bounds``: precomputed key ranges of
+  the mask (``mask_kv_bounds``), ``None`` = derived per call."""
   if attn_bias is None:
     attn_bias = q.new_empty((0,))
   return torch.ops.ffpa_attn._fwd_hip(
@@ -660,4 +767,5 @@ def ffpa_attn_forward_hip(
     int(philox_offset),
     _AUTO_OFFSET if causal_offset is None else int(causal_offset),
     float(rescale_threshold),
+    kv_bounds,
   )

@@ -49,6 +49,7 @@ class _FFPAAttnFunc(torch.autograd.Function):
       philox_seed=seed,
       philox_offset=offset,
       rescale_threshold=-1.0 if thr is None else float(thr),
+      kv_bounds=getattr(meta.forward_meta, "kv_bounds", None) if attn_bias is not None else None,
     )
     needs_grad = meta.attn_meta.is_grad_enabled and any(
       t is not None and t.requires_grad for t in (query, key, value, attn_bias)
@@ -75,7 +76,18 @@ class _FFPAAttnFunc(torch.autograd.Function):
 
 @torch._dynamo.disable
 def _ffpa_apply(query, key, value, attn_bias, meta: FFPAAttnMeta) -> torch.Tensor:
-  """Graph-break boundary, as the reference's ``_ffpa_apply`` (functional.py:1195-1216)."""
+  """Graph-break boundary, as the reference's ``_ffpa_apply`` (functional.py:1195-1216).  A call nothing will ever differentiate —
+  inference: grad mode off, or no input requires a gradient — goes straight to the launch wrapper: no autograd node, no dispatcher
+  round trip, no LSE tensor (what a decode step that synchronises per token pays on the host)."""
+  needs_grad = meta.attn_meta.is_grad_enabled and any(t is not None and t.requires_grad for t in (query, key, value, attn_bias))
+  if not needs_grad and query.is_cuda:
+    from . import hip
+
+    thr = getattr(meta.forward_meta, "rescale_threshold", None)
+    seed, offset = _reserve_dropout_rng(query, key, meta.attn_meta.dropout_p)
+    return hip.forward(query, key, value, attn_bias, meta.attn_meta.is_causal, meta.attn_meta.scale, dropout_p=meta.attn_meta.dropout_p,
+                       philox_seed=seed, philox_offset=offset, rescale_threshold=-1.0 if thr is None else float(thr), return_lse=False,
+                       kv_bounds=getattr(meta.forward_meta, "kv_bounds", None) if attn_bias is not None else None)[0]
   return _FFPAAttnFunc.apply(query, key, value, attn_bias, meta)
 
 
@@ -98,6 +110,12 @@ def ffpa_attn_func(
   ``is_causal``.  ``is_causal=True`` masks ``key > row + (Nkv - Nq)`` (queries aligned to the KV
   tail — FlashAttention's convention, NOT SDPA's top-left one) and requires ``Nkv >= Nq``.
   ``scale`` defaults to ``1/sqrt(D)``.
+
+  Masks: the kernel clips its KV walk to the key ranges of ``attn_mask`` and skips the mask reads where the mask is neutral (an explicit causal
+  mask then costs what ``is_causal`` costs).  The ranges come from a scan kernel — a full read of the mask — that runs on EVERY call with a mask
+  worth scanning; a serving loop with a static mask should scan once (``hip.mask_kv_bounds(mask, Nq, Nkv)``) and pass the result as
+  ``forward_backend=HIPBackend(forward=True, kv_bounds=ranges)`` (or ``TritonBackend`` / ``CUDABackend``: the field exists on all three), or opt
+  into the per-tensor cache with ``FFPA_HIP_MASK_BOUNDS_CACHE=1`` (safe only for masks written through torch ops alone: ``hip.forward``).
 
   Extra keywords: ``backend``, ``forward_backend``, ``backward_backend`` — a name
   (``"hip"``, ``"cuda"``, ``"triton"``, ``"cutedsl"``, ``"sdpa"``) or a

@@ -15,7 +15,8 @@ Two entries:
 * born-sharded (the data-parallel case, what ``bench.py`` measures): every rank holds only its block in
   unit-major layout ``q [U, group, Nq, D]``, ``k / v [U, 1, Nkv, D]`` — ``local_units`` /
   ``synthetic_unit_block`` build it, ``attend_units`` runs the kernel, ``gather_units`` is the optional
-  collective, ``attend_and_gather_units`` overlaps the two (the block in pieces, each piece gathered while the next computes);
+  collective, ``attend_and_gather_units`` overlaps the two (the block in pieces, each piece sent point-to-point into its final place on every other rank
+  while the next computes);
 * replicated inputs (``sharded_attention``): every rank holds the full tensors and takes views of its block.
 """
 
@@ -135,15 +136,63 @@ def gather_units(o_local: torch.Tensor, n_units: int, group: "dist.ProcessGroup 
   return out
 
 
+def _piece_plan_chunks(qu: torch.Tensor, ku: torch.Tensor, chunks: int, kwargs: dict) -> int:
+  """``chunks`` lowered until every piece of this rank's block runs the launch plan of the whole block.  The library picks tile and KV-split count from
+  the size of a launch (ffpa_capi.hip make_plan: under-filled / ragged-round KV splits — fp32 partials + an LSE merge —, the wide-row tile of D = 320, the
+  short-query split rule): the same values to rounding, not to the bit.  Asked of the library itself (``hip.launch_plan``), never re-derived here.  Calls
+  that do not reach the HIP kernel (an SDPA backend, head dims / sequence lengths the dispatch sends to SDPA) and boxes without the library keep the
+  requested count: there is no launch plan to preserve."""
+  per = qu.size(0)
+  if chunks <= 1 or not qu.is_cuda:
+    return max(1, chunks)
+  try:
+    from . import hip
+    from .functional import FFPAAttnMeta
+
+    kw = dict(kwargs)
+    mask = kw.pop("attn_mask", None)
+    dropout_p = float(kw.pop("dropout_p", 0.0))
+    causal = bool(kw.pop("is_causal", False))
+    kw.pop("scale", None)
+    meta = FFPAAttnMeta.from_kwargs(**kw)
+    if meta.fallback(qu, ku, mask, dropout_p):
+      return chunks
+    g, nq, d = qu.shape[1:]
+
+    def plan(units: int) -> tuple:
+      pl = hip.launch_plan(units, g, 1, nq, ku.size(2), d, dtype=qu.dtype, causal=causal, bias_dtype=None if mask is None else mask.dtype,
+                           dropout_p=dropout_p, device=qu.device)
+      return pl["variant"], pl["block_rows"], pl["block_keys"], pl["splits"]
+
+    whole = plan(per)
+    while chunks > 1:
+      sizes = {per * (c + 1) // chunks - per * c // chunks for c in range(chunks)}
+      if all(plan(n) == whole for n in sizes):
+        break
+      chunks -= 1
+    return chunks
+  except (RuntimeError, OSError, ValueError, TypeError, NotImplementedError):
+    return chunks  # (library missing / shape it refuses: the call below raises or falls back exactly as the plain call would)
+
+
 def attend_and_gather_units(qu: torch.Tensor, ku: torch.Tensor, vu: torch.Tensor, n_units: int, *, chunks: int = 4,
                             group: "dist.ProcessGroup | None" = None, out: torch.Tensor | None = None, **kwargs) -> torch.Tensor:
-  """The local step and the optional collective, overlapped: this rank's block is attended in ``chunks`` pieces (whole units)
-  and every finished piece is all-gathered asynchronously (RCCL runs the collective on its own stream, ordered behind the
-  kernel that produced the piece) while the next piece computes — the gather of a 256 MiB shard costs about as much as the
-  kernel (7 x 153 GB/s xGMI links), so hiding it under compute is the difference between ~1x and ~2x the step time.
-  Needs an even split (``n_units % world == 0``); returns ``[n_units, group, Nq, D]`` on every rank.  ``chunks`` is a request: it
-  is lowered until no piece under-fills the chip (see below), so the result does not depend on it — not even at the rounding level."""
+  """The local step and the optional collective, overlapped: this rank's block is attended in ``chunks`` pieces (whole units) and every finished
+  piece travels to the other ranks while the next piece computes — the gather of a 256 MiB shard costs about as much as the kernel (7 x 153 GB/s xGMI
+  links), so hiding it under compute is the difference between ~1x and ~2x the step time.  Needs an even split (``n_units % world == 0``); returns
+  ``[n_units, group, Nq, D]`` on every rank.
+
+  Every piece goes STRAIGHT into its final place: piece c of rank r belongs at ``out[r * per + c0 : r * per + c1]`` — contiguous, but the world's pieces of
+  one chunk are ``per`` units apart, which no single all-gather can write (the list form of ``dist.all_gather`` accepts such views and then gathers into a
+  temporary of ``world x piece`` and copies out: a hidden extra pass over the data on the stream the overlap is meant to keep free).  So a chunk is one
+  batch of point-to-point operations (``dist.batch_isend_irecv``: world - 1 sends of the piece, world - 1 receives into the final slices; RCCL runs the batch
+  as one group on its own stream, ordered behind the kernel that produced the piece) — on xGMI's full mesh of point-to-point links that is also the
+  native pattern: every peer is reached over its own link.  The rank's own piece is one device-to-device copy.
+
+  ``chunks`` is a request: it is lowered until every piece runs the launch plan of the whole block (``_piece_plan_chunks``), so for calls that reach the
+  HIP kernel the result does not depend on it, not even at the rounding level."""
   world = dist.get_world_size(group)
+  rank = dist.get_rank(group)
   if n_units % world != 0:
     return gather_units(attend_units(qu, ku, vu, **kwargs), n_units, group, out)
   per = n_units // world
@@ -155,28 +204,22 @@ def attend_and_gather_units(qu: torch.Tensor, ku: torch.Tensor, vu: torch.Tensor
     out = qu.new_empty((n_units, g, nq, d))
   if per == 0:
     return out
-  chunks = max(1, min(chunks, per))
-  if qu.is_cuda:
-    # A piece must stay out of the launch plan's KV-split rules: a prefill launch of at most 1.5 rounds of workgroups (under-filled, part of a round, a
-    # ragged round: ffpa_capi.hip make_plan) may split the KV axis (fp32 partials + LSE merge — the same values to rounding, not to the bit), so the
-    # gathered tensor would depend on `chunks` at the rounding level.  Pieces are therefore kept at more than 1.5 x CUs workgroups (config 5 on 8 GPUs:
-    # 32 units x 64 row tiles per rank, 4 pieces of 512 workgroups); a block smaller than that is attended as one piece (its plan is then the plan of
-    # the plain call).
-    from . import hip
-
-    cus = torch.cuda.get_device_properties(qu.device).multi_processor_count
-    rows = hip.tile_config(hip.padded_head_dim(d))["block_rows"]
-    per_unit = g * ((nq + rows - 1) // rows)
-    min_units = (3 * cus // 2 + per_unit) // per_unit  # smallest unit count with more than 1.5 x cus workgroups
-    chunks = max(1, min(chunks, per // min_units))
+  chunks = _piece_plan_chunks(qu, ku, max(1, min(chunks, per)), kwargs)
   bounds = [per * c // chunks for c in range(chunks + 1)]
   works = []
   for c0, c1 in zip(bounds, bounds[1:]):
     o_c = attend_units(qu[c0:c1], ku[c0:c1], vu[c0:c1], **kwargs).contiguous()
-    views = [out[r * per + c0 : r * per + c1] for r in range(world)]  # where piece (rank r, chunk c) belongs in the result
-    works.append(dist.all_gather(views, o_c, group=group, async_op=True))
-  for w in works:
-    w.wait()
+    out[rank * per + c0 : rank * per + c1].copy_(o_c)
+    if world > 1:
+      ops = []
+      for step in range(1, world):  # (peers in rotated order: at every step of the batch each rank sends to and receives from a different peer)
+        dst, src = (rank + step) % world, (rank - step) % world
+        ops.append(dist.P2POp(dist.isend, o_c, dst if group is None else dist.get_global_rank(group, dst), group))
+        ops.append(dist.P2POp(dist.irecv, out[src * per + c0 : src * per + c1], src if group is None else dist.get_global_rank(group, src), group))
+      works.append((dist.batch_isend_irecv(ops), o_c))  # (the piece stays referenced until its sends have completed)
+  for reqs, _ in works:
+    for r in reqs:
+      r.wait()
   return out
 
 

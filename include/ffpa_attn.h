@@ -227,8 +227,13 @@ enum ffpa_query {
                                        the missing columns read as zeros in-kernel (no padded copies) */
   FFPA_QUERY_FP16_AVAILABLE = 5,
   FFPA_QUERY_DROPOUT_AVAILABLE = 6,
-  FFPA_QUERY_DEBUG_KERNELS = 7    /* 1 if FFPA_FLAG_DEBUG_SAFE_PATH kernels are built: only in the test-only twin library
+  FFPA_QUERY_DEBUG_KERNELS = 7,   /* 1 if FFPA_FLAG_DEBUG_SAFE_PATH kernels are built: only in the test-only twin library
                                      libffpa_attn_hip_test.so, never in the product library */
+  /* what the launch plan's pricing reads from the CURRENT device (MI355X figures without one): the split rules are priced per device,
+     not per SKU constant */
+  FFPA_QUERY_DEVICE_CUS = 8,        /* compute units */
+  FFPA_QUERY_DEVICE_CLOCK_MHZ = 9,  /* engine clock */
+  FFPA_QUERY_DEVICE_HBM_GBPS = 10   /* HBM peak (4 transfers x memory clock x bus width: HBM3 / HBM3E) */
 };
 int ffpa_attn_query(int what);
 

@@ -217,6 +217,42 @@ def test_wide_tile_rule(lib, over, rows):
   assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0 and plan[1] == (192 if has_build else 128)
 
 
+def test_causal_pricing_uses_the_keys_rows_can_see(lib):
+  """The split pricing walks the KV tiles an average row tile can SEE under the causal flag (causal_offset + Nq / 2 keys, clamped), and no split range may lie
+  entirely behind every row's diagonal.  Top-left causal against a long context (rows see at most Nq keys): a ragged round that used to be cut into three
+  KV ranges — two of them workgroups that did nothing, plus 240 MiB of partials — is one plain launch; tail-aligned causal on the same shape sees the whole
+  context and still splits."""
+  plan = (ctypes.c_int * 4)()
+  p = _params(heads_q=10, heads_kv=10, seqlen_q=4096, seqlen_kv=32768, causal=1, causal_offset=0)
+  p.workspace, p.workspace_bytes = 16, 1 << 40
+  assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0 and plan[3] == 1, list(plan)
+  p.causal_offset = 32768 - 4096
+  assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0 and plan[3] > 1, list(plan)
+  # an under-filled launch (96 workgroups) under a top-left mask that hides all but the first eighth of the context: one range at most per visible eighth
+  p = _params(heads_q=3, heads_kv=3, seqlen_q=4096, seqlen_kv=32768, causal=1, causal_offset=0)
+  p.workspace, p.workspace_bytes = 16, 1 << 40
+  assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0
+  tiles = (32768 + plan[2] - 1) // plan[2]
+  per = (tiles + plan[3] - 1) // plan[3]
+  assert (plan[3] - 1) * per * plan[2] < 4096, list(plan)  # the last range starts inside the visible keys
+
+
+def test_plan_prices_the_device_it_runs_on(lib, monkeypatch):
+  """CU count, engine clock and HBM bandwidth come from the device (MI355X figures without one); FFPA_HIP_FAKE_CUS (test-only) swaps the CU count in.
+  The same launch is a ragged round on 256 CUs, whole rounds on 128 / 320 and under-filled on 1024."""
+  assert lib.ffpa_attn_query(8) == 256 and lib.ffpa_attn_query(9) == 2400 and lib.ffpa_attn_query(10) == 8000  # (no GPU here: the fallbacks)
+  plan = (ctypes.c_int * 4)()
+  p = _params(heads_q=10, heads_kv=10, seqlen_q=4096, seqlen_kv=8192)  # 320 workgroups
+  p.workspace, p.workspace_bytes = 16, 1 << 40
+  got = {}
+  for cus in (128, 256, 320, 1024):
+    monkeypatch.setenv("FFPA_HIP_FAKE_CUS", str(cus))
+    assert lib.ffpa_attn_query(8) == cus
+    assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0
+    got[cus] = plan[3]
+  assert got[256] == 3 and got[128] == 1 and got[320] == 1 and got[1024] == 3, got  # (1024: 320 workgroups x 3 = 960, one round)
+
+
 def test_tile_configs():
   for d in range(64, 1025, 64):
     c = hip.tile_config(d)

@@ -1084,12 +1084,18 @@ def test_randomized_against_oracle(hip, seed):
   np.testing.assert_allclose(_f32(lse)[lfin], lse_ref[lfin], atol=3e-4, rtol=3e-5, err_msg=str(c))
 
 
-@pytest.mark.parametrize("seed", range(24))
-def test_randomized_launch_plans_against_oracle(hip, seed):
+@pytest.mark.parametrize("seed, fake_cus", [(s_, None) for s_ in range(24)] + [(s_, c_) for s_ in range(24, 32) for c_ in (128, 304)])
+def test_randomized_launch_plans_against_oracle(hip, seed, fake_cus, monkeypatch):
   """Long contexts with at most 1.5 rounds of workgroups — where make_plan prices KV splits (under-filled, part of a round, ragged round): whatever count
-  it takes, the result equals the unsplit launch to rounding and the oracle on a row sample, tails and the causal flag included."""
+  it takes, the result equals the unsplit launch to rounding and the oracle on a row sample, tails and the causal flag included.  ``fake_cus``: the same
+  walk with the plan pricing a 128- / 304-CU part (FFPA_HIP_FAKE_CUS, test-only: the rates come from the device, the CU count is what another SKU changes
+  first) — any plan is a correct launch on any device."""
   rng = np.random.default_rng(7000 + seed)
   cus = torch.cuda.get_device_properties(0).multi_processor_count
+  if fake_cus is not None:
+    monkeypatch.setenv("FFPA_HIP_FAKE_CUS", str(fake_cus))
+    assert hip.load_library().ffpa_attn_query(8) == fake_cus
+    cus = fake_cus
   D = int(rng.choice([320, 512, 512, 1024, 448, 640]))
   rows_per_wg = hip.tile_config(hip.padded_head_dim(D))["block_rows"]
   Nq = int(rng.choice([512, 1024, 2048, 4096])) - int(rng.choice([0, 0, 1, 37]))

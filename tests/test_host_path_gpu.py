@@ -1,0 +1,128 @@
+"""The host side of a launch (`pytest -m gpu`): what a call costs before the kernel starts and what it keeps between calls.
+
+Round 5: an inference call (nothing to differentiate) goes straight from `ffpa_attn_func` to the launch wrapper — no autograd node, no dispatcher
+round trip, no LSE tensor; workspace bytes / ticket counts are asked of the library once per shape class; the scratch of short-query (decode)
+launches is kept per (device, stream); precomputed mask ranges travel through the Backend object; FFPA_HIP_PREFILL_SPLITS=0 opts out of the
+prefill KV-split rules; the split pricing reads the device it runs on.
+"""
+
+import os
+
+import pytest
+import torch
+
+from test_fwd_gpu import _rand, hip  # noqa: F401  (fixture + helpers)
+
+pytestmark = pytest.mark.gpu
+
+
+def test_inference_calls_skip_autograd_and_equal_the_training_path(hip):
+  from ffpa_attn_amd import ffpa_attn_func
+
+  q, k, v = _rand((1, 4, 640, 512), seed=1), _rand((1, 2, 1024, 512), seed=2), _rand((1, 2, 1024, 512), seed=3)
+  o_inf = ffpa_attn_func(q, k, v, is_causal=True, enable_gqa=True)
+  assert o_inf.grad_fn is None
+  with torch.no_grad():
+    qg = q.clone().requires_grad_(True)
+    o_ng = ffpa_attn_func(qg, k, v, is_causal=True, enable_gqa=True)  # grad mode off: still the direct path
+  assert o_ng.grad_fn is None and torch.equal(o_ng, o_inf)
+  qg = q.clone().requires_grad_(True)
+  o_tr = ffpa_attn_func(qg, k, v, is_causal=True, enable_gqa=True)
+  assert o_tr.grad_fn is not None and torch.equal(o_tr.detach(), o_inf)  # the same launch behind the autograd node
+  o_tr.float().square().mean().backward()
+  assert qg.grad is not None and torch.isfinite(qg.grad).all()
+  # dropout: both paths reserve the generator offsets the same way -> the same keep mask
+  torch.manual_seed(5)
+  d_inf = ffpa_attn_func(q, k, v, dropout_p=0.2, enable_gqa=True)
+  torch.manual_seed(5)
+  d_tr = ffpa_attn_func(qg, k, v, dropout_p=0.2, enable_gqa=True)
+  assert torch.equal(d_inf, d_tr.detach()) and not torch.equal(d_inf, o_inf)
+
+
+def test_decode_scratch_is_asked_once_and_kept_per_stream(hip):
+  from ffpa_attn_amd import ffpa_attn_func
+
+  q, k, v = _rand((2, 32, 1, 512), seed=11), _rand((2, 8, 8192, 512), seed=12), _rand((2, 8, 8192, 512), seed=13)
+  hip._WORKSPACES.clear()
+  hip._PLAN_SCRATCH.clear()
+  plan = {}
+  hip.forward(q, k, v, None, False, 512 ** -0.5, plan_out=plan)
+  assert plan["variant"] == 1 and plan["splits"] > 1, plan
+  o1 = ffpa_attn_func(q, k, v, enable_gqa=True)
+  cur = torch.cuda.current_stream().cuda_stream
+  assert len(hip._PLAN_SCRATCH) == 1 and list(hip._WORKSPACES) == [(q.device.index, cur)]
+  ws = hip._WORKSPACES[(q.device.index, cur)]
+  ptr = ws.data_ptr()
+  for _ in range(3):
+    o2 = ffpa_attn_func(q, k, v, enable_gqa=True)
+  assert hip._WORKSPACES[(q.device.index, cur)].data_ptr() == ptr and len(hip._PLAN_SCRATCH) == 1 and torch.equal(o1, o2)
+  side = torch.cuda.Stream()
+  side.wait_stream(torch.cuda.current_stream())
+  with torch.cuda.stream(side):
+    o3 = ffpa_attn_func(q, k, v, enable_gqa=True)  # another stream may overlap: its own scratch
+  side.synchronize()
+  assert len(hip._WORKSPACES) == 2 and hip._WORKSPACES[(q.device.index, side.cuda_stream)].data_ptr() != ptr and torch.equal(o1, o3)
+  # a prefill launch that splits the KV axis needs hundreds of MiB of partials: those go back to the caching allocator
+  qp, kp, vp = _rand((1, 9, 4096, 512), seed=14), _rand((1, 9, 8192, 512), seed=15), _rand((1, 9, 8192, 512), seed=16)
+  hip.forward(qp, kp, vp, None, False, 512 ** -0.5, plan_out=plan)
+  assert plan["variant"] == 0 and plan["splits"] > 1 and hip._WORKSPACES[(q.device.index, cur)].data_ptr() == ptr
+  # streams come and go: the tables are bounded
+  for _ in range(hip._SCRATCH_MAX_STREAMS + 4):
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+      ffpa_attn_func(q, k, v, enable_gqa=True)
+    s.synchronize()
+  assert len(hip._WORKSPACES) <= hip._SCRATCH_MAX_STREAMS
+
+
+def test_precomputed_mask_ranges_travel_through_the_backend_object(hip):
+  from ffpa_attn_amd import CUDABackend, HIPBackend, TritonBackend, ffpa_attn_func
+
+  Nq, Nkv = 1024, 2048
+  q, k, v = _rand((1, 4, Nq, 320), seed=21), _rand((1, 2, Nkv, 320), seed=22), _rand((1, 2, Nkv, 320), seed=23)
+  mask = torch.ones(Nq, Nkv, dtype=torch.bool, device="cuda").tril(diagonal=Nkv - Nq)
+  ranges = hip.mask_kv_bounds(mask.view(1, 1, Nq, Nkv), Nq, Nkv)
+  ref = ffpa_attn_func(q, k, v, attn_mask=mask, enable_gqa=True)  # ranges derived by the scan, every call
+  calls = []
+  real = hip.mask_kv_bounds
+  hip.mask_kv_bounds = lambda *a, **kw: calls.append(1) or real(*a, **kw)
+  try:
+    for be in (HIPBackend(forward=True, kv_bounds=ranges), TritonBackend(forward=True, kv_bounds=ranges), CUDABackend(forward=True, kv_bounds=ranges)):
+      assert torch.equal(ffpa_attn_func(q, k, v, attn_mask=mask, enable_gqa=True, forward_backend=be), ref)
+      qg = q.clone().requires_grad_(True)  # ... and through the registered op (the path behind the autograd node)
+      assert torch.equal(ffpa_attn_func(qg, k, v, attn_mask=mask, enable_gqa=True, forward_backend=be).detach(), ref)
+    assert not calls  # no scan ran
+    ffpa_attn_func(q, k, v, attn_mask=mask, enable_gqa=True)
+    assert calls == [1]
+  finally:
+    hip.mask_kv_bounds = real
+  assert torch.equal(ffpa_attn_func(q, k, v, is_causal=True, enable_gqa=True), ref)  # the explicit tail-aligned mask == the flag
+
+
+def test_prefill_split_opt_out(hip, monkeypatch):
+  q, k, v = _rand((1, 9, 4096, 512), seed=31), _rand((1, 9, 8192, 512), seed=32), _rand((1, 9, 8192, 512), seed=33)
+  plan = {}
+  o_split, _ = hip.forward(q, k, v, None, False, 512 ** -0.5, plan_out=plan)
+  assert plan["splits"] > 1, plan  # a ragged round (288 workgroups on 256 CUs)
+  monkeypatch.setenv("FFPA_HIP_PREFILL_SPLITS", "0")
+  o_plain, _ = hip.forward(q, k, v, None, False, 512 ** -0.5, plan_out=plan)
+  assert plan["splits"] == 1
+  o_one, _ = hip.forward(q[:, :1].contiguous(), k[:, :1].contiguous(), v[:, :1].contiguous(), None, False, 512 ** -0.5, num_splits=1)
+  assert torch.equal(o_plain[:, :1], o_one)  # without splits a head's bits do not depend on how many heads share the launch
+  assert (o_split.float() - o_plain.float()).abs().max().item() <= 4e-3
+  qd, kd, vd = _rand((1, 8, 1, 512), seed=34), _rand((1, 8, 8192, 512), seed=35), _rand((1, 8, 8192, 512), seed=36)
+  hip.forward(qd, kd, vd, None, False, 512 ** -0.5, plan_out=plan)
+  assert plan["variant"] == 1 and plan["splits"] > 1  # short-query launches keep their rule
+
+
+def test_the_pricing_reads_the_device(hip):
+  lib = hip.load_library()
+  props = torch.cuda.get_device_properties(0)
+  assert lib.ffpa_attn_query(8) == props.multi_processor_count
+  mhz, gbps = lib.ffpa_attn_query(9), lib.ffpa_attn_query(10)
+  print(f"device pricing inputs: {props.multi_processor_count} CUs, {mhz} MHz, {gbps} GB/s HBM")
+  assert 1000 <= mhz <= 4000 and 500 <= gbps <= 20000
+  pl = hip.launch_plan(1, 32, 32, 8192, 8192, 512, device=0)
+  assert pl["splits"] == 1 and pl["block_rows"] == 128 and pl["kernel"].startswith("ffpa_fwd_m16_kernel<bf16, 512, MK=0")
+  pl = hip.launch_plan(2, 32, 8, 8192, 2048, 320, bias_dtype=torch.bool, device=0)
+  assert pl["kernel"].startswith("ffpa_fwd_m16w_kernel<bf16, 320, RH=3, MK=2") and pl["block_rows"] == 192 and pl["block_keys"] == 64, pl

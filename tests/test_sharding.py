@@ -79,11 +79,23 @@ def _born_worker(rank, world, port, n_units, g, ret):
     import ffpa_attn_amd.sharding as shm
     real = shm.attend_units
     shm.attend_units = lambda a, b, c, **kw: torch.nn.functional.scaled_dot_product_attention(a, b, c, enable_gqa=True)
+    # every piece goes point-to-point into its final slice of the result: no collective that would gather into a world x piece temporary and copy out
+    # (the list form of dist.all_gather does exactly that for non-contiguous output views) — and a caller's buffer is filled in place
+    real_ag, real_agt = dist.all_gather, dist.all_gather_into_tensor
+
+    def forbidden(*a, **kw):
+      raise AssertionError("attend_and_gather_units must not call a gather collective")
+
+    dist.all_gather = dist.all_gather_into_tensor = forbidden
     try:
       for chunks in (1, 2, 3):
         ok = ok and bool(torch.equal(sh.attend_and_gather_units(q, k, v, n_units, chunks=chunks), ref))
+      mine = torch.full_like(ref, float("nan"))
+      got = sh.attend_and_gather_units(q, k, v, n_units, chunks=2, out=mine)
+      ok = ok and got.data_ptr() == mine.data_ptr() and bool(torch.equal(mine, ref))
     finally:
       shm.attend_units = real
+      dist.all_gather, dist.all_gather_into_tensor = real_ag, real_agt
   ret[rank] = (ok, (s, e), bool(torch.equal(q, qa[s:e])))
   dist.barrier()
   dist.destroy_process_group()

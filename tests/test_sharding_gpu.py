@@ -45,6 +45,20 @@ def _worker(rank, world, port, ret):
   # a piece of this small problem would under-fill the chip (its launch would split the KV axis: fp32 partials + LSE merge, the same values
   # to rounding only) — attend_and_gather_units lowers the piece count instead, so the gathered tensor does not depend on `chunks`
   assert torch.equal(overlapped, full)
+  # the overlapped form writes every piece straight into its final slice (its own: one copy; the others': point-to-point receives) — no staging
+  # buffer of world x piece next to the result: the peak above the buffers the caller holds is this rank's own pieces + the call's scratch
+  mine = torch.empty_like(full)
+  torch.cuda.synchronize()
+  torch.cuda.reset_peak_memory_stats()
+  base = torch.cuda.memory_allocated()
+  sh.attend_and_gather_units(q, k, v, N_UNITS, chunks=2, out=mine)
+  torch.cuda.synchronize()
+  peak = torch.cuda.max_memory_allocated() - base
+  own = o_local.numel() * o_local.element_size()
+  assert torch.equal(mine, full)
+  pl = hip.launch_plan(q.size(0), GROUP, 1, NQ, NKV, D, device=q.device)  # (a launch this small splits the KV axis: fp32 partials + LSE as scratch)
+  scratch = pl["splits"] * q.size(0) * GROUP * NQ * (D + 1) * 4 if pl["splits"] > 1 else 0
+  assert peak <= own + scratch + (1 << 20), (peak, own, scratch)  # a world x piece staging buffer (2 x own at two ranks) would not fit the slack
   ref = torch.nn.functional.scaled_dot_product_attention(q, k, v, enable_gqa=True)
   err = (o_local.float() - ref.float()).abs().max().item()
   ret[rank] = (full.cpu(), err, (s, e))
