@@ -33,15 +33,6 @@ static int launch_one(const FwdArgs& a, hipStream_t stream) {
     if (dev >= 0 && dev < 64) attr_done[dev].store(true, std::memory_order_release);
   }
   unsigned grid = (unsigned)a.total_wg;
-#if FFPA_PERSISTENT
-  // one workgroup per CU (this kernel's LDS / register footprint admits exactly one), each walking total / grid ids
-  if (ND <= 2 && a.nsplit == 1 && !(a.flags & 0x4u)) {
-    int cus = 256;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const unsigned g = (unsigned)(cus > 8 ? cus - cus % 8 : 8);
-    if (grid > g) grid = g;
-  }
-#endif
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, stream, a);
   return (int)hipGetLastError();
 }

@@ -97,9 +97,6 @@
 #ifndef FFPA_SQ_NT
 #define FFPA_SQ_NT 1  // 1: the short-query (ND >= 2) builds carry a second form of their K / V LDS-DMA with the non-temporal hint; FwdArgs.flags picks per launch
 #endif
-#ifndef FFPA_PERSISTENT
-#define FFPA_PERSISTENT 0  // 1: a workgroup walks several (batch, head, row tile) ids when the host launches fewer workgroups than ids
-#endif
 #ifndef FFPA_V_EARLY
 #define FFPA_V_EARLY 1  // issue the first PV fragment reads right after barrier A (latency hides under softmax)
 #endif
@@ -111,11 +108,6 @@
 #else
 #define FFPA_M0_CLOBBER
 #endif
-#ifndef FFPA_ABL
-// developer ablations (WRONG RESULTS; tools/gpu_ab.py): 1 no in-loop DMA, 2 no exp, 4 no barriers, 8 no softmax,
-// 16 no DMA drain, 32 s_nop 1 in front of every S MFMA, 64 no LDS fragment reads, 128 no MFMA, 256 no QK MFMA, 512 no PV MFMA
-#define FFPA_ABL 0
-#endif
 
 // The S^T MFMAs are inline asm, so hipcc's hazard recognizer does not see their operands (a VALU write needs 2
 // wait states before an MFMA reads the register).  In the product kernels their A operand comes from ds_read
@@ -124,7 +116,6 @@
 // at D = 512, 2.7 % at D = 320).  tools/check_mfma_hazards.py proves the "no VALU write within the last two
 // instructions" property on the generated ISA of every instantiation.  The register-staged SAFE twins (tests
 // only) do get the pad: there hipcc parks Q fragments in spare AGPRs and restores them right before the MFMA.
-// FFPA_ABL bit 32 pads every kernel.
 #define FFPA_MFMA_PAD "s_nop 1\n\t"
 
 namespace ffpa {
@@ -777,7 +768,7 @@ __device__ __forceinline__ void split_arrive_and_merge(const FwdArgs& a, int D, 
 // D = 320: 1170 vs 1131, N = 2048: + 4 %, measured A/B); 2 = boolean masks only (bytes + mask ranges; what
 // ffpa_attn_func(attn_mask=<bool>) launches: config 4 as specified); 1 = every path.
 template <typename T, int D, int ND, bool SAFE, bool DROP = false, bool BTILE = false, int MK = 1>
-__global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_in) {
+__global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) {
   constexpr bool MASK = MK != 0;
   constexpr bool kBoolOnly = MK == 2;
   using E = Elem<T>;
@@ -806,7 +797,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
   // Head dims whose rows are not a whole number of 1 KiB pieces need ~12 VALU instructions per piece for the
   // per-lane source offset (constant division, swizzle).  The offsets are tile-invariant: where the register
   // budget allows they are hoisted into PPW + PPW VGPRs.
-  constexpr bool kPad = SAFE || (FFPA_ABL & 32) != 0;  // s_nop 1 in front of the asm MFMAs (see FFPA_MFMA_PAD)
+  constexpr bool kPad = SAFE;  // s_nop 1 in front of the asm MFMAs (see FFPA_MFMA_PAD)
   constexpr bool kRowUniform = (D * 2) % 1024 == 0;
   constexpr bool kHoist = FFPA_HOIST != 0 && !kRowUniform && !SAFE && !DROP && (ND == 1 ? D <= FFPA_HOIST_MAX_D : (ND == 2 && D <= FFPA_HOIST_ND2_MAX_D));
   // Row-uniform head dims: wave w stages keys 16 a + 4 w + b (a < BC/16, b < 4) so that only four K and
@@ -838,45 +829,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
   // ---- workgroup -> (batch, head, row tile).  Block b runs on XCD b % 8; give every
   // XCD a contiguous range of virtual ids so that the row tiles of one head (which
   // stream the same K/V) are co-resident on one XCD and hit in its L2.
-#if FFPA_PERSISTENT
-  // Persistent form: the host launches G <= total workgroups (G a multiple of 8); the G / 8 workgroups of an XCD walk that
-  // XCD's id range in rounds of G / 8 consecutive ids (the row tiles that stream the same K/V stay co-resident), odd rounds
-  // in reverse order so that causal launches (ids sorted longest first) hand every workgroup the same amount of work.
-  // The next id's Q fragments and first K tile are requested right behind this id's O stores: the store drain, the
-  // workgroup teardown / launch gap and part of the fetch latency overlap.  The kernel arguments are re-read through a
-  // laundered pointer every round: nothing derived from them may be hoisted out of (and kept live across) the outer loop
-  // — that is what made two earlier persistent attempts lose to scalar-register pressure (profiles/NOTES.md section 6).
-  for (int round = 0;; ++round) {
-  typedef const __attribute__((address_space(4))) FwdArgs CArgs;
-  auto kargs = (CArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(kargs));
-  CArgs& a = *kargs;
-  int vid = blockIdx.x;
-  {
-    const int G = gridDim.x, total = a.total_wg;
-    if (G == total) {
-      if (round > 0) break;
-      if (!(a.flags & kFlagNoXcdRemap)) {
-        const int xcd = vid & 7, idx = vid >> 3, per = total >> 3, rem = total & 7;
-        vid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
-      }
-    } else {
-      const int xcd = vid & 7, idx = vid >> 3, wgs = G >> 3;  // workgroups per XCD
-      const int per = total >> 3, rem = total & 7;
-      const int start = xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per;
-      const int cnt = per + (xcd < rem ? 1 : 0);
-      if (round * wgs >= cnt) break;
-      const int in_round = (round & 1) ? wgs - 1 - idx : idx;
-      const int id = round * wgs + in_round;
-      if (id >= cnt) continue;
-      vid = start + id;
-    }
-  }
-#else
-  const FwdArgs& a = a_in;
   int vid = blockIdx.x;
   if (!(a.flags & kFlagNoXcdRemap)) vid = xcd_logical_id(vid, gridDim.x, a.xcd_group);
-#endif
   const int split = vid % a.nsplit;
   vid /= a.nsplit;
   const int bh = vid / a.nqt;
@@ -1141,7 +1095,6 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
       v8 kf[N1];
       auto k_frag = [&](int n) -> v8 {
         const int s = FFPA_QK_ORDER ? n % KS : n / NKB, kb = FFPA_QK_ORDER ? n / KS : n % NKB;
-        if constexpr ((FFPA_ABL & 64) != 0) return qf[(s + 1) % KS];
         return *(FFPA_LDS const v8*)(kaddr[s & 7] + (s >> 3) * 256 + kb * 32 * RB);
       };
       const int dlane = opaque_lane(lane);
@@ -1152,13 +1105,12 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
         constexpr int n = decltype(ic)::value;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (n + PF1 < N1) kf[n + PF1] = k_frag(n + PF1);
-        if constexpr (kInterleave && !(FFPA_ABL & 1) && n % kStep == 0 && n / kStep < PPW) {
+        if constexpr (kInterleave && n % kStep == 0 && n / kStep < PPW) {
           // V(j) streams in under this tile's QK^T (the V buffer is free since barrier B of tile j-1)
           issue_v(std::integral_constant<int, n / kStep>{}, k0, dlane);
         }
         constexpr int s = FFPA_QK_ORDER ? n % KS : n / NKB, kb = FFPA_QK_ORDER ? n / KS : n % NKB;
-        if constexpr ((FFPA_ABL & (128 | 256)) != 0) { if constexpr (s == 0) sacc[kb] = (f32x16)(0.f); }
-        else if constexpr (s == 0) E::template mfma_v_first<kPad>(sacc[kb], kf[n], qf[s]);
+        if constexpr (s == 0) E::template mfma_v_first<kPad>(sacc[kb], kf[n], qf[s]);
         else E::template mfma_v_acc<kPad>(sacc[kb], kf[n], qf[s]);
       });
       // MFMA result -> VALU reader wait states (invisible to the compiler inside asm)
@@ -1187,7 +1139,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
 
     // FFPA_K_PRE_SPREAD: the kPre early K(j+1) pieces go out in four groups between the softmax stages (the texture-address
     // unit idles there) instead of as one burst of 4 x kPre pieces per CU right behind barrier A1
-    constexpr bool kPreSpread = kSpreadReq && kPre >= 4 && !(FFPA_ABL & 1);
+    constexpr bool kPreSpread = kSpreadReq && kPre >= 4;
     auto pre_k_group = [&](auto gc) __attribute__((always_inline)) {
       if constexpr (kPreSpread) {
         constexpr int g = decltype(gc)::value;
@@ -1212,16 +1164,16 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
     if constexpr (kPre > 0) {
       // split form: A1 only frees the K buffer, so the first K(j+1) pieces stream under the softmax;
       // V(j) (issued before them) is awaited by count right before the PV loop (barrier A2 below).
-      if constexpr (!(FFPA_ABL & 4)) __syncthreads();
-      if constexpr (!(FFPA_ABL & 1) && !kPreSpread) {
+      __syncthreads();
+      if constexpr (!kPreSpread) {
         const int plane = opaque_lane(lane);
         static_for<kPre>([&](auto ic) { issue_k(ic, k0 + BC, plane); });
       }
     } else {
-      if constexpr (!(FFPA_ABL & 16)) dma_wait_all();
-      if constexpr (!(FFPA_ABL & 4)) __syncthreads();
+      dma_wait_all();
+      __syncthreads();
     }
-    if constexpr (!kInterleave && !(FFPA_ABL & 1)) {
+    if constexpr (!kInterleave) {
       if (j + 1 < nt) issue_k_tile(k0 + BC);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1233,7 +1185,6 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
     v8 vf[N2];
     auto v_frag = [&](int n) -> v8 {
       const int db = FFPA_PV_ORDER ? n % NDB : n / NKS, ks = FFPA_PV_ORDER ? n / NDB : n % NKS;
-      if constexpr ((FFPA_ABL & 64) != 0) return qf[(db + ks) % KS];
       if constexpr (!SAFE) {
         const int krow = (kVHi && ks >= 4) ? 32 * ((ks - 4) >> 1) + 8 * (ks & 1) : 32 * (ks >> 1) + 8 * (ks & 1);
         FFPA_LDS const char* vp = ((kVHi && ks >= 4) ? vaddr[4 + (db & 3)] : vaddr[db & 3]) + (db >> 2) * 256 + krow * RB;
@@ -1420,13 +1371,11 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
 
     // ================= online softmax (prefill.cuh:671-870, log2 domain) =================
     float tmax = x[0][0];
-    if constexpr (!(FFPA_ABL & 8)) {
 #pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
+    for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, x[kb][r]);
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-    }
+      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, x[kb][r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
     pre_k_group(std::integral_constant<int, 2>{});
     const float m_new = fmaxf(m_run, tmax);
     // lazy rescale: keep the stale max while it grew by <= thr (prefill.cuh:684-755);
@@ -1457,7 +1406,6 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
       m_run = grow ? m_new : m_run;
     }
     float m_use = (m_run == -INFINITY) ? 0.f : m_run;
-    if constexpr ((FFPA_ABL & 8) != 0) m_use = 0.f;
 
     v8 pf[NKS];
     float psum = 0.f;
@@ -1465,8 +1413,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = (FFPA_ABL & 8) ? x[kb][r] : (FFPA_ABL & 2) ? (x[kb][r] - m_use) : __builtin_amdgcn_exp2f(x[kb][r] - m_use);
-        if constexpr (!(FFPA_ABL & 8)) psum += p;  // row sum from the unrounded P (prefill.cuh:755-756)
+        const float p = __builtin_amdgcn_exp2f(x[kb][r] - m_use);
+        psum += p;  // row sum from the unrounded P (prefill.cuh:755-756)
         // contraction slot (h, r & 7) of key step 2 kb + (r >> 3) <-> this register (key 32 kb + 16 h + r)
         pf[kb * 2 + (r >> 3)][r & 7] = (T)p;
       }
@@ -1498,8 +1446,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (kPre > 0) {
         // barrier A2: V(j) has landed on every wave (all but the kPre younger K pieces have retired)
-        if constexpr (!(FFPA_ABL & 16)) dma_wait_except<kPre>();
-        if constexpr (!(FFPA_ABL & 4)) __syncthreads();
+        dma_wait_except<kPre>();
+        __syncthreads();
       }
       if constexpr (!FFPA_V_EARLY || kPre > 0) {
 #pragma unroll
@@ -1509,13 +1457,13 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
         constexpr int n = decltype(ic)::value;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (n + PF2 < N2) vf[n + PF2] = v_frag(n + PF2);
-        if constexpr (kInterleave && !(FFPA_ABL & 1) && n % kStep == 0 && n / kStep + kPre < PPW) {
+        if constexpr (kInterleave && n % kStep == 0 && n / kStep + kPre < PPW) {
           // K(j+1) streams in under this tile's PV (the K buffer is free since barrier A).  After the
           // last tile that is an empty tile (every lane out of range: zeros, no memory traffic): cheaper
           // than a branch per piece, and barrier B still drains it before the workgroup can exit.
           issue_k(std::integral_constant<int, n / kStep + kPre>{}, k0 + BC, dlane);
         }
-        if constexpr (kBiasTile && kInterleave && !(FFPA_ABL & 1)) {
+        if constexpr (kBiasTile && kInterleave) {
           // the bias tile of step j+1 (this wave's rows only, into its private area: no other wave reads or writes it, so the
           // wave's own queue drain at barrier B is all the synchronisation it needs); slots the K pieces leave free
           constexpr int kBStep = kStep >= 2 ? kStep : 2;
@@ -1524,9 +1472,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
           }
         }
         constexpr int db = FFPA_PV_ORDER ? n % NDB : n / NKS, ks = FFPA_PV_ORDER ? n / NDB : n % NKS;
-        if constexpr (!(FFPA_ABL & (128 | 512))) oacc[db] = E::mfma(vf[n], pf[ks], oacc[db]);
+        oacc[db] = E::mfma(vf[n], pf[ks], oacc[db]);
       });
-      if constexpr (kBiasTile && kInterleave && !(FFPA_ABL & 1)) {
+      if constexpr (kBiasTile && kInterleave) {
         // (short PV loops — small head dims — do not have a slot for every bias piece: the rest go out here)
         constexpr int kBStep = kStep >= 2 ? kStep : 2;
         static_for<kBtPieces>([&](auto ic) {
@@ -1537,9 +1485,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
     }
 
     // barrier B: every wave is done reading V(j); K(j+1) has landed and is visible
-    if constexpr (!(FFPA_ABL & 16)) dma_wait_all();
-    if constexpr (!(FFPA_ABL & 4)) __syncthreads();
-    if constexpr (!kInterleave && !(FFPA_ABL & 1)) {
+    dma_wait_all();
+    __syncthreads();
+    if constexpr (!kInterleave) {
       if (j + 1 < nt) issue_v_tile(k0 + BC);
     }
   }
@@ -1603,9 +1551,6 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a_i
   }
   // KV-split launch with tickets: the last split of this row tile to arrive merges all partials here (one launch per call)
   if (a.nsplit > 1 && a.tickets != nullptr) split_arrive_and_merge<T, true>(a, D, bh * a.nqt + qt, b, hq, q0, BR, Kt);
-#if FFPA_PERSISTENT
-  }  // persistent rounds
-#endif
 }
 
 // Merge the split-KV partials of one launch (the reference's decode stage 2,

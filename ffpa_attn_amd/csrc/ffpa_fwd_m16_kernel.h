@@ -61,12 +61,6 @@
 #ifndef FFPA_M16_K_PRE
 #define FFPA_M16_K_PRE 8  // K(j+1) pieces issued between the softmax stages (a multiple of 4); the rest go out between the PV MFMAs
 #endif
-#ifndef FFPA_M16_ROWDMA
-#define FFPA_M16_ROWDMA 1  // D = 512 mask / bias / dropout builds: scalar row addressing of the LDS-DMA (0: per-lane offset tables, as the other builds)
-#endif
-#ifndef FFPA_M16_ROW_TABLES
-#define FFPA_M16_ROW_TABLES 1  // scalar row form: 1 = a table of one scalar register per staged row, 0 = row offsets computed per piece (2 SALU)
-#endif
 #ifndef FFPA_M16_PF_WAVES
 #define FFPA_M16_PF_WAVES 2  // L2 prefetch: waves of a workgroup that touch (2: one K and one V slice per step; 4: two of each)
 #endif
@@ -76,47 +70,14 @@
 #ifndef FFPA_M16_PF_DIST
 #define FFPA_M16_PF_DIST 2  // L2 prefetch: steps ahead of the step being computed (the DMA queue itself covers 1)
 #endif
-#ifndef FFPA_M16_DEPHASE
-#define FFPA_M16_DEPHASE 0  // (experiment) behind the barriers of FFPA_M16_DEPHASE_AT, wave w idles w x this many x 16 cycles: the four waves leave a barrier in
-#endif                      //   the same cycle, their MFMA streams then tick in lockstep and they offer their DMA pieces to the one texture addresser together
-#ifndef FFPA_M16_DEPHASE_AT
-#define FFPA_M16_DEPHASE_AT 7  // bit 0: behind barrier A1, bit 1: A2, bit 2: B
-#endif
-#ifndef FFPA_M16_DEPHASE_ND
-#define FFPA_M16_DEPHASE_ND 2  // which tiles: 2 = the split-D tiles (D > 512) only, 1 = D <= 512 only, 3 = both
-#endif
 #ifndef FFPA_M16_K_PRE_ND2
 #define FFPA_M16_K_PRE_ND2 64  // ditto for the split-D tiles (D > 512; clamped to the tile's pieces: all of K(j+1) goes out between the softmax stages)
 #endif
-// ---- split-D tiles (D > 512), round 4: the K tile in two 16-key halves.  QK^T walks key block 0 over all of its D-half first, then key
-// block 1, with a fourth workgroup barrier (M) in between: barrier B then only needs K1(j+1) = keys 0 .. 15 of the next tile, K2(j+1) may
-// still be in flight until barrier M of step j + 1 — so K pieces can be issued under the PV MFMAs (the one phase whose texture addresser
-// sat idle) and K1(j+1) already under the second half of QK^T(j), whose K1(j) rows are free behind barrier M.  The schedule is a table of
-// piece counts per phase, in sixteenths of a wave's pieces per tile image (PPW; the last entry of each stream takes the remainder):
-//   V(j):    FFPA_M16_KS_VA in QK^T half 1, _VB in half 2, rest between the softmax stages (first there: it is awaited at barrier A2)
-//   K1(j+1): FFPA_M16_KS_K1B in QK^T half 2, _K1C between the softmax stages, rest at the front of the PV loop (awaited at barrier B)
-//   K2(j+1): FFPA_M16_KS_K2C between the softmax stages (last there), rest in the PV loop behind K1's (awaited at barrier M of step j + 1)
-// Every counted wait is derived from the table (loads retire in order: the wait at a barrier leaves exactly the pieces issued behind the
-// last one it needs).  0 = the round-3 schedule (three barriers, all of K(j+1) between the softmax stages).
-#ifndef FFPA_M16_KSPLIT
-#define FFPA_M16_KSPLIT 0
-#endif
-#ifndef FFPA_M16_KS_VA
-#define FFPA_M16_KS_VA 8
-#endif
-#ifndef FFPA_M16_KS_VB
-#define FFPA_M16_KS_VB 8
-#endif
-#ifndef FFPA_M16_KS_K1B
-#define FFPA_M16_KS_K1B 0
-#endif
-#ifndef FFPA_M16_KS_K1C
-#define FFPA_M16_KS_K1C 8
-#endif
-#ifndef FFPA_M16_KS_K2C
-#define FFPA_M16_KS_K2C 0
-#endif
-// ---- split-D tiles (D > 512), round 4, second step: the SOFTMAX PIPELINE.  With the K tile in two 16-key halves (above), key block 0 of tile
+// ---- split-D tiles (D > 512), round 4: the K tile in two 16-key halves (K1 = keys 0 .. 15, K2 = keys 16 .. 31 of a tile: each wave stages PPW / 2 pieces
+// of either), so that the rows of one half can take the next tile's pieces while the other half is still being contracted — what the softmax pipeline
+// below is built on.  (The intermediate schedule of round 4 — two-half K with a fourth barrier, no pipeline: + 3.9 % where the pipeline gives + 6.5 % —
+// lives on as tools/experiments/r05_pruned_switches.diff.)
+// ---- the SOFTMAX PIPELINE of the split-D tiles.  With the K tile in two 16-key halves, key block 0 of tile
 // j + 1 can be contracted while the softmax of tile j runs: the step becomes
 //     Q: QK^T(j) key block 1                         | DMA: K1(j+2) rest, V(j) first part
 //     barrier A1 (partial S^T of block 1 visible, K2(j) rows free, K1(j+1) landed)
@@ -153,11 +114,9 @@
 #ifndef FFPA_M16_PP_PSTEP
 #define FFPA_M16_PP_PSTEP 2
 #endif
-// (measured, profiles/r04_pipe.txt: at D = 1024 "one per gap" and "all behind the MFMAs" run equally fast — VALU between a wave's own MFMAs is paid in full either way —,
-// at D = 640 behind is + 1.9 %, in front - 3 ... 4 % everywhere; -1 = behind for D < 1024, per gap at D = 1024)
-#ifndef FFPA_M16_PP_SMPOS
-#define FFPA_M16_PP_SMPOS -1  // where the softmax's instruction groups sit in the S phase: 0 = one per MFMA gap, 1 = all behind the phase's MFMAs, 2 = all in front, 4 / 8 = clustered in every 4th / 8th gap
-#endif
+// Where the softmax's instruction groups sit in the S phase (measured, profiles/r04_pipe.txt: at D = 1024 "one per MFMA gap" and "all behind the phase's MFMAs" run equally
+// fast — VALU between a wave's own MFMAs is paid in full either way —, at D = 640 behind is + 1.9 %, in front - 3 ... 4 % everywhere): behind for D < 1024 and for the mask build
+// (whose softmax carries a branch — the mask read; per gap it cost D = 1024 3 ... 5 %: profiles/r05_mask_pipeline.txt), one group per gap at D = 1024.
 #ifndef FFPA_M16_PP_PF
 #define FFPA_M16_PP_PF 3  // K fragments requested ahead of their MFMAs in the S phase (the softmax's registers are live next to them)
 #endif
@@ -165,15 +124,6 @@
 // 1: a DMA piece and the MFMA in front of it are one asm statement (Mfma16::with_dma): the MFMA is the wait state between the M0 write and the piece,
 // no s_nop.  Interleaved A/B, bit-identical (profiles/r04_pipe.txt): config 2 + 1.0 %, cross + 1.7 %, causal + 1.3 %, D = 320 + 1.4 %, config 4 + 0.9 %, D = 1024 +- 0
 #define FFPA_M16_FUSE_DMA 1
-#endif
-#ifndef FFPA_M16_PIECE_IL
-// which 1 KiB pieces of a tile image a wave stages (the per-lane-offset form: every build but D = 512 with a mask path):
-// 0 = a contiguous quarter of the image (wave w: pieces w PPW .. + PPW; the four waves' simultaneous requests lie a quarter image apart),
-// 1 = interleaved (wave w: pieces w, w + 4, w + 8, ..: the four waves' simultaneous requests are 4 KiB of consecutive image bytes)
-#define FFPA_M16_PIECE_IL 0
-#endif
-#ifndef FFPA_M16_KS_PVSTEP
-#define FFPA_M16_KS_PVSTEP 0  // PV loop: one K piece every this many V^T fragments from the loop's start (0: spread evenly over the loop)
 #endif
 
 
@@ -207,7 +157,7 @@ constexpr int m16_block_keys(int D, bool bias_build) {
 // not the build is pipelined, so that the launch side needs to know the mask kind only).
 constexpr int m16_exchange_bytes(int D, bool bias_build) { return D > 512 ? (bias_build ? 4 * 4096 : 4 * 6144) : 0; }
 
-// Two-half K schedule (FFPA_M16_KSPLIT): which of `cnt` pieces, if any, rides on fragment n of a loop of N fragments — piece t sits on
+// Which of `cnt` DMA pieces, if any, rides on fragment n of a loop of N fragments — piece t sits on
 // fragment t * step (step > 0: front-loaded) or floor(t N / cnt) (step == 0: spread evenly); -1 = none.
 constexpr int m16_piece_at(int n, int N, int cnt, int step) {
   for (int t = 0; t < cnt; ++t)
@@ -278,13 +228,9 @@ struct Mfma16<_Float16> {
 // Both 4-lane reductions together in three register swaps (no LDS crossbar): v_permlane32_swap pairs row n's halves in lanes
 // 0 .. 31 and row 16 + n's in lanes 32 .. 63, v_permlane16_swap folds the remaining lane ^ 16 step, and a last
 // v_permlane32_swap hands every lane both results.
-#ifndef FFPA_M16_SWAP_REDUCE
-#define FFPA_M16_SWAP_REDUCE 1
-#endif
 template <bool IS_MAX>
 __device__ __forceinline__ void row4_reduce2(float& t0, float& t1) {
   auto op = [](float x, float y) { return IS_MAX ? fmaxf(x, y) : x + y; };
-#if FFPA_M16_SWAP_REDUCE
   const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t0), __float_as_uint(t1), false, false);
   const float v = op(__uint_as_float(s1[0]), __uint_as_float(s1[1]));
   const auto s2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
@@ -292,12 +238,6 @@ __device__ __forceinline__ void row4_reduce2(float& t0, float& t1) {
   const auto s3 = __builtin_amdgcn_permlane32_swap(__float_as_uint(w), __float_as_uint(w), false, false);
   t0 = __uint_as_float(s3[0]);
   t1 = __uint_as_float(s3[1]);
-#else
-  t0 = op(t0, __shfl_xor(t0, 16));
-  t0 = op(t0, __shfl_xor(t0, 32));
-  t1 = op(t1, __shfl_xor(t1, 16));
-  t1 = op(t1, __shfl_xor(t1, 32));
-#endif
 }
 
 // LDS images of the K / V tiles: row-major [BC][D], 16-byte slot s of row `key` stored at slot s ^ swizzle(key) (applied on the
@@ -320,10 +260,10 @@ __device__ __forceinline__ int m16_v_swizzle(int key) {
 // overwrites LSE rows, experimental schedules — may be anything but its shipped default there.  Variant libraries (build.py --variant)
 // are built without the define, get another file name and say so in ffpa_attn_version().
 #ifdef FFPA_PRODUCT_BUILD
-#if FFPA_ABL != 0 || FFPA_SQ_BC64 != 1 || FFPA_SQ_BC64_ND2 != 1 || FFPA_SQ_NT != 1 || defined(FFPA_M16_TIMING) || FFPA_PERSISTENT != 0 || FFPA_M16_ROWDMA != 1 || FFPA_M16_PF1 != 6 || FFPA_M16_PF2 != 4 || \
-    FFPA_M16_K_PRE != 8 || FFPA_M16_K_PRE_ND2 != 64 || FFPA_M16_DEPHASE != 0 || FFPA_M16_PF_DIST != 2 || FFPA_M16_PF_WAVES != 2 || FFPA_M16_PF_WHICH != 3 || (defined(FFPA_M16_PF_ALL_D) && FFPA_M16_PF_ALL_D != 0) || FFPA_M16_ROW_TABLES != 1 || FFPA_DMA_M0_CLOBBER != 1 || FFPA_M16_SWAP_REDUCE != 1 || FFPA_M16_MIN_D != 128 || FFPA_M16_BC128_MIN_D != 256 || \
-    (defined(FFPA_M16_PHILOX_ILP) && FFPA_M16_PHILOX_ILP != 1) || FFPA_M16_KSPLIT != 0 || FFPA_M16_PIPE != 1 || FFPA_M16_PP_VQ != 6 || FFPA_M16_PP_K1Q != 2 || FFPA_M16_PP_K2S != 2 || \
-    FFPA_M16_PP_QSTEP != 2 || FFPA_M16_PP_SSTEP != 1 || FFPA_M16_PP_PSTEP != 2 || FFPA_M16_PP_PF != 3 || FFPA_M16_PIECE_IL != 0 || FFPA_M16_KS_PVSTEP != 0 || FFPA_M16_FUSE_DMA != 1 || (defined(FFPA_M16_PF_SLICE_BY_XCD_SEQ) && FFPA_M16_PF_SLICE_BY_XCD_SEQ != 1) || (defined(FFPA_M16_PK_FMA) && FFPA_M16_PK_FMA != 1) || FFPA_M16_PP_SMPOS != -1
+#if FFPA_SQ_BC64 != 1 || FFPA_SQ_BC64_ND2 != 1 || FFPA_SQ_NT != 1 || defined(FFPA_M16_TIMING) || FFPA_M16_PF1 != 6 || FFPA_M16_PF2 != 4 || FFPA_M16_K_PRE != 8 || \
+    FFPA_M16_K_PRE_ND2 != 64 || FFPA_M16_PF_DIST != 2 || FFPA_M16_PF_WAVES != 2 || FFPA_M16_PF_WHICH != 3 || FFPA_DMA_M0_CLOBBER != 1 || FFPA_M16_MIN_D != 128 || FFPA_M16_BC128_MIN_D != 256 || \
+    (defined(FFPA_M16_PHILOX_ILP) && FFPA_M16_PHILOX_ILP != 1) || FFPA_M16_PIPE != 1 || FFPA_M16_PP_VQ != 6 || FFPA_M16_PP_K1Q != 2 || FFPA_M16_PP_K2S != 2 || FFPA_M16_PP_QSTEP != 2 || \
+    FFPA_M16_PP_SSTEP != 1 || FFPA_M16_PP_PSTEP != 2 || FFPA_M16_PP_PF != 3 || FFPA_M16_FUSE_DMA != 1 || (defined(FFPA_M16_PK_FMA) && FFPA_M16_PK_FMA != 1)
 #error "FFPA_PRODUCT_BUILD: a developer switch is not at its shipped default"
 #endif
 #endif
@@ -359,7 +299,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   // D = 512 with masks: a tile row is one whole piece -> wave-uniform rows, scalar addressing (the per-lane offset tables of the other form
   // would not fit next to the mask path's registers).  Everything else keeps tile-invariant per-lane offsets in registers: measured equal
   // or better (D = 512 unmasked: + 0 ... 2 %; D = 1024: 927 vs 776 TFLOPS — the scalar row form loses 16 % there on this build).
-  constexpr bool kRowDma = RB % 1024 == 0 && ND == 1 && (MK == 1 || MK == 2 || DROP) && FFPA_M16_ROWDMA;
+  constexpr bool kRowDma = RB % 1024 == 0 && ND == 1 && (MK == 1 || MK == 2 || DROP);
   static_assert(!kRowDma || RB == 1024, "the scalar row form is used where a tile row is exactly one piece");
   constexpr int KPW = BC / 4;                // keys staged per wave per tile
   constexpr int PF1 = FFPA_M16_PF1, PF2 = FFPA_M16_PF2;
@@ -367,16 +307,11 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   constexpr int kPre = ((kPreReq < PPW ? kPreReq : PPW) / 4) * 4;
   constexpr int N1 = KS * NKB;   // K fragments per tile
   constexpr int N2 = NDB * NKS;  // V^T fragments per tile
-  // the two-half K schedule of the split-D tiles (see FFPA_M16_KSPLIT above): needs an even number of pieces per wave (D % 128 == 0)
-  constexpr bool kKS = ND == 2 && (FFPA_M16_KSPLIT != 0 || (FFPA_M16_PIPE != 0 && (MK == 0 || MK == 2) && !DROP)) && PPW % 2 == 0 && NKB == 2;
-  constexpr int kH = PPW / 2;  // K1 / K2 pieces per wave
-  constexpr int ksVA = PPW * FFPA_M16_KS_VA / 16, ksVB = PPW * FFPA_M16_KS_VB / 16, ksVC = PPW - ksVA - ksVB;
-  constexpr int ksK1B = PPW * FFPA_M16_KS_K1B / 16, ksK1C = PPW * FFPA_M16_KS_K1C / 16, ksK1D = kH - ksK1B - ksK1C;
-  constexpr int ksK2C = PPW * FFPA_M16_KS_K2C / 16, ksK2D = kH - ksK2C;
-  static_assert(!kKS || (ksVA >= 0 && ksVB >= 0 && ksVC >= 0 && ksK1B >= 0 && ksK1C >= 0 && ksK1D >= 0 && ksK2C >= 0 && ksK2D >= 0), "piece counts per phase");
-  static_assert(!kKS || (ksVA <= KS && ksVB + ksK1B <= KS && ksK1D + ksK2D <= N2), "at most one piece per fragment");
-  // the softmax pipeline of the split-D tiles (see FFPA_M16_PIPE above); it uses the two-half K piece map
+  // the softmax pipeline of the split-D tiles (see FFPA_M16_PIPE above): needs an even number of pieces per wave (D % 128 == 0), and it stages K as two
+  // 16-key halves — piece i < kH of a wave belongs to K1 (keys 0 .. 15), the rest to K2
   constexpr bool kPipe = ND == 2 && FFPA_M16_PIPE != 0 && PPW % 2 == 0 && NKB == 2 && (MK == 0 || MK == 2) && !DROP;
+  constexpr bool kKS = kPipe;  // the two-half K piece map
+  constexpr int kH = PPW / 2;  // K1 / K2 pieces per wave
   constexpr int ppVQ = PPW * FFPA_M16_PP_VQ / 16, ppVS = PPW - ppVQ;     // V(j): in Q(j), in S(j)
   constexpr int ppK1Q = PPW * FFPA_M16_PP_K1Q / 16, ppK1P = kH - ppK1Q;  // K1(j+1): in P(j-1) (first), in Q(j) (rest)
   constexpr int ppK2S = PPW * FFPA_M16_PP_K2S / 16, ppK2P = kH - ppK2S;  // K2(j+1): in S(j) (first), in P(j) (rest)
@@ -389,25 +324,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   constexpr int ppWaitA1 = ppVQ + (ppK1Q > 0 ? 0 : 0);  // K1(j+1) has landed: the V pieces of Q(j) stay in flight (+ the touch when K1Q == 0)
   constexpr int ppWaitA2 = ppK2S;                       // V(j) has landed
   constexpr int ppWaitB = ppK1P;                        // K2(j+1) has landed (+ the touch)
-  constexpr bool kIL = FFPA_M16_PIECE_IL != 0;  // interleaved piece -> wave map (per-lane-offset form)
-  constexpr int kPStride = kIL ? 4 : 1;         // KiB between two consecutive pieces of one wave in the LDS image
-  constexpr int ksNC = ksVC + ksK1C + ksK2C;  // pieces between the softmax stages
-  constexpr int ksND = ksK1D + ksK2D;         // pieces in the PV loop
-  // counted waits (pieces issued behind the last one the barrier needs; + 1 when the wave also carries a look-ahead touch)
-  constexpr int ksWaitA2 = (ksVC > 0 ? 0 : ksK1B) + ksK1C + ksK2C;                                              // V(j) has landed
-  constexpr int ksWaitB = ksK1D > 0 ? ksK2D : (ksK1C > 0 ? ksK2C + ksK2D : ksVC + ksK2C + ksK2D);             // K1(j+1) has landed (+ touch)
-  constexpr int ksWaitM = (ksK2D > 0 ? 0 : ksK1D) + ksVA;                                                      // K2(j) has landed (+ touch)
-#ifndef FFPA_M16_STEP1_DIV
-#define FFPA_M16_STEP1_DIV 1  // (experiments) > 1: the V pieces go out that much denser, in the front part of the QK^T loop
-#endif
-#ifndef FFPA_M16_STEP2_DIV
-#define FFPA_M16_STEP2_DIV 1
-#endif
-#ifdef FFPA_PRODUCT_BUILD
-  static_assert(FFPA_M16_STEP1_DIV == 1 && FFPA_M16_STEP2_DIV == 1, "FFPA_PRODUCT_BUILD: a developer switch is not at its shipped default");
-#endif
-  constexpr int kStep1 = (N1 / PPW) / FFPA_M16_STEP1_DIV > 0 ? (N1 / PPW) / FFPA_M16_STEP1_DIV : 1;  // one V piece every this many K fragments
-  constexpr int kStep2 = (N2 / PPW) / FFPA_M16_STEP2_DIV > 0 ? (N2 / PPW) / FFPA_M16_STEP2_DIV : 1;  // one K piece every this many V^T fragments
+  constexpr int kStep1 = N1 / PPW > 0 ? N1 / PPW : 1;  // one V piece every this many K fragments
+  constexpr int kStep2 = N2 / PPW > 0 ? N2 / PPW : 1;  // one K piece every this many V^T fragments
   static_assert(kStep1 >= 1 && kStep2 >= 1 && N1 % PPW == 0 && N2 % PPW == 0, "DMA pieces must fit the MFMA loops");
   constexpr int NH = BC > 64 ? BC / 64 : 1;         // 64-key halves of a tile (ds_read immediates are 16 bits: one address base per half)
   constexpr int KV = (D % 128 == 0) ? 4 : 2;        // K fragment address variants: the swizzle reaches slot bits 0 .. 3 / 0 .. 2
@@ -469,7 +387,6 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   uint32_t kro[kRowDma ? KPW : 1], vro[kRowDma ? KPW : 1];
   uint32_t krel[kRowDma ? 1 : PPW], vrel[kRowDma ? 1 : PPW];
   uint32_t k_lds = 0, v_lds = 0;
-  const uint32_t k_wave_off = (uint32_t)(4 * wave) * k_row_bytes, v_wave_off = (uint32_t)(4 * wave) * v_row_bytes;  // (row form: the wave's first staged row)
   if constexpr (kRowDma) {
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) {
@@ -490,7 +407,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     constexpr int SPR = D / 8;  // 16-byte slots per row
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-      const int g = (kIL ? i * 4 + wave : wave * PPW + i) * 64 + lane;
+      const int g = (wave * PPW + i) * 64 + lane;
       const int key = g / SPR;
       const int slot = g - key * SPR;
       const int vs = slot ^ m16_v_swizzle<D>(key);
@@ -498,7 +415,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       if (vs >= slots_valid) vrel[i] = kDmaOob;  // (V too: O^T columns past the head dim stay exact zeros)
       // K: the same pieces, or (two-half schedule) this wave's pieces i < PPW / 2 from the first 16 keys and the rest from the last 16:
       // piece i of wave w is piece w PPW/2 + i of K1 (the image's first 2 PPW KiB), resp. w PPW/2 + i - PPW/2 of K2
-      const int gk = kKS ? ((i < kH ? (kIL ? i * 4 + wave : wave * kH + i) : 2 * PPW + (kIL ? (i - kH) * 4 + wave : wave * kH + (i - kH))) * 64 + lane) : g;
+      const int gk = kKS ? ((i < kH ? wave * kH + i : 2 * PPW + wave * kH + (i - kH)) * 64 + lane) : g;
       const int kkey = gk / SPR;
       const int kslot = gk - kkey * SPR;
       const int ks = kslot ^ m16_k_swizzle<D>(kkey);
@@ -506,27 +423,25 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       if (ks >= slots_valid) krel[i] = kDmaOob;
     }
     // this wave's pieces land at base + i KiB: one scalar base per tile image, the piece index is an immediate of the DMA asm
-    k_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(uintptr_t)Kt + (uint32_t)(wave * (kIL ? 1 : (kKS ? kH : PPW)) * 1024)));
-    v_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(uintptr_t)Vt + (uint32_t)(wave * (kIL ? 1 : PPW) * 1024)));
+    k_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(uintptr_t)Kt + (uint32_t)(wave * (kKS ? kH : PPW) * 1024)));
+    v_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(uintptr_t)Vt + (uint32_t)(wave * PPW * 1024)));
   }
   auto issue_k = [&](auto ic, int key0) {
     constexpr int i = decltype(ic)::value;
     const TileSrc ts = tile_src<BC>(Kg, k_row_bytes, key0, a.Nkv, rb_valid);
     if constexpr (kRowDma) {
-      if constexpr (FFPA_M16_ROW_TABLES != 0) lds_dma_row<(16 * (i >> 2) + (i & 3)) * RB, 0>(ts.rsrc, k_lds, kvo[i & 3], kro[i]);
-      else lds_dma_row_at<(16 * (i >> 2) + (i & 3)) * RB, 16 * (i >> 2) + (i & 3)>(ts.rsrc, k_lds, kvo[i & 3], k_row_bytes, k_wave_off);
+      lds_dma_row<(16 * (i >> 2) + (i & 3)) * RB, 0>(ts.rsrc, k_lds, kvo[i & 3], kro[i]);
     } else {
-      lds_dma_16_at<(kKS && i >= kH ? 2 * PPW + (i - kH) * kPStride : i * kPStride) * 1024>(ts.rsrc, k_lds, krel[i], 0u);
+      lds_dma_16_at<(kKS && i >= kH ? 2 * PPW + (i - kH) : i) * 1024>(ts.rsrc, k_lds, krel[i], 0u);
     }
   };
   auto issue_v = [&](auto ic, int key0) {
     constexpr int i = decltype(ic)::value;
     const TileSrc ts = tile_src<BC>(Vg, v_row_bytes, key0, a.Nkv, rb_valid);
     if constexpr (kRowDma) {
-      if constexpr (FFPA_M16_ROW_TABLES != 0) lds_dma_row<(16 * (i >> 2) + (i & 3)) * RB, 0>(ts.rsrc, v_lds, vvo[i & 3], vro[i]);
-      else lds_dma_row_at<(16 * (i >> 2) + (i & 3)) * RB, 16 * (i >> 2) + (i & 3)>(ts.rsrc, v_lds, vvo[i & 3], v_row_bytes, v_wave_off);
+      lds_dma_row<(16 * (i >> 2) + (i & 3)) * RB, 0>(ts.rsrc, v_lds, vvo[i & 3], vro[i]);
     } else {
-      lds_dma_16_at<i * kPStride * 1024>(ts.rsrc, v_lds, vrel[i], 0u);
+      lds_dma_16_at<i * 1024>(ts.rsrc, v_lds, vrel[i], 0u);
     }
   };
 
@@ -536,12 +451,12 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   auto issue_k_on = [&](auto ic, int key0, auto kindc, f32x4& d, v8 fa, v8 fb) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
     const TileSrc ts = tile_src<BC>(Kg, k_row_bytes, key0, a.Nkv, rb_valid);
-    M::template with_dma<decltype(kindc)::value, (kKS && i >= kH ? 2 * PPW + (i - kH) * kPStride : i * kPStride) * 1024>(d, fa, fb, ts.rsrc, k_lds, krel[kRowDma ? 0 : i], 0u);
+    M::template with_dma<decltype(kindc)::value, (kKS && i >= kH ? 2 * PPW + (i - kH) : i) * 1024>(d, fa, fb, ts.rsrc, k_lds, krel[kRowDma ? 0 : i], 0u);
   };
   auto issue_v_on = [&](auto ic, int key0, auto kindc, f32x4& d, v8 fa, v8 fb) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
     const TileSrc ts = tile_src<BC>(Vg, v_row_bytes, key0, a.Nkv, rb_valid);
-    M::template with_dma<decltype(kindc)::value, i * kPStride * 1024>(d, fa, fb, ts.rsrc, v_lds, vrel[kRowDma ? 0 : i], 0u);
+    M::template with_dma<decltype(kindc)::value, i * 1024>(d, fa, fb, ts.rsrc, v_lds, vrel[kRowDma ? 0 : i], 0u);
   };
 
   // ---- L2 prefetch (FwdArgs::l2_prefetch, set by the launch side for streams that come from HBM): the tile two steps ahead is touched —
@@ -559,10 +474,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   constexpr int kPfSlices = BC / kPfKeys > 0 ? BC / kPfKeys : 1;
   // (built into the split-D tiles only: at D <= 512 a DMA piece has a whole step to land, the touches cost 1 ... 2 %, and the dropout +
   // bias builds there have no register to spare)
-#ifndef FFPA_M16_PF_ALL_D
-#define FFPA_M16_PF_ALL_D 0  // (experiment) 1: the D <= 512 builds carry the touches as well (FFPA_FLAG_L2_PREFETCH turns them on)
-#endif
-  constexpr bool kPf = ND == 2 || FFPA_M16_PF_ALL_D != 0;
+  constexpr bool kPf = ND == 2;
   const bool pf_on = kPf && a.l2_prefetch != 0 && wave < FFPA_M16_PF_WAVES && ((FFPA_M16_PF_WHICH >> (wave & 1)) & 1);
   const bool pf_k = (wave & 1) == 0;  // even waves touch K, odd waves V
   uint32_t pf_off = kDmaOob;
@@ -570,14 +482,11 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   if (pf_on) {
     constexpr int kPer = FFPA_M16_PF_WAVES / 2;  // slices one workgroup touches per step
     constexpr int kGroups = kPfSlices / kPer > 0 ? kPfSlices / kPer : 1;
-#ifndef FFPA_M16_PF_SLICE_BY_XCD_SEQ
-#define FFPA_M16_PF_SLICE_BY_XCD_SEQ 1
-#endif
     // which slice: by the workgroup's sequence number ON ITS XCD (the hardware deals workgroup ids round-robin to the 8 XCDs: id >> 3) — the ~32
     // workgroups resident on an XCD have consecutive numbers, so together they touch every slice of the tile in that XCD's L2.  (Round 3 used
     // (row tile + head) mod slices: with two XCDs per head — config 3 — an XCD holds only the even or only the odd row tiles of a head, i.e. four
     // of the eight slices: half of every tile's lines were never touched in its L2.)
-    const int slice_seq = FFPA_M16_PF_SLICE_BY_XCD_SEQ ? (int)(blockIdx.x >> 3) : qt + hq;
+    const int slice_seq = (int)(blockIdx.x >> 3);
     const int slice = ((slice_seq % kGroups) * kPer + (wave >> 1)) % kPfSlices;
     const uint32_t key = (uint32_t)(slice * kPfKeys + lane / kPfLinesP2), line = (uint32_t)(lane % kPfLinesP2);
     if (line * 128u < rb_valid && key < (uint32_t)BC) pf_off = key * (pf_k ? k_row_bytes : v_row_bytes) + line * 128u;
@@ -633,15 +542,6 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     }
   }
 
-#ifndef FFPA_M16_K_FIRST
-#define FFPA_M16_K_FIRST 0  // (experiment) 1: the first K tile's DMA pieces are issued ahead of the Q fragment loads
-#endif
-#ifdef FFPA_PRODUCT_BUILD
-  static_assert(FFPA_M16_K_FIRST == 0, "FFPA_PRODUCT_BUILD: a developer switch is not at its shipped default");
-#endif
-  if constexpr (FFPA_M16_K_FIRST != 0) {
-    if (nt > t0) static_for<PPW>([&](auto ic) { issue_k(ic, t0 * BC); });
-  }
   // ---- Q fragments (B operand of S^T): lane (n, c) holds Q[row 16 rh + n][32 s + 8 c .. + 8]
   v8 qf[KS][2];
 #pragma unroll
@@ -782,7 +682,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     }
   }
   if (nt > t0) {
-    if constexpr (FFPA_M16_K_FIRST == 0) static_for<PPW>([&](auto ic) { issue_k(ic, t0 * BC); });
+    static_for<PPW>([&](auto ic) { issue_k(ic, t0 * BC); });
     if constexpr (MK == 1) {
       const u32x4 brs = bias_rsrc();
       static_for<kBtMax>([&](auto ic) {
@@ -793,17 +693,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     __syncthreads();
   }
 
-  auto dephase = [&](auto bitc) __attribute__((always_inline)) {
-    if constexpr (FFPA_M16_DEPHASE > 0 && ((FFPA_M16_DEPHASE_AT >> decltype(bitc)::value) & 1) && ((FFPA_M16_DEPHASE_ND >> (ND - 1)) & 1)) {
-      __builtin_amdgcn_sched_barrier(0);
-      if (wave >= 1) static_for<FFPA_M16_DEPHASE>([&](auto) { asm volatile("s_nop 15"); });
-      if (wave >= 2) static_for<FFPA_M16_DEPHASE>([&](auto) { asm volatile("s_nop 15"); });
-      if (wave >= 3) static_for<FFPA_M16_DEPHASE>([&](auto) { asm volatile("s_nop 15"); });
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
 #ifdef FFPA_M16_TIMING
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (6, 7: two-half K schedule — QK^T key block 0, wait at barrier M)
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = __builtin_amdgcn_s_memtime();
   const unsigned long long tstart = tprev;
 #endif
@@ -1027,7 +918,6 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
           constexpr int lo = (g * 32 + 2 * KS - 1) / (2 * KS), hi = ((g + 1) * 32 + 2 * KS - 1) / (2 * KS);
           static_for<hi - lo>([&](auto uc) { softmax_gap(std::integral_constant<int, lo + decltype(uc)::value>{}); });
         };
-        if constexpr (FFPA_M16_PP_SMPOS == 2) static_for<2 * KS>([&](auto gc) { softmax_gaps(gc); });
         static_for<KS>([&](auto sc) {
           constexpr int s_ = decltype(sc)::value;
           __builtin_amdgcn_sched_barrier(0);
@@ -1045,16 +935,15 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
               else issue_k(std::integral_constant<int, kH + (t - ppVS)>{}, k0 + BC);        // K2(j+1), first part
             }
           }
-          constexpr int kSmPos = FFPA_M16_PP_SMPOS < 0 ? ((KS < 16 || MK == 2) ? 1 : 0) : FFPA_M16_PP_SMPOS;  // (the mask build's softmax carries a branch — the mask read: behind the MFMAs at every head dim)
-          if constexpr (kSmPos == 0) softmax_gaps(std::integral_constant<int, 2 * s_>{});
-          else if constexpr (kSmPos >= 4 && (2 * s_) % kSmPos == 0) static_for<kSmPos>([&](auto uc) { if constexpr (2 * s_ + decltype(uc)::value < 2 * KS) softmax_gaps(std::integral_constant<int, 2 * s_ + decltype(uc)::value>{}); });
+          constexpr bool kPerGap = KS >= 16 && MK != 2;  // one group per MFMA gap at D = 1024, all behind the phase's MFMAs elsewhere (see the header of the pipeline)
+          if constexpr (kPerGap) softmax_gaps(std::integral_constant<int, 2 * s_>{});
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (s_ == 0) M::first(s0[1], kf[s_], qf[s_][1]);
           else if constexpr (s_ == KS - 1) M::acc_last(s0[1], s0[0], kf[s_], qf[s_][1]);
           else M::acc(s0[1], kf[s_], qf[s_][1]);
-          if constexpr (kSmPos == 0) softmax_gaps(std::integral_constant<int, 2 * s_ + 1>{});
+          if constexpr (kPerGap) softmax_gaps(std::integral_constant<int, 2 * s_ + 1>{});
         });
-        if constexpr (FFPA_M16_PP_SMPOS == 1 || (FFPA_M16_PP_SMPOS < 0 && (KS < 16 || MK == 2))) static_for<2 * KS>([&](auto gc) { softmax_gaps(gc); });
+        if constexpr (KS < 16 || MK == 2) static_for<2 * KS>([&](auto gc) { softmax_gaps(gc); });
         __builtin_amdgcn_sched_barrier(0);
         *(FFPA_LDS f32x4*)(xw + ((j + 1) & 1) * 2048) = s0[0];
         *(FFPA_LDS f32x4*)(xw + ((j + 1) & 1) * 2048 + 1024) = s0[1];
@@ -1123,16 +1012,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         const int s = n / NKB, kb = n % NKB;
         return *(FFPA_LDS const v8*)(kaddr[kb / 4][s % KV] + (s / KV) * KVB + (kb % 4) * 16 * RB);
       };
-      // (two-half K schedule: fragment index n = kb KS + s — key block 0 over the wave's whole D-half, barrier M, key block 1)
-      auto k_frag_sk = [&](int s, int kb) -> v8 { return *(FFPA_LDS const v8*)(kaddr[kb / 4][s % KV] + (s / KV) * KVB + (kb % 4) * 16 * RB); };
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (kKS) {
 #pragma unroll
-        for (int n = 0; n < PF1 && n < KS; ++n) kf[n] = k_frag_sk(n, 0);
-      } else {
-#pragma unroll
-        for (int n = 0; n < PF1 && n < N1; ++n) kf[n] = k_frag(n);
-      }
+      for (int n = 0; n < PF1 && n < N1; ++n) kf[n] = k_frag(n);
       __builtin_amdgcn_sched_barrier(0);  // (the first K fragments are on their way while the bias tile below is read and converted)
       if constexpr (kBias) {
         // the accumulators start from bias / softmax_scale (zeros where there is no bias): see the header
@@ -1227,63 +1109,22 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         if constexpr (NKB == 4) asm volatile("" : "+v"(sacc[2][0]), "+v"(sacc[2][1]), "+v"(sacc[3][0]), "+v"(sacc[3][1]));
         asm volatile("s_nop 1" : "+v"(sacc[0][0]), "+v"(sacc[0][1]), "+v"(sacc[1][0]), "+v"(sacc[1][1]));
       }
-      if constexpr (kKS) {
-        static_for<2>([&](auto kbc) {
-          constexpr int kb = decltype(kbc)::value;
-          if constexpr (kb == 1) {
-            // barrier M: every wave is done reading keys 0 .. 15 of K(j) — their rows may take K1(j+1) — and K2(j) (issued during step
-            // j - 1's softmax / PV phases) has landed everywhere
-            __builtin_amdgcn_sched_barrier(0);
-            FFPA_TSTAMP(6);  // QK^T, key block 0
-            if (pf_on) dma_wait_except<ksWaitM + 1>();
-            else dma_wait_except<ksWaitM>();
-            __syncthreads();
-            FFPA_TSTAMP(7);  // K2(j) drain + wait at barrier M
-#pragma unroll
-            for (int n = 0; n < PF1 && n < KS; ++n) kf[KS + n] = k_frag_sk(n, 1);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          static_for<KS>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            constexpr int n = kb * KS + s;
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (s + PF1 < KS) kf[n + PF1] = k_frag_sk(s + PF1, kb);
-            constexpr int t = m16_piece_at(s, KS, kb == 0 ? ksVA : ksVB + ksK1B, 0);
-            if constexpr (s == 0 && !kBias) M::first(sacc[kb][0], kf[n], qf[s][0]);
-            else M::acc(sacc[kb][0], kf[n], qf[s][0]);
-            if constexpr (t >= 0) {
-              if constexpr (kb == 0) issue_v(std::integral_constant<int, t>{}, k0);
-              else if constexpr (t < ksVB) issue_v(std::integral_constant<int, ksVA + t>{}, k0);
-              else issue_k(std::integral_constant<int, t - ksVB>{}, k0 + BC);
-            }
-            if constexpr (s == 0 && !kBias) M::first(sacc[kb][1], kf[n], qf[s][1]);
-            else M::acc(sacc[kb][1], kf[n], qf[s][1]);
-          });
-        });
-      } else
       static_for<N1>([&](auto ic) {
         constexpr int n = decltype(ic)::value;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (n + PF1 < N1) kf[n + PF1] = k_frag(n + PF1);
         constexpr int s = n / NKB, kb = n % NKB;
         constexpr bool kPiece = n % kStep1 == 0 && n / kStep1 < PPW;
-#ifndef FFPA_M16_DMA_POS
-#define FFPA_M16_DMA_POS 1  // where a DMA piece sits relative to the fragment's two MFMAs: 0 in front, 1 between (+ 0.4 ... 1.7 %), 2 behind
-#endif
-#ifdef FFPA_PRODUCT_BUILD
-        static_assert(FFPA_M16_DMA_POS == 1, "FFPA_PRODUCT_BUILD: a developer switch is not at its shipped default");
-#endif
-        if constexpr (kPiece && FFPA_M16_DMA_POS == 0) issue_v(std::integral_constant<int, n / kStep1>{}, k0);
-        if constexpr (kPiece && FFPA_M16_DMA_POS == 1 && kFuse) {
+        // (a DMA piece sits BETWEEN the fragment's two MFMAs: + 0.4 ... 1.7 % against in front of / behind them; fused with the first one where the build allows)
+        if constexpr (kPiece && kFuse) {
           issue_v_on(std::integral_constant<int, n / kStep1>{}, k0, std::integral_constant<int, (s == 0 && !kBias) ? 0 : 1>{}, sacc[kb][0], kf[n], qf[s][0]);
         } else {
           if constexpr (s == 0 && !kBias) M::first(sacc[kb][0], kf[n], qf[s][0]);
           else M::acc(sacc[kb][0], kf[n], qf[s][0]);
         }
-        if constexpr (kPiece && FFPA_M16_DMA_POS == 1 && !kFuse) issue_v(std::integral_constant<int, n / kStep1>{}, k0);
+        if constexpr (kPiece && !kFuse) issue_v(std::integral_constant<int, n / kStep1>{}, k0);
         if constexpr (s == 0 && !kBias) M::first(sacc[kb][1], kf[n], qf[s][1]);
         else M::acc(sacc[kb][1], kf[n], qf[s][1]);
-        if constexpr (kPiece && FFPA_M16_DMA_POS == 2) issue_v(std::integral_constant<int, n / kStep1>{}, k0);
       });
       // MFMA result -> VALU reader wait states (invisible to the compiler inside asm); every accumulator is named so that no read
       // of one can be scheduled ahead of the statement
@@ -1299,20 +1140,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 
     auto pre_k_group = [&](auto gc) __attribute__((always_inline)) {
       constexpr int g = decltype(gc)::value;
-      if constexpr (kKS) {
-        // group g of the ksNC pieces that go out between the softmax stages, in the order V(j) rest, K1(j+1), K2(j+1)
-        constexpr int lo = g * ksNC / 4, hi = (g + 1) * ksNC / 4;
-        if constexpr (hi > lo) {
-          __builtin_amdgcn_sched_barrier(0);
-          static_for<hi - lo>([&](auto ic) {
-            constexpr int t = lo + decltype(ic)::value;
-            if constexpr (t < ksVC) issue_v(std::integral_constant<int, ksVA + ksVB + t>{}, k0);
-            else if constexpr (t < ksVC + ksK1C) issue_k(std::integral_constant<int, ksK1B + (t - ksVC)>{}, k0 + BC);
-            else issue_k(std::integral_constant<int, kH + (t - ksVC - ksK1C)>{}, k0 + BC);
-          });
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      } else if constexpr (kPre >= 4) {
+      if constexpr (kPre >= 4) {
         __builtin_amdgcn_sched_barrier(0);
         static_for<kPre / 4>([&](auto ic) { issue_k(std::integral_constant<int, g * (kPre / 4) + decltype(ic)::value>{}, k0 + BC); });
         __builtin_amdgcn_sched_barrier(0);
@@ -1330,7 +1158,6 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     // barrier A1: every wave is done reading K(j) (ND == 2: and the partial S^T tiles are visible)
     __syncthreads();
     FFPA_TSTAMP(1);  // wait at barrier A1
-    dephase(std::integral_constant<int, 0>{});
     __builtin_amdgcn_sched_barrier(0);
     pre_k_group(std::integral_constant<int, 0>{});
 
@@ -1531,11 +1358,10 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       FFPA_TSTAMP(2);  // softmax + the K(j+1) pieces issued inside it
       // barrier A2: V(j) has landed on every wave (all but the kPre younger K pieces have retired)
-      dma_wait_except<kKS ? ksWaitA2 : kPre>();
+      dma_wait_except<kPre>();
       __syncthreads();
       FFPA_TSTAMP(3);  // V(j) drain + wait at barrier A2
-      dephase(std::integral_constant<int, 1>{});
-      // pieces of the next step's bias tile to stage (none when that step lies in the mask's neutral interior or past the last tile)
+        // pieces of the next step's bias tile to stage (none when that step lies in the mask's neutral interior or past the last tile)
       const int b_next = (MK == 1 && j + 1 < nt && !(k0 + BC >= free_lo && k0 + 2 * BC <= free_hi)) ? b_pieces : 0;
       const u32x4 brs = bias_rsrc();
       v8 vf[N2];
@@ -1552,17 +1378,13 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         constexpr int n = decltype(ic)::value;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (n + PF2 < N2) vf[n + PF2] = v_frag(n + PF2);
-        // (two-half K schedule: the ksND pieces of the PV loop — K1(j+1) rest first, then K2(j+1) rest — by m16_piece_at)
-        constexpr int tks = kKS ? m16_piece_at(n, N2, ksND, FFPA_M16_KS_PVSTEP) : -1;
-        constexpr bool kPiece = kKS ? tks >= 0 : (n % kStep2 == 0 && n / kStep2 + kPre < PPW);
-        constexpr int kIdx = !kKS ? n / kStep2 + kPre : (tks < 0 ? 0 : (tks < ksK1D ? ksK1B + ksK1C + tks : kH + ksK2C + (tks - ksK1D)));
+        constexpr bool kPiece = n % kStep2 == 0 && n / kStep2 + kPre < PPW;  // the K(j+1) pieces that did not go out between the softmax stages
+        constexpr int kIdx = n / kStep2 + kPre;
         constexpr int db = n % NDB, ks = n / NDB;
-        if constexpr (kPiece && FFPA_M16_DMA_POS == 0) issue_k(std::integral_constant<int, kIdx>{}, k0 + BC);
-        if constexpr (kPiece && FFPA_M16_DMA_POS == 1 && kFuse) issue_k_on(std::integral_constant<int, kIdx>{}, k0 + BC, std::integral_constant<int, 2>{}, oacc[db][0], vf[n], pf[ks][0]);
+        if constexpr (kPiece && kFuse) issue_k_on(std::integral_constant<int, kIdx>{}, k0 + BC, std::integral_constant<int, 2>{}, oacc[db][0], vf[n], pf[ks][0]);
         else M::acc_a(oacc[db][0], vf[n], pf[ks][0]);
-        if constexpr (kPiece && FFPA_M16_DMA_POS == 1 && !kFuse) issue_k(std::integral_constant<int, kIdx>{}, k0 + BC);
+        if constexpr (kPiece && !kFuse) issue_k(std::integral_constant<int, kIdx>{}, k0 + BC);
         M::acc_a(oacc[db][1], vf[n], pf[ks][1]);
-        if constexpr (kPiece && FFPA_M16_DMA_POS == 2) issue_k(std::integral_constant<int, kIdx>{}, k0 + BC);
         if constexpr (MK == 1) {
           // the bias tile of step j + 1 (this wave's rows, its private staging area) in the slots the K pieces leave free
           constexpr int kBStep = kStep2 >= 2 ? kStep2 : 2;
@@ -1586,22 +1408,18 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 
     FFPA_TSTAMP(4);  // PV loop
     // barrier B: every wave is done reading V(j); K(j+1) has landed and is visible
-    // (two-half K schedule: K1(j+1) must have landed, the K2(j+1) pieces behind it stay in flight until barrier M of the next step;
-    // the additive-bias build stages a run-time number of bias pieces among them and keeps the full drain)
-    constexpr int kWaitB = (kKS && MK != 1) ? ksWaitB : 0;
     if (pf_on) {  // (wave-uniform)
       issue_prefetch(k0 + FFPA_M16_PF_DIST * BC);
-      dma_wait_except<kWaitB + 1>();
+      dma_wait_except<1>();
     } else {
-      dma_wait_except<kWaitB>();
+      dma_wait_except<0>();
     }
     __syncthreads();
     FFPA_TSTAMP(5);  // K(j+1) drain + wait at barrier B
-    dephase(std::integral_constant<int, 2>{});
   }
 
-  if (pf_on || kKS) {  // the last touches land before their destination register is given to anything else (two-half K schedule: and the
-    dma_wait_all();    // zero-filled K2 pieces of the tile past the last one before the workgroup's LDS is)
+  if (pf_on || kPipe) {  // the last touches land before their destination register is given to anything else (pipelined loop: and the
+    dma_wait_all();      // zero-filled K pieces of the tile past the last one before the workgroup's LDS is)
     asm volatile("" : : "v"(pf_junk));
   }
   // ================= epilogue (prefill.cuh:1018-1093) =================

@@ -62,7 +62,7 @@ enum ffpa_bias_dtype {
 /* ffpa_fwd_params.flags */
 #define FFPA_FLAG_DEBUG_SAFE_PATH 0x1u /* test-only: register-staged K/V + scalar V gather  */
 #define FFPA_FLAG_NO_XCD_REMAP    0x2u /* bench-only: dispatch-order block mapping          */
-#define FFPA_FLAG_NO_PERSISTENT   0x4u /* bench-only (builds with FFPA_PERSISTENT): one workgroup per id */
+/* (0x4u: retired — it belonged to the persistent-workgroup experiment, tools/experiments/r05_pruned_switches.diff) */
 #define FFPA_FLAG_NO_BIAS_LDS     0x8u /* bench-only: read a key bias from global memory in every tile   */
 #define FFPA_FLAG_L2_PREFETCH     0x10u /* bench-only: touch the K/V tile two steps ahead in every prefill launch (default: the launch side decides) */
 #define FFPA_FLAG_NO_L2_PREFETCH  0x20u /* bench-only: never                                           */
