@@ -33,8 +33,14 @@
 //     and share K/V through that XCD's L2.
 //
 // ffpa_fwd_m16_kernel.h holds a second mapping of the same tiles and pipeline onto the 16x16x32 MFMA shape (it sustains a higher
-// power-capped rate on this chip): unmasked, boolean-mask and dropout launches at head dims >= 320 run there; this file's kernel
-// serves the smaller head dims, additive biases, the short-query / decode tiles and the test-only register-staged twins.
+// power-capped rate on this chip): EVERY prefill launch at head dims >= 128 runs there (ffpa_fwd_m16w_kernel.h: its wide-row tile for D = 320).
+// What this file's kernel still serves, and why its prefill tiles (ND = 1 / 2) stay:
+//   * the short-query / decode tiles of every head dim (ND = 4 / 2, KV axis split over workgroups), the split-KV merge and the mask-range scan;
+//   * the PRODUCT prefill launches of D = 64 only — measured: the 16x16x32 mapping is 5 % slower there (899 vs 855 TFLOPS, profiles/r03_m16_small_d.txt:
+//     a 64-wide head dim is two contraction steps of the 16x16x32 shape, its fragment sharing has nothing to amortise);
+//   * the TEST-ONLY register-staged twins (SAFE = true; libffpa_attn_hip_test.so, D = 64 / 128 / 320 / 512 / 640 / 1024): the same recurrence on
+//     another mapping of the matrix core and another data path (no LDS-DMA, no transpose reads) — what tests/test_m16_gpu.py bisects the
+//     product kernels against.  They are why the ND = 2 prefill tile and the 128-key tile are still here although no product launch reaches them.
 #pragma once
 
 #include <hip/hip_runtime.h>
