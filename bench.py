@@ -710,7 +710,8 @@ def main() -> None:
               "what": "the same step back to back after >= 150 ms of continuous load, one HIP event pair around the launches; outside the timed region"}
     if w["bound"] == "hbm":
       steady["gbps"] = round(algorithmic_bytes(w, global_B) / (ss_ms * 1e-3) / 1e9, 1)
-  plan = planned_kernel(w, q[:1], k[:1], v[:1], mask, scale) if rank == 0 else {}
+  # (the whole local problem, not a slice of it: since round 5 the launch plan depends on how many workgroups a launch has — the wide-row tile of D = 320)
+  plan = planned_kernel(w, q, k, v, mask, scale) if rank == 0 else {}
 
   if rank == 0:
     build = build_identity()

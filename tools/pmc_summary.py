@@ -46,7 +46,7 @@ def trace_stats(src, kernel, warmup, steps=None):
 
 def main():
   argv = sys.argv[1:]
-  kernel = r"ffpa_fwd_(split_d|m16)_kernel"  # (regex) the prefill kernels: 32x32x16-MFMA build / 16x16x32-MFMA build
+  kernel = r"ffpa_fwd_(split_d|m16w?)_kernel"  # (regex) the prefill kernels: 32x32x16-MFMA build / 16x16x32-MFMA build (+ its wide-row tile)
   if "--kernel" in argv:
     i = argv.index("--kernel")
     kernel = argv[i + 1]
