@@ -155,7 +155,9 @@ constexpr int m16_block_keys(int D, bool bias_build) {
 // Bytes of the partial-S^T exchange area behind the two tile images of the split-D tiles (D > 512): 4 KiB per wave; 6 KiB in the builds without
 // an additive bias, whose softmax pipeline publishes key block 0 one step early into a double-buffered half (FFPA_M16_PIPE; reserved whether or
 // not the build is pipelined, so that the launch side needs to know the mask kind only).
-constexpr int m16_exchange_bytes(int D, bool bias_build) { return D > 512 ? (bias_build ? 4 * 4096 : 4 * 6144) : 0; }
+// + 5 KiB behind it in those builds since round 5: the two waves of a row block share the softmax by rows and trade P^T fragments (4 x 1 KiB) and
+// per-row scalars (4 x 256 B) instead of both running all of it.
+constexpr int m16_exchange_bytes(int D, bool bias_build) { return D > 512 ? (bias_build ? 4 * 4096 : 4 * 6144 + 4 * 1024 + 4 * 256) : 0; }
 
 // Which of `cnt` DMA pieces, if any, rides on fragment n of a loop of N fragments — piece t sits on
 // fragment t * step (step > 0: front-loaded) or floor(t N / cnt) (step == 0: spread evenly); -1 = none.
@@ -240,6 +242,16 @@ __device__ __forceinline__ void row4_reduce2(float& t0, float& t1) {
   t1 = __uint_as_float(s3[1]);
 }
 
+// one value per lane, reduced over the 4 lanes (n, n + 16, n + 32, n + 48) of a query row: two register swaps, in row4_reduce2's order
+// (lane ^ 32 first, then lane ^ 16: a row sum comes out in the same bits whichever of the two reduced it)
+template <bool IS_MAX>
+__device__ __forceinline__ void row4_reduce1(float& t) {
+  auto op = [](float x, float y) { return IS_MAX ? fmaxf(x, y) : x + y; };
+  const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+  const float v = op(__uint_as_float(s1[0]), __uint_as_float(s1[1]));
+  const auto s2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  t = op(__uint_as_float(s2[0]), __uint_as_float(s2[1]));
+}
 // LDS images of the K / V tiles: row-major [BC][D], 16-byte slot s of row `key` stored at slot s ^ swizzle(key) (applied on the
 // DMA's per-lane source offset).  K fragments are fetched by ds_read_b128 whose 16-lane groups hold 16 different keys and two
 // neighbouring slots; V^T fragments by ds_read_b64_tr_b16 whose 32-lane halves hold 8 keys x 32 bytes.  Row strides that are whole
@@ -708,6 +720,16 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     auto k_frag_sk = [&](int s_, int kb_) -> v8 { return *(FFPA_LDS const v8*)(kaddr[kb_ / 4][s_ % KV] + (s_ / KV) * KVB + (kb_ % 4) * 16 * RB); };
     FFPA_LDS char* const xw = Xb + wave * kXW + lane * 16;        // this wave's partials
     FFPA_LDS const char* const xr = Xb + (wave ^ 1) * kXW + lane * 16;  // the other D-half's
+    // the softmax shared by rows (see the S phase): P^T fragments [row block][row half][lane x 16 B] and per-row scalars [row block][row half][lane x 4 B]
+    FFPA_LDS char* const Pb = Xb + 4 * kXW;
+    FFPA_LDS char* const Ab = Pb + 4 * 1024;
+    FFPA_LDS char* const pxw = Pb + (qb * 2 + dh) * 1024 + lane * 16;
+    FFPA_LDS const char* const pxr = Pb + qb * 2048 + lane * 16;
+    FFPA_LDS char* const axw = Ab + (qb * 2 + dh) * 256 + lane * 4;
+    FFPA_LDS const char* const axr = Ab + qb * 512 + lane * 4;
+    const int qrow_own = wq0 + 16 * dh + n16;  // the row of this lane in the half whose softmax this wave runs
+    const int qrow_c_own = qrow_own < a.Nq ? qrow_own : a.Nq - 1;
+    float m_own = -INFINITY, l_own = 0.f;      // its running max (log2 domain) and this lane's share of its row sum
     if (nt > t0) {
       f32x4 s0[2];  // partial S^T of key block 0 of the first tile (this wave's D-half); in the loop it is contracted one step early
       // prologue: key block 0 of the first tile (K(t0) has landed and is visible: the barrier above)
@@ -781,22 +803,25 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       FFPA_TSTAMP(1);  // K1(j+1) drain + wait at barrier A1
 
       // ================= S: softmax of tile j in the gaps of S^T key block 0 of tile j + 1 =================
-      // (this wave's own block-0 partial of tile j comes back from LDS like the other D-half's: carried in registers across the step, hipcc
-      // keeps two sets and copies one into the other at the loop's end — a VALU read of an MFMA result placed inside its wait states)
+      // Round 5: the softmax is SHARED BY ROWS between the two waves of a row block.  Both hold the same 32 x 32 scores once the partials are summed, and
+      // until round 4 both ran the whole softmax on them (the price of splitting D over waves: twice the exponentials per FLOP).  Now wave (qb, dh) sums and
+      // exponentiates only row half dh (rows 16 dh .. + 16 of the block: 8 scores per lane instead of 16, two partner partials to read instead of four) and
+      // hands the other wave its P^T fragment — already in the PV MFMA's B-operand layout, 16 bytes per lane — and its rescale factor through LDS, next to
+      // barrier A2 which both need anyway.  Same sums in the same order per score and per row (a + b == b + a): bit-identical outputs.
+      // (this wave's own partials of tile j come back from LDS like the other D-half's: carried in registers across the step, hipcc keeps two sets and
+      // copies one into the other at the loop's end — a VALU read of an MFMA result placed inside its wait states)
       f32x4 s0[2];  // partial S^T of key block 0 of tile j + 1
-      float x[NKB][2][4];
-      float tmax[2] = {0.f, 0.f};
-      float m_use[2] = {0.f, 0.f}, psum[2] = {0.f, 0.f}, earg[2] = {0.f, 0.f};
-      v8 pf[NKS][2];
+      float x[NKB][4];
+      float tmax = 0.f, m_use = 0.f, psum = 0.f, alpha_own = 1.f, earg[2] = {0.f, 0.f};
+      v8 pf_own;
+      static_assert(NKS == 1, "one P^T fragment per row half and tile");
       {
-        f32x4 tp[NKB][2], xc[2];
+        f32x4 tp[NKB], xc[NKB];
         __builtin_amdgcn_sched_barrier(0);
-        xc[0] = *(FFPA_LDS const f32x4*)(xw + (j & 1) * 2048);
-        xc[1] = *(FFPA_LDS const f32x4*)(xw + (j & 1) * 2048 + 1024);
-        tp[0][0] = *(FFPA_LDS const f32x4*)(xr + (j & 1) * 2048);
-        tp[0][1] = *(FFPA_LDS const f32x4*)(xr + (j & 1) * 2048 + 1024);
-        tp[1][0] = *(FFPA_LDS const f32x4*)(xr + 4096);
-        tp[1][1] = *(FFPA_LDS const f32x4*)(xr + 4096 + 1024);
+        xc[0] = *(FFPA_LDS const f32x4*)(xw + (j & 1) * 2048 + dh * 1024);
+        xc[1] = *(FFPA_LDS const f32x4*)(xw + 4096 + dh * 1024);
+        tp[0] = *(FFPA_LDS const f32x4*)(xr + (j & 1) * 2048 + dh * 1024);
+        tp[1] = *(FFPA_LDS const f32x4*)(xr + 4096 + dh * 1024);
         v8 kf[KS];
 #pragma unroll
         for (int n = 0; n < PFS && n < KS; ++n) kf[n] = k_frag_sk(n, 0);
@@ -806,10 +831,10 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         // one group of the softmax's instructions per MFMA gap: g = 2 * fragment + (0: behind the first, 1: behind the second MFMA)
         auto softmax_gap = [&](auto gc) __attribute__((always_inline)) {
           constexpr int g = decltype(gc)::value;
-          if constexpr (g >= 3 && g <= 6) {  // + the other D-half's partial (a + b == b + a: both waves of a row block see bit-identical scores)
-            constexpr int kb = (g - 3) >> 1, rh = (g - 3) & 1;
+          if constexpr (g == 3 || g == 5) {  // + the other D-half's partial
+            constexpr int kb = (g - 3) >> 1;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x[kb][rh][r] = (kb == 0 ? xc[rh][r] : s1[rh][r]) + tp[kb][rh][r];
+            for (int r = 0; r < 4; ++r) x[kb][r] = xc[kb][r] + tp[kb][r];
           } else if constexpr (g == 7) {
             if constexpr (MK == 2) {
               // boolean mask bytes (non-zero = visible), straight from the caller's tensor, exactly as the loop below reads them; steps in the mask's
@@ -817,99 +842,72 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
               // pieces issued so far in this phase — only on the steps that read the mask.)
               const bool mask_free = k0 >= free_lo && k0 + BC <= free_hi;
               if (a.bias_dtype == 4 && !mask_free) {
-                const uint8_t* mp = (const uint8_t*)a.bias + b * a.sbias[0] + hq * a.sbias[1];
+                const uint8_t* mr = (const uint8_t*)a.bias + b * a.sbias[0] + hq * a.sbias[1] + (int64_t)qrow_c_own * a.sbias[2];
+                if (a.bias_vec == 16 && k0 + BC <= a.Nkv) {
+                  uint32_t raw[NKB];
 #pragma unroll
-                for (int rh = 0; rh < 2; ++rh) {
-                  const uint8_t* mr = mp + (int64_t)qrow_c[rh] * a.sbias[2];
-                  if (a.bias_vec == 16 && k0 + BC <= a.Nkv) {
-                    uint32_t raw[NKB];
+                  for (int kb = 0; kb < NKB; ++kb) raw[kb] = *(const uint32_t*)(mr + k0 + kb * 16 + 4 * c);
 #pragma unroll
-                    for (int kb = 0; kb < NKB; ++kb) raw[kb] = *(const uint32_t*)(mr + k0 + kb * 16 + 4 * c);
+                  for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-                    for (int kb = 0; kb < NKB; ++kb)
+                    for (int r = 0; r < 4; ++r)
+                      if (((raw[kb] >> (8 * r)) & 0xffu) == 0u) x[kb][r] = -INFINITY;
+                } else {
 #pragma unroll
-                      for (int r = 0; r < 4; ++r)
-                        if (((raw[kb] >> (8 * r)) & 0xffu) == 0u) x[kb][rh][r] = -INFINITY;
-                  } else {
+                  for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-                    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-                      for (int r = 0; r < 4; ++r) {
-                        int key = k0 + kb * 16 + 4 * c + r;
-                        key = key < a.Nkv ? key : a.Nkv - 1;
-                        if (mr[key * a.sbias[3]] == 0) x[kb][rh][r] = -INFINITY;
-                      }
-                  }
+                    for (int r = 0; r < 4; ++r) {
+                      int key = k0 + kb * 16 + 4 * c + r;
+                      key = key < a.Nkv ? key : a.Nkv - 1;
+                      if (mr[key * a.sbias[3]] == 0) x[kb][r] = -INFINITY;
+                    }
                 }
               }
             }
             if (tail || diag) {
+              const int crow = a.causal_row_mod ? qrow_own % a.causal_row_mod : qrow_own;
+              const int64_t lim = a.causal ? (int64_t)crow + a.causal_offset : (int64_t)a.Nkv;
 #pragma unroll
-              for (int rh = 0; rh < 2; ++rh) {
-                const int crow = a.causal_row_mod ? qrow[rh] % a.causal_row_mod : qrow[rh];
-                const int64_t lim = a.causal ? (int64_t)crow + a.causal_offset : (int64_t)a.Nkv;
+              for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-                for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-                  for (int r = 0; r < 4; ++r) {
-                    const int key = k0 + kb * 16 + 4 * c + r;
-                    if (key >= a.Nkv || key > lim) x[kb][rh][r] = -INFINITY;
-                  }
-              }
+                for (int r = 0; r < 4; ++r) {
+                  const int key = k0 + kb * 16 + 4 * c + r;
+                  if (key >= a.Nkv || key > lim) x[kb][r] = -INFINITY;
+                }
             }
-          } else if constexpr (g == 8 || g == 9) {  // row max, this lane's 8 keys of row half g - 8 (same order as the loop below)
-            constexpr int rh = g - 8;
-            float t = x[0][rh][0];
+          } else if constexpr (g == 8) {  // row max, this lane's 8 keys (same order as the loop below)
+            float t = x[0][0];
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-              for (int r = 0; r < 4; ++r) t = fmaxf(t, x[kb][rh][r]);
-            tmax[rh] = t;
+              for (int r = 0; r < 4; ++r) t = fmaxf(t, x[kb][r]);
+            tmax = t;
           } else if constexpr (g == 10) {
-            row4_reduce2<true>(tmax[0], tmax[1]);
-            tmax[0] *= a.scale_log2;
-            tmax[1] *= a.scale_log2;
+            row4_reduce1<true>(tmax);
+            tmax *= a.scale_log2;
           } else if constexpr (g == 12) {
-            const float m_new0 = fmaxf(m_run[0], tmax[0]), m_new1 = fmaxf(m_run[1], tmax[1]);
-            const bool grow0 = m_new0 > m_run[0] + a.thr, grow1 = m_new1 > m_run[1] + a.thr;
-            if (__any(grow0 || grow1)) {
-              const float alpha0 = grow0 ? __builtin_amdgcn_exp2f(m_run[0] - m_new0) : 1.f;
-              const float alpha1 = grow1 ? __builtin_amdgcn_exp2f(m_run[1] - m_new1) : 1.f;
-              if (j > t0) {
-#pragma unroll
-                for (int i = 0; i < NDB; ++i)
-#pragma unroll
-                  for (int rh = 0; rh < 2; ++rh) {
-                    f32x4 t = oacc[i][rh];
-                    asm volatile("" : "+a"(t));
-                    t *= (rh ? alpha1 : alpha0);
-                    asm volatile("" : "+a"(t));
-                    oacc[i][rh] = t;
-                    __builtin_amdgcn_sched_barrier(0);
-                  }
-              }
-              l_run[0] *= alpha0;
-              l_run[1] *= alpha1;
-              m_run[0] = grow0 ? m_new0 : m_run[0];
-              m_run[1] = grow1 ? m_new1 : m_run[1];
-            }
-            m_use[0] = (m_run[0] == -INFINITY) ? 0.f : m_run[0];
-            m_use[1] = (m_run[1] == -INFINITY) ? 0.f : m_run[1];
-          } else if constexpr (g >= 14 && g <= 29) {  // one exponential per gap, row half by row half in the loop's order (the row sum adds up in that order)
-            constexpr int i = g - 14, rh = i >> 3, kb = (i >> 2) & 1, r = i & 3;
+            // lazy rescale (threshold FwdArgs.thr): the factor goes to BOTH waves of the row block (each owns half of O^T's columns of these rows) next to
+            // the P^T fragment; O^T itself is scaled behind barrier A2, where the partner's factor is known too
+            const float m_new = fmaxf(m_own, tmax);
+            const bool grow = m_new > m_own + a.thr;
+            alpha_own = grow ? __builtin_amdgcn_exp2f(m_own - m_new) : 1.f;
+            l_own *= alpha_own;
+            m_own = grow ? m_new : m_own;
+            m_use = (m_own == -INFINITY) ? 0.f : m_own;
+          } else if constexpr (g >= 14 && g <= 28 && (g & 1) == 0) {  // one exponential every other gap, in the loop's order (the row sum adds up in that order)
+            constexpr int i = (g - 14) >> 1, kb = (i >> 2) & 1, r = i & 3;
             if constexpr ((r & 1) == 0) {  // (the pair's two exponents in one packed FMA: the same roundings)
               typedef __attribute__((ext_vector_type(2))) float f32x2;
-              const f32x2 xv = {x[kb][rh][r], x[kb][rh][r + 1]};
-              const f32x2 av = __builtin_elementwise_fma(xv, (f32x2)(a.scale_log2), (f32x2)(-m_use[rh]));
+              const f32x2 xv = {x[kb][r], x[kb][r + 1]};
+              const f32x2 av = __builtin_elementwise_fma(xv, (f32x2)(a.scale_log2), (f32x2)(-m_use));
               earg[0] = av[0];
               earg[1] = av[1];
             }
             const float pv = __builtin_amdgcn_exp2f(earg[r & 1]);
-            psum[rh] += pv;
-            pf[kb >> 1][rh][4 * (kb & 1) + r] = (T)pv;
+            psum += pv;
+            pf_own[4 * kb + r] = (T)pv;
           } else if constexpr (g == 30) {
-            l_run[0] += psum[0];
-            l_run[1] += psum[1];
+            l_own += psum;
           }
         };
         // the 32 groups are written for the 32 MFMA gaps of D = 1024; a smaller head dim has 2 KS < 32 gaps and takes several groups per gap
@@ -947,6 +945,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         *(FFPA_LDS f32x4*)(xw + ((j + 1) & 1) * 2048) = s0[0];
         *(FFPA_LDS f32x4*)(xw + ((j + 1) & 1) * 2048 + 1024) = s0[1];
+        // this wave's share of the softmax for the other D-half's wave (read behind barrier A2; the slot is free: its last readers passed barrier B)
+        *(FFPA_LDS v8*)(pxw) = pf_own;
+        *(FFPA_LDS float*)(axw) = alpha_own;
       }
 
       // ================= P: O^T += V^T.P^T =================
@@ -957,6 +958,11 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         dma_wait_except<ppWaitA2>();
         __syncthreads();
         FFPA_TSTAMP(3);  // V(j) drain + wait at barrier A2
+        // both row halves' P^T fragments and rescale factors (this wave's own come back from LDS too: no register selects on the wave's D-half index)
+        v8 pf[NKS][2];
+        pf[0][0] = *(FFPA_LDS const v8*)(pxr);
+        pf[0][1] = *(FFPA_LDS const v8*)(pxr + 1024);
+        const float alpha0 = *(FFPA_LDS const float*)(axr), alpha1 = *(FFPA_LDS const float*)(axr + 256);
         v8 vf[N2];
         auto v_frag = [&](int n) -> v8 {
           const int db = n % NDB, ks = n / NDB;
@@ -967,6 +973,20 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         };
 #pragma unroll
         for (int n = 0; n < PF2 && n < N2; ++n) vf[n] = v_frag(n);
+        if (j > t0 && __any(alpha0 != 1.f || alpha1 != 1.f)) {
+          // rare path: a row's max grew by more than the threshold — O^T (AGPRs) is scaled in place through one temporary VGPR tile
+#pragma unroll
+          for (int i = 0; i < NDB; ++i)
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh) {
+              f32x4 t = oacc[i][rh];
+              asm volatile("" : "+a"(t));
+              t *= (rh ? alpha1 : alpha0);
+              asm volatile("" : "+a"(t));
+              oacc[i][rh] = t;
+              __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         static_for<N2>([&](auto ic) {
           constexpr int n = decltype(ic)::value;
           __builtin_amdgcn_sched_barrier(0);
@@ -999,6 +1019,15 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       __syncthreads();
       FFPA_TSTAMP(5);  // K2(j+1) drain + wait at barrier B
     }
+    // the epilogue below wants both row halves' running max and this lane's share of both row sums: the other half's come from its owner (the
+    // exchange slots are free: their last readers passed barrier B of the last step)
+    *(FFPA_LDS float*)(axw) = m_own;
+    *(FFPA_LDS float*)(pxw) = l_own;
+    __syncthreads();
+    m_run[0] = *(FFPA_LDS const float*)(axr);
+    m_run[1] = *(FFPA_LDS const float*)(axr + 256);
+    l_run[0] = *(FFPA_LDS const float*)(pxr);
+    l_run[1] = *(FFPA_LDS const float*)(pxr + 1024);
   } else
   for (int j = t0; j < nt; ++j) {
     const int k0 = j * BC;

@@ -53,16 +53,6 @@ constexpr int m16w_lds_bytes(int D) { return 4 * m16w_block_keys(D) * D * 2; }
 #endif
 constexpr int m16w_row_halves(int D) { return 256 / (D / 4) > FFPA_M16W_MAX_RH ? FFPA_M16W_MAX_RH : 256 / (D / 4); }
 
-// one value per lane, reduced over the 4 lanes (n, n + 16, n + 32, n + 48) of a query row: two register swaps, in row4_reduce2's order
-// (lane ^ 32 first, then lane ^ 16: a row sum comes out in the same bits whichever of the two reduced it)
-template <bool IS_MAX>
-__device__ __forceinline__ void row4_reduce1(float& t) {
-  auto op = [](float x, float y) { return IS_MAX ? fmaxf(x, y) : x + y; };
-  const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
-  const float v = op(__uint_as_float(s1[0]), __uint_as_float(s1[1]));
-  const auto s2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  t = op(__uint_as_float(s2[0]), __uint_as_float(s2[1]));
-}
 template <bool IS_MAX, int RH>
 __device__ __forceinline__ void row4_reduce_n(float (&t)[RH]) {
 #pragma unroll

@@ -75,7 +75,10 @@ def test_prefill_builds_have_no_scratch_inside_their_mfma_loops(capsys, monkeypa
         n_ops = int(re.search(r"first\.\.last MFMA: scratch ops (\d+)", l).group(1))
         assert n_ops <= (2 if piped_mask else 0), l
         size = int(re.search(r"scratch\s+(\d+) B", l).group(1))
-        assert size == 0 or (" 2 b0" in l and size <= 128), l
+        # (the pipelined split-D builds of round 5 keep 12 bytes for their prologue / epilogue — the row-shared softmax's exchange addresses —: no access
+        # between the first and the last MFMA, checked above)
+        piped = int(re.match(r"D=\s*(\d+)", l).group(1)) > 512
+        assert size == 0 or ((" 2 b0" in l or piped) and size <= 128), l
   # the 32x32x16 prefill kernels that are left (D = 64): no spill code inside their MFMA loops either
   small = [l for l in _stats(monkeypatch, capsys, 64) if "bf16  64 1 b0 b0 b0" in l]
   assert len(small) == 3, small  # mask kinds 0 / 2 / 1

@@ -56,7 +56,11 @@ __device__ __forceinline__ void nops16() {
 
 // P0 / PS / P1: pieces per wave in the QK / softmax / PV phase (P0 + PS + P1 = 32 at D = 1024); NV: VALU instructions of the softmax
 // stand-in; DEPH: see the header; XCH: the partial-S exchange (4 ds_write_b128 + 4 ds_read_b128 per lane around barrier A1)
-template <int P0, int PS, int P1, int NV, int DEPH, bool XCH, bool TIMED, int RD = 1>
+// Round 5, ROWSPLIT: the "row-split QK^T" layout of the split-D tiles — a wave contracts ALL of D for ONE 16-row half of its row block (its K fragments feed
+// one MFMA each: 64 fragment reads in the QK phase instead of 32), runs the softmax of those 16 rows only (NV halves: nothing is computed twice) and hands the
+// other D-half's wave its P^T fragments (one ds_write_b128 + one ds_read_b128 per lane around barrier A2) instead of trading fp32 partial S^T tiles around A1.
+// ROWSPLIT 2: the same without barrier A1 (no exchange needs it any more; K(j+1) then has to wait for A2: its pieces ride on the PV MFMAs).
+template <int P0, int PS, int P1, int NV, int DEPH, bool XCH, bool TIMED, int RD = 1, int ROWSPLIT = 0>
 __global__ __launch_bounds__(256) void probe_tile(const Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -99,11 +103,13 @@ __global__ __launch_bounds__(256) void probe_tile(const Args a) {
     for (int f = 0; f < NF; ++f) {
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (RD == 1) fr[(f + PF) & 3] = frag_read((h * NF + f + PF) % (2 * NF));
+      bf16x8 fr2 = fr[f & 3];
+      if constexpr (ROWSPLIT != 0 && h == 0) fr2 = frag_read((h * NF + f + 17) % (2 * NF));  // the second MFMA of the pair has its own K fragment
       if constexpr (RD == 2) { if (f % 8 == 0) { for (int q = 0; q < 4; ++q) fr[q] = frag_read((h * NF + f + q) % (2 * NF)); } }  // reads in bursts of 4, none in flight at the pieces
       const int ai = (2 * (h * NF + f)) & (NACC - 1);
       acc[ai] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[f & 3], b0, acc[ai], 0, 0, 0);
       if (NPH > 0 && f % STEP == 0 && f / STEP < NPH) piece(first + f / STEP);  // between the pair (the kernel's FFPA_M16_DMA_POS 1)
-      acc[ai + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[f & 3], b1, acc[ai + 1], 0, 0, 0);
+      acc[ai + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr2, b1, acc[ai + 1], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -139,16 +145,18 @@ __global__ __launch_bounds__(256) void probe_tile(const Args a) {
   for (int t = 0; t < a.tiles; ++t) {
     dephase();
     mfma_phase(std::integral_constant<int, 0>{}, std::integral_constant<int, P0>{}, std::integral_constant<int, 0>{});
-    if constexpr (XCH) {
+    if constexpr (XCH && ROWSPLIT == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) *(LDSAS f32x4*)(xw + i * 1024) = acc[i];
     }
     stamp(0);
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-    __builtin_amdgcn_s_barrier();        // A1
+    if constexpr (ROWSPLIT != 2) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+      __builtin_amdgcn_s_barrier();        // A1
+    }
     stamp(1);
     dephase();
-    if constexpr (XCH) {
+    if constexpr (XCH && ROWSPLIT == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const f32x4 x = *(LDSAS const f32x4*)(xr + i * 1024);
@@ -164,6 +172,11 @@ __global__ __launch_bounds__(256) void probe_tile(const Args a) {
       }
       valu_stage();
     }
+    if constexpr (ROWSPLIT != 0) {  // this wave's P^T fragments for the other D-half's wave
+      const u32x4 pw = {__float_as_uint(vs[0]), __float_as_uint(vs[1]), __float_as_uint(vs[2]), __float_as_uint(vs[3])};
+      *(LDSAS u32x4*)xw = pw;
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
     stamp(2);
     {  // the V pieces (older than the K pieces issued above) have landed: vmcnt(PS)
       constexpr int W = PS > 63 ? 63 : PS;
@@ -172,6 +185,10 @@ __global__ __launch_bounds__(256) void probe_tile(const Args a) {
     __builtin_amdgcn_s_barrier();  // A2
     stamp(3);
     dephase();
+    if constexpr (ROWSPLIT != 0) {
+      const u32x4 pr = *(LDSAS const u32x4*)xr;
+      vs[4] += __uint_as_float(pr[0]) + __uint_as_float(pr[3]);
+    }
     mfma_phase(std::integral_constant<int, 1>{}, std::integral_constant<int, P1>{}, std::integral_constant<int, P0 + PS>{});
     stamp(4);
     __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -192,13 +209,13 @@ __global__ __launch_bounds__(256) void probe_tile(const Args a) {
   }
 }
 
-template <int P0, int PS, int P1, int NV, int DEPH, bool XCH = true, int RD = 1>
+template <int P0, int PS, int P1, int NV, int DEPH, bool XCH = true, int RD = 1, int ROWSPLIT = 0>
 static void run_tile(const char* name, Args a, int tiles) {
   const int lds = 144 * 1024;
   a.tiles = tiles;
   float ms = 0;
   {
-    auto k = probe_tile<P0, PS, P1, NV, DEPH, XCH, false, RD>;
+    auto k = probe_tile<P0, PS, P1, NV, DEPH, XCH, false, RD, ROWSPLIT>;
     CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(k, dim3(256), dim3(256), lds, 0, a);
     CHECK(hipDeviceSynchronize());
@@ -214,7 +231,7 @@ static void run_tile(const char* name, Args a, int tiles) {
   }
   double ph[6] = {0, 0, 0, 0, 0, 0};
   {
-    auto k = probe_tile<P0, PS, P1, NV, DEPH, XCH, true, RD>;
+    auto k = probe_tile<P0, PS, P1, NV, DEPH, XCH, true, RD, ROWSPLIT>;
     CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(k, dim3(256), dim3(256), lds, 0, a);
     CHECK(hipDeviceSynchronize());
@@ -263,6 +280,18 @@ int main(int argc, char** argv) {
   CHECK(hipMalloc(&a.sink, 64));
   CHECK(hipMalloc(&a.ticks, 256 * 4 * 6 * 8));
   const int T = argc > 1 ? atoi(argv[1]) : 4096;
+  if (argc > 2 && atoi(argv[2]) == 5) {  // round 5: the row-split QK^T layout against the shipped one
+    for (int rep = 0; rep < 3; ++rep) {
+      run_tile<16, 16, 0, 160, 0>("shipped layout: 16 / 16 / 0, 160 VALU, S exchange", a, T);
+      run_tile<16, 16, 0, 80, 0, true, 1, 1>("row-split: 16 / 16 / 0, 80 VALU, P exchange", a, T);
+      run_tile<16, 8, 8, 80, 0, true, 1, 1>("row-split: 16 / 8 / 8", a, T);
+      run_tile<16, 0, 16, 80, 0, true, 1, 2>("row-split, no barrier A1: 16 / 0 / 16", a, T);
+      run_tile<8, 0, 24, 80, 0, true, 1, 2>("row-split, no barrier A1: 8 / 0 / 24", a, T);
+      run_tile<16, 16, 0, 160, 0, true, 1, 1>("row-split reads only (160 VALU kept)", a, T);
+      run_tile<16, 16, 0, 80, 0>("shipped layout with 80 VALU (what halving the softmax alone buys)", a, T);
+    }
+    return 0;
+  }
   for (int rep = 0; rep < 2; ++rep) {
     // the shipped placement: V(j) under QK^T, K(j+1) between the softmax stages, nothing under PV
     run_tile<16, 16, 0, 160, 0>("shipped: 16 / 16 / 0", a, T);
