@@ -1028,7 +1028,25 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     m_run[1] = *(FFPA_LDS const float*)(axr + 256);
     l_run[0] = *(FFPA_LDS const float*)(pxr);
     l_run[1] = *(FFPA_LDS const float*)(pxr + 1024);
-  } else
+  } else {
+  // The DROPOUT builds of the split-D tiles (ND == 2) share the softmax BY ROWS between the two waves of a row block, as the pipelined loop above does: both hold
+  // the same 32 x BC scores once the partials are summed; wave (qb, dh) exponentiates — and draws the Philox bits of — row half dh only and trades its P^T fragment
+  // and rescale factor through LDS around barrier A2, in the slots of its own partial-S area that nobody else reads.  Measured (profiles/r05_row_shared_softmax.txt):
+  // dropout at D = 1024 + 14 % (the Philox rounds halve); WITHOUT dropout the extra LDS round trip in front of the PV loop costs this un-pipelined loop more than
+  // half a softmax returns (key bias - 1 %, bias tiles - 2 %, D = 576 ... 960 - 2.5 ... - 8.6 %): those builds keep the softmax in both waves.
+  // RHS = row halves whose softmax this wave runs; when shared, entry 0 of the per-row-half arrays below is THE OWN half (dh), and m_run / l_run hold its state in
+  // entry 0 until the exchange behind the loop.
+  constexpr bool kRowShare = ND == 2 && DROP;
+  constexpr int RHS = kRowShare ? 1 : 2;
+  int qrow_s[RHS], qrow_cs[RHS];
+#pragma unroll
+  for (int rh = 0; rh < RHS; ++rh) {
+    qrow_s[rh] = kRowShare ? wq0 + 16 * dh + n16 : qrow[rh];
+    qrow_cs[rh] = qrow_s[rh] < a.Nq ? qrow_s[rh] : a.Nq - 1;
+  }
+  FFPA_LDS char* const xw_nd2 = Xb + wave * 4096 + lane * 16;                 // this wave's partial-S area: slot (kb, rh) at + (2 kb + rh) KiB
+  FFPA_LDS const char* const xr_nd2 = Xb + (wave ^ 1) * 4096 + lane * 16;     // the other D-half's
+  FFPA_LDS const char* const xb_nd2 = Xb + (qb * 2) * 4096 + lane * 16;       // the row block's two areas (wave dh = 0 first)
   for (int j = t0; j < nt; ++j) {
     const int k0 = j * BC;
 
@@ -1177,11 +1195,10 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     };
 
     if constexpr (ND == 2) {  // publish this wave's partial S^T (lane-linear, conflict free)
-      FFPA_LDS char* xw = Xb + wave * 4096 + lane * 16;
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-        for (int rh = 0; rh < 2; ++rh) *(FFPA_LDS f32x4*)(xw + (kb * 2 + rh) * 1024) = sacc[kb][rh];
+        for (int rh = 0; rh < 2; ++rh) *(FFPA_LDS f32x4*)(xw_nd2 + (kb * 2 + rh) * 1024) = sacc[kb][rh];
     }
     FFPA_TSTAMP(0);  // QK^T loop (+ ND == 2: partial S^T stores)
     // barrier A1: every wave is done reading K(j) (ND == 2: and the partial S^T tiles are visible)
@@ -1194,24 +1211,34 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     // is folded into the exponent's FMA (p = exp2(x sc - m): one instruction instead of a multiply here and a subtract there, 32 VALU
     // instructions per tile less) and applied to the row max after its reduction — max(x sc) = sc max(x) for sc > 0, and the kernel only
     // ever sees sc > 0: the launch side turns a negative scale into (-Q, |sc|) and a zero scale into (Q = 0, 1) (FwdArgs.q_mode).
-    float x[NKB][2][4];
+    float x[NKB][RHS][4];
+    if constexpr (kRowShare) {
+      // the own row half: this wave's partial (back from LDS: no register select on dh) + the other D-half's (a + b == b + a: whichever wave owns a row sees
+      // the scores both waves computed until round 4)
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
+      for (int kb = 0; kb < NKB; ++kb) {
+        const f32x4 own = *(FFPA_LDS const f32x4*)(xw_nd2 + (kb * 2 + dh) * 1024);
+        const f32x4 t = *(FFPA_LDS const f32x4*)(xr_nd2 + (kb * 2 + dh) * 1024);
 #pragma unroll
-      for (int rh = 0; rh < 2; ++rh)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x[kb][rh][r] = sacc[kb][rh][r];
-    if constexpr (ND == 2) {
+        for (int r = 0; r < 4; ++r) x[kb][0][r] = own[r] + t[r];
+      }
+    } else if constexpr (ND == 2) {
       // + the other D-half's partial (a + b == b + a: both waves of a row block see bit-identical scores, so their softmax states agree)
-      FFPA_LDS const char* xr = Xb + (wave ^ 1) * 4096 + lane * 16;
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int rh = 0; rh < 2; ++rh) {
-          const f32x4 t = *(FFPA_LDS const f32x4*)(xr + (kb * 2 + rh) * 1024);
+          const f32x4 t = *(FFPA_LDS const f32x4*)(xr_nd2 + (kb * 2 + rh) * 1024);
 #pragma unroll
           for (int r = 0; r < 4; ++r) x[kb][rh][r] = sacc[kb][rh][r] + t[r];
         }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[kb][rh][r] = sacc[kb][rh][r];
     }
     pre_k_group(std::integral_constant<int, 1>{});
 
@@ -1221,8 +1248,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       if (a.bias_dtype == 4 && !mask_free) {
         const uint8_t* mp = (const uint8_t*)a.bias + b * a.sbias[0] + hq * a.sbias[1];
 #pragma unroll
-        for (int rh = 0; rh < 2; ++rh) {
-          const uint8_t* mr = mp + (int64_t)qrow_c[rh] * a.sbias[2];
+        for (int rh = 0; rh < RHS; ++rh) {
+          const uint8_t* mr = mp + (int64_t)qrow_cs[rh] * a.sbias[2];
           if (a.bias_vec == 16 && k0 + BC <= a.Nkv) {
             uint32_t raw[NKB];
 #pragma unroll
@@ -1249,8 +1276,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     const bool diag = a.causal && ((int64_t)k0 + BC - 1 > (int64_t)(a.causal_row_mod ? 0 : wq0) + a.causal_offset);
     if (tail || diag) {
 #pragma unroll
-      for (int rh = 0; rh < 2; ++rh) {
-        const int crow = a.causal_row_mod ? qrow[rh] % a.causal_row_mod : qrow[rh];
+      for (int rh = 0; rh < RHS; ++rh) {
+        const int crow = a.causal_row_mod ? qrow_s[rh] % a.causal_row_mod : qrow_s[rh];
         const int64_t lim = a.causal ? (int64_t)crow + a.causal_offset : (int64_t)a.Nkv;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
@@ -1263,9 +1290,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     }
 
     // ================= online softmax (prefill.cuh:671-870, log2 domain) =================
-    float tmax[2];
+    float tmax[RHS];
 #pragma unroll
-    for (int rh = 0; rh < 2; ++rh) {
+    for (int rh = 0; rh < RHS; ++rh) {
       float t = x[0][rh][0];
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb)
@@ -1273,15 +1300,24 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         for (int r = 0; r < 4; ++r) t = fmaxf(t, x[kb][rh][r]);
       tmax[rh] = t;
     }
-    row4_reduce2<true>(tmax[0], tmax[1]);
-    tmax[0] *= a.scale_log2;  // (exact: rounding is monotonic, fl(sc max x) = max fl(sc x) for sc > 0; -inf stays -inf)
-    tmax[1] *= a.scale_log2;
+    if constexpr (RHS == 2) row4_reduce2<true>(tmax[0], tmax[1]);
+    else row4_reduce1<true>(tmax[0]);
+#pragma unroll
+    for (int rh = 0; rh < RHS; ++rh) tmax[rh] *= a.scale_log2;  // (exact: rounding is monotonic, fl(sc max x) = max fl(sc x) for sc > 0; -inf stays -inf)
     pre_k_group(std::integral_constant<int, 2>{});
-    const float m_new0 = fmaxf(m_run[0], tmax[0]), m_new1 = fmaxf(m_run[1], tmax[1]);
-    const bool grow0 = m_new0 > m_run[0] + a.thr, grow1 = m_new1 > m_run[1] + a.thr;
-    if (__any(grow0 || grow1)) {
+    float alpha_own = 1.f;  // shared softmax: the own half's rescale factor of this step (1 = none), traded next to the P^T fragment
+    if constexpr (kRowShare) {
+      const float m_new = fmaxf(m_run[0], tmax[0]);
+      const bool grow = m_new > m_run[0] + a.thr;
+      alpha_own = grow ? __builtin_amdgcn_exp2f(m_run[0] - m_new) : 1.f;
+      l_run[0] *= alpha_own;
+      m_run[0] = grow ? m_new : m_run[0];
+    }
+    const float m_new0 = fmaxf(m_run[0], tmax[0]), m_new1 = fmaxf(m_run[RHS - 1], tmax[RHS - 1]);
+    const bool grow0 = !kRowShare && m_new0 > m_run[0] + a.thr, grow1 = !kRowShare && m_new1 > m_run[RHS - 1] + a.thr;
+    if (!kRowShare && __any(grow0 || grow1)) {
       const float alpha0 = grow0 ? __builtin_amdgcn_exp2f(m_run[0] - m_new0) : 1.f;
-      const float alpha1 = grow1 ? __builtin_amdgcn_exp2f(m_run[1] - m_new1) : 1.f;
+      const float alpha1 = grow1 ? __builtin_amdgcn_exp2f(m_run[RHS - 1] - m_new1) : 1.f;
       if (j > t0) {
         // rare path: O^T lives in AGPRs; scale in place through one temporary VGPR (see ffpa_fwd_kernel.h)
 #pragma unroll
@@ -1297,43 +1333,43 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
           }
       }
       l_run[0] *= alpha0;
-      l_run[1] *= alpha1;
+      l_run[RHS - 1] *= alpha1;
       m_run[0] = grow0 ? m_new0 : m_run[0];
-      m_run[1] = grow1 ? m_new1 : m_run[1];
+      m_run[RHS - 1] = grow1 ? m_new1 : m_run[RHS - 1];
     }
 
     // dropout keep bits of this step (bit 4 kb + r of keep_bits[rh][.] <-> key 16 kb + 4 c + r), drawn BEFORE the exponentials: the Philox
     // temporaries are dead by the time the P^T fragments come alive.  The lane's 4 keys of a block are one Philox group of the row's
     // counter stream (element offset = ((b Hq + hq) Nq + row) Nkv + key).
-    uint32_t keep_bits[2][NKB > 8 ? NKB / 8 : 1] = {};
+    uint32_t keep_bits[RHS][NKB > 8 ? NKB / 8 : 1] = {};
     if constexpr (DROP) {
 #ifndef FFPA_M16_PHILOX_ILP
 #define FFPA_M16_PHILOX_ILP 1  // Philox groups advanced in lockstep between two scheduling fences (2 / 4 measured: nothing, profiles/r03_philox.txt)
 #endif
-      unsigned long long erow[2];
+      unsigned long long erow[RHS];
 #pragma unroll
-      for (int rh = 0; rh < 2; ++rh)
-        erow[rh] = a.philox_offset + (((unsigned long long)b * a.Hq + hq) * a.Nq + (unsigned long long)qrow_c[rh]) * (unsigned long long)a.Nkv;
+      for (int rh = 0; rh < RHS; ++rh)
+        erow[rh] = a.philox_offset + (((unsigned long long)b * a.Hq + hq) * a.Nq + (unsigned long long)qrow_cs[rh]) * (unsigned long long)a.Nkv;
       // every lane's 4-key group a whole Philox block (philox_offset and Nkv multiples of 4: the usual case; the key part 16 kb + 4 c always is)?
       // Then the groups of the step are branch-free and sit in ONE basic block.
-      if (__builtin_amdgcn_ballot_w64(((erow[0] | erow[1]) & 3ull) != 0) == 0ull) {
+      if (__builtin_amdgcn_ballot_w64(((erow[0] | erow[RHS - 1]) & 3ull) != 0) == 0ull) {
         constexpr int kIlp = FFPA_M16_PHILOX_ILP;
-        static_assert(kIlp >= 1 && (2 * NKB) % kIlp == 0, "Philox groups per batch");
+        static_assert(kIlp >= 1 && (RHS * NKB) % kIlp == 0, "Philox groups per batch");
 #pragma unroll
-        for (int g0 = 0; g0 < 2 * NKB; g0 += kIlp) {
+        for (int g0 = 0; g0 < RHS * NKB; g0 += kIlp) {
           __builtin_amdgcn_sched_barrier(0);
           unsigned long long quad[kIlp];
           uint32_t bits[kIlp];
 #pragma unroll
-          for (int i = 0; i < kIlp; ++i) quad[i] = (erow[(g0 + i) & 1] + (unsigned long long)(k0 + ((g0 + i) >> 1) * 16 + 4 * c)) >> 2;
+          for (int i = 0; i < kIlp; ++i) quad[i] = (erow[(g0 + i) % RHS] + (unsigned long long)(k0 + ((g0 + i) / RHS) * 16 + 4 * c)) >> 2;
           dropout_keep_bits4_aligned_n<kIlp>(a.philox_seed, quad, a.keep_threshold, bits);
 #pragma unroll
-          for (int i = 0; i < kIlp; ++i) keep_bits[(g0 + i) & 1][((g0 + i) >> 1) >> 3] |= bits[i] << (4 * (((g0 + i) >> 1) & 7));
+          for (int i = 0; i < kIlp; ++i) keep_bits[(g0 + i) % RHS][((g0 + i) / RHS) >> 3] |= bits[i] << (4 * (((g0 + i) / RHS) & 7));
         }
       } else {
 #pragma unroll
-        for (int g = 0; g < 2 * NKB; ++g) {
-          const int kb = g >> 1, rh = g & 1;
+        for (int g = 0; g < RHS * NKB; ++g) {
+          const int kb = g / RHS, rh = g % RHS;
           __builtin_amdgcn_sched_barrier(0);
           keep_bits[rh][kb >> 3] |= dropout_keep_bits4(a.philox_seed, erow[rh] + (unsigned long long)(k0 + kb * 16 + 4 * c), a.keep_threshold) << (4 * (kb & 7));
         }
@@ -1343,8 +1379,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 
     // P^T fragments: contraction slot 8 c + e of key step ks <-> key 32 ks + 16 (e / 4) + 4 c + e % 4 = x[2 ks + e / 4][rh][e % 4]
     v8 pf[NKS][2];
+    v8 pfs[NKS][RHS];
 #pragma unroll
-    for (int rh = 0; rh < 2; ++rh) {
+    for (int rh = 0; rh < RHS; ++rh) {
       const float m_use = (m_run[rh] == -INFINITY) ? 0.f : m_run[rh];
       float psum = 0.f;
 #pragma unroll
@@ -1373,12 +1410,24 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
             // (prefill.cuh:508-546); the keep bit was drawn above: AND with 0 / ~0 (P >= 0: no sign games)
             const float scaled = (float)(T)p * a.keep_scale;
             const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)keep_bits[rh][kb >> 3], 4 * (kb & 7) + r, 1);
-            pf[kb >> 1][rh][4 * (kb & 1) + r] = (T)__uint_as_float(__float_as_uint(scaled) & m);
+            pfs[kb >> 1][rh][4 * (kb & 1) + r] = (T)__uint_as_float(__float_as_uint(scaled) & m);
           } else {
-            pf[kb >> 1][rh][4 * (kb & 1) + r] = (T)p;
+            pfs[kb >> 1][rh][4 * (kb & 1) + r] = (T)p;
           }
         }
       l_run[rh] += psum;
+    }
+    if constexpr (kRowShare) {
+      // this wave's share of the softmax for the other D-half's wave, in the two slots of its own partial-S area that only it has read (kb = 0 / 1 of row
+      // half dh); read behind barrier A2, overwritten by the next step's partials only behind barrier B
+      static_assert(!kRowShare || NKS == 1, "one P^T fragment per row half and tile");
+      *(FFPA_LDS v8*)(xw_nd2 + dh * 1024) = pfs[0][0];
+      *(FFPA_LDS float*)(xw_nd2 + (2 + dh) * 1024) = alpha_own;
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int rh = 0; rh < RHS; ++rh) pf[ks][rh] = pfs[ks][rh];
     }
     pre_k_group(std::integral_constant<int, 3>{});
 
@@ -1390,6 +1439,26 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       dma_wait_except<kPre>();
       __syncthreads();
       FFPA_TSTAMP(3);  // V(j) drain + wait at barrier A2
+      if constexpr (kRowShare) {
+        // both row halves' P^T fragments and rescale factors: half rh sits in the area of the row block's wave dh = rh, slots (0, rh) and (1, rh)
+        pf[0][0] = *(FFPA_LDS const v8*)(xb_nd2);
+        pf[0][1] = *(FFPA_LDS const v8*)(xb_nd2 + 4096 + 1024);
+        const float alpha0 = *(FFPA_LDS const float*)(xb_nd2 + 2048), alpha1 = *(FFPA_LDS const float*)(xb_nd2 + 4096 + 3072);
+        if (j > t0 && __any(alpha0 != 1.f || alpha1 != 1.f)) {
+          // rare path: O^T lives in AGPRs; scale in place through one temporary VGPR tile
+#pragma unroll
+          for (int i = 0; i < NDB; ++i)
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh) {
+              f32x4 t = oacc[i][rh];
+              asm volatile("" : "+a"(t));
+              t *= (rh ? alpha1 : alpha0);
+              asm volatile("" : "+a"(t));
+              oacc[i][rh] = t;
+              __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+      }
         // pieces of the next step's bias tile to stage (none when that step lies in the mask's neutral interior or past the last tile)
       const int b_next = (MK == 1 && j + 1 < nt && !(k0 + BC >= free_lo && k0 + 2 * BC <= free_hi)) ? b_pieces : 0;
       const u32x4 brs = bias_rsrc();
@@ -1446,6 +1515,18 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     __syncthreads();
     FFPA_TSTAMP(5);  // K(j+1) drain + wait at barrier B
   }
+  if constexpr (kRowShare) {
+    // the epilogue wants both row halves' running max and this lane's share of both row sums: the other half's come from its owner (the slots are free:
+    // their last readers passed barrier B of the last step)
+    *(FFPA_LDS float*)(xw_nd2 + dh * 1024) = m_run[0];
+    *(FFPA_LDS float*)(xw_nd2 + (2 + dh) * 1024) = l_run[0];
+    __syncthreads();
+    m_run[0] = *(FFPA_LDS const float*)(xb_nd2);
+    m_run[1] = *(FFPA_LDS const float*)(xb_nd2 + 4096 + 1024);
+    l_run[0] = *(FFPA_LDS const float*)(xb_nd2 + 2048);
+    l_run[1] = *(FFPA_LDS const float*)(xb_nd2 + 4096 + 3072);
+  }
+  }  // (the loop of the builds without the softmax pipeline)
 
   if (pf_on || kPipe) {  // the last touches land before their destination register is given to anything else (pipelined loop: and the
     dma_wait_all();      // zero-filled K pieces of the tile past the last one before the workgroup's LDS is)
