@@ -163,8 +163,11 @@ def measured_traffic(workload: str, lib_sha16: str | None):
   itself, so this is a profile artefact named by `traffic_source` — and it is only quoted when the profile's
   `provenance.lib_sha16` IS the library this run loaded: a profile of another binary gives (None, its path, True) and the line
   says `traffic_stale`.  (None, None, False) when no profile is committed."""
-  for rnd in ("r04", "r03", "r02", "r01"):
-    path = os.path.join(ROOT, "profiles", f"{rnd}_bench_{workload}_pmc.json")
+  import glob
+  import re
+
+  found = [p_ for p_ in glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_bench_{workload}_pmc.json")) if re.fullmatch(rf"r\d\d_bench_{re.escape(workload)}_pmc\.json", os.path.basename(p_))]
+  for path in sorted(found, reverse=True):  # the newest round's profile first
     if os.path.exists(path):
       try:
         doc = json.load(open(path))
