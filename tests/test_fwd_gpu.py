@@ -1015,8 +1015,11 @@ def _random_case(rng):
   return dict(B=int(rng.choice([1, 2])), Hq=Hkv * group, Hkv=Hkv, Nq=Nq, Nkv=Nkv, D=D, mode=str(mode), dtype=dtype, strided=strided)
 
 
-# FFPA_FUZZ_SEEDS=a:b widens the sweep for a one-off fuzz run (the default 48 cases keep the suite short)
+# FFPA_FUZZ_SEEDS=a:b widens the sweep for a one-off fuzz run (the default 48 cases keep the suite short); FFPA_FUZZ_FLAGS=<int> ORs launch flags into every
+# call of the sweep (0x1000 = FFPA_FLAG_WIDE_TILE: the cases the wide-row tile has a build for — D in (256, 320], no additive bias, no dropout — run it
+# whatever their size; the plan's own rule only takes it for thousands of workgroups)
 _FUZZ = os.environ.get("FFPA_FUZZ_SEEDS", "0:48").split(":")
+_FUZZ_FLAGS = int(os.environ.get("FFPA_FUZZ_FLAGS", "0"), 0)
 
 
 @pytest.mark.parametrize("seed", range(int(_FUZZ[0]), int(_FUZZ[1])))
@@ -1050,7 +1053,7 @@ def test_randomized_against_oracle(hip, seed):
     okw.update(dropout_p=0.3, philox_seed=kw["philox_seed"], philox_offset=kw["philox_offset"])
   scale = float(rng.choice([D ** -0.5, 0.03, 0.11]))
   plan = {}
-  o, lse = hip.forward(q, k, v, bias, causal, scale, plan_out=plan, **kw)
+  o, lse = hip.forward(q, k, v, bias, causal, scale, plan_out=plan, flags=_FUZZ_FLAGS, **kw)
   assert o.shape == (B, Hq, Nq, D) and lse.shape == (B, Hq, Nq)
   qb, dname = fo.torch_to_bits(q)
   kb, _ = fo.torch_to_bits(k)
