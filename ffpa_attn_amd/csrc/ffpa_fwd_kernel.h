@@ -496,9 +496,25 @@ __device__ __forceinline__ int opaque_lane(int lane) {
   return lane;
 }
 
+// a ^ b ^ k, with X3 in ONE VALU instruction (gfx950: v_bitop3_b32, truth table 0x96 = three-input XOR; k is the wave-uniform round key in a scalar register).
+// hipcc emits two v_xor_b32 for the expression: of the six VALU instructions of a Philox round two were this second XOR.  Round 5, the 16x16x32 dropout build
+// without a bias: + 2.4 % at D = 512, + 3.0 % at D = 320, + 0.5 % at D = 1024, bit-identical (profiles/r05_philox_xor3.txt); the bias + dropout build keeps the plain
+// form (with the asm its register allocation puts scratch accesses into the MFMA loops).
+template <bool X3>
+__device__ __forceinline__ uint32_t philox_xor3(uint32_t a, uint32_t b, uint32_t k) {
+  if constexpr (X3) {
+    uint32_t d;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(d) : "v"(a), "v"(b), "s"(k));
+    return d;
+  } else {
+    return a ^ b ^ k;
+  }
+}
+
 // Philox4x32-10 (Salmon et al., SC'11) on counter (quad_lo, quad_hi, 0, 0) with key = seed: the generator
 // behind torch / cuRAND / Triton dropout.  The reference keys it by the logical score index so that masks
 // line up with SDPA's (csrc/cuffpa/native/prefill.cuh:398-452): element e uses word e & 3 of block e >> 2.
+template <bool X3 = false>
 __device__ __forceinline__ void philox4x32_10(unsigned long long seed, unsigned long long quad, uint32_t (&out)[4]) {
   uint32_t c0 = (uint32_t)quad, c1 = (uint32_t)(quad >> 32), c2 = 0u, c3 = 0u;
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
@@ -509,8 +525,8 @@ __device__ __forceinline__ void philox4x32_10(unsigned long long seed, unsigned 
     const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
     const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
     const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-    c0 = hi1 ^ c1 ^ k0;
-    c2 = hi0 ^ c3 ^ k1;
+    c0 = philox_xor3<X3>(hi1, c1, k0);
+    c2 = philox_xor3<X3>(hi0, c3, k1);
     c1 = lo1;
     c3 = lo0;
     k0 += 0x9E3779B9u;
@@ -555,13 +571,14 @@ __device__ __forceinline__ void dropout_keep4(unsigned long long seed, unsigned 
 // The same decision as 4 bits (bit t <-> element e0 + t is kept): the 16x16x32 build draws the bits of a whole KV step before its
 // exponentials and applies them when it packs P (the Philox temporaries are dead by then).  This form takes any element offset (a group that
 // straddles two Philox blocks draws both): the rare case — philox_offset or Nkv not a multiple of 4.
+template <bool X3 = false>
 __device__ __forceinline__ uint32_t dropout_keep_bits4(unsigned long long seed, unsigned long long e0, uint32_t threshold) {
   uint32_t blk[4];
   const unsigned a = (unsigned)(e0 & 3ull);
-  philox4x32_10(seed, e0 >> 2, blk);
+  philox4x32_10<X3>(seed, e0 >> 2, blk);
   uint32_t w[8] = {blk[0], blk[1], blk[2], blk[3], 0, 0, 0, 0};
   if (a != 0) {  // the group straddles two Philox blocks
-    philox4x32_10(seed, (e0 >> 2) + 1, blk);
+    philox4x32_10<X3>(seed, (e0 >> 2) + 1, blk);
 #pragma unroll
     for (int i = 0; i < 4; ++i) w[4 + i] = blk[i];
   }
@@ -578,7 +595,7 @@ __device__ __forceinline__ uint32_t dropout_keep_bits4(unsigned long long seed, 
 // lockstep, round by round (written out in the source because hipcc, at the register limit, keeps the source order).  Measured on the dropout
 // workloads (profiles/r03_philox.txt): the branch-free form is + 3 ... 5 % over a wave-uniform branch per group; N = 2 / 4 add nothing — the
 // cost is the VALU instruction count, not the latency of the multiply chain — so the kernels use N = 1.
-template <int N>
+template <int N, bool X3 = false>
 __device__ __forceinline__ void dropout_keep_bits4_aligned_n(unsigned long long seed, const unsigned long long (&quad)[N], uint32_t threshold, uint32_t (&bits)[N]) {
   uint32_t c0[N], c1[N], c2[N], c3[N];
 #pragma unroll
@@ -602,8 +619,8 @@ __device__ __forceinline__ void dropout_keep_bits4_aligned_n(unsigned long long 
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      c0[i] = hi1[i] ^ c1[i] ^ k0;
-      c2[i] = hi0[i] ^ c3[i] ^ k1;
+      c0[i] = philox_xor3<X3>(hi1[i], c1[i], k0);
+      c2[i] = philox_xor3<X3>(hi0[i], c3[i], k1);
       c1[i] = lo1[i];
       c3[i] = lo0[i];
     }

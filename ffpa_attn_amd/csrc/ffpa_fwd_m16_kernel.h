@@ -1362,7 +1362,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
           uint32_t bits[kIlp];
 #pragma unroll
           for (int i = 0; i < kIlp; ++i) quad[i] = (erow[(g0 + i) % RHS] + (unsigned long long)(k0 + ((g0 + i) / RHS) * 16 + 4 * c)) >> 2;
-          dropout_keep_bits4_aligned_n<kIlp>(a.philox_seed, quad, a.keep_threshold, bits);
+          dropout_keep_bits4_aligned_n<kIlp, MK == 0>(a.philox_seed, quad, a.keep_threshold, bits);
 #pragma unroll
           for (int i = 0; i < kIlp; ++i) keep_bits[(g0 + i) % RHS][((g0 + i) / RHS) >> 3] |= bits[i] << (4 * (((g0 + i) / RHS) & 7));
         }
@@ -1371,7 +1371,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         for (int g = 0; g < RHS * NKB; ++g) {
           const int kb = g / RHS, rh = g % RHS;
           __builtin_amdgcn_sched_barrier(0);
-          keep_bits[rh][kb >> 3] |= dropout_keep_bits4(a.philox_seed, erow[rh] + (unsigned long long)(k0 + kb * 16 + 4 * c), a.keep_threshold) << (4 * (kb & 7));
+          keep_bits[rh][kb >> 3] |= dropout_keep_bits4<MK == 0>(a.philox_seed, erow[rh] + (unsigned long long)(k0 + kb * 16 + 4 * c), a.keep_threshold) << (4 * (kb & 7));
         }
       }
       __builtin_amdgcn_sched_barrier(0);
