@@ -309,7 +309,20 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
                       pl.lds + stage <= 160 * 1024;
       for (int i = 0; i < 3 && stage_ok; ++i) stage_ok = (p->bias_stride[i] * esz) % 16 == 0;
       const bool cache16 = esz == 2 && pl.lds + cache / 2 <= 160 * 1024;  // ... or as the caller's 16-bit elements, converted per step
-      if (lds_ok && p->bias_stride[2] == 0 && (pl.lds + cache <= 160 * 1024 || cache16)) {
+      // split-D tiles with the softmax pipeline (D > 512, D % 128 == 0), nothing but a key bias: the key-bias build runs the pipeline too (round 5); its LDS is the
+      // unmasked build's (6 KiB of exchange per wave) + a RING of fp32 bias entries — a power of two, at least 2048 (all D = 1024 has left), refilled half a ring
+      // at a time 1024+ keys ahead of the walk (ffpa_fwd_m16_kernel.h)
+      const bool ring = lds_ok && p->bias_stride[2] == 0 && dk > 512 && dk % 128 == 0 && p->kv_bounds == nullptr && !(p->dropout_p > 0.f);
+      if (ring) {
+        int br0 = 0, bc0 = 0, lds0 = 0;
+        de->config(4, &br0, &bc0, &lds0);
+        int bytes = 8192;
+        while (2 * bytes <= 160 * 1024 - lds0 && bytes < 65536) bytes *= 2;
+        pl.lds = lds0;
+        pl.bias_raw = 0;
+        pl.bias_lds = bytes;
+        pl.mk = 3;
+      } else if (lds_ok && p->bias_stride[2] == 0 && (pl.lds + cache <= 160 * 1024 || cache16)) {
         pl.bias_raw = pl.lds + cache <= 160 * 1024 ? 0 : 1;
         pl.bias_lds = (int)(pl.bias_raw ? cache / 2 : cache);
         if (p->kv_bounds == nullptr && !(p->dropout_p > 0.f)) pl.mk = 3;  // nothing but a cached key bias: the lean key-bias build

@@ -41,7 +41,7 @@ static int launch_one(const FwdArgs& a, hipStream_t stream) {
 template <typename T, int D, int MK, bool DROP = false>
 static int launch_m16(const FwdArgs& a, hipStream_t stream) {
   constexpr int BC = m16_block_keys(D, MK == 1 || MK == 3);
-  constexpr int LDS_BASE = 2 * BC * D * 2 + m16_exchange_bytes(D, MK == 1 || MK == 3);
+  constexpr int LDS_BASE = 2 * BC * D * 2 + m16_exchange_bytes(D, MK);
   const int LDS = LDS_BASE + (a.bias_lds > 0 ? a.bias_lds : -a.bias_lds);  // + the key-bias row cache or the bias-tile staging areas, sized by the C-ABI layer (<= 160 KiB in total)
   auto kern = ffpa_fwd_m16_kernel<T, D, MK, DROP>;
   static std::atomic<bool> attr_done[64];
@@ -194,7 +194,8 @@ void FFPA_CAT(tile_config_d, FFPA_INST_D)(int variant, int* br, int* bc, int* ld
   constexpr int D = FFPA_INST_D;
   // variant 0: prefill tiles, 1: short-query tiles, 2: prefill tiles of the additive-bias builds (64 keys at every head dim <= 512:
   // the 16x16x32 build with any additive bias, the 32x32x16 build with LDS-staged bias tiles), 3: the wide-row prefill tile
-  // (ffpa_fwd_m16w_kernel.h; *br = 0 where the head dim has none)
+  // (ffpa_fwd_m16w_kernel.h; *br = 0 where the head dim has none), 4: the key-bias build of the split-D tiles where it runs the softmax pipeline (the tiles of
+  // variant 0; its LDS without the ring cache)
   if (variant == 3) {
     *br = m16w_available(D) ? m16w_block_rows(m16w_row_halves(D)) : 0;
     *bc = m16w_block_keys(D);
@@ -206,7 +207,7 @@ void FFPA_CAT(tile_config_d, FFPA_INST_D)(int variant, int* br, int* bc, int* ld
   if (variant != 1 && D >= FFPA_M16_MIN_D) BC = m16_block_keys(D, variant == 2);  // (the 16x16x32 kernel's own rule)
   *br = 32 * (4 / ND);
   *bc = BC;
-  *lds = 2 * BC * D * 2 + (variant == 1 ? splitd_exchange_bytes(D, ND) : (D >= FFPA_M16_MIN_D ? m16_exchange_bytes(D, variant == 2) : (ND > 1 ? 4 * 4096 : 0)));
+  *lds = 2 * BC * D * 2 + (variant == 1 ? splitd_exchange_bytes(D, ND) : (D >= FFPA_M16_MIN_D ? m16_exchange_bytes(D, variant == 2 ? 1 : (variant == 4 ? 3 : 0)) : (ND > 1 ? 4 * 4096 : 0)));
 }
 
 }  // namespace ffpa

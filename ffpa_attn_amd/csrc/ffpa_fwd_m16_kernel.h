@@ -155,9 +155,13 @@ constexpr int m16_block_keys(int D, bool bias_build) {
 // Bytes of the partial-S^T exchange area behind the two tile images of the split-D tiles (D > 512): 4 KiB per wave; 6 KiB in the builds without
 // an additive bias, whose softmax pipeline publishes key block 0 one step early into a double-buffered half (FFPA_M16_PIPE; reserved whether or
 // not the build is pipelined, so that the launch side needs to know the mask kind only).
-// + 5 KiB behind it in those builds since round 5: the two waves of a row block share the softmax by rows and trade P^T fragments (4 x 1 KiB) and
-// per-row scalars (4 x 256 B) instead of both running all of it.
-constexpr int m16_exchange_bytes(int D, bool bias_build) { return D > 512 ? (bias_build ? 4 * 4096 : 4 * 6144 + 4 * 1024 + 4 * 256) : 0; }
+// Since round 5 the two waves of a row block share the softmax by rows and trade P^T fragments (4 x 1 KiB) and per-row scalars (4 x 256 B) behind it: 5 KiB more
+// in the builds without an additive bias.  MK: 1 = the additive-bias build with staged tiles (4 KiB per wave), 3 = the key-bias build: 6 KiB where it runs the
+// softmax pipeline (D % 128 == 0; its bias lives in a ring cache behind the exchange, and its P^T / scalar slots are slots of a wave's own partials that only
+// the wave itself reads back: D = 1024 has no 5 KiB to spare next to the ring — the own-slot form measured 0.5 ... 1 % slower on the unmasked build), 4 KiB elsewhere.
+constexpr int m16_exchange_bytes(int D, int MK) {
+  return D > 512 ? ((MK == 1 || (MK == 3 && D % 128 != 0)) ? 4 * 4096 : (MK == 3 ? 4 * 6144 : 4 * 6144 + 4 * 1024 + 4 * 256)) : 0;
+}
 
 // Which of `cnt` DMA pieces, if any, rides on fragment n of a loop of N fragments — piece t sits on
 // fragment t * step (step > 0: front-loaded) or floor(t N / cnt) (step == 0: spread evenly); -1 = none.
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   constexpr int N2 = NDB * NKS;  // V^T fragments per tile
   // the softmax pipeline of the split-D tiles (see FFPA_M16_PIPE above): needs an even number of pieces per wave (D % 128 == 0), and it stages K as two
   // 16-key halves — piece i < kH of a wave belongs to K1 (keys 0 .. 15), the rest to K2
-  constexpr bool kPipe = ND == 2 && FFPA_M16_PIPE != 0 && PPW % 2 == 0 && NKB == 2 && (MK == 0 || MK == 2) && !DROP;
+  constexpr bool kPipe = ND == 2 && FFPA_M16_PIPE != 0 && PPW % 2 == 0 && NKB == 2 && (MK == 0 || MK == 2 || MK == 3) && !DROP;
   constexpr bool kKS = kPipe;  // the two-half K piece map
   constexpr int kH = PPW / 2;  // K1 / K2 pieces per wave
   constexpr int ppVQ = PPW * FFPA_M16_PP_VQ / 16, ppVS = PPW - ppVQ;     // V(j): in Q(j), in S(j)
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   FFPA_LDS char* const Kt = (FFPA_LDS char*)smem;
   FFPA_LDS char* const Vt = Kt + TILE;
   FFPA_LDS char* const Xb = Kt + 2 * TILE;  // ND == 2: partial-S exchange, 4 KiB per wave (6 KiB in the builds without an additive bias)
-  FFPA_LDS char* const Bl = Kt + 2 * TILE + m16_exchange_bytes(D, kBias);  // key-bias row cache (FwdArgs.bias_lds bytes, when enabled)
+  FFPA_LDS char* const Bl = Kt + 2 * TILE + m16_exchange_bytes(D, MK);  // key-bias row cache (FwdArgs.bias_lds bytes, when enabled)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -720,28 +724,55 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     auto k_frag_sk = [&](int s_, int kb_) -> v8 { return *(FFPA_LDS const v8*)(kaddr[kb_ / 4][s_ % KV] + (s_ / KV) * KVB + (kb_ % 4) * 16 * RB); };
     FFPA_LDS char* const xw = Xb + wave * kXW + lane * 16;        // this wave's partials
     FFPA_LDS const char* const xr = Xb + (wave ^ 1) * kXW + lane * 16;  // the other D-half's
-    // the softmax shared by rows (see the S phase): P^T fragments [row block][row half][lane x 16 B] and per-row scalars [row block][row half][lane x 4 B]
+    // the softmax shared by rows (see the S phase): where a wave's P^T fragment (lane x 16 B) and rescale factor (lane x 4 B) travel.
+    //   builds with LDS to spare (MK 0 / 2): an area of their own behind the partials — P^T [row block][row half] x 1 KiB, scalars [row block][row half] x 256 B;
+    //   the key-bias build (the ring takes what is left): the slots of the wave's OWN partials that only it reads back — (key block 1, row half dh) and (key
+    //   block 0 of this tile's parity, row half dh): both have been read by the time the softmax ends, the partner reads them behind barrier A2, and the partials of
+    //   the next tile overwrite them behind barrier B at the earliest; row half rh's slots sit in the area of the row block's wave dh = rh.
+    constexpr bool kOwnSlots = MK == 3;
     FFPA_LDS char* const Pb = Xb + 4 * kXW;
     FFPA_LDS char* const Ab = Pb + 4 * 1024;
-    FFPA_LDS char* const pxw = Pb + (qb * 2 + dh) * 1024 + lane * 16;
-    FFPA_LDS const char* const pxr = Pb + qb * 2048 + lane * 16;
-    FFPA_LDS char* const axw = Ab + (qb * 2 + dh) * 256 + lane * 4;
-    FFPA_LDS const char* const axr = Ab + qb * 512 + lane * 4;
+    FFPA_LDS char* const pxw = kOwnSlots ? Xb + wave * kXW + 4096 + dh * 1024 + lane * 16 : Pb + (qb * 2 + dh) * 1024 + lane * 16;
+    FFPA_LDS const char* const pxr0 = kOwnSlots ? Xb + (qb * 2) * kXW + 4096 + lane * 16 : Pb + qb * 2048 + lane * 16;
+    FFPA_LDS const char* const pxr1 = kOwnSlots ? Xb + (qb * 2 + 1) * kXW + 4096 + 1024 + lane * 16 : Pb + qb * 2048 + 1024 + lane * 16;
+    constexpr int kAPar = kOwnSlots ? 2048 : 0;  // own slots: the scalar sits in the key-block-0 slot of the tile's parity
+    FFPA_LDS char* const axw_base = kOwnSlots ? Xb + wave * kXW + dh * 1024 + lane * 16 : Ab + (qb * 2 + dh) * 256 + lane * 4;
+    FFPA_LDS const char* const axr0_base = kOwnSlots ? Xb + (qb * 2) * kXW + lane * 16 : Ab + qb * 512 + lane * 4;
+    FFPA_LDS const char* const axr1_base = kOwnSlots ? Xb + (qb * 2 + 1) * kXW + 1024 + lane * 16 : Ab + qb * 512 + 256 + lane * 4;
     const int qrow_own = wq0 + 16 * dh + n16;  // the row of this lane in the half whose softmax this wave runs
     const int qrow_c_own = qrow_own < a.Nq ? qrow_own : a.Nq - 1;
     float m_own = -INFINITY, l_own = 0.f;      // its running max (log2 domain) and this lane's share of its row sum
+    // Key-bias build (MK 3) on the pipeline, round 5: the bias enters through the S^T accumulators as in the loop below (the dh = 0 wave's chains start from
+    // bias / scale, the other's from zero: bit-identical to that loop), read from a RING of FwdArgs.bias_lds / 4 fp32 entries (2048: all the LDS has left next to the
+    // pipeline's exchange) indexed by key mod size: filled with keys [0, size) in front of the loop and refilled half a ring at a time, 1024 keys ahead of the walk.
+    const uint32_t ring_mask = MK == 3 ? (uint32_t)((a.bias_lds >> 2) - 1) : 0u;
+    auto bias_init = [&](f32x4 (&s)[2], int key0) __attribute__((always_inline)) {
+      if constexpr (MK == 3) {
+        // no branch in the MFMA stream: both waves read the quad, the wave that does not carry the bias selects zeros (a select, not a multiply by 0: a
+        // key-padding bias holds -inf)
+        const f32x4 w = *(FFPA_LDS const f32x4*)(Bl + ((((uint32_t)key0 + 4u * (uint32_t)c) & ring_mask) << 2));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s[0][r] = bias_owner ? w[r] : 0.f;
+          s[1][r] = bias_owner ? w[r] : 0.f;
+        }
+        asm volatile("s_nop 1" : "+v"(s[0]), "+v"(s[1]));  // VALU write -> MFMA SrcC read wait states (the MFMAs are inline asm)
+      }
+    };
+    constexpr bool kFromBias = MK == 3;  // the chains accumulate onto their initial value instead of starting from zero
     if (nt > t0) {
       f32x4 s0[2];  // partial S^T of key block 0 of the first tile (this wave's D-half); in the loop it is contracted one step early
       // prologue: key block 0 of the first tile (K(t0) has landed and is visible: the barrier above)
       v8 kf[KS];
 #pragma unroll
       for (int n = 0; n < PF1 && n < KS; ++n) kf[n] = k_frag_sk(n, 0);
+      bias_init(s0, t0 * BC);
       static_for<KS>([&](auto sc) {
         constexpr int s_ = decltype(sc)::value;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (s_ + PF1 < KS) kf[s_ + PF1] = k_frag_sk(s_ + PF1, 0);
         static_assert(KS >= 2, "the last MFMA of a chain carries the wait states");
-        if constexpr (s_ == 0) {
+        if constexpr (s_ == 0 && !kFromBias) {
           M::first(s0[0], kf[s_], qf[s_][0]);
           M::first(s0[1], kf[s_], qf[s_][1]);
         } else {
@@ -759,6 +790,25 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     }
     for (int j = t0; j < nt; ++j) {
       const int k0 = j * BC;
+      if constexpr (MK == 3) {
+        // the ring's half that the walk has left behind takes the keys 1024 ... 2048 ahead (nobody reads them before 31 more steps — every barrier
+        // in between publishes them —, nobody still reads what they replace: keys below k0).  The loads are the compiler's: its wait in front of the
+        // LDS stores also drains the DMA queue, once per 32 steps.
+        const int half = (a.bias_lds >> 3);  // entries of half a ring
+        if (k0 > t0 * BC && ((k0 - t0 * BC) & (half - 1)) == 0) {
+          const int64_t src0 = b * a.sbias[0] + hq * a.sbias[1];
+          for (int i = tid; i < half; i += 256) {
+            const int key = k0 + half + i;
+            float w = 0.f;
+            if (key < a.Nkv) {
+              const int64_t e = src0 + key * a.sbias[3];
+              w = a.bias_dtype == 3 ? ((const float*)a.bias)[e] : a.bias_dtype == 2 ? (float)((const __bf16*)a.bias)[e] : (float)((const _Float16*)a.bias)[e];
+              w *= a.inv_scale;
+            }
+            *(FFPA_LDS float*)(Bl + (((uint32_t)key & ring_mask) << 2)) = w;
+          }
+        }
+      }
       // ================= Q: S^T key block 1 of tile j =================
       f32x4 s1[2];
       {
@@ -766,24 +816,25 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int n = 0; n < PF1 && n < KS; ++n) kf[n] = k_frag_sk(n, 1);
+        bias_init(s1, k0 + 16);
         static_for<KS>([&](auto sc) {
           constexpr int s_ = decltype(sc)::value;
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (s_ + PF1 < KS) kf[s_ + PF1] = k_frag_sk(s_ + PF1, 1);
           constexpr int t = m16_piece_at(s_, KS, ppK1Q + ppVQ, FFPA_M16_PP_QSTEP);
           if constexpr (t >= 0 && kFuse) {
-            using kind = std::integral_constant<int, s_ == 0 ? 0 : 1>;
+            using kind = std::integral_constant<int, (s_ == 0 && !kFromBias) ? 0 : 1>;
             if constexpr (t < ppK1Q) issue_k_on(std::integral_constant<int, ppK1P + t>{}, k0 + BC, kind{}, s1[0], kf[s_], qf[s_][0]);
             else issue_v_on(std::integral_constant<int, t - ppK1Q>{}, k0, kind{}, s1[0], kf[s_], qf[s_][0]);
           } else {
-            if constexpr (s_ == 0) M::first(s1[0], kf[s_], qf[s_][0]);
+            if constexpr (s_ == 0 && !kFromBias) M::first(s1[0], kf[s_], qf[s_][0]);
             else M::acc(s1[0], kf[s_], qf[s_][0]);
             if constexpr (t >= 0) {
               if constexpr (t < ppK1Q) issue_k(std::integral_constant<int, ppK1P + t>{}, k0 + BC);  // K1(j+1), rest
               else issue_v(std::integral_constant<int, t - ppK1Q>{}, k0);                           // V(j), first part
             }
           }
-          if constexpr (s_ == 0) M::first(s1[1], kf[s_], qf[s_][1]);
+          if constexpr (s_ == 0 && !kFromBias) M::first(s1[1], kf[s_], qf[s_][1]);
           else if constexpr (s_ == KS - 1) M::acc_last(s1[1], s1[0], kf[s_], qf[s_][1]);
           else M::acc(s1[1], kf[s_], qf[s_][1]);
         });
@@ -825,6 +876,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         v8 kf[KS];
 #pragma unroll
         for (int n = 0; n < PFS && n < KS; ++n) kf[n] = k_frag_sk(n, 0);
+        bias_init(s0, k0 + BC);
         __builtin_amdgcn_sched_barrier(0);
         const bool tail = k0 + BC > a.Nkv;
         const bool diag = a.causal && ((int64_t)k0 + BC - 1 > (int64_t)(a.causal_row_mod ? 0 : wq0) + a.causal_offset);
@@ -922,11 +974,11 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
           if constexpr (s_ + PFS < KS) kf[s_ + PFS] = k_frag_sk(s_ + PFS, 0);
           constexpr int t = m16_piece_at(s_, KS, ppVS + ppK2S, FFPA_M16_PP_SSTEP);
           if constexpr (t >= 0 && kFuse) {
-            using kind = std::integral_constant<int, s_ == 0 ? 0 : 1>;
+            using kind = std::integral_constant<int, (s_ == 0 && !kFromBias) ? 0 : 1>;
             if constexpr (t < ppVS) issue_v_on(std::integral_constant<int, ppVQ + t>{}, k0, kind{}, s0[0], kf[s_], qf[s_][0]);
             else issue_k_on(std::integral_constant<int, kH + (t - ppVS)>{}, k0 + BC, kind{}, s0[0], kf[s_], qf[s_][0]);
           } else {
-            if constexpr (s_ == 0) M::first(s0[0], kf[s_], qf[s_][0]);
+            if constexpr (s_ == 0 && !kFromBias) M::first(s0[0], kf[s_], qf[s_][0]);
             else M::acc(s0[0], kf[s_], qf[s_][0]);
             if constexpr (t >= 0) {
               if constexpr (t < ppVS) issue_v(std::integral_constant<int, ppVQ + t>{}, k0);  // V(j), rest
@@ -936,7 +988,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
           constexpr bool kPerGap = KS >= 16 && MK != 2;  // one group per MFMA gap at D = 1024, all behind the phase's MFMAs elsewhere (see the header of the pipeline)
           if constexpr (kPerGap) softmax_gaps(std::integral_constant<int, 2 * s_>{});
           __builtin_amdgcn_sched_barrier(0);
-          if constexpr (s_ == 0) M::first(s0[1], kf[s_], qf[s_][1]);
+          if constexpr (s_ == 0 && !kFromBias) M::first(s0[1], kf[s_], qf[s_][1]);
           else if constexpr (s_ == KS - 1) M::acc_last(s0[1], s0[0], kf[s_], qf[s_][1]);
           else M::acc(s0[1], kf[s_], qf[s_][1]);
           if constexpr (kPerGap) softmax_gaps(std::integral_constant<int, 2 * s_ + 1>{});
@@ -947,7 +999,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         *(FFPA_LDS f32x4*)(xw + ((j + 1) & 1) * 2048 + 1024) = s0[1];
         // this wave's share of the softmax for the other D-half's wave (read behind barrier A2; the slot is free: its last readers passed barrier B)
         *(FFPA_LDS v8*)(pxw) = pf_own;
-        *(FFPA_LDS float*)(axw) = alpha_own;
+        *(FFPA_LDS float*)(axw_base + (j & 1) * kAPar) = alpha_own;
       }
 
       // ================= P: O^T += V^T.P^T =================
@@ -960,9 +1012,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
         FFPA_TSTAMP(3);  // V(j) drain + wait at barrier A2
         // both row halves' P^T fragments and rescale factors (this wave's own come back from LDS too: no register selects on the wave's D-half index)
         v8 pf[NKS][2];
-        pf[0][0] = *(FFPA_LDS const v8*)(pxr);
-        pf[0][1] = *(FFPA_LDS const v8*)(pxr + 1024);
-        const float alpha0 = *(FFPA_LDS const float*)(axr), alpha1 = *(FFPA_LDS const float*)(axr + 256);
+        pf[0][0] = *(FFPA_LDS const v8*)(pxr0);
+        pf[0][1] = *(FFPA_LDS const v8*)(pxr1);
+        const float alpha0 = *(FFPA_LDS const float*)(axr0_base + (j & 1) * kAPar), alpha1 = *(FFPA_LDS const float*)(axr1_base + (j & 1) * kAPar);
         v8 vf[N2];
         auto v_frag = [&](int n) -> v8 {
           const int db = n % NDB, ks = n / NDB;
@@ -1021,13 +1073,13 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     }
     // the epilogue below wants both row halves' running max and this lane's share of both row sums: the other half's come from its owner (the
     // exchange slots are free: their last readers passed barrier B of the last step)
-    *(FFPA_LDS float*)(axw) = m_own;
+    *(FFPA_LDS float*)(axw_base) = m_own;
     *(FFPA_LDS float*)(pxw) = l_own;
     __syncthreads();
-    m_run[0] = *(FFPA_LDS const float*)(axr);
-    m_run[1] = *(FFPA_LDS const float*)(axr + 256);
-    l_run[0] = *(FFPA_LDS const float*)(pxr);
-    l_run[1] = *(FFPA_LDS const float*)(pxr + 1024);
+    m_run[0] = *(FFPA_LDS const float*)(axr0_base);
+    m_run[1] = *(FFPA_LDS const float*)(axr1_base);
+    l_run[0] = *(FFPA_LDS const float*)(pxr0);
+    l_run[1] = *(FFPA_LDS const float*)(pxr1);
   } else {
   // The DROPOUT builds of the split-D tiles (ND == 2) share the softmax BY ROWS between the two waves of a row block, as the pipelined loop above does: both hold
   // the same 32 x BC scores once the partials are summed; wave (qb, dh) exponentiates — and draws the Philox bits of — row half dh only and trades its P^T fragment

@@ -271,6 +271,32 @@ def test_key_bias_row_cache_in_lds_is_bit_identical_to_the_global_reads(hip, D, 
       _check_vs_oracle(o1, l1, q, k, v, bias=_f32(bias.float()), name="key bias")
 
 
+@pytest.mark.parametrize("D", [640, 768, 1024])
+@pytest.mark.parametrize("bdtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_key_bias_ring_cache_of_the_pipelined_split_d_tiles(hip, D, bdtype):
+  """Round 5: at D > 512 (D % 128 == 0) the key-bias build runs the softmax pipeline and reads its bias from a RING of fp32 entries (2048 at D = 1024: all the
+  LDS has left) that is refilled half a ring at a time ahead of the walk.  Contexts of several ring lengths, ragged ends, -inf entries on both sides of every
+  refill boundary, GQA, per-head biases: the same bits as the per-tile global loads (FFPA_FLAG_NO_BIAS_LDS: the additive-bias build), the oracle on a row sample."""
+  B, Hq, Hkv, Nq = 1, 4, 2, 300
+  dt = torch.float16 if bdtype == torch.float16 else torch.bfloat16
+  for Nkv, shape in ((5000, (1, 1, 1, 5000)), (8192, (1, 4, 1, 8192)), (3073, (1, 1, 1, 3073)), (2049, (1, 4, 1, 2049))):
+    q, k, v = _rand((B, Hq, Nq, D), dt, seed=D), _rand((B, Hkv, Nkv, D), dt, seed=D + 1), _rand((B, Hkv, Nkv, D), dt, seed=D + 2)
+    g = torch.Generator(device="cuda").manual_seed(Nkv)
+    bias = (torch.randn(shape, device="cuda", generator=g) * 0.5).to(bdtype)
+    bias[..., 5::7] = float("-inf")
+    for edge in (1023, 1024, 2047, 2048, 3071, 3072, 4095, 4096):
+      if edge < Nkv:
+        bias[..., edge] = float("-inf") if edge % 2 else 1.5
+    plan = {}
+    o1, l1 = hip.forward(q, k, v, bias, False, D ** -0.5, num_splits=1, plan_out=plan)
+    assert f"ffpa_fwd_m16_kernel<{'fp16' if dt == torch.float16 else 'bf16'}, {D}, MK=3" in plan["kernel"], plan
+    o0, l0 = hip.forward(q, k, v, bias, False, D ** -0.5, num_splits=1, flags=hip.FLAG_NO_BIAS_LDS, plan_out=plan)
+    assert "MK=1" in plan["kernel"], plan
+    assert torch.equal(o1, o0) and torch.equal(l1, l0), (D, Nkv, shape)
+    if Nkv == 5000:
+      _check_vs_oracle(o1[:, :2], l1[:, :2], q[:, :2], k[:, :1], v[:, :1], bias=_f32(bias.float()), rows=(100, 164), block_keys=32, name=f"ring D{D} {bdtype}")
+
+
 @pytest.mark.parametrize("D", [64, 128, 256, 320, 384, 512, 640, 1024])
 def test_bias_tiles_staged_through_lds_are_bit_identical_to_the_global_reads(hip, D):
   """A 16-bit bias WITH a row axis is LDS-DMA'd one KV step ahead into a private area per wave (the build with 64-key tiles at
