@@ -683,10 +683,14 @@ def main() -> None:
   kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
   value = flops_global * args.steps / elapsed / 1e12
   gather_extra = None
-  if want_gather_extra:  # the same K steps once more with the all_gather of O inside the step: both figures in one line
-    g_elapsed, g_per_rank, _ = timed(step_gather)
-    gather_extra = {"value": round(flops_global * args.steps / g_elapsed / 1e12, 2), "unit": "TFLOPS", "ms_per_step": round(g_elapsed / args.steps * 1e3, 4),
-                    "per_rank_tflops": g_per_rank, "what": f"the step + RCCL all_gather_into_tensor of O ({args.gather_chunks} pieces overlapped with compute)"}
+  if want_gather_extra:  # the same K steps once more with the gather of O inside the step: both figures in one line
+    try:
+      g_elapsed, g_per_rank, _ = timed(step_gather)
+      gather_extra = {"value": round(flops_global * args.steps / g_elapsed / 1e12, 2), "unit": "TFLOPS", "ms_per_step": round(g_elapsed / args.steps * 1e3, 4),
+                      "per_rank_tflops": g_per_rank,
+                      "what": f"the step + the gather of O: the block in <= {args.gather_chunks} pieces, each sent point-to-point (RCCL batch_isend_irecv) into its final slice on every other rank while the next piece computes"}
+    except Exception as e:  # noqa: BLE001 — the extra figure must never cost the line its contract figure (this leg has only ever run at world size 1 on hardware)
+      gather_extra = {"error": f"{type(e).__name__}: {e}"[:300]}
   steady = None
   if world == 1 and not args.no_steady and not args.stub_backend:
     # Context for `value`, never `value` itself: a GPU coming out of idle runs its first ~ 10 - 25 ms of work slower than it does under
