@@ -41,6 +41,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import torch
@@ -545,6 +546,32 @@ def spawn_ranks(n: int, argv: list[str]) -> int:
   return worst
 
 
+def guarded_extra_leg(leg, timeout_s, emit):
+  """An OPTIONAL extra figure must never cost the line its contract figure.  ``leg()`` returns the extra object; ``emit(extra)`` prints the (already
+  complete) line with it — on rank 0; a no-op elsewhere.  An exception in the leg is recorded in the line.  A leg that does not come back (the gather
+  of O has only ever run at world size 1 on hardware: one rank failing leaves the others in a barrier) ends THIS process after ``timeout_s`` with exit
+  code 0 — every rank runs the same watchdog —, the line printed without the figure."""
+  once = threading.Lock()
+
+  def give_up():
+    if once.acquire(blocking=False):
+      emit({"error": f"no result within {timeout_s:g} s (watchdog): the line is the sharded step's alone"})
+      sys.stdout.flush()
+      os._exit(0)
+
+  watchdog = threading.Timer(timeout_s, give_up)
+  watchdog.daemon = True
+  watchdog.start()
+  try:
+    extra = leg()
+  except Exception as e:  # noqa: BLE001
+    extra = {"error": f"{type(e).__name__}: {e}"[:300]}
+  if not once.acquire(blocking=False):
+    time.sleep(3600)  # (the watchdog got there first: it is printing and about to end the process)
+  watchdog.cancel()
+  emit(extra)
+
+
 def main() -> None:
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -557,6 +584,7 @@ def main() -> None:
   ap.add_argument("--no-sdpa", action="store_true", help="skip the SDPA-on-GPU accuracy / speed comparison")
   ap.add_argument("--no-ref-protocol", action="store_true", help="skip the reference bench's own timing protocol (2 warm-ups + 10 iterations)")
   ap.add_argument("--no-gather-extra", action="store_true", help="N > 1: skip the second timed region that adds the all_gather of O")
+  ap.add_argument("--gather-extra-timeout", type=float, default=180.0, help="N > 1: seconds the gather leg may take before every rank gives up on it and rank 0 prints the line without it")
   ap.add_argument("--no-steady", action="store_true", help="N = 1: skip the steady-state leg (the step again after >= 150 ms of continuous load, outside the timed region)")
   ap.add_argument("--sweep", action="store_true", help="the reference bench's case table for --sweep-dims in one process (python -m ffpa_attn.bench)")
   ap.add_argument("--sweep-dims", default="320,512,1024")
@@ -682,15 +710,6 @@ def main() -> None:
   device = telemetry.summary()  # (of the first timed region: the bench line's own)
   kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
   value = flops_global * args.steps / elapsed / 1e12
-  gather_extra = None
-  if want_gather_extra:  # the same K steps once more with the gather of O inside the step: both figures in one line
-    try:
-      g_elapsed, g_per_rank, _ = timed(step_gather)
-      gather_extra = {"value": round(flops_global * args.steps / g_elapsed / 1e12, 2), "unit": "TFLOPS", "ms_per_step": round(g_elapsed / args.steps * 1e3, 4),
-                      "per_rank_tflops": g_per_rank,
-                      "what": f"the step + the gather of O: the block in <= {args.gather_chunks} pieces, each sent point-to-point (RCCL batch_isend_irecv) into its final slice on every other rank while the next piece computes"}
-    except Exception as e:  # noqa: BLE001 — the extra figure must never cost the line its contract figure (this leg has only ever run at world size 1 on hardware)
-      gather_extra = {"error": f"{type(e).__name__}: {e}"[:300]}
   steady = None
   if world == 1 and not args.no_steady and not args.stub_backend:
     # Context for `value`, never `value` itself: a GPU coming out of idle runs its first ~ 10 - 25 ms of work slower than it does under
@@ -779,8 +798,6 @@ def main() -> None:
       line["rccl_world_size"] = world
       line["frac_of_mfma_peak_aggregate"] = round(value / (MFMA_BF16_PEAK_TFLOPS * world), 4)
       line["timed_step_includes_gather"] = bool(args.gather)
-      if gather_extra is not None:
-        line["with_gather"] = gather_extra
     if world == 1 and not sharded and not args.no_ref_protocol:
       # the reference bench's protocol: 2 warm-ups, 10 iterations, perf_counter around a synchronize (cli/_runner_fwd.py:84-103)
       for _ in range(2):
@@ -806,7 +823,26 @@ def main() -> None:
                                "bit-for-bit against the oracle in tests/test_fwd_gpu.py")
     if world == 1 and not args.no_cpu_baseline:
       line["cpu_baseline"] = cpu_baseline(w)
-    print(json.dumps(line), flush=True)
+  else:
+    line = None
+
+  def emit(extra=None):
+    if line is not None:
+      if extra is not None:
+        line["with_gather"] = extra
+      print(json.dumps(line), flush=True)
+
+  if want_gather_extra:
+    # The same K steps once more with the gather of O inside the step: both figures in one line.  It runs LAST, with the line already complete.
+    def gather_leg():
+      g_elapsed, g_per_rank, _ = timed(step_gather)
+      return {"value": round(flops_global * args.steps / g_elapsed / 1e12, 2), "unit": "TFLOPS", "ms_per_step": round(g_elapsed / args.steps * 1e3, 4),
+              "per_rank_tflops": g_per_rank,
+              "what": f"the step + the gather of O: the block in <= {args.gather_chunks} pieces, each sent point-to-point (RCCL batch_isend_irecv) into its final slice on every other rank while the next piece computes"}
+
+    guarded_extra_leg(gather_leg, args.gather_extra_timeout, emit)
+  else:
+    emit()
 
   if dist is not None:
     dist.destroy_process_group()

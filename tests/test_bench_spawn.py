@@ -69,3 +69,22 @@ def test_a_failing_rank_fails_the_launcher_promptly(tmp_path):
   finally:
     bench.__file__ = real
   assert rc == 3 and time.time() - t0 < 20
+
+
+def _leg(code: str):
+  e = dict(os.environ, PYTHONPATH=ROOT)
+  return subprocess.run([sys.executable, "-c", "import json, sys, time\nimport bench\n" + code], capture_output=True, text=True, timeout=240, env=e, cwd=ROOT)
+
+
+def test_an_optional_leg_cannot_cost_the_line():
+  """N > 1: the gather of O is timed after the contract figure and under a watchdog (bench.guarded_extra_leg) — it returns, raises or hangs; the
+  line is printed exactly once and the process ends with exit code 0 in all three cases."""
+  emit = "emit = lambda extra: print(json.dumps({'value': 1.0, 'with_gather': extra}), flush=True)\n"
+  r = _leg(emit + "bench.guarded_extra_leg(lambda: {'value': 2.0}, 30.0, emit)")
+  assert r.returncode == 0 and [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")] == [{"value": 1.0, "with_gather": {"value": 2.0}}], r.stdout + r.stderr
+  r = _leg(emit + "bench.guarded_extra_leg(lambda: 1 / 0, 30.0, emit)")
+  (d,) = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+  assert r.returncode == 0 and d["value"] == 1.0 and d["with_gather"]["error"].startswith("ZeroDivisionError"), r.stdout + r.stderr
+  r = _leg(emit + "bench.guarded_extra_leg(lambda: time.sleep(600), 0.5, emit)\nprint('{\"never\": 1}')")
+  (d,) = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+  assert r.returncode == 0 and d["value"] == 1.0 and "watchdog" in d["with_gather"]["error"], r.stdout + r.stderr
