@@ -19,8 +19,9 @@ block is BORN sharded (per-unit seeds, nothing replicated), no data-path collect
   * default workloads: every rank owns one workload-shaped batch element -> "scaling": "weak" (8 x cfg2 is config 5);
   * --workload cfg5: the fixed global problem B=8 H=32 N=8192 D=512 (256 units) is split over the ranks ->
     "scaling": "strong"; per-rank TFLOPS are listed next to the aggregate;
-  * --gather adds the RCCL all_gather of O a caller wanting the full tensor on every rank would pay, in --gather-chunks pieces
-    that overlap with the compute of the next piece (sharding.attend_and_gather_units).
+  * --gather puts the gather of O a caller wanting the full tensor on every rank would pay INTO the timed step, in --gather-chunks pieces
+    sent point-to-point over RCCL while the next piece computes (sharding.attend_and_gather_units); without it the same K steps are timed a
+    second time with the gather, after the contract figure and under a watchdog (guarded_extra_leg), and reported as "with_gather".
 Timing: barrier + synchronize on both sides of exactly K steps, max over ranks.
 
 Rank 0 prints ONE JSON line.  `roofline` is the dominant kernel against the dense bf16 MFMA peak (HBM peak for the
@@ -782,7 +783,7 @@ def main() -> None:
         "global_batch": global_B,
         "seq_len": Nq,
         "parallelism": (f"(batch,kv-head) units born sharded x{world}: {Hkv * global_B} units, {Hkv * global_B / world:g} per rank, no data-path collective"
-                        if sharded else "single GPU") + (f" + all_gather(O) in {args.gather_chunks} pieces overlapped with compute" if gathered is not None else ""),
+                        if sharded else "single GPU") + (f" + gather of O on every rank in <= {args.gather_chunks} pieces overlapped with compute" if (sharded and world > 1 and args.gather) else ""),
         "flops_model": "4*B*Hq*D*valid_pairs",
         "step": "hip.ffpa_attn_forward_hip(causal=True, causal_offset=0)" if w["via"] == "op_offset0" else
                 ("sharding.attend_units -> ffpa_attn_func" if sharded else "ffpa_attn_func"),
