@@ -80,7 +80,7 @@ def _ffpa_apply(query, key, value, attn_bias, meta: FFPAAttnMeta) -> torch.Tenso
   inference: grad mode off, or no input requires a gradient — goes straight to the launch wrapper: no autograd node, no dispatcher
   round trip, no LSE tensor (what a decode step that synchronises per token pays on the host)."""
   needs_grad = meta.attn_meta.is_grad_enabled and any(t is not None and t.requires_grad for t in (query, key, value, attn_bias))
-  if not needs_grad and query.is_cuda:
+  if not needs_grad and query.is_cuda and type(query) is torch.Tensor and type(key) is torch.Tensor and type(value) is torch.Tensor:  # (fake / functional / subclass tensors: the registered op has the rules for them)
     from . import hip
 
     thr = getattr(meta.forward_meta, "rescale_threshold", None)

@@ -142,3 +142,21 @@ def test_package_version_matches_the_library():
 
   lib = hip.load_library()
   assert lib.ffpa_attn_version().decode().split()[1] == ffpa_attn_amd.__version__
+
+
+def test_fake_tensors_take_the_registered_op_not_the_launch_wrapper():
+  """The inference short cut of `_ffpa_apply` (no autograd node, straight to the launch wrapper) is for real tensors only: fake tensors — export,
+  make_fx, shape propagation — must reach `ffpa_attn::_fwd_hip`'s registered fake, on a box without a GPU or the library too."""
+  from torch._subclasses.fake_tensor import FakeTensor, FakeTensorMode
+
+  from ffpa_attn_amd import ffpa_attn_func
+
+  with FakeTensorMode():
+    q = torch.empty(1, 4, 1024, 512, dtype=torch.bfloat16, device="cuda")
+    k = torch.empty(1, 2, 2048, 512, dtype=torch.bfloat16, device="cuda")
+    v = torch.empty(1, 2, 2048, 512, dtype=torch.bfloat16, device="cuda")
+    o = ffpa_attn_func(q, k, v, is_causal=True, enable_gqa=True)
+    mask = torch.empty(1, 1, 1024, 2048, dtype=torch.bool, device="cuda")
+    om = ffpa_attn_func(q, k, v, attn_mask=mask, enable_gqa=True)
+  for t in (o, om):
+    assert isinstance(t, FakeTensor) and t.shape == (1, 4, 1024, 512) and t.dtype == torch.bfloat16 and t.device.type == "cuda"
