@@ -456,15 +456,17 @@ def _workspace(device: torch.device, stream: int, nbytes: int) -> torch.Tensor:
 
 
 # What a launch needs besides its tensors — workspace bytes and ticket count — is a function of the shape class only (ffpa_capi.hip make_plan): asked
-# once per class, not once per call (two ctypes round trips less per decode token).
+# once per class, not once per call (two ctypes round trips less per decode token).  The class names everything make_plan prices with (the mask KIND too: the
+# wide-row tile of D = 320 is for boolean masks only, and another tile is another number of workgroups); the library clamps the split count to the scratch it is
+# handed, so a class missing from the key could cost splits, never memory safety.
 _PLAN_SCRATCH: "dict[tuple, tuple[int, int]]" = {}
 
 
 def _plan_scratch(lib, p: "FfpaFwdParams", num_splits: int, want_tickets: bool, device_index: int) -> tuple[int, int]:
   if num_splits == 1:
     return 0, 0
-  key = (id(lib), device_index, p.dtype, p.batch, p.heads_q, p.heads_kv, p.seqlen_q, p.seqlen_kv, p.head_dim, p.causal, p.bias is not None,
-         p.kv_bounds is not None, p.dropout_p > 0.0, p.flags, num_splits, p.causal_row_mod, p.causal_offset, want_tickets, os.environ.get("FFPA_HIP_FAKE_CUS"))
+  key = (id(lib), device_index, p.dtype, p.batch, p.heads_q, p.heads_kv, p.seqlen_q, p.seqlen_kv, p.head_dim, p.causal, p.bias_dtype if p.bias else 0,
+         bool(p.bias) and p.bias_stride[2] == 0, p.kv_bounds is not None, p.dropout_p > 0.0, p.flags, num_splits, p.causal_row_mod, p.causal_offset, want_tickets, os.environ.get("FFPA_HIP_FAKE_CUS"))
   hit = _PLAN_SCRATCH.get(key)
   if hit is None:
     ws = int(lib.ffpa_attn_fwd_workspace_bytes(ctypes.byref(p)))
