@@ -23,20 +23,15 @@ from dataclasses import dataclass, field
 import torch
 
 
+_GRAD_STORAGE = {None: None, "fp16": torch.float16, "fp32": torch.float32, torch.float16: torch.float16, torch.float32: torch.float32}
+
+
 def _normalize_grad_storage_dtype(dtype):
-  """``None`` / ``"fp16"`` / ``"fp32"`` / ``torch.float16`` / ``torch.float32`` (functional.py:158-172)."""
-  if dtype is None:
-    return None
-  if dtype == "fp16":
-    return torch.float16
-  if dtype == "fp32":
-    return torch.float32
-  if dtype in (torch.float16, torch.float32):
-    return dtype
-  raise ValueError(
-    "grad_kv_storage_dtype must be None, 'fp16', 'fp32', torch.float16, or torch.float32, "
-    f"got {dtype!r}"
-  )
+  """``None`` / ``"fp16"`` / ``"fp32"`` / ``torch.float16`` / ``torch.float32`` (functional.py:158-172), the reference's error text otherwise."""
+  try:
+    return _GRAD_STORAGE[dtype]
+  except (KeyError, TypeError):
+    raise ValueError(f"grad_kv_storage_dtype must be None, 'fp16', 'fp32', torch.float16, or torch.float32, got {dtype!r}") from None
 
 
 @dataclass
@@ -49,12 +44,10 @@ class Backend:
   backward: bool | None = None
 
   def __post_init__(self) -> None:
-    if self.forward is None and self.backward is None:
-      self.forward = self.backward = True
-    elif self.forward is None:
-      self.forward = not self.backward
-    elif self.backward is None:
-      self.backward = not self.forward
+    fwd, bwd = self.forward, self.backward
+    # a side left open is the complement of the side that was given; both open = both passes
+    self.forward = (bwd is None or not bwd) if fwd is None else fwd
+    self.backward = (fwd is None or not fwd) if bwd is None else bwd
 
 
 @dataclass
@@ -114,8 +107,13 @@ class HIPBackend(Backend):
     return None
 
 
-_QUANT_METHODS_QK = ("per_block", "per_thread")
-_QUANT_METHODS_V = ("per_block", "per_channel")
+_CUDA_CHOICES = (
+  ("fp8_q_quant_method", ("per_block", "per_thread"), "'per_block' or 'per_thread'"),
+  ("fp8_k_quant_method", ("per_block", "per_thread"), "'per_block' or 'per_thread'"),
+  ("fp8_v_quant_method", ("per_block", "per_channel"), "'per_block' or 'per_channel'"),
+  ("fp8_pv_acc_type", ("f16", "f32"), "'f32' or 'f16'"),
+  ("fp8_qk_mm_type", ("fp8", "int8"), "'fp8' or 'int8'"),
+)
 
 
 @dataclass
@@ -152,32 +150,12 @@ class CUDABackend(HIPBackend):
     assert not self.backward, "cuda backend does not support backward"
     self._check_acc()
     assert not (self.enable_fp8 and self.enable_fp4), ("enable_fp8 and enable_fp4 are mutually exclusive")
-    assert self.fp8_q_quant_method in _QUANT_METHODS_QK, (
-      f"fp8_q_quant_method must be 'per_block' or 'per_thread', "
-      f"got {self.fp8_q_quant_method!r}"
-    )
-    assert self.fp8_k_quant_method in _QUANT_METHODS_QK, (
-      f"fp8_k_quant_method must be 'per_block' or 'per_thread', "
-      f"got {self.fp8_k_quant_method!r}"
-    )
-    assert self.fp8_v_quant_method in _QUANT_METHODS_V, (
-      f"fp8_v_quant_method must be 'per_block' or 'per_channel', "
-      f"got {self.fp8_v_quant_method!r}"
-    )
-    assert self.fp8_pv_acc_type in ("f16", "f32"), (
-      f"fp8_pv_acc_type must be 'f32' or 'f16', got {self.fp8_pv_acc_type!r}"
-    )
-    assert self.fp8_qk_mm_type in ("fp8", "int8"), (
-      f"fp8_qk_mm_type must be 'fp8' or 'int8', got {self.fp8_qk_mm_type!r}"
-    )
-    assert not self.fp8_smooth_v or self.fp8_v_quant_method == "per_channel", (
-      "fp8_smooth_v requires fp8_v_quant_method='per_channel'"
-    )
+    for name, allowed, wording in _CUDA_CHOICES:  # (the reference's messages, functional.py:270-300: call sites and tests match on them)
+      value = getattr(self, name)
+      assert value in allowed, f"{name} must be {wording}, got {value!r}"
+    assert self.fp8_v_quant_method == "per_channel" or not self.fp8_smooth_v, ("fp8_smooth_v requires fp8_v_quant_method='per_channel'")
     # the reference resolves enable_tma / enable_cute = None to what its build and device offer (functional.py:304-325): neither exists here
-    if self.enable_tma is None:
-      self.enable_tma = False
-    if self.enable_cute is None:
-      self.enable_cute = False
+    self.enable_tma, self.enable_cute = bool(self.enable_tma), bool(self.enable_cute)
 
   @property
   def quantized(self) -> str | None:
@@ -203,15 +181,14 @@ class TritonBackend(HIPBackend):
 
   def __post_init__(self) -> None:
     super().__post_init__()
-    assert self.autotune_mode in ("fast", "max"), \
-      f"Unsupported autotune_mode={self.autotune_mode!r}; choose 'fast' or 'max'."
+    assert self.autotune_mode in ("fast", "max"), f"Unsupported autotune_mode={self.autotune_mode!r}; choose 'fast' or 'max'."
     self.grad_kv_storage_dtype = _normalize_grad_storage_dtype(self.grad_kv_storage_dtype)
     self.grad_q_storage_dtype = _normalize_grad_storage_dtype(self.grad_q_storage_dtype)
     if self.persist_dkdv:
       assert self.backward, "persist_dkdv is only valid for Triton backward"
       assert self.enable_tma, "persist_dkdv requires enable_tma=True"
-    if self.split_launch or self.preprocess_d_chunk or self.grad_kv_storage_dtype is not None or self.grad_q_storage_dtype is not None:
-      assert self.backward, "backward-only Triton options require backward=True"
+    backward_only = (self.split_launch, self.preprocess_d_chunk, self.grad_kv_storage_dtype is not None, self.grad_q_storage_dtype is not None)
+    assert self.backward or not any(backward_only), "backward-only Triton options require backward=True"
 
 
 @dataclass
@@ -225,9 +202,7 @@ class CuTeDSLBackend(Backend):
   def __post_init__(self) -> None:
     super().__post_init__()
     self.grad_kv_storage_dtype = _normalize_grad_storage_dtype(self.grad_kv_storage_dtype)
-    if self.grad_kv_storage_dtype is not None:
-      assert self.backward, \
-        "grad_kv_storage_dtype is a backward-only option; requires backward=True"
+    assert self.backward or self.grad_kv_storage_dtype is None, "grad_kv_storage_dtype is a backward-only option; requires backward=True"
 
 
 _BACKEND_BY_NAME = {
