@@ -737,6 +737,40 @@ def main() -> None:
               "what": "the same step back to back after >= 150 ms of continuous load, one HIP event pair around the launches; outside the timed region"}
     if w["bound"] == "hbm":
       steady["gbps"] = round(algorithmic_bytes(w, global_B) / (ss_ms * 1e-3) / 1e9, 1)
+  graph_replay = None
+  if world == 1 and w["bound"] == "hbm" and not args.no_steady and not args.stub_backend:
+    # Context, never `value`: the decode step is launch-bound on the host (two kernels of ~ 85 + 5 us behind ~ 30 us of Python per call).  A serving loop captures its
+    # layers into a HIP graph; this leg captures the step once — and 32 of them, a token's worth of layers — into torch.cuda.CUDAGraph and replays back to back: what the
+    # kernels alone sustain when nothing is launched from Python (the C-ABI allocates nothing, never synchronises and launches on the caller's stream, so it captures as is).
+    try:
+      graph_replay = {"what": "the step captured into a HIP graph (torch.cuda.CUDAGraph) and replayed back to back after >= 150 ms of load; outside the timed region"}
+      side = torch.cuda.Stream()
+      side.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(side):
+        for _ in range(3):
+          step()
+      torch.cuda.current_stream().wait_stream(side)
+      for per_graph in (1, 32):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+          for _ in range(per_graph):
+            keep = step()  # noqa: F841 — (the outputs live in the graph's pool)
+        est_ms = max(kernel_ms_avg, 1e-3) * per_graph
+        n_pre, n_timed = max(3, int(150.0 / est_ms)), max(5, min(400, int(60.0 / est_ms)))
+        for _ in range(n_pre):
+          g.replay()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(n_timed):
+          g.replay()
+        ev1.record()
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1) / (n_timed * per_graph)
+        graph_replay[f"steps_per_graph_{per_graph}"] = {"ms_per_step": round(ms, 4), "gbps": round(algorithmic_bytes(w, global_B) / (ms * 1e-3) / 1e9, 1),
+                                                       "frac_of_hbm_peak": round(algorithmic_bytes(w, global_B) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "replays": n_timed}
+        del g
+    except Exception as e:  # noqa: BLE001 — informative only
+      graph_replay = {"error": f"{type(e).__name__}: {e}"[:300]}
   # (the whole local problem, not a slice of it: since round 5 the launch plan depends on how many workgroups a launch has — the wide-row tile of D = 320)
   plan = planned_kernel(w, q, k, v, mask, scale) if rank == 0 else {}
 
@@ -791,6 +825,7 @@ def main() -> None:
       "roofline": roof,
       "device": device,
       "steady_state": steady,
+      **({"graph_replay": graph_replay} if graph_replay is not None else {}),
       "build": build,
       "plan": {k_: plan.get(k_) for k_ in ("variant", "block_rows", "block_keys", "splits")},
     }
