@@ -47,3 +47,20 @@ def test_bench_line_of_a_short_workload_is_whole():
   assert steady["launches"] >= 20 and steady["after_launches"] >= 20 and steady["ms_per_step"] > 0
   assert abs(steady["tflops"] - roof["flops_per_launch"] / steady["ms_per_step"] / 1e9) / steady["tflops"] < 0.01
   assert line["build"]["lib"].endswith("libffpa_attn_hip.so") and len(line["build"]["lib_sha16"]) == 16
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_decode_line_is_priced_against_hbm_and_carries_the_graph_replay_leg():
+  """The decode workload's roofline is the HBM one; its step is launch-bound from Python, so the line also says what the same step does when it is
+  captured into a HIP graph and replayed (one step per graph, and 32 — a token's layers)."""
+  line = _bench("--gpus", "1", "--workload", "decode", "--steps", "10", "--warmup", "3", "--no-sdpa", "--no-cpu-baseline")
+  roof = line["roofline"]
+  assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0 and 0.0 < roof["frac"] < 1.0
+  assert roof["kernel"].startswith("ffpa_fwd_split_d_kernel<bf16, 512")
+  g = line["graph_replay"]
+  assert "error" not in g, g
+  for key in ("steps_per_graph_1", "steps_per_graph_32"):
+    leg = g[key]
+    assert leg["ms_per_step"] > 0 and abs(leg["gbps"] - roof["bytes_per_launch"] / leg["ms_per_step"] / 1e6) / leg["gbps"] < 0.01 and 0.0 < leg["frac_of_hbm_peak"] < 1.0
+  # no host work per step: a replayed step cannot be slower than the step launched from Python by more than timer noise
+  assert g["steps_per_graph_32"]["ms_per_step"] <= line["ms_per_step"] * 1.10
