@@ -286,7 +286,7 @@ class DeviceTelemetry:
       p = [x[1] for x in self.samples if x[1] == x[1]]
       out.update(sclk_mhz_avg=round(sum(f) / len(f), 1), sclk_mhz_min=round(min(f), 1), sclk_mhz_max=round(max(f), 1),
                  power_w_avg=round(sum(p) / len(p), 1) if p else None, power_w_max=round(max(p), 1) if p else None, samples=len(f),
-                 sampled="freq1_input / power1_* of the GPU's hwmon node, every 1 ms over the timed region")
+                 sampled="freq1_input / power1_* of the GPU's hwmon node, at its start, every 10 ms and at its end, over the timed region")
     return out
 
 
