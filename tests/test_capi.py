@@ -352,3 +352,72 @@ def test_integration_md_binding_mirrors_the_header():
   assert [f[0] for f in doc._fields_] == [f[0] for f in hip.FfpaFwdParams._fields_]
   assert ctypes.sizeof(doc) == ctypes.sizeof(hip.FfpaFwdParams)
   assert f"abi_version={hip.ABI_VERSION}," in text
+
+
+def test_plan_invariants_on_random_launches(lib, monkeypatch):
+  """3000 seeded random launches x three CU counts (the plan needs no GPU): whatever make_plan picks, the answers of the three query entry points
+  agree with each other and with the documented contract — the scratch is exactly splits x B x Hq x Nq x (built D + 1) fp32 (0 without splits) and stays under
+  the 1 GiB cap for automatic prefill splits, `num_splits = 1` and a missing scratch mean one range, a requested count is a ceiling, every split keeps
+  whole KV tiles, tiles come from the built set, the wide-row tile only where it exists (D in (256, 320], no additive bias, no dropout) and never
+  against FFPA_FLAG_NO_WIDE_TILE, and the kernel name says what the plan says."""
+  import random
+
+  rng = random.Random(20250927)
+  plan = (ctypes.c_int * 4)()
+  name = ctypes.create_string_buffer(160)
+  dims = [64 * i for i in range(1, 17)] + [72, 264, 300, 520, 1000]
+  for cus in ("", "128", "304"):
+    if cus:
+      monkeypatch.setenv("FFPA_HIP_FAKE_CUS", cus)
+    else:
+      monkeypatch.delenv("FFPA_HIP_FAKE_CUS", raising=False)
+    for _ in range(1000):
+      D = rng.choice(dims)
+      group = rng.choice([1, 1, 2, 4, 8])
+      hkv = rng.choice([1, 2, 3, 8, 9, 32])
+      B = rng.choice([1, 1, 2, 3, 8])
+      nq = rng.choice([1, 2, 7, 8, 31, 32, 33, 100, 512, 1000, 2048, 4096, 8192])
+      nkv = rng.choice([1, 63, 64, 500, 1024, 2048, 8192, 10000, 32768])
+      causal = rng.random() < 0.3
+      bias = rng.choice([0, 0, 0, 1, 3, 4])  # none / fp16 / fp32 / bool
+      drop = 0.1 if rng.random() < 0.15 else 0.0
+      flags = rng.choice([0, 0, 0, hip.FLAG_WIDE_TILE, hip.FLAG_NO_WIDE_TILE])
+      req = rng.choice([0, 0, 0, 1, 2, 5])
+      Dp = (D + 7) // 8 * 8
+      p = _params(batch=B, heads_q=hkv * group, heads_kv=hkv, seqlen_q=nq, seqlen_kv=nkv, head_dim=Dp, causal=int(causal), causal_offset=max(0, nkv - nq),
+                  dropout_p=drop, flags=flags, num_splits=req)
+      for n, rows in (("q_stride", nq), ("o_stride", nq), ("k_stride", nkv), ("v_stride", nkv)):
+        heads = hkv * group if n[0] in "qo" else hkv
+        getattr(p, n)[:] = [heads * rows * Dp, rows * Dp, Dp]
+      if bias:
+        p.bias, p.bias_dtype = p.q, bias
+        p.bias_stride[:] = [0, 0, rng.choice([0, nkv]), 1]
+      what = dict(cus=cus, D=D, B=B, hq=hkv * group, hkv=hkv, nq=nq, nkv=nkv, causal=causal, bias=bias, drop=drop, flags=hex(flags), req=req)
+      # without scratch: one range
+      assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0, (what, lib.ffpa_attn_last_error())
+      assert plan[3] == 1, (what, list(plan))
+      need = lib.ffpa_attn_fwd_workspace_bytes(ctypes.byref(p))
+      p.workspace, p.workspace_bytes = 16, 1 << 42
+      assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0, what
+      variant, br, bc, splits = plan
+      assert variant in (0, 1) and br in (32, 64, 128, 192) and bc in (32, 64, 128) and splits >= 1, (what, list(plan))
+      assert (variant == 1) == (nq <= 32), (what, list(plan))
+      per_split = 4 * B * hkv * group * nq * ((Dp + 63) // 64 * 64 + 1)  # (partials in the BUILT head dim: the next multiple of 64)
+      assert need == (splits * per_split if splits > 1 else 0), (what, list(plan), need)
+      if req == 1:
+        assert splits == 1, (what, list(plan))
+      elif req > 1:
+        assert splits <= req, (what, list(plan))
+      if splits > 1:
+        assert -(-nkv // bc) >= splits, (what, list(plan))  # every range holds at least one KV tile
+        if variant == 0 and req == 0:
+          assert need <= 1 << 30, (what, need)
+      assert lib.ffpa_attn_fwd_kernel(ctypes.byref(p), name, len(name)) == 0, what
+      kernel = name.value.decode()
+      wide = kernel.startswith("ffpa_fwd_m16w_kernel")
+      assert wide == (br == 192), (what, kernel, list(plan))
+      if wide:
+        assert 256 < Dp <= 320 and bias in (0, 4) and drop == 0.0 and not (flags & hip.FLAG_NO_WIDE_TILE), (what, kernel)
+      if variant == 1:
+        assert kernel.startswith("ffpa_fwd_split_d_kernel"), (what, kernel)
+      assert f" {(Dp + 63) // 64 * 64}," in kernel or f" {(Dp + 63) // 64 * 64}>" in kernel, (what, kernel)
