@@ -55,23 +55,11 @@
 #ifndef FFPA_PF2
 #define FFPA_PF2 4  // PV: ditto (two transpose reads per MFMA)
 #endif
-#ifndef FFPA_DMA_INTERLEAVE
-#define FFPA_DMA_INTERLEAVE 1  // 1: issue LDS-DMA pieces between the MFMAs (2: on the ND = 4 tiles too); 0: bursts after the barriers
-#endif
 #ifndef FFPA_DMA_STEP
 #define FFPA_DMA_STEP 4  // interleaved mode: one DMA piece every this many MFMAs (ND == 1): spreads the tile evenly over the loop
 #endif
 #ifndef FFPA_DMA_STEP_ND2
 #define FFPA_DMA_STEP_ND2 2  // ditto for the split-D kernels (+2 % over 1)
-#endif
-#ifndef FFPA_PV_ORDER
-#define FFPA_PV_ORDER 1  // PV MFMA order: 0 = column-block outer (4 back-to-back MFMAs per accumulator),
-#endif                   //               1 = key-step outer (consecutive MFMAs rotate over all accumulators)
-#ifndef FFPA_QK_ORDER
-#define FFPA_QK_ORDER 0  // QK MFMA order: 0 = d-step outer (alternate the two S accumulators), 1 = key-block outer
-#endif
-#ifndef FFPA_BIAS_EARLY
-#define FFPA_BIAS_EARLY 1  // split-D kernels, 16-bit bias tiles: issue the loads right after QK^T, ahead of the barrier and the K burst
 #endif
 #ifndef FFPA_HOIST_MAX_D
 #define FFPA_HOIST_MAX_D 448      // ND == 1: hoist the per-lane DMA source offsets up to this head dim
@@ -79,41 +67,21 @@
 #ifndef FFPA_HOIST_ND2_MAX_D
 #define FFPA_HOIST_ND2_MAX_D 960  // ND == 2 (split-D): every head dim whose rows are not whole pieces
 #endif
-#ifndef FFPA_ROW_DMA
-#define FFPA_ROW_DMA 1  // D = 512: wave-uniform rows, 3 scalar-only instructions per DMA piece
-#endif
 #ifndef FFPA_BC128_MAX_D
 #define FFPA_BC128_MAX_D 320  // ND == 1 head dims up to this use 128-key tiles (2*128*D*2 B of LDS <= 160 KiB)
-#endif
-#ifndef FFPA_HOIST
-#define FFPA_HOIST 1  // hoist the tile-invariant per-lane DMA source offsets (head dims with non-1KiB rows)
 #endif
 #ifndef FFPA_K_PRE
 #define FFPA_K_PRE 8  // interleaved mode: this many K(j+1) pieces are issued right after QK^T (they stream under
 #endif                //   the softmax); V(j) is then awaited with a counted vmcnt just before PV.  0 = one barrier A
-#ifndef FFPA_K_PRE_SPREAD
-#define FFPA_K_PRE_SPREAD 1  // ND == 1; 1: the FFPA_K_PRE pieces go out in four groups between the softmax stages instead of as one burst behind
-#endif                       //   barrier A1 (+0.2 ... 1.4 % on every head dim 128 ... 512; re-measured on the bias-free build)
 #ifndef FFPA_K_PRE_ND2
-#define FFPA_K_PRE_ND2 64  // split-D kernels: as FFPA_K_PRE; with FFPA_K_PRE_SPREAD_ND2 it is clamped to the tile's pieces (a multiple of 4)
+#define FFPA_K_PRE_ND2 64  // split-D kernels: as FFPA_K_PRE; it is clamped to the tile's pieces (a multiple of 4)
 #endif
-#ifndef FFPA_K_PRE_SPREAD_ND2
-#define FFPA_K_PRE_SPREAD_ND2 1  // split-D kernels: all of K(j+1) goes out between the softmax stages, none between the PV MFMAs (D = 1024: +7 %)
-#endif
-#ifndef FFPA_SQ_NT
-#define FFPA_SQ_NT 1  // 1: the short-query (ND >= 2) builds carry a second form of their K / V LDS-DMA with the non-temporal hint; FwdArgs.flags picks per launch
-#endif
-#ifndef FFPA_V_EARLY
-#define FFPA_V_EARLY 1  // issue the first PV fragment reads right after barrier A (latency hides under softmax)
-#endif
-#ifndef FFPA_DMA_M0_CLOBBER
-#define FFPA_DMA_M0_CLOBBER 1  // the LDS-DMA asm declares M0 clobbered (0: as rounds 1 - 2 shipped it, for the A/B that showed no difference)
-#endif
-#if FFPA_DMA_M0_CLOBBER
-#define FFPA_M0_CLOBBER , "m0"
-#else
-#define FFPA_M0_CLOBBER
-#endif
+// Settled schedule choices that used to be on / off switches here (each measured, tools/experiments/r05_pruned_switches_2.diff restores them): DMA pieces go out
+// between the MFMAs of the prefill tiles (ND <= 2; the short-query ND = 4 tiles keep bursts); the early K(j+1) pieces are spread over the softmax stages in four
+// groups (+ 0.2 ... 1.4 % at D <= 512, + 7 % at D = 1024); tile-invariant per-lane DMA source offsets are hoisted where the registers allow; D % 512 == 0 rows use the
+// wave-uniform row form (3 scalar instructions per piece); the first PV fragments are read right behind barrier A; QK^T runs d-step outer, PV key-step outer; the 16-bit
+// bias tile of the split-D tiles is loaded ahead of barrier A; the short-query builds carry a non-temporal form of their K / V DMA (FwdArgs.flags picks per launch).
+#define FFPA_M0_CLOBBER , "m0"  // the LDS-DMA asm writes M0 behind the compiler's back and says so
 
 // The S^T MFMAs are inline asm, so hipcc's hazard recognizer does not see their operands (a VALU write needs 2
 // wait states before an MFMA reads the register).  In the product kernels their A operand comes from ds_read
@@ -154,17 +122,11 @@ constexpr unsigned kFlagStreamKV = 0x80000000u;  // set by the launch side only 
 // 64 KiB tiles of D = 1024 reach 6.1).  D = 384 / 512 run ONE workgroup per CU (the split rule for these head dims, ffpa_capi.hip), so the LDS has
 // the room; D = 128 still fits two.  D = 256 does not (96 KiB per workgroup: one per CU, + 6 % time: measured, profiles/r03_decode_splits.txt).
 // The partial-S exchange area grows with the tile: 4 KiB per wave and 32-key block.
-#ifndef FFPA_SQ_BC64
-#define FFPA_SQ_BC64 1
-#endif
 // Round 4: the two-wave split (ND = 2: head dims that are not multiples of 128) takes 64-key tiles too where the LDS has the room — D = 320 (112 KiB)
 // and D = 448 (144 KiB); 576 and up would need 176 KiB.  Interleaved A/B on one box (profiles/r04_decode_nd2.txt): D = 320 B1 H32 Nkv 8192 75.9 -> 66.9 us
 // (4.4 -> 5.0 TB/s of K / V), B8 GQA 144 -> 123 us (5.45 TB/s), 64k keys 144 -> 124 us, 16 query rows - 11 %; D = 448 - 2 % / +- 0.
-#ifndef FFPA_SQ_BC64_ND2
-#define FFPA_SQ_BC64_ND2 1
-#endif
 constexpr int splitd_block_keys(int D, int ND) {
-  return ((FFPA_SQ_BC64 != 0 && ND == 4 && (D == 128 || D == 384 || D == 512)) || (FFPA_SQ_BC64_ND2 != 0 && ND == 2 && (D == 320 || D == 448))) ? 64 : 32;
+  return ((ND == 4 && (D == 128 || D == 384 || D == 512)) || (ND == 2 && (D == 320 || D == 448))) ? 64 : 32;
 }
 constexpr int splitd_exchange_bytes(int D, int ND) { return ND > 1 ? 4 * 4096 * (splitd_block_keys(D, ND) / 32) : 0; }
 
@@ -814,7 +776,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   constexpr int PF1 = FFPA_PF1;
   constexpr int PF2 = FFPA_PF2;
   constexpr int PPW = BC * D * 2 / 4096;  // 1 KiB DMA pieces per wave per tile
-  constexpr bool kInterleave = FFPA_DMA_INTERLEAVE != 0 && (ND <= 2 || FFPA_DMA_INTERLEAVE == 2);  // short-query (ND = 4) tiles keep bursts
+  constexpr bool kInterleave = ND <= 2;  // LDS-DMA pieces go out between the MFMAs; the short-query (ND = 4) tiles keep bursts behind the barriers
   constexpr int kStep = (ND == 1) ? FFPA_DMA_STEP : (ND == 2) ? FFPA_DMA_STEP_ND2 : 1;  // MFMAs between two DMA pieces
   static_assert(!kInterleave || PPW * kStep <= (DW / 16) * (BC / 32), "DMA pieces must fit the QK loop");
   // Head dims whose rows are not a whole number of 1 KiB pieces need ~12 VALU instructions per piece for the
@@ -822,15 +784,15 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   // budget allows they are hoisted into PPW + PPW VGPRs.
   constexpr bool kPad = SAFE;  // s_nop 1 in front of the asm MFMAs (see FFPA_MFMA_PAD)
   constexpr bool kRowUniform = (D * 2) % 1024 == 0;
-  constexpr bool kHoist = FFPA_HOIST != 0 && !kRowUniform && !SAFE && !DROP && (ND == 1 ? D <= FFPA_HOIST_MAX_D : (ND == 2 && D <= FFPA_HOIST_ND2_MAX_D));
+  constexpr bool kHoist = !kRowUniform && !SAFE && !DROP && (ND == 1 ? D <= FFPA_HOIST_MAX_D : (ND == 2 && D <= FFPA_HOIST_ND2_MAX_D));
   // Row-uniform head dims: wave w stages keys 16 a + 4 w + b (a < BC/16, b < 4) so that only four K and
   // four V swizzled lane offsets exist (K: slot ^ (4 w + b); V: slot ^ 4 b) and live in 8 VGPRs.
-  constexpr bool kRowDma = FFPA_ROW_DMA != 0 && kRowUniform && !SAFE && kInterleave;  // (burst-mode kernels keep stage_piece)
+  constexpr bool kRowDma = kRowUniform && !SAFE && kInterleave;  // (burst-mode kernels keep stage_piece)
   constexpr int RPP = kRowUniform ? RB / 1024 : 1;  // pieces per row
   constexpr int KPW = BC / 4;                       // keys staged per wave per tile
   static_assert(!kRowDma || (D % 128 == 0 && KPW * RPP == PPW && BC % 16 == 0), "row DMA layout");
   constexpr int kPreReq = (ND == 2) ? FFPA_K_PRE_ND2 : FFPA_K_PRE;
-  constexpr bool kSpreadReq = ((ND == 2) ? FFPA_K_PRE_SPREAD_ND2 : FFPA_K_PRE_SPREAD) != 0 && !SAFE;
+  constexpr bool kSpreadReq = !SAFE;  // the early K(j+1) pieces go out in four groups between the softmax stages (split-D tiles: all of K(j+1) does)
   constexpr int kPre = !(kInterleave && kPreReq > 0) ? 0
                        : kSpreadReq              ? ((kPreReq < PPW ? kPreReq : PPW) / 4) * 4
                                                  : (kPreReq <= PPW ? kPreReq : 0);
@@ -943,7 +905,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
   }
   // All three forms address the tile through tile_src(): offsets are relative to the tile's first row and the
   // descriptor zero-fills rows past the last key.
-  constexpr bool kNt = FFPA_SQ_NT != 0 && ND >= 2;  // the short-query builds can stream K / V past the caches (see lds_dma_16) ...
+  constexpr bool kNt = ND >= 2;  // the short-query builds can stream K / V past the caches (see lds_dma_16) ...
   const bool stream_kv = kNt && (a.flags & kFlagStreamKV) != 0;  // ... when the launch side says every byte has one reader and the caches cannot hold them
   auto issue_k = [&](auto ic, int key0, int dlane) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
@@ -1117,7 +1079,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
       constexpr int N1 = KS * NKB;
       v8 kf[N1];
       auto k_frag = [&](int n) -> v8 {
-        const int s = FFPA_QK_ORDER ? n % KS : n / NKB, kb = FFPA_QK_ORDER ? n / KS : n % NKB;
+        const int s = n / NKB, kb = n % NKB;  // d-step outer: consecutive MFMAs alternate the S accumulators
         return *(FFPA_LDS const v8*)(kaddr[s & 7] + (s >> 3) * 256 + kb * 32 * RB);
       };
       const int dlane = opaque_lane(lane);
@@ -1132,7 +1094,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
           // V(j) streams in under this tile's QK^T (the V buffer is free since barrier B of tile j-1)
           issue_v(std::integral_constant<int, n / kStep>{}, k0, dlane);
         }
-        constexpr int s = FFPA_QK_ORDER ? n % KS : n / NKB, kb = FFPA_QK_ORDER ? n / KS : n % NKB;
+        constexpr int s = n / NKB, kb = n % NKB;
         if constexpr (s == 0) E::template mfma_v_first<kPad>(sacc[kb], kf[n], qf[s]);
         else E::template mfma_v_acc<kPad>(sacc[kb], kf[n], qf[s]);
       });
@@ -1144,7 +1106,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
 
     // 16-bit bias tile of this step (two 16-byte loads per lane and key block): issued here, ahead of barrier A and of
     // the K(j+1) burst, so that their latency overlaps both; consumed in the score-modifier section below.
-    constexpr bool kBiasEarly = FFPA_BIAS_EARLY != 0 && !SAFE && ND > 1;  // measured: -10 % at D = 1024; D <= 512 has no registers to spare (+2 %)
+    constexpr bool kBiasEarly = !SAFE && ND > 1;  // measured: -10 % at D = 1024; D <= 512 has no registers to spare (+2 %)
     u32x4 braw[kBiasEarly ? 2 * NKB : 1];
     const bool mask_free = k0 >= free_lo && k0 + BC <= free_hi;  // wave-uniform: this tile lies in the mask's neutral interior
     const bool bias_early = MASK && !kBoolOnly && kBiasEarly && a.bias_vec == 8 && a.bias_dtype != 4 && a.bias_lds == 0 && a.bias_tile == 0 && k0 + BC <= a.Nkv && !mask_free;
@@ -1160,7 +1122,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
       __builtin_amdgcn_sched_barrier(0);
     }
 
-    // FFPA_K_PRE_SPREAD: the kPre early K(j+1) pieces go out in four groups between the softmax stages (the texture-address
+    // The kPre early K(j+1) pieces go out in four groups between the softmax stages (the texture-address
     // unit idles there) instead of as one burst of 4 x kPre pieces per CU right behind barrier A1
     constexpr bool kPreSpread = kSpreadReq && kPre >= 4;
     auto pre_k_group = [&](auto gc) __attribute__((always_inline)) {
@@ -1207,7 +1169,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
     constexpr int N2 = NDB * NKS;
     v8 vf[N2];
     auto v_frag = [&](int n) -> v8 {
-      const int db = FFPA_PV_ORDER ? n % NDB : n / NKS, ks = FFPA_PV_ORDER ? n / NDB : n % NKS;
+      const int db = n % NDB, ks = n / NDB;  // key-step outer: consecutive MFMAs rotate over all accumulators
       if constexpr (!SAFE) {
         const int krow = (kVHi && ks >= 4) ? 32 * ((ks - 4) >> 1) + 8 * (ks & 1) : 32 * (ks >> 1) + 8 * (ks & 1);
         FFPA_LDS const char* vp = ((kVHi && ks >= 4) ? vaddr[4 + (db & 3)] : vaddr[db & 3]) + (db >> 2) * 256 + krow * RB;
@@ -1226,7 +1188,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
         return r;
       }
     };
-    if constexpr (FFPA_V_EARLY && kPre == 0) {
+    if constexpr (kPre == 0) {
 #pragma unroll
       for (int n = 0; n < PF2 && n < N2; ++n) vf[n] = v_frag(n);
       __builtin_amdgcn_sched_barrier(0);
@@ -1472,7 +1434,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
         dma_wait_except<kPre>();
         __syncthreads();
       }
-      if constexpr (!FFPA_V_EARLY || kPre > 0) {
+      if constexpr (kPre > 0) {
 #pragma unroll
         for (int n = 0; n < PF2 && n < N2; ++n) vf[n] = v_frag(n);
       }
@@ -1494,7 +1456,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_split_d_kernel(const FwdArgs a) 
             issue_bias(std::integral_constant<int, n / kBStep>{}, k0 + BC);
           }
         }
-        constexpr int db = FFPA_PV_ORDER ? n % NDB : n / NKS, ks = FFPA_PV_ORDER ? n / NDB : n % NKS;
+        constexpr int db = n % NDB, ks = n / NDB;
         oacc[db] = E::mfma(vf[n], pf[ks], oacc[db]);
       });
       if constexpr (kBiasTile && kInterleave) {

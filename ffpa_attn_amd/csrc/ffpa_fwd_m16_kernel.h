@@ -91,11 +91,8 @@
 // sixteenths of a wave's pieces per tile image: FFPA_M16_PP_VQ (V pieces in Q; the rest in S), _K1Q (K1 pieces in Q; the rest in the P phase
 // before), _K2S (K2 pieces in S; the rest in P).  Builds: no additive bias, no dropout (MK 0 and, since round 5, the boolean-mask / mask-range build MK 2); D % 128 == 0.
 // Measured (config 3, B1 H32 N8192 D1024, interleaved A/B on one box, outputs bit-identical; profiles/r04_pipe.txt): round-3 loop 945 ... 975 TFLOPS,
-// two-half K alone (FFPA_M16_KSPLIT, best table) + 3.9 %, the pipeline + 6.2 ... 6.6 % (VQ / K1Q / K2S = 6 / 2 / 2, three K fragments ahead in S;
+// two-half K alone (best table) + 3.9 %, the pipeline + 6.2 ... 6.6 % (VQ / K1Q / K2S = 6 / 2 / 2, three K fragments ahead in S;
 // 7 / 1 / 1: + 5 %, 8 / 0 / 0: + 4.2 %, 10 / 1 / 1: + 1.8 %); D = 640 / 768 / 896: + 4.4 / + 7.6 / + 3.4 %, causal + 4.7 %, Nq 1024 + 9.9 %, 32k keys + 3.5 %.
-#ifndef FFPA_M16_PIPE
-#define FFPA_M16_PIPE 1
-#endif
 #ifndef FFPA_M16_PP_VQ
 #define FFPA_M16_PP_VQ 6
 #endif
@@ -120,11 +117,8 @@
 #ifndef FFPA_M16_PP_PF
 #define FFPA_M16_PP_PF 3  // K fragments requested ahead of their MFMAs in the S phase (the softmax's registers are live next to them)
 #endif
-#ifndef FFPA_M16_FUSE_DMA
-// 1: a DMA piece and the MFMA in front of it are one asm statement (Mfma16::with_dma): the MFMA is the wait state between the M0 write and the piece,
-// no s_nop.  Interleaved A/B, bit-identical (profiles/r04_pipe.txt): config 2 + 1.0 %, cross + 1.7 %, causal + 1.3 %, D = 320 + 1.4 %, config 4 + 0.9 %, D = 1024 +- 0
-#define FFPA_M16_FUSE_DMA 1
-#endif
+// A DMA piece and the MFMA in front of it are one asm statement (Mfma16::with_dma): the MFMA is the wait state between the M0 write and the piece,
+// no s_nop.  Interleaved A/B against separate statements, bit-identical (profiles/r04_pipe.txt): config 2 + 1.0 %, cross + 1.7 %, causal + 1.3 %, D = 320 + 1.4 %, config 4 + 0.9 %, D = 1024 +- 0
 
 
 // Developer instrumentation (-DFFPA_M16_TIMING, tools/gpu_phase_times.py; never in the shipped build): every wave accumulates the shader
@@ -153,7 +147,7 @@ constexpr int m16_block_keys(int D, bool bias_build) {
 }
 
 // Bytes of the partial-S^T exchange area behind the two tile images of the split-D tiles (D > 512): 4 KiB per wave; 6 KiB in the builds without
-// an additive bias, whose softmax pipeline publishes key block 0 one step early into a double-buffered half (FFPA_M16_PIPE; reserved whether or
+// an additive bias, whose softmax pipeline publishes key block 0 one step early into a double-buffered half (reserved whether or
 // not the build is pipelined, so that the launch side needs to know the mask kind only).
 // Since round 5 the two waves of a row block share the softmax by rows and trade P^T fragments (4 x 1 KiB) and per-row scalars (4 x 256 B) behind it: 5 KiB more
 // in the builds without an additive bias.  MK: 1 = the additive-bias build with staged tiles (4 KiB per wave), 3 = the key-bias build: 6 KiB where it runs the
@@ -188,7 +182,7 @@ struct Mfma16<__bf16> {
   static __device__ __forceinline__ void acc_last(f32x4& d, f32x4& other, v8 a, v8 b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n\ts_nop 15\n\ts_nop 3" : "+v"(d), "+v"(other) : "v"(a), "v"(b));
   }
-  // An MFMA with a 1 KiB LDS-DMA piece riding on it (FFPA_M16_FUSE_DMA): M0 is written in FRONT of the MFMA, which then is the wait state an
+  // An MFMA with a 1 KiB LDS-DMA piece riding on it: M0 is written in FRONT of the MFMA, which then is the wait state an
   // LDS-DMA needs behind an M0 write — the piece costs the stream two issue slots instead of three (s_add, s_nop, buffer_load).
   // KIND 0: first MFMA of a chain (C = 0, VGPR), 1: accumulate (VGPR), 2: accumulate (AGPR tile).
   template <int KIND, int LCONST>
@@ -213,7 +207,7 @@ struct Mfma16<_Float16> {
   static __device__ __forceinline__ void acc_last(f32x4& d, f32x4& other, v8 a, v8 b) {
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %2, %3, %0\n\ts_nop 15\n\ts_nop 3" : "+v"(d), "+v"(other) : "v"(a), "v"(b));
   }
-  // An MFMA with a 1 KiB LDS-DMA piece riding on it (FFPA_M16_FUSE_DMA): M0 is written in FRONT of the MFMA, which then is the wait state an
+  // An MFMA with a 1 KiB LDS-DMA piece riding on it: M0 is written in FRONT of the MFMA, which then is the wait state an
   // LDS-DMA needs behind an M0 write — the piece costs the stream two issue slots instead of three (s_add, s_nop, buffer_load).
   // KIND 0: first MFMA of a chain (C = 0, VGPR), 1: accumulate (VGPR), 2: accumulate (AGPR tile).
   template <int KIND, int LCONST>
@@ -276,10 +270,10 @@ __device__ __forceinline__ int m16_v_swizzle(int key) {
 // overwrites LSE rows, experimental schedules — may be anything but its shipped default there.  Variant libraries (build.py --variant)
 // are built without the define, get another file name and say so in ffpa_attn_version().
 #ifdef FFPA_PRODUCT_BUILD
-#if FFPA_SQ_BC64 != 1 || FFPA_SQ_BC64_ND2 != 1 || FFPA_SQ_NT != 1 || defined(FFPA_M16_TIMING) || FFPA_M16_PF1 != 6 || FFPA_M16_PF2 != 4 || FFPA_M16_K_PRE != 8 || \
-    FFPA_M16_K_PRE_ND2 != 64 || FFPA_M16_PF_DIST != 2 || FFPA_M16_PF_WAVES != 2 || FFPA_M16_PF_WHICH != 3 || FFPA_DMA_M0_CLOBBER != 1 || FFPA_M16_MIN_D != 128 || FFPA_M16_BC128_MIN_D != 256 || \
-    (defined(FFPA_M16_PHILOX_ILP) && FFPA_M16_PHILOX_ILP != 1) || FFPA_M16_PIPE != 1 || FFPA_M16_PP_VQ != 6 || FFPA_M16_PP_K1Q != 2 || FFPA_M16_PP_K2S != 2 || FFPA_M16_PP_QSTEP != 2 || \
-    FFPA_M16_PP_SSTEP != 1 || FFPA_M16_PP_PSTEP != 2 || FFPA_M16_PP_PF != 3 || FFPA_M16_FUSE_DMA != 1 || (defined(FFPA_M16_PK_FMA) && FFPA_M16_PK_FMA != 1)
+#if defined(FFPA_M16_TIMING) || FFPA_M16_PF1 != 6 || FFPA_M16_PF2 != 4 || FFPA_M16_K_PRE != 8 || \
+    FFPA_M16_K_PRE_ND2 != 64 || FFPA_M16_PF_DIST != 2 || FFPA_M16_PF_WAVES != 2 || FFPA_M16_PF_WHICH != 3 || FFPA_M16_MIN_D != 128 || FFPA_M16_BC128_MIN_D != 256 || \
+    FFPA_M16_PP_VQ != 6 || FFPA_M16_PP_K1Q != 2 || FFPA_M16_PP_K2S != 2 || FFPA_M16_PP_QSTEP != 2 || \
+    FFPA_M16_PP_SSTEP != 1 || FFPA_M16_PP_PSTEP != 2 || FFPA_M16_PP_PF != 3
 #error "FFPA_PRODUCT_BUILD: a developer switch is not at its shipped default"
 #endif
 #endif
@@ -323,9 +317,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   constexpr int kPre = ((kPreReq < PPW ? kPreReq : PPW) / 4) * 4;
   constexpr int N1 = KS * NKB;   // K fragments per tile
   constexpr int N2 = NDB * NKS;  // V^T fragments per tile
-  // the softmax pipeline of the split-D tiles (see FFPA_M16_PIPE above): needs an even number of pieces per wave (D % 128 == 0), and it stages K as two
+  // the softmax pipeline of the split-D tiles (header comment above the FFPA_M16_PP_* piece counts): needs an even number of pieces per wave (D % 128 == 0), and it stages K as two
   // 16-key halves — piece i < kH of a wave belongs to K1 (keys 0 .. 15), the rest to K2
-  constexpr bool kPipe = ND == 2 && FFPA_M16_PIPE != 0 && PPW % 2 == 0 && NKB == 2 && (MK == 0 || MK == 2 || MK == 3) && !DROP;
+  constexpr bool kPipe = ND == 2 && PPW % 2 == 0 && NKB == 2 && (MK == 0 || MK == 2 || MK == 3) && !DROP;
   constexpr bool kKS = kPipe;  // the two-half K piece map
   constexpr int kH = PPW / 2;  // K1 / K2 pieces per wave
   constexpr int ppVQ = PPW * FFPA_M16_PP_VQ / 16, ppVS = PPW - ppVQ;     // V(j): in Q(j), in S(j)
@@ -463,7 +457,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 
   // the same pieces riding on an MFMA (kind: 0 first of a chain, 1 accumulate in VGPRs, 2 accumulate in an AGPR tile); the row-addressed form keeps
   // its own statement
-  constexpr bool kFuse = FFPA_M16_FUSE_DMA != 0 && !kRowDma;
+  constexpr bool kFuse = !kRowDma;  // DMA pieces ride on the MFMA in front of them (the scalar row form of the D = 512 bias / mask / dropout builds issues its own pieces)
   auto issue_k_on = [&](auto ic, int key0, auto kindc, f32x4& d, v8 fa, v8 fb) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
     const TileSrc ts = tile_src<BC>(Kg, k_row_bytes, key0, a.Nkv, rb_valid);
@@ -716,7 +710,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 #endif
   if constexpr (kPipe) {
     // =====================================================================================================================================
-    // The softmax pipeline of the split-D tiles (FFPA_M16_PIPE; header comment at the macro).  Same arithmetic as the loop below, instruction
+    // The softmax pipeline of the split-D tiles (header comment above the FFPA_M16_PP_* piece counts).  Same arithmetic as the loop below, instruction
     // for instruction per score — only WHEN each part runs differs: bit-identical outputs (tests/test_m16_gpu.py).
     // =====================================================================================================================================
     constexpr int kXW = 6144;  // exchange bytes per wave: block 0 of even tiles, block 0 of odd tiles, block 1
@@ -1395,9 +1389,6 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     // counter stream (element offset = ((b Hq + hq) Nq + row) Nkv + key).
     uint32_t keep_bits[RHS][NKB > 8 ? NKB / 8 : 1] = {};
     if constexpr (DROP) {
-#ifndef FFPA_M16_PHILOX_ILP
-#define FFPA_M16_PHILOX_ILP 1  // Philox groups advanced in lockstep between two scheduling fences (2 / 4 measured: nothing, profiles/r03_philox.txt)
-#endif
       unsigned long long erow[RHS];
 #pragma unroll
       for (int rh = 0; rh < RHS; ++rh)
@@ -1405,7 +1396,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       // every lane's 4-key group a whole Philox block (philox_offset and Nkv multiples of 4: the usual case; the key part 16 kb + 4 c always is)?
       // Then the groups of the step are branch-free and sit in ONE basic block.
       if (__builtin_amdgcn_ballot_w64(((erow[0] | erow[RHS - 1]) & 3ull) != 0) == 0ull) {
-        constexpr int kIlp = FFPA_M16_PHILOX_ILP;
+        constexpr int kIlp = 1;  // Philox groups advanced in lockstep between two scheduling fences (2 / 4 measured: nothing, profiles/r03_philox.txt)
         static_assert(kIlp >= 1 && (RHS * NKB) % kIlp == 0, "Philox groups per batch");
 #pragma unroll
         for (int g0 = 0; g0 < RHS * NKB; g0 += kIlp) {
@@ -1440,14 +1431,11 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-#ifndef FFPA_M16_PK_FMA
-// the exponents' x * scale - m as packed FMAs (v_pk_fma_f32: two scores per instruction, the same roundings — bit-identical): config 2 + 0.6 %, causal + 2.0 %,
-// cross + 1.2 %, config 4 + 2.2 %, D = 320 + 0.7 % (interleaved A/B, profiles/r04_pipe.txt)
-#define FFPA_M16_PK_FMA 1
-#endif
+          // the exponents' x * scale - m as packed FMAs (v_pk_fma_f32: two scores per instruction, the same roundings — bit-identical): config 2 + 0.6 %, causal + 2.0 %,
+          // cross + 1.2 %, config 4 + 2.2 %, D = 320 + 0.7 % (interleaved A/B, profiles/r04_pipe.txt)
           float arg;
           // (not in the boolean-mask build of D = 512: there the packed form costs the allocator one scalar lane spill inside the MFMA loops)
-          if constexpr (FFPA_M16_PK_FMA != 0 && !(D == 512 && MK == 2)) {
+          if constexpr (!(D == 512 && MK == 2)) {
             typedef __attribute__((ext_vector_type(2))) float f32x2;
             const f32x2 xv = {x[kb][rh][r & ~1], x[kb][rh][r | 1]};
             const f32x2 av = __builtin_elementwise_fma(xv, (f32x2)(a.scale_log2), (f32x2)(-m_use));
