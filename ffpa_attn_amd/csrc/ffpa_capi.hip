@@ -540,7 +540,7 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
     }
   }
   // A key bias (no row axis, unit key stride, 16-byte aligned rows, 16- or 32-bit) is cached in LDS once per workgroup when the
-  // head dim's tiles leave room for a whole number of tiles' worth of it (ffpa_fwd_kernel.h: FwdArgs.bias_lds)
+  // head dim's tiles leave room for a whole number of tiles' worth of it (ffpa_common.h: FwdArgs.bias_lds)
   if (!pl.m16 && p->bias != nullptr && pl.variant == 0 && pl.splits == 1 && p->seqlen_q > 1 && p->bias_stride[2] == 0 && p->bias_stride[3] == 1 &&
       p->bias_dtype >= FFPA_BIAS_FP16 && p->bias_dtype <= FFPA_BIAS_FP32 && !(p->flags & FFPA_FLAG_NO_BIAS_LDS) && !safe) {
     const int esz = p->bias_dtype == FFPA_BIAS_FP32 ? 4 : 2;
@@ -561,7 +561,7 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   a.dropout_p = p->dropout_p;
   a.keep_scale = p->dropout_p > 0.f ? 1.f / (1.f - p->dropout_p) : 1.f;
   a.keep_threshold = dropout_keep_threshold(p->dropout_p);
-  // XCDs per head (xcd_logical_id, ffpa_fwd_kernel.h).  One XCD per head keeps a head's K/V stream in one L2; but then eight heads are in flight chip-wide,
+  // XCDs per head (xcd_logical_id, ffpa_common.h).  One XCD per head keeps a head's K/V stream in one L2; but then eight heads are in flight chip-wide,
   // and once their K + V no longer fit the Infinity Cache the second and later rounds of a head's row tiles come from HBM instead (config 3: eight heads x
   // 32 MiB = the whole 256 MiB).  Prefill launches with at least two rounds of row tiles per head and XCD therefore share a head between the smallest
   // power-of-two number of XCDs that brings the K + V in flight under 200 MiB (measured, profiles/r03_xcd_group.txt).
