@@ -32,9 +32,6 @@
 #ifndef FFPA_M16W_QK_PIECES
 #define FFPA_M16W_QK_PIECES 16  // sixteenths of a step's 2 PPW DMA pieces that ride on the QK^T loop's fragments (the rest: on the PV loop's, front-loaded)
 #endif
-#ifndef FFPA_M16W_ORDER
-#define FFPA_M16W_ORDER 0  // piece order inside a step: 0 = K(j+1) then V(j+1), 1 = alternating
-#endif
 
 namespace ffpa {
 
@@ -52,6 +49,11 @@ constexpr int m16w_lds_bytes(int D) { return 4 * m16w_block_keys(D) * D * 2; }
 #define FFPA_M16W_MAX_RH 4
 #endif
 constexpr int m16w_row_halves(int D) { return 256 / (D / 4) > FFPA_M16W_MAX_RH ? FFPA_M16W_MAX_RH : 256 / (D / 4); }
+#ifdef FFPA_PRODUCT_BUILD  // (as in ffpa_fwd_m16_kernel.h: the product library is built from the shipped values only)
+#if FFPA_M16W_PF1 != 3 || FFPA_M16W_PF2 != 3 || FFPA_M16W_QK_PIECES != 16 || FFPA_M16W_MAX_RH != 4
+#error "FFPA_PRODUCT_BUILD: a developer switch of the wide-row tile is not at its shipped default"
+#endif
+#endif
 
 template <bool IS_MAX, int RH>
 __device__ __forceinline__ void row4_reduce_n(float (&t)[RH]) {
@@ -151,10 +153,10 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16w_kernel(const FwdArgs a) {
   // this wave's pieces of image `buf` land at base + buf TILE + i KiB
   const uint32_t k_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(uintptr_t)Kt + (uint32_t)(wave * PPW * 1024)));
   const uint32_t v_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(uintptr_t)Vt + (uint32_t)(wave * PPW * 1024)));
-  // piece t of a step (t < PPW: K, else V; FFPA_M16W_ORDER 1: alternating), alone or riding on an MFMA (kind: 0 first of a chain, 1 accumulate in
+  // piece t of a step (t < PPW: K, else V — alternating K / V pieces measured the same: word1 in profiles/r05_wide_tile.txt), alone or riding on an MFMA (kind: 0 first of a chain, 1 accumulate in
   // VGPRs, 2 accumulate in an AGPR tile)
-  auto piece_is_k = [](int t) constexpr { return FFPA_M16W_ORDER == 0 ? t < PPW : (t % 2 == 0); };
-  auto piece_idx = [](int t) constexpr { return FFPA_M16W_ORDER == 0 ? (t < PPW ? t : t - PPW) : t / 2; };
+  auto piece_is_k = [](int t) constexpr { return t < PPW; };
+  auto piece_idx = [](int t) constexpr { return t < PPW ? t : t - PPW; };
   auto issue_piece = [&](auto tc, int key0, uint32_t buf_off) {
     constexpr int t = decltype(tc)::value;
     constexpr int i = piece_idx(t);
