@@ -93,6 +93,36 @@ def _check_isa(verbose: bool) -> None:
     raise RuntimeError("ISA check failed: an inline-asm MFMA operand is written inside its hazard window, or M0 is written outside the DMA asm")
 
 
+def _prune_temps() -> None:
+  """-save-temps leaves ~20 MB per TU (bitcode, preprocessed source, host assembly ...) and the whole tree travels to the GPU box with every
+  snapshot.  What the ISA rules (tools/check_mfma_hazards.py, tools/isa_stats.py, tests/test_isa_rules.py) read is the device assembly alone: it
+  stays, gzip-compressed (10 : 1); everything else goes.  354 MB -> ~6 MB."""
+  import glob
+  import gzip
+
+  for tdir in glob.glob(os.path.join(OBJ_DIR, "temps_d*")):
+    for path in glob.glob(os.path.join(tdir, "*")):
+      if path.endswith("gfx950.s"):
+        with open(path, "rb") as src, gzip.open(path + ".gz", "wb", compresslevel=6) as dst:
+          shutil.copyfileobj(src, dst)
+      elif path.endswith("gfx950.s.gz") and not os.path.exists(path[:-3]):
+        continue  # (the assembly of a TU this run did not recompile)
+      if os.path.isdir(path):
+        shutil.rmtree(path, ignore_errors=True)
+      else:
+        os.remove(path)
+
+
+def clean_dev() -> None:
+  """Remove what only a development session needs and the round-end snapshot should not carry: variant libraries (build_variant) and their objects."""
+  import glob
+
+  shutil.rmtree(os.path.join(HERE, "variants"), ignore_errors=True)
+  for d in glob.glob(os.path.join(OBJ_DIR, "var_*")):
+    shutil.rmtree(d, ignore_errors=True)
+  _prune_temps()
+
+
 def build(force: bool = False, jobs: int | None = None, save_temps: bool = True, verbose: bool = True, test_lib: bool = True) -> str:
   """Compile every kernel for gfx950, link ``libffpa_attn_hip.so`` (product kernels only) and — with ``test_lib`` —
   ``libffpa_attn_hip_test.so`` (the same library plus the register-staged SAFE twins behind FFPA_FLAG_DEBUG_SAFE_PATH,
@@ -151,6 +181,7 @@ def build(force: bool = False, jobs: int | None = None, save_temps: bool = True,
     list(pool.map(lambda t: _run(t[1], cwd=t[2]), tasks))
   if save_temps:
     _check_isa(verbose)
+    _prune_temps()
   _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH, *objs, "-Wl,-rpath,/opt/rocm/lib"])
   if test_lib:
     _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", TEST_LIB_PATH, *test_objs, "-Wl,-rpath,/opt/rocm/lib"])
@@ -205,7 +236,11 @@ def main() -> None:
   ap.add_argument("--no-test-lib", action="store_true", help="skip libffpa_attn_hip_test.so (the SAFE twin kernels the GPU tests use)")
   ap.add_argument("--variant", nargs="+", metavar=("TAG", "DEF"), help="build variants/libffpa_attn_hip_TAG.so with -D defs")
   ap.add_argument("--dims", type=lambda s: [int(x) for x in s.split(",")], default=None, help="variant: only recompile these head dims")
+  ap.add_argument("--clean-dev", action="store_true", help="remove variants/ and their objects, prune the ISA temps (what a round-end snapshot should not carry)")
   args = ap.parse_args()
+  if args.clean_dev:
+    clean_dev()
+    return
   if args.variant:
     print(build_variant(args.variant[0], [d if d.startswith("-D") else "-D" + d for d in args.variant[1:]], jobs=args.jobs, head_dims=args.dims))
     return

@@ -74,13 +74,29 @@ class _FFPAAttnFunc(torch.autograd.Function):
     return dq, dk, dv, dbias, None
 
 
+def _plain_call(query, key, value, attn_bias) -> bool:
+  """May this call skip the dispatcher?  Only when nobody is listening on it and every tensor is a plain ``torch.Tensor``: fake / functional /
+  subclass tensors (the mask included — it reaches ctypes as a raw pointer), an active ``TorchDispatchMode`` (FlopCounterMode, profiler op records,
+  FakeTensorMode) and functorch transforms (vmap's BatchedTensor has type ``torch.Tensor``) all go through the registered op
+  ``ffpa_attn::_fwd_hip``, which has the rules for them."""
+  if not (type(query) is torch.Tensor and type(key) is torch.Tensor and type(value) is torch.Tensor):
+    return False
+  if attn_bias is not None and type(attn_bias) is not torch.Tensor:
+    return False
+  if torch._C._len_torch_dispatch_stack() != 0:
+    return False
+  if torch._C._functorch.peek_interpreter_stack() is not None:
+    return False
+  return True
+
+
 @torch._dynamo.disable
 def _ffpa_apply(query, key, value, attn_bias, meta: FFPAAttnMeta) -> torch.Tensor:
   """Graph-break boundary, as the reference's ``_ffpa_apply`` (functional.py:1195-1216).  A call nothing will ever differentiate —
   inference: grad mode off, or no input requires a gradient — goes straight to the launch wrapper: no autograd node, no dispatcher
   round trip, no LSE tensor (what a decode step that synchronises per token pays on the host)."""
   needs_grad = meta.attn_meta.is_grad_enabled and any(t is not None and t.requires_grad for t in (query, key, value, attn_bias))
-  if not needs_grad and query.is_cuda and type(query) is torch.Tensor and type(key) is torch.Tensor and type(value) is torch.Tensor:  # (fake / functional / subclass tensors: the registered op has the rules for them)
+  if not needs_grad and query.is_cuda and _plain_call(query, key, value, attn_bias):
     from . import hip
 
     thr = getattr(meta.forward_meta, "rescale_threshold", None)

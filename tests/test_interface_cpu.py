@@ -160,3 +160,31 @@ def test_fake_tensors_take_the_registered_op_not_the_launch_wrapper():
     om = ffpa_attn_func(q, k, v, attn_mask=mask, enable_gqa=True)
   for t in (o, om):
     assert isinstance(t, FakeTensor) and t.shape == (1, 4, 1024, 512) and t.dtype == torch.bfloat16 and t.device.type == "cuda"
+
+
+def test_inference_short_cut_is_for_plain_undecorated_calls_only():
+  """`_plain_call` (the gate of `_ffpa_apply`'s inference short cut): an active TorchDispatchMode (FlopCounterMode, profiler op records), a functorch
+  transform (vmap's BatchedTensor has type torch.Tensor) or a subclass / fake MASK must reach the registered op, not the ctypes launch wrapper."""
+  from torch.utils.flop_counter import FlopCounterMode
+
+  from ffpa_attn_amd.interface import _plain_call
+
+  q = torch.zeros(1, 1, 8, 8)
+  assert _plain_call(q, q, q, None) and _plain_call(q, q, q, torch.zeros(8, 8, dtype=torch.bool))
+  with FlopCounterMode(display=False):
+    assert not _plain_call(q, q, q, None)
+  seen = []
+
+  def f(x):
+    seen.append(_plain_call(x, x, x, None))
+    return x
+
+  torch.vmap(f)(torch.zeros(2, 1, 1, 8, 8))
+  assert seen == [False]
+
+  class Sub(torch.Tensor):
+    pass
+
+  assert not _plain_call(q, q, q, torch.zeros(8, 8).as_subclass(Sub))
+  assert not _plain_call(q.as_subclass(Sub), q, q, None)
+  assert _plain_call(q, q, q, None)  # (nothing leaked from the modes above)

@@ -8,7 +8,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TEMPS = glob.glob(os.path.join(ROOT, "ffpa_attn_amd", "csrc", "build", "temps_d*", "*gfx950.s"))
+TEMPS = glob.glob(os.path.join(ROOT, "ffpa_attn_amd", "csrc", "build", "temps_d*", "*gfx950.s*"))  # (.s, or .s.gz as build() leaves them)
 
 
 def _tool(name):
@@ -84,3 +84,43 @@ def test_prefill_builds_have_no_scratch_inside_their_mfma_loops(capsys, monkeypa
   assert len(small) == 3, small  # mask kinds 0 / 2 / 1
   for l in small:
     assert "inside MFMA loops: scratch 0, lane spills 0" in l, l
+
+
+@pytest.mark.skipif(not TEMPS, reason="no --save-temps assembly in csrc/build")
+def test_the_isa_check_fails_on_a_planted_hazard(tmp_path, capsys):
+  """build() keeps only the gzip-compressed device assembly of every TU — and its ISA check must still bite: a copy of one TU's assembly with a VALU
+  write to an asm MFMA's operand planted right in front of it, an early reader of an asm MFMA's result, and an M0 write outside the DMA asm are all
+  reported (exit status 1); the untouched copy passes."""
+  chk = _tool("check_mfma_hazards")
+  src = chk.isa_files(64)
+  assert src, "D = 64 assembly"
+  text = chk.read_isa(src[0])
+  lines = text.split("\n")
+  # the first inline-asm VGPR-form MFMA of the file: "v_mfma_... v[a:b], v[c:d], v[e:f], ..."
+  import re
+  idx = next(i for i, l in enumerate(lines) if l.strip().startswith("v_mfma") and re.match(r"\s*v_mfma\S+\s+v\[\d+:\d+\], v\[(\d+):\d+\]", l)
+             and any(x.strip().startswith(";;#ASMSTART") for x in lines[max(0, i - 4):i]))
+  a_reg = int(re.match(r"\s*v_mfma\S+\s+v\[\d+:\d+\], v\[(\d+):\d+\]", lines[idx]).group(1))
+  d_reg = int(re.match(r"\s*v_mfma\S+\s+v\[(\d+):\d+\]", lines[idx]).group(1))
+
+  def run(mutated):
+    d = tmp_path / "temps_d64"
+    d.mkdir(exist_ok=True)
+    (d / "x-gfx950.s").write_text("\n".join(mutated))
+    old_root, old_argv = chk.ROOT, sys.argv
+    chk.ROOT, sys.argv = str(tmp_path), ["check_mfma_hazards", "64"]
+    try:
+      rc = chk.main()
+    finally:
+      chk.ROOT, sys.argv = old_root, old_argv
+    return rc, capsys.readouterr().out
+
+  rc, out = run(lines)
+  assert rc == 0, out[-1500:]
+  rc, out = run(lines[:idx] + [f"\tv_mov_b32_e32 v{a_reg}, 0"] + lines[idx:])
+  assert rc == 1 and "HAZARD" in out, out[-1500:]
+  rc, out = run(lines[:idx + 1] + [f"\tv_add_f32_e32 v0, v{d_reg}, v{d_reg}"] + lines[idx + 1:])
+  assert rc == 1 and "READ-AFTER-MFMA" in out, out[-1500:]
+  end = next(i for i in range(idx, len(lines)) if lines[i].strip().startswith(";;#ASMEND"))
+  rc, out = run(lines[:end + 1] + ["\ts_mov_b32 m0, 0"] + lines[end + 1:])
+  assert rc == 1 and "M0" in out, out[-1500:]

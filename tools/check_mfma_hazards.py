@@ -16,6 +16,24 @@ READ_WAIT = 18  # wait states between an MFMA and a non-accumulator reader of it
 REG = re.compile(r"v\[(\d+):(\d+)\]|v(\d+)")
 
 
+
+def isa_files(d):
+  """The device assembly of head dim d's TU: kept gzip-compressed by ffpa_attn_amd.build (10 : 1 — the repo snapshot travels to the GPU box on every
+  run), plain while a developer build (tools/dev_compile.sh) is being looked at."""
+  base = os.path.join(ROOT, f"temps_d{d}")
+  return glob.glob(os.path.join(base, "*gfx950.s")) or glob.glob(os.path.join(base, "*gfx950.s.gz"))
+
+
+def read_isa(path):
+  if path.endswith(".gz"):
+    import gzip
+
+    with gzip.open(path, "rt") as f:
+      return f.read()
+  with open(path) as f:
+    return f.read()
+
+
 def regs(tok):
   m = REG.fullmatch(tok.strip())
   if not m:
@@ -33,8 +51,8 @@ def main():
   dims = sys.argv[1:] or sorted((os.path.basename(d)[7:] for d in glob.glob(os.path.join(ROOT, "temps_d*"))), key=int)
   bad = total = 0
   for d in dims:
-    for path in glob.glob(os.path.join(ROOT, f"temps_d{d}", "*gfx950.s")):
-      lines = open(path).read().split("\n")
+    for path in isa_files(d):
+      lines = read_isa(path).split("\n")
       in_asm = False
       for i, l in enumerate(lines):
         t = l.strip()
@@ -65,8 +83,8 @@ def main():
   # does not know these registers are MFMA results: a register copy it places for a loop-carried value is enough to break the rule (round 4).
   raw_bad = 0
   for d in dims:
-    for path in glob.glob(os.path.join(ROOT, f"temps_d{d}", "*gfx950.s")):
-      lines = open(path).read().split("\n")
+    for path in isa_files(d):
+      lines = read_isa(path).split("\n")
       in_asm = False
       for i, l in enumerate(lines):
         t = l.strip()
@@ -104,9 +122,9 @@ def main():
   # M0 is carried from one LDS-DMA asm statement to the next: nothing outside the asm blocks may write it
   m0_bad = 0
   for d in dims:
-    for path in glob.glob(os.path.join(ROOT, f"temps_d{d}", "*gfx950.s")):
+    for path in isa_files(d):
       in_asm = False
-      for i, l in enumerate(open(path).read().split("\n")):
+      for i, l in enumerate(read_isa(path).split("\n")):
         t = l.strip()
         if t.startswith(";;#ASMSTART"):
           in_asm = True

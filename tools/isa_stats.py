@@ -9,9 +9,27 @@ import glob, os, re, sys
 ROOT = os.environ.get("FFPA_ISA_ROOT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ffpa_attn_amd", "csrc", "build")
 
 
+
+def isa_files(d):
+  """The device assembly of head dim d's TU: kept gzip-compressed by ffpa_attn_amd.build (10 : 1 — the repo snapshot travels to the GPU box on every
+  run), plain while a developer build (tools/dev_compile.sh) is being looked at."""
+  base = os.path.join(ROOT, f"temps_d{d}")
+  return glob.glob(os.path.join(base, "*gfx950.s")) or glob.glob(os.path.join(base, "*gfx950.s.gz"))
+
+
+def read_isa(path):
+  if path.endswith(".gz"):
+    import gzip
+
+    with gzip.open(path, "rt") as f:
+      return f.read()
+  with open(path) as f:
+    return f.read()
+
+
 def kernels(path):
   name, body = None, []
-  for line in open(path):
+  for line in read_isa(path).splitlines(keepends=True):
     m = re.match(r"^(_ZN4ffpa\w+):", line)
     if m:
       if name:
@@ -26,7 +44,7 @@ def kernels(path):
 def main():
   dims = sys.argv[1:] or sorted((os.path.basename(d)[7:] for d in glob.glob(os.path.join(ROOT, "temps_d*"))), key=int)
   for d in dims:
-    path = glob.glob(os.path.join(ROOT, f"temps_d{d}", "*gfx950.s"))
+    path = isa_files(d)
     if not path:
       continue
     for name, body in kernels(path[0]):
