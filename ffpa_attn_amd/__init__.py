@@ -8,6 +8,7 @@ ffpa_attn_func``; see INTEGRATION.md.
 from .backends import Backend, CUDABackend, CuTeDSLBackend, HIPBackend, SDPABackend, TritonBackend
 from .flops import attention_fwd_flops, attention_valid_pairs
 from .functional import FFPAAttnMeta
+from .decode import DecodeStep
 from .interface import ffpa_attn_func, ffpa_attn_varlen_func
 
 
@@ -91,6 +92,7 @@ __all__ = [
   "ffpa_attn_func",
   "ffpa_attn_varlen_func",
   "install_alias",
+  "DecodeStep",
   "Backend",
   "HIPBackend",
   "CUDABackend",

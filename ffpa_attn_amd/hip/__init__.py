@@ -211,6 +211,10 @@ _CAPABILITY_CONSTANTS = {
 
 
 def __getattr__(name: str):
+  if name == "DecodeStep":  # (the graph-replayed decode step lives above the op: ffpa_attn_amd/decode.py; reachable as hip.DecodeStep too)
+    from ..decode import DecodeStep
+
+    return DecodeStep
   if name in _CAPABILITY_CONSTANTS:
     return _CAPABILITY_CONSTANTS[name]
   if name in _CAPABILITY_QUERIES:

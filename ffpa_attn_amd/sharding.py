@@ -139,13 +139,18 @@ def gather_units(o_local: torch.Tensor, n_units: int, group: "dist.ProcessGroup 
 def _piece_plan_chunks(qu: torch.Tensor, ku: torch.Tensor, chunks: int, kwargs: dict) -> int:
   """``chunks`` lowered until every piece of this rank's block runs the launch plan of the whole block.  The library picks tile and KV-split count from
   the size of a launch (ffpa_capi.hip make_plan: under-filled / ragged-round KV splits — fp32 partials + an LSE merge —, the wide-row tile of D = 320, the
-  short-query split rule): the same values to rounding, not to the bit.  Asked of the library itself (``hip.launch_plan``), never re-derived here.  Calls
+  short-query split rule): the same values to rounding, not to the bit.  Asked of the library itself (``hip.launch_plan``), never re-derived here, for the
+  launch ``hip.forward`` would make of it: GQA heads packed into the row axis for Nq <= 7 (``[B, Hkv, group Nq]``), ``FFPA_HIP_PREFILL_SPLITS=0`` honoured.
+  What the question does NOT carry: the mask's strides (a key-bias layout is assumed) and precomputed mask ranges — for masked calls the plan of a piece
+  can still differ from the whole's in the rare shapes where those decide a rule; the result then agrees to rounding instead of to the bit.  Calls
   that do not reach the HIP kernel (an SDPA backend, head dims / sequence lengths the dispatch sends to SDPA) and boxes without the library keep the
   requested count: there is no launch plan to preserve."""
   per = qu.size(0)
   if chunks <= 1 or not qu.is_cuda:
     return max(1, chunks)
   try:
+    import os
+
     from . import hip
     from .functional import FFPAAttnMeta
 
@@ -158,10 +163,15 @@ def _piece_plan_chunks(qu: torch.Tensor, ku: torch.Tensor, chunks: int, kwargs: 
     if meta.fallback(qu, ku, mask, dropout_p):
       return chunks
     g, nq, d = qu.shape[1:]
+    # the launch hip.forward makes of a piece: packed GQA heads for short queries, the prefill-split opt-out of the environment
+    packed = g > 1 and nq <= 7 and g * nq <= 32 and mask is None and dropout_p == 0.0
+    heads_q, rows = (1, g * nq) if packed else (g, nq)
+    no_prefill_splits = os.environ.get("FFPA_HIP_PREFILL_SPLITS", "1").lower() in ("0", "off", "false", "no")
+    num_splits = 1 if (rows > 32 and no_prefill_splits) else 0
 
     def plan(units: int) -> tuple:
-      pl = hip.launch_plan(units, g, 1, nq, ku.size(2), d, dtype=qu.dtype, causal=causal, bias_dtype=None if mask is None else mask.dtype,
-                           dropout_p=dropout_p, device=qu.device)
+      pl = hip.launch_plan(units, heads_q, 1, rows, ku.size(2), d, dtype=qu.dtype, causal=causal, bias_dtype=None if mask is None else mask.dtype,
+                           dropout_p=dropout_p, device=qu.device, num_splits=num_splits)
       return pl["variant"], pl["block_rows"], pl["block_keys"], pl["splits"]
 
     whole = plan(per)
@@ -171,12 +181,67 @@ def _piece_plan_chunks(qu: torch.Tensor, ku: torch.Tensor, chunks: int, kwargs: 
         break
       chunks -= 1
     return chunks
-  except (RuntimeError, OSError, ValueError, TypeError, NotImplementedError):
-    return chunks  # (library missing / shape it refuses: the call below raises or falls back exactly as the plain call would)
+  except (RuntimeError, OSError, ValueError, TypeError, NotImplementedError, LookupError):
+    return chunks  # (library missing / shape or dtype it refuses: the call below raises or falls back exactly as the plain call would)
+
+
+# ---- what the ranks of a group have agreed on, once per process: how pieces travel, and into how many pieces a block of a given shape class is cut.
+# Both MUST be the same on every rank (the receives one rank posts have to match the sends of the others): each is settled by a MIN all-reduce the
+# first time it is needed and remembered, so the steady state pays no extra collective and no host synchronisation.
+_TRANSPORT: "dict[object, str]" = {}
+_AGREED_CHUNKS: "dict[tuple, int]" = {}
+
+
+def _group_key(group) -> object:
+  return id(group) if group is not None else None
+
+
+def _agree_min(value: int, like: torch.Tensor, group) -> int:
+  t = torch.tensor([int(value)], dtype=torch.int64, device=like.device)
+  dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+  return int(t.item())
+
+
+def gather_transport(like: torch.Tensor, group: "dist.ProcessGroup | None" = None) -> str:
+  """How ``attend_and_gather_units`` moves a finished piece: ``"p2p"`` — ``dist.batch_isend_irecv`` straight into the final slices — or
+  ``"all_gather"`` — ``all_gather_into_tensor`` into a ``world x piece`` temporary + one copy per peer.  Decided ONCE per group: a two-element
+  point-to-point ring exchange is tried (RCCL P2P needs peer access between the GPUs of the node; where it is unavailable the call raises), the ranks take
+  the MIN of their outcomes, and everybody uses the same form from then on.  ``FFPA_SHARDING_TRANSPORT=p2p|all_gather`` pins it (tests; a node whose
+  P2P hangs instead of raising)."""
+  import os
+
+  key = _group_key(group)
+  hit = _TRANSPORT.get(key)
+  if hit is not None:
+    return hit
+  forced = os.environ.get("FFPA_SHARDING_TRANSPORT", "").lower()
+  if forced in ("p2p", "all_gather"):
+    _TRANSPORT[key] = forced
+    return forced
+  world, rank = dist.get_world_size(group), dist.get_rank(group)
+  ok = 1
+  if world > 1:
+    try:
+      send = torch.full((2,), float(rank), dtype=torch.float32, device=like.device)
+      recv = torch.empty_like(send)
+      dst, src = (rank + 1) % world, (rank - 1) % world
+      ops = [dist.P2POp(dist.isend, send, dst if group is None else dist.get_global_rank(group, dst), group),
+             dist.P2POp(dist.irecv, recv, src if group is None else dist.get_global_rank(group, src), group)]
+      for r in dist.batch_isend_irecv(ops):
+        r.wait()
+      if like.is_cuda:
+        torch.cuda.synchronize(like.device)
+      ok = 1 if float(recv[0].item()) == float(src) else 0
+    except RuntimeError:
+      ok = 0
+    ok = _agree_min(ok, like, group)
+  _TRANSPORT[key] = "p2p" if ok else "all_gather"
+  return _TRANSPORT[key]
 
 
 def attend_and_gather_units(qu: torch.Tensor, ku: torch.Tensor, vu: torch.Tensor, n_units: int, *, chunks: int = 4,
-                            group: "dist.ProcessGroup | None" = None, out: torch.Tensor | None = None, **kwargs) -> torch.Tensor:
+                            group: "dist.ProcessGroup | None" = None, out: torch.Tensor | None = None, stats: dict | None = None,
+                            **kwargs) -> torch.Tensor:
   """The local step and the optional collective, overlapped: this rank's block is attended in ``chunks`` pieces (whole units) and every finished
   piece travels to the other ranks while the next piece computes — the gather of a 256 MiB shard costs about as much as the kernel (7 x 153 GB/s xGMI
   links), so hiding it under compute is the difference between ~1x and ~2x the step time.  Needs an even split (``n_units % world == 0``); returns
@@ -189,8 +254,13 @@ def attend_and_gather_units(qu: torch.Tensor, ku: torch.Tensor, vu: torch.Tensor
   as one group on its own stream, ordered behind the kernel that produced the piece) — on xGMI's full mesh of point-to-point links that is also the
   native pattern: every peer is reached over its own link.  The rank's own piece is one device-to-device copy.
 
-  ``chunks`` is a request: it is lowered until every piece runs the launch plan of the whole block (``_piece_plan_chunks``), so for calls that reach the
-  HIP kernel the result does not depend on it, not even at the rounding level."""
+  Where RCCL point-to-point is unavailable (``gather_transport``: probed once per group, agreed by all ranks) a chunk travels as one asynchronous
+  ``all_gather_into_tensor`` into a ``world x piece`` temporary and is copied to its slices on arrival — the same result, one more pass over the data.
+  ``stats``, if given, receives ``transport`` (``"p2p"`` / ``"all_gather"`` / ``"local"``), ``chunks`` and ``world``.
+
+  ``chunks`` is a request: it is lowered until every piece runs the launch plan of the whole block (``_piece_plan_chunks``) and then to the smallest count
+  any rank arrived at (agreed once per shape class), so for unmasked calls that reach the HIP kernel the result does not depend on it, not even at the
+  rounding level (masked calls: see ``_piece_plan_chunks``)."""
   world = dist.get_world_size(group)
   rank = dist.get_rank(group)
   if n_units % world != 0:
@@ -204,22 +274,47 @@ def attend_and_gather_units(qu: torch.Tensor, ku: torch.Tensor, vu: torch.Tensor
     out = qu.new_empty((n_units, g, nq, d))
   if per == 0:
     return out
-  chunks = _piece_plan_chunks(qu, ku, max(1, min(chunks, per)), kwargs)
+  want = max(1, min(chunks, per))
+  ckey = (_group_key(group), want, tuple(qu.shape), tuple(ku.shape), qu.dtype, str(qu.device.type),
+          tuple(sorted((k_, (tuple(v_.shape), v_.dtype) if isinstance(v_, torch.Tensor) else repr(v_)) for k_, v_ in kwargs.items())))
+  chunks = _AGREED_CHUNKS.get(ckey)
+  if chunks is None:
+    # the lowered count is derived from local device state (CU count, environment): ranks that disagreed would post mismatched receives — a hang or
+    # a corrupted gather.  The smallest count every rank can honour is one every rank's plan rule accepts (fewer, larger pieces only move a piece
+    # TOWARDS the whole block's plan).
+    chunks = _piece_plan_chunks(qu, ku, want, kwargs)
+    if world > 1:
+      chunks = max(1, _agree_min(chunks, qu, group))
+    if len(_AGREED_CHUNKS) >= 256:
+      _AGREED_CHUNKS.clear()
+    _AGREED_CHUNKS[ckey] = chunks
+  transport = gather_transport(qu, group) if world > 1 else "local"
+  if stats is not None:
+    stats.update(transport=transport, chunks=chunks, world=world)
   bounds = [per * c // chunks for c in range(chunks + 1)]
   works = []
   for c0, c1 in zip(bounds, bounds[1:]):
     o_c = attend_units(qu[c0:c1], ku[c0:c1], vu[c0:c1], **kwargs).contiguous()
-    out[rank * per + c0 : rank * per + c1].copy_(o_c)
-    if world > 1:
+    if world == 1 or transport == "p2p":
+      out[rank * per + c0 : rank * per + c1].copy_(o_c)
+    if world > 1 and transport == "p2p":
       ops = []
       for step in range(1, world):  # (peers in rotated order: at every step of the batch each rank sends to and receives from a different peer)
         dst, src = (rank + step) % world, (rank - step) % world
         ops.append(dist.P2POp(dist.isend, o_c, dst if group is None else dist.get_global_rank(group, dst), group))
         ops.append(dist.P2POp(dist.irecv, out[src * per + c0 : src * per + c1], src if group is None else dist.get_global_rank(group, src), group))
-      works.append((dist.batch_isend_irecv(ops), o_c))  # (the piece stays referenced until its sends have completed)
-  for reqs, _ in works:
+      works.append((dist.batch_isend_irecv(ops), o_c, None))  # (the piece stays referenced until its sends have completed)
+    elif world > 1:
+      # no point-to-point on this node: the world's pieces of this chunk into a temporary (asynchronously, RCCL's stream), copied to their slices — ``per``
+      # units apart in the result — once they have arrived
+      tmp = o_c.new_empty((world, c1 - c0, g, nq, d))
+      works.append(([dist.all_gather_into_tensor(tmp.view(world * (c1 - c0), g, nq, d), o_c, group=group, async_op=True)], o_c, (tmp, c0, c1)))
+  for reqs, _, landed in works:
     for r in reqs:
       r.wait()
+    if landed is not None:
+      tmp, c0, c1 = landed
+      out.view(world, per, g, nq, d)[:, c0:c1].copy_(tmp)
   return out
 
 

@@ -37,6 +37,15 @@ def test_bench_plumbing_at_the_scaling_curves_world_sizes():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == n and len(d["per_rank_s"]) == n and d["ms_per_step"] * 2e-3 >= max(d["per_rank_s"]) * 0.99
+    # the gather leg's report (round 6): which transport the ranks agreed on, the agreed piece count, and the self-judging figures
+    g = d["with_gather"]
+    assert g["transport"] == "p2p" and g["chunks"] == 2 and g["chunks_requested"] == 4 and g["equal_to_plain_gather"] is True, g
+    assert g["received_bytes_per_rank"] == g["shard_bytes"] * (n - 1) and g["expected_ms_one_shard_per_link"] > 0 and g["alone_ms"] > 0 and "alone_over_expected" in g, g
+  # the fallback transport, pinned through the environment (what the probe selects on a node without RCCL point-to-point)
+  r = _run(["--gpus", "4", "--stub-backend", "gloo", "--steps", "2", "--warmup", "1"], env={"FFPA_SHARDING_TRANSPORT": "all_gather"})
+  assert r.returncode == 0, r.stderr[-2000:]
+  g = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])["with_gather"]
+  assert g["transport"] == "all_gather" and g["equal_to_plain_gather"] is True and "all_gather_into_tensor" in g["what"], g
 
 
 def test_bench_under_a_launcher_does_not_spawn_and_checks_the_world_size():
@@ -88,3 +97,13 @@ def test_an_optional_leg_cannot_cost_the_line():
   r = _leg(emit + "bench.guarded_extra_leg(lambda: time.sleep(600), 0.5, emit)\nprint('{\"never\": 1}')")
   (d,) = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
   assert r.returncode == 0 and d["value"] == 1.0 and "watchdog" in d["with_gather"]["error"], r.stdout + r.stderr
+
+
+def test_gather_report_prices_a_shard_per_link():
+  sys.path.insert(0, ROOT)
+  import bench
+
+  rep = bench.gather_report({"transport": "p2p", "chunks": 4, "world": 8}, 256 << 20, 8, 3.2, 3.5, 2.1, 4)
+  assert abs(rep["expected_ms_one_shard_per_link"] - 1.7545) < 1e-3 and rep["received_bytes_per_rank"] == 7 * (256 << 20)  # 256 MiB / 153 GB/s = 1.75 ms
+  assert abs(rep["exposed_ms"] - 0.3) < 1e-9 and rep["alone_ms"] == 2.1 and abs(rep["alone_over_expected"] - 1.197) < 1e-3 and "point-to-point" in rep["what"]
+  assert "unavailable" in bench.gather_report({"transport": "all_gather", "chunks": 1}, 1 << 20, 2, 1.0, 1.2, None, 4)["what"]

@@ -126,3 +126,73 @@ def test_the_pricing_reads_the_device(hip):
   assert pl["splits"] == 1 and pl["block_rows"] == 128 and pl["kernel"].startswith("ffpa_fwd_m16_kernel<bf16, 512, MK=0")
   pl = hip.launch_plan(2, 32, 8, 8192, 2048, 320, bias_dtype=torch.bool, device=0)
   assert pl["kernel"].startswith("ffpa_fwd_m16w_kernel<bf16, 320, RH=3, MK=2") and pl["block_rows"] == 192 and pl["block_keys"] == 64, pl
+
+
+def test_decode_step_replays_equal_eager_calls_bit_for_bit(hip):
+  """`DecodeStep` (ffpa_attn_amd/decode.py): the step captured into a HIP graph once per (tensors, shapes, stream) and replayed — equal to the plain call
+  bit for bit on three shapes (MHA decode, GQA decode with packed heads, a 4-row speculative step with a static boolean key mask), again after the
+  inputs' CONTENT changed in place, again after the KV length changed (another key: another capture), and the entries are bounded (LRU)."""
+  from ffpa_attn_amd import DecodeStep, ffpa_attn_func
+
+  shapes = [
+    dict(q=(1, 32, 1, 512), kv=(1, 32, 4096, 512), gqa=False, mask=False),
+    dict(q=(2, 32, 1, 512), kv=(2, 8, 8192, 512), gqa=True, mask=False),
+    dict(q=(1, 8, 4, 320), kv=(1, 8, 2048, 320), gqa=False, mask=True),
+  ]
+  for i, sh in enumerate(shapes):
+    step = DecodeStep(enable_gqa=sh["gqa"], max_graphs=2)
+    q, k, v = _rand(sh["q"], seed=40 + i), _rand(sh["kv"], seed=50 + i), _rand(sh["kv"], seed=60 + i)
+    mask = None
+    if sh["mask"]:  # a static-capacity cache whose valid length lives in a device-side mask: its content changes between replays, its address does not
+      mask = torch.zeros(1, 1, 1, sh["kv"][2], dtype=torch.bool, device=q.device)
+      mask[..., :1500] = True
+    want = ffpa_attn_func(q, k, v, attn_mask=mask, enable_gqa=sh["gqa"])
+    got = step(q, k, v, mask)
+    assert step.captures == 1 and len(step) == 1 and torch.equal(got, want), sh
+    for _ in range(3):
+      assert torch.equal(step(q, k, v, mask), want)
+    assert step.captures == 1
+    # new content at the same addresses (the next token's q, a longer valid length): the replay reads it
+    q.copy_(_rand(sh["q"], seed=70 + i))
+    if mask is not None:
+      mask[..., 1500:1777] = True
+    want2 = ffpa_attn_func(q, k, v, attn_mask=mask, enable_gqa=sh["gqa"])
+    assert not torch.equal(want2, want) and torch.equal(step(q, k, v, mask), want2) and step.captures == 1
+    # a KV-length change is another key: captured once, the old entry stays valid
+    n2 = sh["kv"][2] - 128
+    k2, v2 = k[:, :, :n2], v[:, :, :n2]
+    m2 = mask[..., :n2] if mask is not None else None
+    want3 = ffpa_attn_func(q, k2, v2, attn_mask=m2, enable_gqa=sh["gqa"])
+    assert torch.equal(step(q, k2, v2, m2), want3) and step.captures == 2 and len(step) == 2
+    assert torch.equal(step(q, k, v, mask), want2) and step.captures == 2
+    # a third key evicts the least recently used entry (max_graphs = 2) — and everything still answers correctly
+    k3, v3 = k[:, :, :n2 - 64], v[:, :, :n2 - 64]
+    m3 = mask[..., :n2 - 64] if mask is not None else None
+    assert torch.equal(step(q, k3, v3, m3), ffpa_attn_func(q, k3, v3, attn_mask=m3, enable_gqa=sh["gqa"])) and len(step) == 2 and step.captures == 3
+    assert torch.equal(step(q, k2, v2, m2), want3) and step.captures == 4  # (it was the evicted one)
+    step.clear()
+    assert len(step) == 0
+
+
+def test_decode_step_on_a_side_stream_and_inside_a_callers_capture(hip):
+  from ffpa_attn_amd import DecodeStep, ffpa_attn_func
+
+  q, k, v = _rand((1, 32, 1, 512), seed=81), _rand((1, 32, 2048, 512), seed=82), _rand((1, 32, 2048, 512), seed=83)
+  want = ffpa_attn_func(q, k, v)
+  step = DecodeStep()
+  assert torch.equal(step(q, k, v), want)
+  side = torch.cuda.Stream()
+  side.wait_stream(torch.cuda.current_stream())
+  with torch.cuda.stream(side):
+    o_side = step(q, k, v)  # another stream is another key (two replays of one graph on two streams would share its scratch)
+  torch.cuda.current_stream().wait_stream(side)
+  assert step.captures == 2 and torch.equal(o_side, want)
+  # a caller capturing a graph of its own gets the plain call captured into ITS graph (no nested capture)
+  g = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(g):
+    o_g = step(q, k, v)
+  g.replay()
+  torch.cuda.synchronize()
+  assert step.captures == 2 and torch.equal(o_g, want)
+  with pytest.raises(ValueError, match="dropout"):
+    DecodeStep(dropout_p=0.1)

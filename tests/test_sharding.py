@@ -64,6 +64,7 @@ def _worker(rank, world, port, B, Hq, Hkv, ret):
 def _born_worker(rank, world, port, n_units, g, ret):
   """The born-sharded path bench.py measures: per-unit seeded blocks, local attention, one all_gather."""
   os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+  os.environ.pop("FFPA_SHARDING_TRANSPORT", None)
   dist.init_process_group("gloo", rank=rank, world_size=world)
   from ffpa_attn_amd import sharding as sh
 
@@ -88,14 +89,41 @@ def _born_worker(rank, world, port, n_units, g, ret):
 
     dist.all_gather = dist.all_gather_into_tensor = forbidden
     try:
+      st = {}
       for chunks in (1, 2, 3):
-        ok = ok and bool(torch.equal(sh.attend_and_gather_units(q, k, v, n_units, chunks=chunks), ref))
+        ok = ok and bool(torch.equal(sh.attend_and_gather_units(q, k, v, n_units, chunks=chunks, stats=st), ref))
+        ok = ok and st == {"transport": "p2p", "chunks": min(chunks, n_units // world), "world": world}  # (gloo has point-to-point: the probe says so on every rank)
       mine = torch.full_like(ref, float("nan"))
       got = sh.attend_and_gather_units(q, k, v, n_units, chunks=2, out=mine)
       ok = ok and got.data_ptr() == mine.data_ptr() and bool(torch.equal(mine, ref))
     finally:
       shm.attend_units = real
       dist.all_gather, dist.all_gather_into_tensor = real_ag, real_agt
+    # the other transport (a node without RCCL point-to-point: gather_transport's probe fails on some rank -> every rank agrees on all_gather): the same
+    # result through all_gather_into_tensor + the copy to the final slices, and NO point-to-point operation after the probe
+    shm.attend_units = lambda a, b, c, **kw: torch.nn.functional.scaled_dot_product_attention(a, b, c, enable_gqa=True)
+    shm._TRANSPORT.clear()
+    real_batch = dist.batch_isend_irecv
+    broke = {"n": 0}
+
+    def failing(ops):
+      broke["n"] += 1
+      # (a node property: every rank's point-to-point raises; a rank that raised while the others posted theirs would leave them waiting — the probe
+      # cannot cure that, FFPA_SHARDING_TRANSPORT=all_gather pins the fallback for such a node)
+      raise RuntimeError("peer access is not available (stand-in)")
+
+    dist.batch_isend_irecv = failing
+    try:
+      st = {}
+      for chunks in (1, 3):
+        ok = ok and bool(torch.equal(sh.attend_and_gather_units(q, k, v, n_units, chunks=chunks, stats=st), ref)) and st["transport"] == "all_gather"
+      ok = ok and broke["n"] == 1  # (probed once per group, remembered)
+      mine = torch.full_like(ref, float("nan"))
+      ok = ok and bool(torch.equal(sh.attend_and_gather_units(q, k, v, n_units, chunks=2, out=mine), ref))
+    finally:
+      dist.batch_isend_irecv = real_batch
+      shm.attend_units = real
+      shm._TRANSPORT.clear()
   ret[rank] = (ok, (s, e), bool(torch.equal(q, qa[s:e])))
   dist.barrier()
   dist.destroy_process_group()

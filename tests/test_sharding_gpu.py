@@ -26,8 +26,8 @@ def _free_port():
     return s.getsockname()[1]
 
 
-def _worker(rank, world, port, ret):
-  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _worker(rank, world, port, ret, transport=""):
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", FFPA_SHARDING_TRANSPORT=transport)
   torch.cuda.set_device(rank)
   dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
   from ffpa_attn_amd import hip
@@ -38,7 +38,9 @@ def _worker(rank, world, port, ret):
   q, k, v = sh.synthetic_unit_block(s, e, GROUP, NQ, NKV, D, device=f"cuda:{rank}", seed=11)
   o_local = sh.attend_units(q, k, v)
   full = sh.gather_units(o_local, N_UNITS)
-  overlapped = sh.attend_and_gather_units(q, k, v, N_UNITS, chunks=2)  # pieces gathered on RCCL's stream while the next computes
+  st = {}
+  overlapped = sh.attend_and_gather_units(q, k, v, N_UNITS, chunks=2, stats=st)  # pieces gathered on RCCL's stream while the next computes
+  assert st["transport"] == (transport or ("p2p" if world > 1 else "local")) or (world > 1 and not transport and st["transport"] == "all_gather"), st
   whole = sh.attend_and_gather_units(q, k, v, N_UNITS, chunks=1)
   torch.cuda.synchronize()
   assert torch.equal(whole, full)
@@ -58,24 +60,39 @@ def _worker(rank, world, port, ret):
   assert torch.equal(mine, full)
   pl = hip.launch_plan(q.size(0), GROUP, 1, NQ, NKV, D, device=q.device)  # (a launch this small splits the KV axis: fp32 partials + LSE as scratch)
   scratch = pl["splits"] * q.size(0) * GROUP * NQ * (D + 1) * 4 if pl["splits"] > 1 else 0
-  assert peak <= own + scratch + (1 << 20), (peak, own, scratch)  # a world x piece staging buffer (2 x own at two ranks) would not fit the slack
+  if st["transport"] != "all_gather":  # (the fallback transport IS the world x piece temporary)
+    assert peak <= own + scratch + (1 << 20), (peak, own, scratch)  # a world x piece staging buffer (2 x own at two ranks) would not fit the slack
   ref = torch.nn.functional.scaled_dot_product_attention(q, k, v, enable_gqa=True)
   err = (o_local.float() - ref.float()).abs().max().item()
-  ret[rank] = (full.cpu(), err, (s, e))
+  ret[rank] = (full.cpu(), err, (s, e), st["transport"])
   dist.barrier()
   dist.destroy_process_group()
 
 
-def _run(world):
+RANKS_TIMEOUT_S = 420  # a first contact with N > 1 ranks must end in a verdict, not in a hung collective
+
+
+def _run(world, transport=""):
+  """`world` ranks of _worker under a deadline of their own: ranks that do not come back (a collective one of them never entered) are killed and the
+  test FAILS with words — pytest's own timeout would take the whole session down with it."""
+  import time
+
   ret = mp.Manager().dict()
-  mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+  ctx = mp.spawn(_worker, args=(world, _free_port(), ret, transport), nprocs=world, join=False)
+  deadline = time.time() + RANKS_TIMEOUT_S
+  while not ctx.join(timeout=5):
+    if time.time() > deadline:
+      for pr in ctx.processes:
+        if pr.is_alive():
+          pr.kill()
+      pytest.fail(f"{world} ranks over RCCL did not finish within {RANKS_TIMEOUT_S} s (transport {transport or 'auto'}): killed")
   return ret
 
 
 def test_one_rank_rccl_born_sharded_flow_with_the_hip_kernel():
   ret = _run(1)
-  full, err, span = ret[0]
-  assert span == (0, N_UNITS) and full.shape == (N_UNITS, GROUP, NQ, D)
+  full, err, span, transport = ret[0]
+  assert transport == "local" and span == (0, N_UNITS) and full.shape == (N_UNITS, GROUP, NQ, D)
   assert err <= 1e-2  # the north star's max-abs bound vs SDPA on the same inputs
 
 
@@ -86,10 +103,16 @@ def test_two_ranks_over_rccl_reproduce_the_one_rank_result_bit_for_bit():
   assert ret[0][2] == (0, N_UNITS // 2) and ret[1][2] == (N_UNITS // 2, N_UNITS)
   assert torch.equal(ret[0][0], one) and torch.equal(ret[1][0], one)
   assert max(ret[0][1], ret[1][1]) <= 1e-2
+  assert ret[0][3] == ret[1][3] and ret[0][3] in ("p2p", "all_gather")  # (the ranks agreed, whatever the node offers)
+  # the fallback transport pinned (what the probe selects on a node without RCCL point-to-point): the same bits
+  if ret[0][3] == "p2p":
+    alt = _run(2, "all_gather")
+    assert alt[0][3] == "all_gather" and torch.equal(alt[0][0], one) and torch.equal(alt[1][0], one)
 
 
+# (`pytest -m gpu -k two_ranks` on a 2-GPU box runs exactly the N > 1 tests)
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (runs on the driver's multi-GPU node)")
-def test_bench_launches_itself_on_two_gpus_over_rccl():
+def test_two_ranks_bench_launches_itself_over_rccl():
   """`python bench.py --gpus 2 --workload cfg5` — the command the scaling curve is taken with — as a subprocess: one JSON line, RCCL world
   size 2, one TFLOPS figure per rank, the kernel-only figure and the figure with the all_gather of O inside the step.  (No number is
   asserted: the plumbing must not be what fails when the curve is taken.)"""
@@ -102,7 +125,7 @@ def test_bench_launches_itself_on_two_gpus_over_rccl():
   for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
     env.pop(k_, None)
   out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "cfg5", "--steps", "2", "--warmup", "1"],
-                       capture_output=True, text=True, timeout=900, env=env)
+                       capture_output=True, text=True, timeout=RANKS_TIMEOUT_S + 180, env=env)
   assert out.returncode == 0, out.stderr[-2000:]
   lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
   assert len(lines) == 1, out.stdout[-2000:]
@@ -110,4 +133,6 @@ def test_bench_launches_itself_on_two_gpus_over_rccl():
   assert line["n_gpus"] == 2 and line["rccl_world_size"] == 2 and line["scaling"] == "strong"
   assert len(line["per_rank_tflops"]) == 2 and all(x > 0 for x in line["per_rank_tflops"])
   assert line["with_gather"]["value"] > 0 and line["value"] > 0 and line["timed_step_includes_gather"] is False
+  g = line["with_gather"]  # the self-judging figures of the first multi-GPU run: transport, agreed pieces, measured vs one shard per xGMI link
+  assert g["transport"] in ("p2p", "all_gather") and g["chunks"] >= 1 and g["alone_ms"] > 0 and g["expected_ms_one_shard_per_link"] > 0 and g["shard_bytes"] == 128 * 8192 * 512 * 2, g
   assert line["config"]["global_batch"] == 8 and "256 units, 128 per rank" in line["config"]["parallelism"]
