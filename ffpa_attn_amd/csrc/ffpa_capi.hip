@@ -68,6 +68,7 @@ struct Plan {
   int mk;     // m16: the mask kind of the build (0 none, 1 additive bias, 2 boolean mask / ranges)
   int bias_raw;  // FwdArgs.bias_cache_raw
   int bias_lds;  // FwdArgs.bias_lds: > 0 bytes of the key-bias row cache, < 0 -(bytes of the bias-tile staging areas), 0 neither
+  int pair;      // 1: row tiles i and nqt - 1 - i share a workgroup (FwdArgs.pair_tiles): the grid holds (nqt + 1) / 2 workgroups per (batch, head)
   size_t ws_bytes;
 };
 
@@ -77,9 +78,10 @@ constexpr int kMaxDevices = 64;
 std::atomic<int> g_cu_count[kMaxDevices];  // 0 = not looked up yet
 std::atomic<int> g_arch_ok[kMaxDevices];   // 0 = not looked up yet, 1 = gfx950, 2 = something else
 
-// Test-only: FFPA_HIP_FAKE_CUS=<n> makes the launch plan price a device of n compute units (the plan fuzz of tests/test_fwd_gpu.py and the CPU plan
-// tables of tests/test_capi.py walk 128 / 256 / 304).  Read on every call while set (no cached state to go stale); the kernels never see it — any
-// grid is correct on any device, the plan only decides how fast.
+// FFPA_HIP_FAKE_CUS=<n> makes the launch plan price a device of n compute units — a SUPPORTED override: a process that owns a CU-masked
+// slice of the GPU (HSA_CU_MASK, partition modes) still reads the whole chip's count from the attribute below; the plan fuzz of tests/test_fwd_gpu.py and
+// the CPU plan tables of tests/test_capi.py walk 128 / 256 / 304 with it.  Read on every call while set (no cached state to go stale); the kernels never
+// see it — any grid is correct on any device, the plan only decides how fast.
 int device_cu_count() {
   if (const char* fake = getenv("FFPA_HIP_FAKE_CUS")) {
     const int n = atoi(fake);
@@ -97,14 +99,14 @@ int device_cu_count() {
 
 // What the split pricing needs to know about the device besides its CU count: the matrix rate of ONE compute unit and the HBM bandwidth — both read
 // from the device (engine clock; memory clock x bus width) instead of being MI355X constants, scaled by what this library's kernels were MEASURED to
-// sustain of them on gfx950 (a table next to the tile configuration: the same fractions the bench lines report as roofline.frac).  A part with other
+// sustain of them on gfx950 (PlanTunables below: the same fractions the bench lines report as roofline.frac).  A part with other
 // clocks or another stack count prices itself; without a device (plan queries on a CPU box) the MI355X figures are the fallback.
 struct DeviceRates {
   double cu_flops;   // dense bf16 MFMA peak of one CU: 4 SIMDs x 1024 FLOP / clk x engine clock
   double hbm_bytes;  // HBM peak, bytes / s
 };
-std::atomic<long long> g_clock_khz[kMaxDevices];   // 0 = not looked up yet
-std::atomic<long long> g_hbm_mbps[kMaxDevices];    // MB / s
+// (one word per device — engine clock in kHz << 32 | HBM bandwidth in MB / s —, so that a concurrent first caller sees both figures or neither)
+std::atomic<unsigned long long> g_rates[kMaxDevices];  // 0 = not looked up yet
 
 DeviceRates device_rates() {
   DeviceRates r = {4.0 * 1024.0 * 2.4e9, 8.0e12};  // MI355X: 2.4 GHz, 8 TB/s (MI355X_MICROARCH.md)
@@ -113,11 +115,11 @@ DeviceRates device_rates() {
     (void)hipGetLastError();
     return r;
   }
-  long long khz = g_clock_khz[dev].load(std::memory_order_relaxed), mbps = g_hbm_mbps[dev].load(std::memory_order_relaxed);
-  if (khz == 0) {
+  unsigned long long packed = g_rates[dev].load(std::memory_order_acquire);
+  if (packed == 0) {
     int clk = 0, mclk = 0, bus = 0;
+    long long mbps = 0;
     if (hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, dev) != hipSuccess || clk <= 0) clk = 2400000;
-    khz = clk;
     // HBM3 / HBM3E (every gfx94x / gfx950 part; this library only loads on gfx950): four transfers per reported memory clock x bus width —
     // MI355X: 2000 MHz x 8192 bit x 4 / 8 = 8.19 TB/s, MI300X: 1300 MHz -> 5.3 TB/s.  A driver that does not report them leaves the MI355X figure
     if (hipDeviceGetAttribute(&mclk, hipDeviceAttributeMemoryClockRate, dev) == hipSuccess && mclk > 0 &&
@@ -125,17 +127,42 @@ DeviceRates device_rates() {
       mbps = (long long)(4.0 * (double)mclk * 1e3 * (double)bus / 8.0 / 1e6);
     if (mbps < 500000 || mbps > 20000000) mbps = 8000000;  // (0.5 ... 20 TB/s: anything else is a driver reporting another unit)
     (void)hipGetLastError();
-    g_clock_khz[dev].store(khz, std::memory_order_relaxed);
-    g_hbm_mbps[dev].store(mbps, std::memory_order_relaxed);
+    packed = ((unsigned long long)(unsigned)clk << 32) | (unsigned long long)(unsigned)mbps;
+    g_rates[dev].store(packed, std::memory_order_release);
   }
-  r.cu_flops = 4.0 * 1024.0 * (double)khz * 1e3;
-  r.hbm_bytes = (double)mbps * 1e6;
+  r.cu_flops = 4.0 * 1024.0 * (double)(packed >> 32) * 1e3;
+  r.hbm_bytes = (double)(packed & 0xffffffffull) * 1e6;
   return r;
 }
-// measured on gfx950 (profiles/r04_bench_*.json, r05): fraction of a CU's MFMA peak one workgroup of the prefill tiles sustains while it walks KV tiles, and
-// the fraction of the HBM peak the partial-write + merge traffic of a KV-split launch moves at
-constexpr double kTileRateFracD512 = 5.0e12 / 9.8304e12, kTileRateFracSplitD = 4.0e12 / 9.8304e12, kMergeBwFrac = 5.0e12 / 8.0e12;  // (5.0 / 4.0 TFLOP/s per CU, 5 TB/s on MI355X: what profiles/r04_launch_side.txt was priced with)
-constexpr double kMaxAutoWorkspaceBytes = 1024.0 * 1048576.0;  // the pricing never asks a caller for more scratch than this on its own (a forced num_splits may)
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// The launch plan.  Every FITTED number it uses lives in this one block, keyed by architecture (this library holds gfx950 code objects only:
+// one entry); the rules that use them are a table further down, each with its predicate, its candidates, its margin and the file under
+// profiles/ that justifies it.
+// ------------------------------------------------------------------------------------------------------------------------------------
+struct PlanTunables {
+  // fraction of a CU's MFMA peak one workgroup of the prefill tiles sustains while it walks KV tiles (D <= 512 / split-D tiles), and the fraction of
+  // the HBM peak the partial-write + merge traffic of a KV-split launch moves at (5.0 / 4.0 TFLOP/s per CU, 5 TB/s on MI355X: profiles/r04_launch_side.txt)
+  double tile_rate_frac_d512, tile_rate_frac_splitd, merge_bw_frac;
+  double fixed_tiles;          // per-workgroup fixed cost (prologue, epilogue, dispatch) in KV-tile times (profiles/r04_launch_side.txt)
+  double max_auto_ws_bytes;    // the pricing never asks a caller for more scratch than this on its own (a forced num_splits may)
+  double wide_gain;            // rows per unit time, wide-row tile : 32-row tile — the low end of the measured 2 ... 7 % (profiles/r05_wide_tile.txt)
+  int wide_min_wg_per_cu;      // ragged launches (causal flag, masks, ranges): workgroups per CU from which the wide tile is taken (profiles/r05_wide_tile.txt)
+  int min_tiles_prefill, min_tiles_short;  // KV tiles a split range holds at least: the merge stays cheap (profiles/r03_decode_splits.txt, r04_launch_side.txt)
+  int short_one_per_cu_min_d, short_one_per_cu_lds;  // short-query tiles that want ONE workgroup per CU: head dims from here up, or tiles above this much LDS (profiles/r03_decode_splits.txt)
+  int det_tiles_per_split;     // FFPA_FLAG_DETERMINISTIC: KV tiles per split range of a short-query launch (a function of the KV length alone)
+};
+constexpr PlanTunables kPlanGfx950 = {
+    5.0e12 / 9.8304e12, 4.0e12 / 9.8304e12, 5.0e12 / 8.0e12,
+    4.0,
+    1024.0 * 1048576.0,
+    1.04,
+    8,
+    8, 4,
+    320, 80 * 1024,
+    16,
+};
+constexpr const PlanTunables& kT = kPlanGfx950;
 
 // FFPA_OK iff the current device is a gfx950 (the only target of the embedded code objects)
 int check_device() {
@@ -159,6 +186,77 @@ int check_device() {
   return FFPA_OK;
 }
 
+// What every rule of the plan looks at: the call, the tile the launch would run, the device, and the pricing model's inputs.
+struct PlanCtx {
+  const ffpa_fwd_params* p;
+  const DimEntry* de;
+  Plan* pl;
+  int64_t cus, base;     // compute units; workgroups of the unsplit launch (batch x heads x row tiles)
+  int dk;                // head dim of the kernel instantiation
+  double nt_eff;         // KV tiles an average row tile walks (causal flag: up to its diagonal)
+  int nt_visible;        // KV tiles any row can see: a split range past them would be workgroups that do nothing
+  double tile_s, out_elems, merge_bw;
+  bool priced;           // the split count is the pricing's to choose (prefill tile, no forced count, scratch offered)
+  bool deterministic;    // FFPA_FLAG_DETERMINISTIC
+};
+
+// The pricing model of a prefill launch split over s KV ranges (round 4, profiles/r04_launch_side.txt; it over-prices the splits by ~ 10 % on every measured shape):
+//   time(s) = rounds(s) x (tiles per split + fixed_tiles of per-workgroup fixed cost) x tile time  +  (8 s + 2) bytes per output element / merge bandwidth
+double predicted(const PlanCtx& c, int64_t s) {
+  const double rounds = (double)((c.base * s + c.cus - 1) / c.cus);
+  return rounds * (c.nt_eff / s + kT.fixed_tiles) * c.tile_s + (s > 1 ? c.out_elems * (8.0 * s + 2.0) / c.merge_bw : 0.0);
+}
+// a split count is admissible for the pricing's own rules if its last KV range still holds keys some row can see and its scratch stays under the cap
+bool admissible(const PlanCtx& c, int64_t s) {
+  const int64_t tps = (c.pl->nt + s - 1) / s;
+  return (s - 1) * tps < c.nt_visible && (double)s * c.out_elems / c.dk * (c.dk + 1.0) * 4.0 <= kT.max_auto_ws_bytes;
+}
+
+// A PRICED rule: where `applies`, every split count of `range` (ascending; the walk stops at the first count that leaves a range fewer than
+// min_tiles_prefill KV tiles) is priced against the count the plan holds so far, and the cheapest one that beats `margin` x that price is taken.
+struct PricedRule {
+  const char* name;
+  bool (*applies)(const PlanCtx&, int64_t cur);
+  void (*range)(const PlanCtx&, int64_t cur, int64_t* lo, int64_t* hi);
+  double margin;
+  const char* evidence;
+};
+int64_t run_priced(const PlanCtx& c, const PricedRule& r, int64_t cur) {
+  if (!r.applies(c, cur)) return cur;
+  int64_t lo = 0, hi = -1, pick = cur;
+  r.range(c, cur, &lo, &hi);
+  const double t0 = predicted(c, cur);
+  double best = t0;
+  for (int64_t s = lo; s <= hi; ++s) {
+    if (c.pl->nt / s < kT.min_tiles_prefill) break;
+    if (!admissible(c, s)) continue;
+    const double t = predicted(c, s);
+    if (t < r.margin * t0 && t < best) best = t, pick = s;
+  }
+  return pick;
+}
+const PricedRule kRaggedRound = {
+    // a prefill launch of a little over one round of workgroups — 288 ... 384 on 256 CUs — takes two rounds' time.  Split over 2 or 3 KV ranges it fills whole
+    // rounds (9 heads x 32 row tiles x 3 = 864 = 3.4 rounds), and on a long context the partials and their merge cost little next to that: B1 H9 / H10 / H11 /
+    // H12 x Nq 4096 x Nkv 8192 D512 + 18 / + 15 / + 10 / + 5 %, H40 x Nq 1024 + 14 %, D = 1024 H5 + 19 %; against 2048 keys or under the causal flag the same
+    // splits LOSE 18 ... 37 % — the rule prices both sides and splits only for a predicted gain of 10 %.  The same pricing serves a launch of PART of a round
+    // (CUs / 2 < workgroups < CUs): 160 workgroups in three KV ranges are 480 = two rounds of a third of the length — B1 H5 x Nq 4096 D512 + 10 % at 8192 keys,
+    // + 19 % at 16384, D = 320 + 7 %, H20 x Nq 1024 + 8 %; 192 and 224 workgroups (H6, H7, D = 1024 H3) gain from no split count, and the model picks none.
+    "ragged round",
+    [](const PlanCtx& c, int64_t) {
+      return c.priced && 2 * c.base > c.cus && 2 * c.base <= 3 * c.cus && c.p->bias == nullptr && c.p->kv_bounds == nullptr && !(c.p->dropout_p > 0.f);
+    },
+    [](const PlanCtx&, int64_t, int64_t* lo, int64_t* hi) { *lo = 2, *hi = 3; },
+    0.9, "profiles/r04_launch_side.txt"};
+const PricedRule kTwoRounds = {
+    // under-filled launches whose CUs / workgroups is far from a whole number (96 workgroups: two ranges fill 192 of 256 CUs): a count that makes two rounds of
+    // shorter workgroups can beat the one-round count on a long context — 96 workgroups x 5 = 480: + 6 ... 11 % at 16384 keys, + 7 % at D = 1024 / 8192 keys,
+    // + 2 % at D = 512 / 8192 keys; 80 x 3 and 56 x 4 stay.  Both sides pay partials and a merge, so the margin is 5 % here.
+    "two rounds of shorter workgroups",
+    [](const PlanCtx& c, int64_t cur) { return c.priced && c.base * 2 <= c.cus && cur >= 2; },
+    [](const PlanCtx&, int64_t cur, int64_t* lo, int64_t* hi) { *lo = cur + 1, *hi = 3 * cur < ffpa::kMergeMaxSplits ? 3 * cur : ffpa::kMergeMaxSplits; },
+    0.95, "profiles/r04_launch_side.txt"};
+
 // The wide-row prefill tile (ffpa_fwd_m16w_kernel.h: 16 RH rows per wave, RH sized to the accumulator file; 64-key tiles, double-buffered, one barrier
 // per KV step): does this launch take it?  The builds that exist: no additive bias, no dropout.  Measured on D = 320 (profiles/r05_wide_tile.txt, interleaved
 // same-box A/B): a row of the 192-row tile costs 2 ... 7 % less than a row of the 128-row tile, so what decides is how the launch quantises into rounds of
@@ -166,10 +264,8 @@ int check_device() {
 // 5.4 -> SIX rounds against 8: - 4 %.  Launches whose workgroups differ in length (causal flag, masks, mask ranges: longest first, the last round's tail is short
 // workgroups) have no such quantum but need enough workgroups per CU for the lengths to even out: config 4 (10.75 per CU) + 1.0 ... 1.6 %, B1 H32 causal 8192
 // (5.4 per CU) - 3 %.
-constexpr double kWideGain = 1.04;     // rows per unit time, wide : 32-row tile (the pricing's figure: low end of the measured range)
-constexpr int kWideMinWgPerCu = 8;     // ragged launches: workgroups per CU from which the wide tile is taken
 bool pick_wide_tile(const ffpa_fwd_params* p, const DimEntry* de, const Plan& pl, int64_t cus) {
-  if (pl.variant != 0 || (p->flags & (FFPA_FLAG_DEBUG_SAFE_PATH | FFPA_FLAG_NO_WIDE_TILE))) return false;
+  if (pl.variant != 0 || (p->flags & (FFPA_FLAG_DEBUG_SAFE_PATH | FFPA_FLAG_NO_WIDE_TILE | FFPA_FLAG_DETERMINISTIC))) return false;
   if (p->dropout_p > 0.f || !(p->bias == nullptr || p->bias_dtype == FFPA_BIAS_BOOL8)) return false;
   int br = 0, bc = 0, lds = 0;
   de->config(3, &br, &bc, &lds);
@@ -177,12 +273,154 @@ bool pick_wide_tile(const ffpa_fwd_params* p, const DimEntry* de, const Plan& pl
   if (p->flags & FFPA_FLAG_WIDE_TILE) return true;
   const int64_t wgs_wide = (int64_t)p->batch * p->heads_q * ((p->seqlen_q + br - 1) / br);
   const int64_t wgs_now = (int64_t)p->batch * p->heads_q * ((p->seqlen_q + pl.br - 1) / pl.br);
-  if (p->causal || p->bias != nullptr || p->kv_bounds != nullptr) return wgs_wide >= kWideMinWgPerCu * cus;
-  if (wgs_wide < 2 * cus) return false;  // (launches of a round or two: the KV-split rules below were measured on the 128-row tile)
-  const double t_wide = (double)((wgs_wide + cus - 1) / cus) * br / kWideGain, t_now = (double)((wgs_now + cus - 1) / cus) * pl.br;
+  if (p->causal || p->bias != nullptr || p->kv_bounds != nullptr) return wgs_wide >= kT.wide_min_wg_per_cu * cus;
+  if (wgs_wide < 2 * cus) return false;  // (launches of a round or two: the KV-split rules were measured on the 128-row tile)
+  const double t_wide = (double)((wgs_wide + cus - 1) / cus) * br / kT.wide_gain, t_now = (double)((wgs_now + cus - 1) / cus) * pl.br;
   return t_wide < t_now;
 }
 
+// The pricing's inputs for this call (`pl` holds variant, tile and tile counts already).
+PlanCtx plan_context(const ffpa_fwd_params* p, const DimEntry* de, Plan* pl, int64_t cus) {
+  PlanCtx c = {};
+  c.p = p, c.de = de, c.pl = pl, c.cus = cus;
+  c.base = (int64_t)p->batch * p->heads_q * pl->nqt;
+  c.dk = kernel_head_dim(p->head_dim);
+  // KV tiles an average row tile walks: all of them — or, under the causal flag, those up to its diagonal: rows r see keys <= r + causal_offset, the mean
+  // over the rows is causal_offset + Nq / 2, clamped to [0, Nkv] (top-left causal against a long context: Nq / 2 keys, not Nkv / 2; tail-aligned: Nkv - Nq / 2)
+  c.nt_eff = (double)pl->nt;
+  int64_t visible_end = p->seqlen_kv;  // keys at and past this index are hidden from EVERY row of the launch
+  if (p->causal) {
+    double mean = (double)p->causal_offset + 0.5 * (double)(p->causal_row_mod ? p->causal_row_mod : p->seqlen_q);
+    mean = mean < 0.0 ? 0.0 : (mean > (double)p->seqlen_kv ? (double)p->seqlen_kv : mean);
+    c.nt_eff = mean / pl->bc > 1.0 ? mean / pl->bc : 1.0;
+    const int64_t last = (int64_t)(p->causal_row_mod ? p->causal_row_mod : p->seqlen_q) - 1 + p->causal_offset + 1;
+    visible_end = last < 0 ? 0 : (last < p->seqlen_kv ? last : p->seqlen_kv);
+  }
+  c.nt_visible = (int)((visible_end + pl->bc - 1) / pl->bc);
+  const DeviceRates rates = device_rates();
+  c.tile_s = 4.0 * pl->br * pl->bc * c.dk / ((c.dk > 512 ? kT.tile_rate_frac_splitd : kT.tile_rate_frac_d512) * rates.cu_flops);  // one KV tile of one workgroup
+  c.out_elems = (double)p->batch * p->heads_q * p->seqlen_q * c.dk;
+  c.merge_bw = kT.merge_bw_frac * rates.hbm_bytes;
+  c.deterministic = (p->flags & FFPA_FLAG_DETERMINISTIC) != 0;
+  c.priced = pl->variant == 0 && !(p->flags & (FFPA_FLAG_DEBUG_SAFE_PATH | FFPA_FLAG_FORCE_SPLITS | FFPA_FLAG_DETERMINISTIC)) && p->num_splits == 0 && p->workspace != nullptr;
+  return c;
+}
+
+// KV-split launches (partials + LSE merge): over how many KV ranges?  Short-query tiles: occupancy heuristic cf. select_decode_num_splits
+// (native/launch.cuh:17-67) — aim at one (head dims >= 320) or two workgroups per CU, at least 4 KV tiles per split so the merge stays cheap.  Prefill tiles
+// split when the launch would leave more than half of the chip idle (chunked prefill against a long context with few heads per GPU: one workgroup per CU, at
+// least 8 KV tiles per split), or when a priced rule says so.
+int64_t pick_splits(const PlanCtx& c) {  // (0: this launch does not split — no clamp applies)
+  const ffpa_fwd_params* p = c.p;
+  const Plan& pl = *c.pl;
+  if (c.deterministic) {
+    // batch-invariant bits: a prefill launch never splits; a short-query launch splits by the KV length ALONE (a fixed number of tiles per range) — the
+    // plan of a (batch, head) slice then does not depend on how many slices share the launch, and neither does a single bit of its output
+    if (pl.variant == 0 || p->num_splits == 1) return 0;
+    return (pl.nt + kT.det_tiles_per_split - 1) / kT.det_tiles_per_split;
+  }
+  const bool forced = pl.variant == 0 && (p->flags & FFPA_FLAG_FORCE_SPLITS) && p->num_splits > 1;  // (the flag: sweeps of the rules, tools/gpu_prefill_splits.py)
+  const int64_t ragged = run_priced(c, kRaggedRound, 1);
+  const bool underfilled = pl.variant == 0 && !(p->flags & FFPA_FLAG_DEBUG_SAFE_PATH) && (c.base * 2 <= c.cus || ragged > 1 || forced);
+  if (!((pl.variant == 1 || underfilled) && p->num_splits != 1)) return 0;
+  // short-query tiles, measured (tools/gpu_decode_splits.py, profiles/r03_decode_splits.txt): head dims >= 320 want ONE workgroup per CU — their tiles are
+  // 20 KiB and up, one workgroup keeps enough bytes in flight, and half the splits are half the partials to write and merge (- 3 ... 14 % per step
+  // against two per CU; rounded DOWN: at most two of these workgroups fit a CU, above D = 512 one, and a launch a little over one per CU takes twice
+  // as long as one a little under) — the small head dims two (8 KiB tiles at D = 128: one per CU is 40 ... 60 % slower, three or four 10 ... 25 %)
+  const bool sq_one_per_cu = c.dk >= kT.short_one_per_cu_min_d || pl.lds > kT.short_one_per_cu_lds;  // (or tiles of which only one workgroup fits a CU)
+  int64_t want = pl.variant == 1 ? (sq_one_per_cu ? c.cus / c.base : (2 * c.cus + c.base - 1) / c.base) : c.cus / c.base;
+  if (forced) want = p->num_splits;
+  if (ragged > 1) want = ragged;
+  want = run_priced(c, kTwoRounds, want);
+  return want < 1 ? 1 : want;
+}
+
+// What every split count is clamped by, whoever chose it: tiles per range, ranges nobody can see, the merge kernel's LDS, the caller's request and scratch.
+int64_t clamp_splits(const PlanCtx& c, int64_t want) {
+  const ffpa_fwd_params* p = c.p;
+  const Plan& pl = *c.pl;
+  const int min_tiles = pl.variant == 1 ? kT.min_tiles_short : kT.min_tiles_prefill;
+  const int64_t cap = pl.nt / min_tiles > 0 ? pl.nt / min_tiles : 1;
+  if (want > cap) want = cap;
+  // prefill under the causal flag: no KV range entirely behind every row's diagonal (top-left causal against a long context: rows see at most Nq keys —
+  // ranges past them would be workgroups that do nothing, their partials and the merge pure cost)
+  if (pl.variant == 0 && !(p->flags & FFPA_FLAG_FORCE_SPLITS))
+    while (want > 1 && (want - 1) * ((pl.nt + want - 1) / want) >= c.nt_visible) --want;
+  if (want > ffpa::kMergeMaxSplits) want = ffpa::kMergeMaxSplits;  // the merge kernel keeps the split weights in LDS
+  if (p->num_splits > 1 && want > p->num_splits) want = p->num_splits;
+  if (want < 1) want = 1;
+  const size_t per_split = (size_t)p->batch * p->heads_q * p->seqlen_q * ((size_t)c.dk + 1) * sizeof(float);
+  if (p->workspace == nullptr) want = 1;
+  else if ((uint64_t)want * per_split > p->workspace_bytes) want = (int64_t)(p->workspace_bytes / per_split);
+  return want < 1 ? 1 : want;
+}
+
+// The 16x16x32 prefill build of this call (ffpa_fwd_inst.hip): no bias / boolean masks and mask ranges / additive biases (and anything next to dropout) — and,
+// for an additive bias, where the initial S^T accumulators come from (an LDS row cache, a ring, staged tiles, or element loads).
+void pick_m16_build(const ffpa_fwd_params* p, const DimEntry* de, Plan& pl, int dk) {
+  const bool no_bias = p->bias == nullptr && p->kv_bounds == nullptr;
+  const bool additive = p->bias != nullptr && p->bias_dtype >= FFPA_BIAS_FP16 && p->bias_dtype <= FFPA_BIAS_FP32;
+  pl.mk = no_bias ? 0 : ((additive || p->dropout_p > 0.f) ? 1 : 2);
+  if (pl.mk != 1) return;
+  // 64-key tiles at every head dim <= 512 (the LDS also holds the bias)
+  de->config(2, &pl.br, &pl.bc, &pl.lds);
+  pl.nt = (p->seqlen_kv + pl.bc - 1) / pl.bc;
+  const int esz = p->bias_dtype == FFPA_BIAS_FP32 ? 4 : 2;
+  const int stagers = dk > 512 ? 2 : 4;  // waves that carry a bias tile (D > 512: one of the two waves of a row block)
+  const bool lds_ok = additive && pl.splits == 1 && !(p->flags & FFPA_FLAG_NO_BIAS_LDS);
+  const int64_t cache = (int64_t)pl.nt * pl.bc * 4;  // a key bias as fp32 / scale, a whole number of tiles
+  const int64_t stage = (int64_t)stagers * 32 * pl.bc * esz;
+  bool stage_ok = lds_ok && p->bias_stride[3] == 1 && reinterpret_cast<uintptr_t>(p->bias) % 16 == 0 && p->bias_stride[2] < (1LL << 24) &&
+                  pl.lds + stage <= 160 * 1024;
+  for (int i = 0; i < 3 && stage_ok; ++i) stage_ok = (p->bias_stride[i] * esz) % 16 == 0;
+  const bool cache16 = esz == 2 && pl.lds + cache / 2 <= 160 * 1024;  // ... or as the caller's 16-bit elements, converted per step
+  // split-D tiles with the softmax pipeline (D > 512, D % 128 == 0), nothing but a key bias: the key-bias build runs the pipeline too (round 5); its LDS is the
+  // unmasked build's (6 KiB of exchange per wave) + a RING of fp32 bias entries — a power of two, at least 2048 (all D = 1024 has left), refilled half a ring
+  // at a time 1024+ keys ahead of the walk (ffpa_fwd_m16_kernel.h)
+  const bool ring = lds_ok && p->bias_stride[2] == 0 && dk > 512 && dk % 128 == 0 && p->kv_bounds == nullptr && !(p->dropout_p > 0.f);
+  if (ring) {
+    int br0 = 0, bc0 = 0, lds0 = 0;
+    de->config(4, &br0, &bc0, &lds0);
+    int bytes = 8192;
+    while (2 * bytes <= 160 * 1024 - lds0 && bytes < 65536) bytes *= 2;
+    pl.lds = lds0;
+    pl.bias_raw = 0;
+    pl.bias_lds = bytes;
+    pl.mk = 3;
+  } else if (lds_ok && p->bias_stride[2] == 0 && (pl.lds + cache <= 160 * 1024 || cache16)) {
+    pl.bias_raw = pl.lds + cache <= 160 * 1024 ? 0 : 1;
+    pl.bias_lds = (int)(pl.bias_raw ? cache / 2 : cache);
+    if (p->kv_bounds == nullptr && !(p->dropout_p > 0.f)) pl.mk = 3;  // nothing but a cached key bias: the lean key-bias build
+  } else if (stage_ok) {
+    pl.btile = 1;
+    pl.bias_lds = -(int)stage;
+  }
+}
+
+// 32x32x16 build (head dims <= 64): a 16-bit bias with a real row axis is staged through LDS by LDS-DMA one KV step ahead
+// (4 waves x [32 rows x 64 keys]); those launches run the build with 64-key tiles at every head dim (tile config variant 2)
+void pick_small_d_bias_tiles(const ffpa_fwd_params* p, const DimEntry* de, Plan& pl) {
+  if (pl.m16 || pl.variant != 0 || pl.splits != 1 || p->bias == nullptr || p->bias_stride[2] == 0 || p->bias_stride[3] != 1) return;
+  if (!(p->bias_dtype == FFPA_BIAS_FP16 || p->bias_dtype == FFPA_BIAS_BF16) || (p->flags & (FFPA_FLAG_NO_BIAS_LDS | FFPA_FLAG_DEBUG_SAFE_PATH)) || p->dropout_p > 0.f) return;
+  bool ok = reinterpret_cast<uintptr_t>(p->bias) % 16 == 0 && p->bias_stride[2] < (1LL << 24);
+  for (int i = 0; i < 3; ++i) ok = ok && (p->bias_stride[i] * 2) % 16 == 0;
+  int br = 0, bc = 0, lds = 0;
+  de->config(2, &br, &bc, &lds);
+  if (!(ok && lds + 4 * 32 * bc * 2 <= 160 * 1024)) return;
+  pl.btile = 1;
+  pl.br = br, pl.bc = bc, pl.lds = lds;
+  pl.nt = (p->seqlen_kv + pl.bc - 1) / pl.bc;
+}
+
+// Paired row tiles (ffpa_fwd_m16_kernel.h, FwdArgs::pair_tiles): under the causal flag workgroup i of a head walks row tile nqt - 1 - i and then row tile i — equal
+// work per workgroup, half the dispatches.  The builds that can: the 16x16x32 prefill kernel (not its wide-row tile), unsplit, no bias / ranges / packed rows.
+bool pick_pair_tiles(const ffpa_fwd_params* p, const Plan& pl) {
+  if (!pl.m16 || pl.wide || pl.splits != 1 || !p->causal || p->bias != nullptr || p->kv_bounds != nullptr || p->causal_row_mod != 0 || pl.nqt < 2) return false;
+  if (p->flags & (FFPA_FLAG_NO_PAIR_TILES | FFPA_FLAG_DEBUG_SAFE_PATH)) return false;
+  return (p->flags & FFPA_FLAG_PAIR_TILES) != 0;  // (round 6: behind its flag until the A/B says where it pays)
+}
+
+// Launch plan: tile variant -> wide-row tile? -> KV splits (rules above) -> build and bias placement -> scratch.
 Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
   Plan pl = {};
   // <= 32 query rows per (batch, head): one 32-row block per workgroup with D split over all four waves;
@@ -194,166 +432,18 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
   if (pl.wide) de->config(3, &pl.br, &pl.bc, &pl.lds);
   pl.nqt = (p->seqlen_q + pl.br - 1) / pl.br;
   pl.nt = (p->seqlen_kv + pl.bc - 1) / pl.bc;
-  pl.splits = 1;
-  // KV-split launches (partials + LSE merge).  Short-query tiles: occupancy heuristic cf. select_decode_num_splits
-  // (native/launch.cuh:17-67) — aim at one (head dims >= 320) or two workgroups per CU, at least 4 KV tiles per split so the merge stays
-  // cheap.  Prefill tiles split too when the launch would leave more than half of the chip idle (chunked prefill
-  // against a long context with few heads per GPU): one workgroup per CU, at least 8 KV tiles per split.
-  const int64_t base = (int64_t)p->batch * p->heads_q * pl.nqt;
-  // Ragged rounds (round 4, profiles/r04_launch_side.txt): a prefill launch of a little over one round of workgroups — 288 ... 384 on 256 CUs — takes two
-  // rounds' time.  Split over 2 or 3 KV ranges it fills whole rounds (9 heads x 32 row tiles x 3 = 864 = 3.4 rounds), and on a long context the partials
-  // and their merge cost little next to that: B1 H9 / H10 / H11 / H12 x Nq 4096 x Nkv 8192 D512 + 18 / + 15 / + 10 / + 5 %, H40 x Nq 1024 + 14 %,
-  // D = 1024 H5 + 19 %; against 2048 keys or under the causal flag the same splits LOSE 18 ... 37 % — the rule prices both sides and splits only for a
-  // predicted gain of 10 % (the model errs on the launch's side: it over-prices the splits by ~ 10 % on every measured shape):
-  //   time(s) = rounds(s) x (tiles per split + 4 tiles of per-workgroup fixed cost) x tile time  +  (8 s + 2) bytes per output element / 5 TB/s
-  // The same pricing serves a launch of PART of a round (CUs / 2 < workgroups < CUs; at most half of the chip is the under-filled rule below): 160 workgroups
-  // in three KV ranges are 480 = two rounds of a third of the length — B1 H5 x Nq 4096 D512 + 10 % at 8192 keys, + 19 % at 16384, D = 320 + 7 %, H20 x Nq 1024
-  // + 8 %; 192 and 224 workgroups (H6, H7, D = 1024 H3) gain from no split count, and the model picks none.
-  const int dk_price = kernel_head_dim(p->head_dim);
-  // KV tiles an average row tile walks: all of them — or, under the causal flag, those up to its diagonal: rows r see keys <= r + causal_offset, the mean
-  // over the rows is causal_offset + Nq / 2, clamped to [0, Nkv] (top-left causal against a long context: Nq / 2 keys, not Nkv / 2; tail-aligned: Nkv - Nq / 2)
-  double nt_eff = (double)pl.nt;
-  int64_t visible_end = p->seqlen_kv;  // keys at and past this index are hidden from EVERY row of the launch
-  if (p->causal) {
-    double mean = (double)p->causal_offset + 0.5 * (double)(p->causal_row_mod ? p->causal_row_mod : p->seqlen_q);
-    mean = mean < 0.0 ? 0.0 : (mean > (double)p->seqlen_kv ? (double)p->seqlen_kv : mean);
-    nt_eff = mean / pl.bc > 1.0 ? mean / pl.bc : 1.0;
-    const int64_t last = (int64_t)(p->causal_row_mod ? p->causal_row_mod : p->seqlen_q) - 1 + p->causal_offset + 1;
-    visible_end = last < 0 ? 0 : (last < p->seqlen_kv ? last : p->seqlen_kv);
-  }
-  const int nt_visible = (int)((visible_end + pl.bc - 1) / pl.bc);  // KV tiles any row can see: a split range past them would be workgroups that do nothing
-  const DeviceRates rates = device_rates();
-  const double tile_s = 4.0 * pl.br * pl.bc * dk_price / ((dk_price > 512 ? kTileRateFracSplitD : kTileRateFracD512) * rates.cu_flops);  // one KV tile of one workgroup
-  const double out_elems = (double)p->batch * p->heads_q * p->seqlen_q * dk_price;
-  const double merge_bw = kMergeBwFrac * rates.hbm_bytes;
-  auto predicted = [&](int64_t s) {
-    const double rounds = (double)((base * s + cus - 1) / cus);
-    return rounds * (nt_eff / s + 4.0) * tile_s + (s > 1 ? out_elems * (8.0 * s + 2.0) / merge_bw : 0.0);
-  };
-  // a split count is admissible for the pricing's own rules if its last KV range still holds keys some row can see and its scratch stays under the cap
-  auto admissible = [&](int64_t s) {
-    const int64_t tps = (pl.nt + s - 1) / s;
-    return (s - 1) * tps < nt_visible && (double)s * out_elems / dk_price * (dk_price + 1.0) * 4.0 <= kMaxAutoWorkspaceBytes;
-  };
-  const bool priced = pl.variant == 0 && !(p->flags & (FFPA_FLAG_DEBUG_SAFE_PATH | FFPA_FLAG_FORCE_SPLITS)) && p->num_splits == 0 && p->workspace != nullptr;
-  int ragged_splits = 1;
-  if (priced && 2 * base > cus && 2 * base <= 3 * cus && p->bias == nullptr && p->kv_bounds == nullptr && !(p->dropout_p > 0.f)) {
-    const double t1 = predicted(1);
-    double best = t1;
-    for (int s = 2; s <= 3; ++s) {
-      if (pl.nt / s < 8) break;  // (>= 8 KV tiles per split, as the under-filled rule)
-      if (!admissible(s)) continue;
-      const double t = predicted(s);
-      if (t < 0.9 * t1 && t < best) best = t, ragged_splits = s;
-    }
-  }
-  const bool underfilled = pl.variant == 0 && !(p->flags & FFPA_FLAG_DEBUG_SAFE_PATH) &&
-                           (base * 2 <= cus || ragged_splits > 1 || ((p->flags & FFPA_FLAG_FORCE_SPLITS) && p->num_splits > 1));  // (the flag: sweeps of the rule, tools/gpu_prefill_splits.py)
-  if ((pl.variant == 1 || underfilled) && p->num_splits != 1) {
-    // short-query tiles, measured (tools/gpu_decode_splits.py, profiles/r03_decode_splits.txt): head dims >= 320 want ONE workgroup per CU — their tiles are
-    // 20 KiB and up, one workgroup keeps enough bytes in flight, and half the splits are half the partials to write and merge (- 3 ... 14 % per step
-    // against two per CU; rounded DOWN: at most two of these workgroups fit a CU, above D = 512 one, and a launch a little over one per CU takes twice
-    // as long as one a little under) — the small head dims two (8 KiB tiles at D = 128: one per CU is 40 ... 60 % slower, three or four 10 ... 25 %)
-    const bool sq_one_per_cu = kernel_head_dim(p->head_dim) >= 320 || pl.lds > 80 * 1024;  // (or tiles of which only one workgroup fits a CU)
-    int64_t want = pl.variant == 1 ? (sq_one_per_cu ? cus / base : (2 * cus + base - 1) / base) : cus / base;
-    if (pl.variant == 0 && (p->flags & FFPA_FLAG_FORCE_SPLITS) && p->num_splits > 1) want = p->num_splits;
-    if (ragged_splits > 1) want = ragged_splits;
-    if (priced && base * 2 <= cus && want >= 2) {
-      // CUs / workgroups far from a whole number (96 workgroups: two ranges fill 192 of 256 CUs): a count that makes two rounds of shorter workgroups can
-      // beat the one-round count on a long context — 96 workgroups x 5 = 480: + 6 ... 11 % at 16384 keys, + 7 % at D = 1024 / 8192 keys, + 2 % at D = 512 /
-      // 8192 keys (profiles/r04_launch_side.txt); 80 x 3 and 56 x 4 stay.  Both sides pay partials and a merge, so the pricing's margin is 5 % here.
-      const double t0 = predicted(want);
-      double best = t0;
-      const int64_t one_round = want;
-      for (int64_t s = one_round + 1; s <= 3 * one_round && s <= ffpa::kMergeMaxSplits; ++s) {
-        if (pl.nt / s < 8) break;
-        if (!admissible(s)) continue;
-        const double t = predicted(s);
-        if (t < 0.95 * t0 && t < best) best = t, want = s;
-      }
-    }
-    const int min_tiles = pl.variant == 1 ? 4 : 8;
-    const int64_t cap = pl.nt / min_tiles > 0 ? pl.nt / min_tiles : 1;
-    if (want > cap) want = cap;
-    // prefill under the causal flag: no KV range entirely behind every row's diagonal (top-left causal against a long context: rows see at most Nq keys —
-    // ranges past them would be workgroups that do nothing, their partials and the merge pure cost)
-    if (pl.variant == 0 && !(p->flags & FFPA_FLAG_FORCE_SPLITS))
-      while (want > 1 && (want - 1) * ((pl.nt + want - 1) / want) >= nt_visible) --want;
-    if (want > ffpa::kMergeMaxSplits) want = ffpa::kMergeMaxSplits;  // the merge kernel keeps the split weights in LDS
-    if (p->num_splits > 1 && want > p->num_splits) want = p->num_splits;
-    if (want < 1) want = 1;
-    const size_t per_split = (size_t)p->batch * p->heads_q * p->seqlen_q * ((size_t)kernel_head_dim(p->head_dim) + 1) * sizeof(float);
-    if (p->workspace == nullptr) want = 1;
-    else if ((uint64_t)want * per_split > p->workspace_bytes) want = (int64_t)(p->workspace_bytes / per_split);
-    if (want < 1) want = 1;
-    pl.splits = (int)want;
-  }
-  const bool safe_path = (p->flags & FFPA_FLAG_DEBUG_SAFE_PATH) != 0;
-  const int dk = kernel_head_dim(p->head_dim);
-  pl.m16 = (pl.variant == 0 && !safe_path && dk >= FFPA_M16_MIN_D) ? 1 : 0;
-  if (pl.m16) {
-    // the build (ffpa_fwd_inst.hip): no bias / boolean masks and mask ranges / additive biases (and anything next to dropout)
-    const bool no_bias = p->bias == nullptr && p->kv_bounds == nullptr;
-    const bool additive = p->bias != nullptr && p->bias_dtype >= FFPA_BIAS_FP16 && p->bias_dtype <= FFPA_BIAS_FP32;
-    pl.mk = no_bias ? 0 : ((additive || p->dropout_p > 0.f) ? 1 : 2);
-    if (pl.mk == 1) {
-      // 64-key tiles at every head dim <= 512 (the LDS also holds the bias); where the initial S^T accumulators come from:
-      de->config(2, &pl.br, &pl.bc, &pl.lds);
-      pl.nt = (p->seqlen_kv + pl.bc - 1) / pl.bc;
-      const int esz = p->bias_dtype == FFPA_BIAS_FP32 ? 4 : 2;
-      const int stagers = dk > 512 ? 2 : 4;  // waves that carry a bias tile (D > 512: one of the two waves of a row block)
-      const bool lds_ok = additive && pl.splits == 1 && !(p->flags & FFPA_FLAG_NO_BIAS_LDS);
-      const int64_t cache = (int64_t)pl.nt * pl.bc * 4;  // a key bias as fp32 / scale, a whole number of tiles
-      const int64_t stage = (int64_t)stagers * 32 * pl.bc * esz;
-      bool stage_ok = lds_ok && p->bias_stride[3] == 1 && reinterpret_cast<uintptr_t>(p->bias) % 16 == 0 && p->bias_stride[2] < (1LL << 24) &&
-                      pl.lds + stage <= 160 * 1024;
-      for (int i = 0; i < 3 && stage_ok; ++i) stage_ok = (p->bias_stride[i] * esz) % 16 == 0;
-      const bool cache16 = esz == 2 && pl.lds + cache / 2 <= 160 * 1024;  // ... or as the caller's 16-bit elements, converted per step
-      // split-D tiles with the softmax pipeline (D > 512, D % 128 == 0), nothing but a key bias: the key-bias build runs the pipeline too (round 5); its LDS is the
-      // unmasked build's (6 KiB of exchange per wave) + a RING of fp32 bias entries — a power of two, at least 2048 (all D = 1024 has left), refilled half a ring
-      // at a time 1024+ keys ahead of the walk (ffpa_fwd_m16_kernel.h)
-      const bool ring = lds_ok && p->bias_stride[2] == 0 && dk > 512 && dk % 128 == 0 && p->kv_bounds == nullptr && !(p->dropout_p > 0.f);
-      if (ring) {
-        int br0 = 0, bc0 = 0, lds0 = 0;
-        de->config(4, &br0, &bc0, &lds0);
-        int bytes = 8192;
-        while (2 * bytes <= 160 * 1024 - lds0 && bytes < 65536) bytes *= 2;
-        pl.lds = lds0;
-        pl.bias_raw = 0;
-        pl.bias_lds = bytes;
-        pl.mk = 3;
-      } else if (lds_ok && p->bias_stride[2] == 0 && (pl.lds + cache <= 160 * 1024 || cache16)) {
-        pl.bias_raw = pl.lds + cache <= 160 * 1024 ? 0 : 1;
-        pl.bias_lds = (int)(pl.bias_raw ? cache / 2 : cache);
-        if (p->kv_bounds == nullptr && !(p->dropout_p > 0.f)) pl.mk = 3;  // nothing but a cached key bias: the lean key-bias build
-      } else if (stage_ok) {
-        pl.btile = 1;
-        pl.bias_lds = -(int)stage;
-      }
-    }
-  }
-  // 32x32x16 build (head dims <= 256): a 16-bit bias with a real row axis is staged through LDS by LDS-DMA one KV step ahead
-  // (4 waves x [32 rows x 64 keys]); those launches run the build with 64-key tiles at every head dim (tile config variant 2)
-  if (!pl.m16 && pl.variant == 0 && pl.splits == 1 && p->bias != nullptr && p->bias_stride[2] != 0 && p->bias_stride[3] == 1 &&
-      (p->bias_dtype == FFPA_BIAS_FP16 || p->bias_dtype == FFPA_BIAS_BF16) && !(p->flags & (FFPA_FLAG_NO_BIAS_LDS | FFPA_FLAG_DEBUG_SAFE_PATH)) &&
-      !(p->dropout_p > 0.f)) {
-    bool ok = reinterpret_cast<uintptr_t>(p->bias) % 16 == 0 && p->bias_stride[2] < (1LL << 24);
-    for (int i = 0; i < 3; ++i) ok = ok && (p->bias_stride[i] * 2) % 16 == 0;
-    int br = 0, bc = 0, lds = 0;
-    de->config(2, &br, &bc, &lds);
-    if (ok && lds + 4 * 32 * bc * 2 <= 160 * 1024) {
-      pl.btile = 1;
-      pl.br = br;
-      pl.bc = bc;
-      pl.lds = lds;
-      pl.nt = (p->seqlen_kv + pl.bc - 1) / pl.bc;
-    }
-  }
+  const PlanCtx c = plan_context(p, de, &pl, cus);
+  const int64_t want = pick_splits(c);
+  pl.splits = want > 0 ? (int)clamp_splits(c, want) : 1;
+  pl.m16 = (pl.variant == 0 && !(p->flags & FFPA_FLAG_DEBUG_SAFE_PATH) && c.dk >= FFPA_M16_MIN_D) ? 1 : 0;
+  if (pl.m16) pick_m16_build(p, de, pl, c.dk);
+  pick_small_d_bias_tiles(p, de, pl);
+  pl.pair = pick_pair_tiles(p, pl) ? 1 : 0;
   pl.tiles_per_split = (pl.nt + pl.splits - 1) / pl.splits;
   if (pl.tiles_per_split < 1) pl.tiles_per_split = 1;
   pl.splits = (pl.nt + pl.tiles_per_split - 1) / pl.tiles_per_split;
   if (pl.splits < 1) pl.splits = 1;
-  pl.ws_bytes = pl.splits > 1 ? (size_t)pl.splits * p->batch * p->heads_q * p->seqlen_q * ((size_t)kernel_head_dim(p->head_dim) + 1) * sizeof(float) : 0;
+  pl.ws_bytes = pl.splits > 1 ? (size_t)pl.splits * p->batch * p->heads_q * p->seqlen_q * ((size_t)c.dk + 1) * sizeof(float) : 0;
   return pl;
 }
 
@@ -459,7 +549,7 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   const Plan pl = make_plan(p, de);
   const int lds = pl.lds;
   const int64_t nqt = pl.nqt;
-  const int64_t grid = (int64_t)p->batch * p->heads_q * nqt * pl.splits;
+  const int64_t grid = (int64_t)p->batch * p->heads_q * (pl.pair ? (nqt + 1) / 2 : nqt) * pl.splits;
   if (grid > 0x7fffffffLL) return fail(FFPA_ERR_BAD_SHAPE, "grid of %lld workgroups is too large", (long long)grid);
 
   ffpa::FwdArgs a;
@@ -485,6 +575,7 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   a.d_valid = p->head_dim;
   a.group = p->heads_q / p->heads_kv;
   a.nqt = (int)nqt;
+  a.pair_tiles = pl.pair;
   a.total_wg = (int)grid;
   a.bias_dtype = p->bias_dtype;
   a.causal = p->causal ? 1 : 0;

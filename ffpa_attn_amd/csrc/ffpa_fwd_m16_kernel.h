@@ -362,11 +362,21 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   if (!(a.flags & kFlagNoXcdRemap)) vid = xcd_logical_id(vid, gridDim.x, a.xcd_group);
   const int split = vid % a.nsplit;
   vid /= a.nsplit;
-  const int bh = vid / a.nqt;
-  int qt = vid - bh * a.nqt;
+  // PAIRED ROW TILES (FwdArgs::pair_tiles, round 6: launches under the causal flag): workgroup i of a head walks row tile nqt - 1 - i (its long one) and then
+  // row tile i (the short one) — every workgroup of the launch walks nqt + 1 diagonal-bounded tiles' worth of KV steps, the launch has half the workgroups
+  // (half the dispatches, no tail of short workgroups), and per row nothing changes: the same tile, the same recurrence, the same bits.  The whole body
+  // below — tile range, Q fragments, KV loop, epilogue — runs once per pass; LDS is free between the passes (every wave has passed the last step's barrier
+  // B, and the pipelined loop's own post-loop barrier, before any wave can start the next pass's prologue DMA).
+  const int nqt_wg = a.pair_tiles ? (a.nqt + 1) >> 1 : a.nqt;
+  const int bh = vid / nqt_wg;
+  const int qt_wg = vid - bh * nqt_wg;
+  const int npass = (a.pair_tiles && 2 * qt_wg != a.nqt - 1) ? 2 : 1;  // (an odd tile count: the middle tile is its own partner)
+  for (int pass = 0; pass < npass; ++pass) {
+  int qt = qt_wg;
   // longest rows first: with the causal flag — and with mask ranges, whose usual source is a causal-like boolean mask (later rows see
   // more keys; for any other mask the order of a head's row tiles does not matter) — so that the launch ends on its short workgroups
-  if (a.causal || (MASK && a.kv_bounds != nullptr)) qt = a.nqt - 1 - qt;
+  if (a.pair_tiles) qt = pass == 0 ? a.nqt - 1 - qt_wg : qt_wg;
+  else if (a.causal || (MASK && a.kv_bounds != nullptr)) qt = a.nqt - 1 - qt;
   const int b = bh / a.Hq;
   const int hq = bh - b * a.Hq;
   const int hkv = hq / a.group;
@@ -1599,7 +1609,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
       // turns into an output ulp here and there; every build must produce the same bits for the same scores)
       if (c == 0 && dh == 0) a.ws_lse[prow] = dead ? -INFINITY : __builtin_fmaf(m_run[rh], 0.6931471805599453f, __logf(l_tot[rh]));
     }
-    return;
+    continue;
   }
   {
     // lanes c (even) and c + 1 trade one 4-column group per block: the even lane ends up with columns 16 db + 4 c .. + 8 of row
@@ -1644,6 +1654,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
     }
 #endif
   }
+  }  // (pass: the second row tile of a paired workgroup)
 }
 
 }  // namespace ffpa

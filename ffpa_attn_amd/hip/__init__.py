@@ -57,6 +57,9 @@ FLAG_KV_STREAM = 0x80      # bench-only: force the non-temporal K / V fetch of s
 FLAG_NO_KV_STREAM = 0x800  # bench-only: never
 FLAG_WIDE_TILE = 0x1000     # bench / test: prefill launches take the wide-row tile wherever one is built (default: the library decides)
 FLAG_NO_WIDE_TILE = 0x2000  # bench / test: never
+FLAG_PAIR_TILES = 0x8000      # bench / test: causal prefill launches pair row tiles i and n - 1 - i in one workgroup (default: the library decides)
+FLAG_NO_PAIR_TILES = 0x20000  # bench / test: never
+FLAG_DETERMINISTIC = 0x4000  # batch-invariant bits: no prefill KV splits, no wide-row tile, short-query splits by the KV length alone (FFPA_HIP_DETERMINISTIC=1 sets it on every call)
 
 
 def FLAG_XCD_GROUP(n: int) -> int:
@@ -625,7 +628,7 @@ def forward(
   p.softmax_scale = float(softmax_scale)
   p.rescale_threshold = float(rescale_threshold)
   p.dropout_p = float(dropout_p)
-  p.flags = int(flags)
+  p.flags = int(flags) | (FLAG_DETERMINISTIC if os.environ.get("FFPA_HIP_DETERMINISTIC", "0").lower() not in ("0", "", "off", "false", "no") else 0)
   p.philox_seed = int(philox_seed) & 0xFFFFFFFFFFFFFFFF
   p.philox_offset = int(philox_offset) & 0xFFFFFFFFFFFFFFFF
 

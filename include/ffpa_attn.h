@@ -71,6 +71,12 @@ enum ffpa_bias_dtype {
 #define FFPA_FLAG_NO_KV_STREAM    0x800u /* bench-only: never                                          */
 #define FFPA_FLAG_WIDE_TILE       0x1000u /* bench / test: prefill launches take the wide-row tile (ffpa_fwd_m16w_kernel) wherever the head dim and the mask kind have one (default: the launch side decides) */
 #define FFPA_FLAG_NO_WIDE_TILE    0x2000u /* bench / test: never                                       */
+#define FFPA_FLAG_PAIR_TILES      0x8000u /* bench / test: causal prefill launches pair row tiles i and n - 1 - i in one workgroup wherever the build can (default: the launch side decides) */
+#define FFPA_FLAG_NO_PAIR_TILES   0x20000u /* bench / test: never                                      */
+#define FFPA_FLAG_DETERMINISTIC   0x4000u /* batch-invariant bits: the plan of a (batch, head) slice does not depend on how many slices share the launch — prefill
+                                             launches never split the KV axis and never take the wide-row tile (128-row tiles, one pass per row), short-query launches
+                                             split by the KV length alone (a fixed number of KV tiles per range).  Costs what the launch-size rules would have gained
+                                             (under-filled / ragged-round prefill launches: up to ~ 20 %).  Python: FFPA_HIP_DETERMINISTIC=1 sets it on every call. */
 #define FFPA_FLAG_XCD_GROUP(log2p1) ((unsigned)(log2p1) << 8) /* bench-only: bits 8..10 = 1 + log2 of the XCDs that share a head's row tiles (1 -> 1, 2 -> 2, 3 -> 4, 4 -> 8); 0 = the launch side decides */
 
 /*

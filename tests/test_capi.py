@@ -421,3 +421,31 @@ def test_plan_invariants_on_random_launches(lib, monkeypatch):
       if variant == 1:
         assert kernel.startswith("ffpa_fwd_split_d_kernel"), (what, kernel)
       assert f" {(Dp + 63) // 64 * 64}," in kernel or f" {(Dp + 63) // 64 * 64}>" in kernel, (what, kernel)
+
+
+def test_deterministic_flag_pins_the_plan_of_a_slice(lib):
+  """FFPA_FLAG_DETERMINISTIC (Python: FFPA_HIP_DETERMINISTIC=1): the plan of a (batch, head) slice does not depend on how many slices share the launch —
+  prefill launches never split the KV axis and never take the wide-row tile; short-query launches split by the KV length alone."""
+  plan = (ctypes.c_int * 4)()
+
+  def ask(flags=0, **over):
+    p = _params(**over)
+    p.workspace, p.workspace_bytes = 16, 1 << 40
+    p.flags = flags
+    assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0
+    return list(plan)
+
+  det = hip.FLAG_DETERMINISTIC
+  # prefill: the launch-size rules (under-filled: H2 -> 4 ranges; ragged round: H9 x Nq 4096 -> 3; wide tile: config 4) all depend on the head / batch count
+  assert ask(batch=1, heads_q=2, heads_kv=2, seqlen_q=4096, seqlen_kv=16384)[3] > 1 and ask(batch=1, heads_q=9, heads_kv=9, seqlen_q=4096, seqlen_kv=8192)[3] > 1
+  assert ask(batch=2, heads_q=32, heads_kv=8, seqlen_q=8192, seqlen_kv=2048, head_dim=320, causal=1)[1] == 192
+  for heads in (1, 2, 5, 9, 32):
+    assert ask(det, batch=1, heads_q=heads, heads_kv=heads, seqlen_q=4096, seqlen_kv=16384) == [0, 128, 64, 1]
+    assert ask(det, batch=2, heads_q=4 * heads, heads_kv=heads, seqlen_q=8192, seqlen_kv=2048, head_dim=320, causal=1) == [0, 128, 128, 1]
+  # short query: the default rule aims at a workgroup count (so the split count moves with batch x heads); pinned, it is a function of the KV length
+  assert ask(batch=1, heads_q=32, heads_kv=32, seqlen_q=1, seqlen_kv=8192)[3] != ask(batch=8, heads_q=8, heads_kv=8, seqlen_q=1, seqlen_kv=8192)[3]
+  for nkv, want in ((8192, 8), (4096, 4), (1000, 1), (140000, 137)):  # 16 tiles of 64 keys per range
+    got = {tuple(ask(det, batch=b, heads_q=h, heads_kv=h, seqlen_q=1, seqlen_kv=nkv)) for b, h in ((1, 1), (1, 32), (8, 8), (16, 32))}
+    assert got == {(1, 32, 64, want)}, (nkv, got)
+  assert ask(det, batch=1, heads_q=32, heads_kv=32, seqlen_q=1, seqlen_kv=8192, num_splits=1)[3] == 1  # (an explicit "never split" still wins)
+  assert hip.FLAG_DETERMINISTIC == 0x4000

@@ -196,3 +196,34 @@ def test_decode_step_on_a_side_stream_and_inside_a_callers_capture(hip):
   assert step.captures == 2 and torch.equal(o_g, want)
   with pytest.raises(ValueError, match="dropout"):
     DecodeStep(dropout_p=0.1)
+
+
+def test_deterministic_mode_makes_a_slice_batch_invariant_to_the_bit(hip, monkeypatch):
+  """FFPA_HIP_DETERMINISTIC=1 (FFPA_FLAG_DETERMINISTIC): the bits of a (batch, head) slice do not depend on how many slices share the launch — checked where
+  the default plan does depend on it: an under-filled prefill launch (2 heads split the KV axis, 32 heads do not) and a decode step (the split count aims at
+  a workgroup count)."""
+  from ffpa_attn_amd import ffpa_attn_func
+
+  monkeypatch.setenv("FFPA_HIP_DETERMINISTIC", "1")
+  q, k, v = _rand((1, 32, 1024, 512), seed=91), _rand((1, 32, 8192, 512), seed=92), _rand((1, 32, 8192, 512), seed=93)
+  plan_few, plan_all = {}, {}
+  hip.forward(q[:, :2], k[:, :2], v[:, :2], None, False, 512 ** -0.5, plan_out=plan_few)
+  hip.forward(q, k, v, None, False, 512 ** -0.5, plan_out=plan_all)
+  assert plan_few["splits"] == plan_all["splits"] == 1 and plan_few["block_rows"] == plan_all["block_rows"] == 128
+  o_all = ffpa_attn_func(q, k, v)
+  o_few = ffpa_attn_func(q[:, :2].contiguous(), k[:, :2].contiguous(), v[:, :2].contiguous())
+  assert torch.equal(o_few, o_all[:, :2])
+  qd = _rand((8, 32, 1, 512), seed=94)
+  kd, vd = _rand((8, 32, 4096, 512), seed=95), _rand((8, 32, 4096, 512), seed=96)
+  pd1, pd8 = {}, {}
+  hip.forward(qd[:1, :1], kd[:1, :1], vd[:1, :1], None, False, 512 ** -0.5, plan_out=pd1)
+  hip.forward(qd, kd, vd, None, False, 512 ** -0.5, plan_out=pd8)
+  assert pd1["splits"] == pd8["splits"] == 4, (pd1, pd8)  # 64 tiles of 64 keys, 16 per range
+  o8 = ffpa_attn_func(qd, kd, vd)
+  o1 = ffpa_attn_func(qd[:1, :1].contiguous(), kd[:1, :1].contiguous(), vd[:1, :1].contiguous())
+  assert torch.equal(o1, o8[:1, :1])
+  # without the pin the under-filled launch splits (equal to rounding only)
+  monkeypatch.delenv("FFPA_HIP_DETERMINISTIC")
+  plan_def = {}
+  hip.forward(q[:, :2], k[:, :2], v[:, :2], None, False, 512 ** -0.5, plan_out=plan_def)
+  assert plan_def["splits"] > 1

@@ -453,3 +453,35 @@ def test_the_xcd_grouping_of_workgroups_changes_no_bit(hip, case):
     o, l = hip.forward(q, k, v, None, causal, D ** -0.5, flags=flags)
     assert torch.equal(o.view(torch.int16), ref_o.view(torch.int16)), f"{case} flags {flags:#x}: outputs differ"
     assert torch.equal(torch.nan_to_num(l, nan=-7.0), torch.nan_to_num(ref_l, nan=-7.0)), f"{case} flags {flags:#x}: LSE differs"
+
+
+@pytest.mark.parametrize("shape", [
+  # (B, Hq, Hkv, Nq, Nkv, D, causal_offset or None = tail-aligned)
+  (1, 4, 4, 1024, 1024, 512, None),     # 8 row tiles: four pairs
+  (1, 4, 2, 1152, 1152, 512, None),     # 9 row tiles: the middle one is its own partner; GQA
+  (2, 2, 2, 1000, 1500, 512, None),     # ragged rows and keys, tail-aligned against a longer context
+  (1, 4, 4, 1024, 2048, 512, 0),        # top-left causal against a longer context
+  (1, 2, 2, 640, 640, 1024, None),      # split-D tiles (64 rows per tile, the softmax pipeline): ten tiles
+  (1, 2, 2, 448, 777, 1024, None),      # ... seven tiles, ragged keys
+  (1, 4, 4, 1024, 1024, 320, None),     # 128-key tiles
+  (1, 4, 1, 512, 512, 128, None),
+  (1, 2, 2, 384, 384, 576, None),       # D % 128 == 64: the un-pipelined split-D loop
+])
+def test_paired_row_tiles_are_bit_identical_to_unpaired(hip, shape):
+  """FFPA_FLAG_PAIR_TILES (round 6): under the causal flag workgroup i of a head walks row tile n - 1 - i and then row tile i.  Per row nothing changes — the
+  same tile, the same recurrence — so O and LSE must equal the unpaired launch bit for bit, with dropout too (the Philox counter is the row's)."""
+  B, Hq, Hkv, Nq, Nkv, D, off = shape
+  q, k, v = _rand((B, Hq, Nq, D), seed=7), _rand((B, Hkv, Nkv, D), seed=8), _rand((B, Hkv, Nkv, D), seed=9)
+  for drop in (0.0, 0.15):
+    kw = dict(causal_offset=off, dropout_p=drop, philox_seed=1234, philox_offset=8)
+    o0, l0 = hip.forward(q, k, v, None, True, D ** -0.5, flags=hip.FLAG_NO_PAIR_TILES, **kw)
+    plan = {}
+    o1, l1 = hip.forward(q, k, v, None, True, D ** -0.5, flags=hip.FLAG_PAIR_TILES, plan_out=plan, **kw)
+    assert torch.equal(o0, o1) and torch.equal(l0, l1), (shape, drop, (o0.float() - o1.float()).abs().max().item())
+  # and against SDPA (top-left / tail-aligned mask built explicitly)
+  rows = torch.arange(Nq, device=q.device)[:, None]
+  cols = torch.arange(Nkv, device=q.device)[None, :]
+  keep = cols <= rows + ((Nkv - Nq) if off is None else off)
+  ref = torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=keep, enable_gqa=Hq != Hkv)
+  o1, _ = hip.forward(q, k, v, None, True, D ** -0.5, causal_offset=off, flags=hip.FLAG_PAIR_TILES)
+  assert (o1.float() - ref.float()).abs().max().item() <= 2e-2

@@ -40,7 +40,11 @@ def main():
     v = torch.randn(B, Hkv, Nkv, D, dtype=torch.bfloat16, device="cuda")
     qg = q.clone().requires_grad_(True)
     gqa = Hq != Hkv
+    from ffpa_attn_amd import DecodeStep
+
+    dstep = DecodeStep(enable_gqa=gqa)
     rows = [
+      ("DecodeStep (the call captured once, hipGraphLaunch per step)", lambda: dstep(q, k, v)),
       ("ffpa_attn_func, inference path", lambda: ffpa_attn_func(q, k, v, enable_gqa=gqa)),
       ("ffpa_attn_func, autograd path (q.requires_grad)", lambda: ffpa_attn_func(qg, k, v, enable_gqa=gqa)),
       ("hip.forward (launch wrapper alone, no LSE)", lambda: hip.forward(q, k, v, None, False, D ** -0.5, return_lse=False)),
@@ -56,7 +60,27 @@ def main():
     print(f"HOST {name}: GPU time per step under continuous load {s.elapsed_time(e) / 500 * 1e3:.1f} us")
     for label, fn in rows:
       med, best = host_us(fn)
-      print(f"HOST   {label:52s} median {med:6.1f} us  best {best:6.1f} us per call")
+      print(f"HOST   {label:62s} median {med:6.1f} us  best {best:6.1f} us per call")
+    # what a caller that synchronises per token pays (host + GPU, nothing overlaps): 200 steps, each followed by a synchronize
+    for label, fn in rows[:2]:
+      for _ in range(20):
+        fn()
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      for _ in range(200):
+        fn()
+        torch.cuda.synchronize()
+      print(f"HOST   {label:62s} {(time.perf_counter() - t0) / 200 * 1e6:6.1f} us per step when the caller synchronises after every step")
+    # capture cost: a new key (another KV length) is a new graph
+    ts = []
+    for i in range(8):
+      kk, vv = k[:, :, : Nkv - 64 * (i + 1)], v[:, :, : Nkv - 64 * (i + 1)]
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      dstep(q, kk, vv)
+      torch.cuda.synchronize()
+      ts.append(time.perf_counter() - t0)
+    print(f"HOST   DecodeStep, first call with a new KV length (warm-up call + capture + first replay): median {statistics.median(ts) * 1e3:.2f} ms")
 
 
 if __name__ == "__main__":
