@@ -54,7 +54,7 @@ def _hipcc() -> str:
 
 
 def _sources_mtime() -> float:
-  paths = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]
+  paths = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".inc"))]
   paths.append(os.path.join(INCLUDE, "ffpa_attn.h"))
   paths.append(os.path.abspath(__file__))
   return max(os.path.getmtime(p) for p in paths)

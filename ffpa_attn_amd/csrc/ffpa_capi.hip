@@ -151,6 +151,7 @@ struct PlanTunables {
   int min_tiles_prefill, min_tiles_short;  // KV tiles a split range holds at least: the merge stays cheap (profiles/r03_decode_splits.txt, r04_launch_side.txt)
   int short_one_per_cu_min_d, short_one_per_cu_lds;  // short-query tiles that want ONE workgroup per CU: head dims from here up, or tiles above this much LDS (profiles/r03_decode_splits.txt)
   int det_tiles_per_split;     // FFPA_FLAG_DETERMINISTIC: KV tiles per split range of a short-query launch (a function of the KV length alone)
+  int pair_max_row_tiles;      // causal launches pair row tiles i and n - 1 - i in one workgroup up to this many row tiles per head (profiles/r06_pair_tiles.txt)
 };
 constexpr PlanTunables kPlanGfx950 = {
     5.0e12 / 9.8304e12, 4.0e12 / 9.8304e12, 5.0e12 / 8.0e12,
@@ -161,6 +162,7 @@ constexpr PlanTunables kPlanGfx950 = {
     8, 4,
     320, 80 * 1024,
     16,
+    32,
 };
 constexpr const PlanTunables& kT = kPlanGfx950;
 
@@ -413,11 +415,20 @@ void pick_small_d_bias_tiles(const ffpa_fwd_params* p, const DimEntry* de, Plan&
 }
 
 // Paired row tiles (ffpa_fwd_m16_kernel.h, FwdArgs::pair_tiles): under the causal flag workgroup i of a head walks row tile nqt - 1 - i and then row tile i — equal
-// work per workgroup, half the dispatches.  The builds that can: the 16x16x32 prefill kernel (not its wide-row tile), unsplit, no bias / ranges / packed rows.
+// work per workgroup, half the dispatches, bit-identical outputs.  The builds that can: the 16x16x32 prefill kernel (not its wide-row tile), unsplit, no bias /
+// ranges / packed rows.  Measured (interleaved same-box A/B over 19 causal shapes, profiles/r06_pair_tiles.txt): what it buys is the launch's TAIL — the last
+// round of an unpaired launch is its short workgroups, most of a CU's time there is idle — so it pays where a head has FEW row tiles: 16 tiles (B4 H32 N 2048 D512)
+// + 2 ... 12.7 % (three boxes), 32 tiles 0 ... + 3.6 % (D512) / + 2 ... 7.1 % (D320), 64 tiles - 1 ... + 2.4 % (D 128 ... 768; D = 1024 N 4096 + 0.3 %: not taken), 96 tiles - 0.9 %,
+// 128 tiles - 1.2 % (D512 N 16384) ... - 7 / - 9 % (D = 1024 N 8192) — and only where the diagonal makes tiles unequal (tail-aligned causal against a context four
+// times the query: - 3.1 %).  The rule: up to 32 row tiles per head.
 bool pick_pair_tiles(const ffpa_fwd_params* p, const Plan& pl) {
   if (!pl.m16 || pl.wide || pl.splits != 1 || !p->causal || p->bias != nullptr || p->kv_bounds != nullptr || p->causal_row_mod != 0 || pl.nqt < 2) return false;
   if (p->flags & (FFPA_FLAG_NO_PAIR_TILES | FFPA_FLAG_DEBUG_SAFE_PATH)) return false;
-  return (p->flags & FFPA_FLAG_PAIR_TILES) != 0;  // (round 6: behind its flag until the A/B says where it pays)
+  if (p->flags & FFPA_FLAG_PAIR_TILES) return true;
+  // keys the first / the last row tile can see: the pairing evens out what the diagonal makes unequal — at least a factor of two between them
+  auto clampkv = [&](int64_t x) { return x < 0 ? (int64_t)0 : (x > p->seqlen_kv ? (int64_t)p->seqlen_kv : x); };
+  const int64_t lo = clampkv((int64_t)p->causal_offset + pl.br), hi = clampkv((int64_t)p->causal_offset + p->seqlen_q);
+  return pl.nqt <= kT.pair_max_row_tiles && 2 * lo <= hi;
 }
 
 // Launch plan: tile variant -> wide-row tile? -> KV splits (rules above) -> build and bias placement -> scratch.
@@ -786,7 +797,7 @@ int ffpa_attn_fwd_kernel(const ffpa_fwd_params* params, char* buf, size_t n) {
   if (pl.wide) {
     snprintf(buf, n, "ffpa_fwd_m16w_kernel<%s, %d, RH=%d, MK=%d>%s", dt, de->d, pl.br / 64, pl.mk, merge);
   } else if (pl.m16) {
-    snprintf(buf, n, "ffpa_fwd_m16_kernel<%s, %d, MK=%d, DROP=%d>%s", dt, de->d, pl.mk, drop, merge);
+    snprintf(buf, n, "ffpa_fwd_m16_kernel<%s, %d, MK=%d, DROP=%d%s>%s", dt, de->d, pl.mk, drop, pl.pair ? ", PAIR" : "", merge);
   } else {
     const int nd = pl.variant == 1 ? ((de->d % 128 == 0) ? 4 : 2) : (de->d <= 512 ? 1 : 2);
     snprintf(buf, n, "ffpa_fwd_split_d_kernel<%s, %d, ND=%d%s%s%s>%s", dt, de->d, nd, (params->flags & FFPA_FLAG_DEBUG_SAFE_PATH) ? ", SAFE" : "",

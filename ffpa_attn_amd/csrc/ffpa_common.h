@@ -121,10 +121,11 @@ struct FwdArgs {
   float keep_scale;         // 1 / (1 - p)
   int xcd_group;            // XCDs that share a contiguous range of the launch's logical workgroup order: 1 (default), 2, 4 or 8 (xcd_logical_id)
   int l2_prefetch;          // 16x16x32 prefill builds: touch the K/V tile two steps ahead (ffpa_fwd_m16_kernel.h; ffpa_capi.hip decides)
-  int pair_tiles;           // 16x16x32 prefill builds under the causal flag: a workgroup walks row tile nqt - 1 - i and then row tile i (the grid holds (nqt + 1) / 2 workgroups per head)
   uint32_t keep_threshold;  // smallest Philox word whose element is kept: word >= keep_threshold <=> ((float)word + 1.0f) * 2^-32 > dropout_p
   unsigned long long philox_seed;
   unsigned long long philox_offset;
+  int pair_tiles;           // 16x16x32 prefill builds under the causal flag: a workgroup walks row tile nqt - 1 - i and then row tile i (the grid holds (nqt + 1) / 2 workgroups per
+                            // head).  LAST on purpose: the field offsets in front of it — and with them every kernel that does not read it — stay what they were.
 };
 
 template <typename T>

@@ -38,12 +38,17 @@ static int launch_one(const FwdArgs& a, hipStream_t stream) {
 }
 
 // The prefill kernel on the 16x16x32 MFMA shape (ffpa_fwd_m16_kernel.h): every prefill launch at head dims >= FFPA_M16_MIN_D.
-template <typename T, int D, int MK, bool DROP = false>
+template <typename T, int D, int MK, bool DROP = false, bool PAIR = false>
 static int launch_m16(const FwdArgs& a, hipStream_t stream) {
+  if constexpr (MK == 0 && !PAIR) {
+    if (a.pair_tiles) return launch_m16<T, D, MK, DROP, true>(a, stream);  // (the kernel whose workgroups walk two row tiles: causal launches, ffpa_capi.hip::pick_pair_tiles)
+  }
   constexpr int BC = m16_block_keys(D, MK == 1 || MK == 3);
   constexpr int LDS_BASE = 2 * BC * D * 2 + m16_exchange_bytes(D, MK);
   const int LDS = LDS_BASE + (a.bias_lds > 0 ? a.bias_lds : -a.bias_lds);  // + the key-bias row cache or the bias-tile staging areas, sized by the C-ABI layer (<= 160 KiB in total)
-  auto kern = ffpa_fwd_m16_kernel<T, D, MK, DROP>;
+  void (*kern)(const FwdArgs);
+  if constexpr (PAIR) kern = ffpa_fwd_m16_pair_kernel<T, D, DROP>;
+  else kern = ffpa_fwd_m16_kernel<T, D, MK, DROP>;
   static std::atomic<bool> attr_done[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return -1;

@@ -449,3 +449,31 @@ def test_deterministic_flag_pins_the_plan_of_a_slice(lib):
     assert got == {(1, 32, 64, want)}, (nkv, got)
   assert ask(det, batch=1, heads_q=32, heads_kv=32, seqlen_q=1, seqlen_kv=8192, num_splits=1)[3] == 1  # (an explicit "never split" still wins)
   assert hip.FLAG_DETERMINISTIC == 0x4000
+
+
+@pytest.mark.parametrize("over, paired", [
+  (dict(batch=1, heads_q=32, heads_kv=32, seqlen_q=4096, seqlen_kv=4096, causal=1), True),      # 32 row tiles per head
+  (dict(batch=4, heads_q=32, heads_kv=32, seqlen_q=2048, seqlen_kv=2048, causal=1), True),      # 16
+  (dict(batch=1, heads_q=32, heads_kv=32, seqlen_q=8192, seqlen_kv=8192, causal=1), False),     # 64 row tiles: measured neutral (- 1 ... + 2.4 %): not taken
+  (dict(batch=1, heads_q=32, heads_kv=32, seqlen_q=12288, seqlen_kv=12288, causal=1), False),   # 96 row tiles: two rounds of long workgroups lose
+  (dict(batch=1, heads_q=32, heads_kv=32, seqlen_q=8192, seqlen_kv=8192, head_dim=1024, causal=1), False),  # 64-row tiles: 128 of them
+  (dict(batch=2, heads_q=32, heads_kv=32, seqlen_q=2048, seqlen_kv=2048, head_dim=1024, causal=1), True),   # 64-row tiles: 32 of them
+  (dict(batch=1, heads_q=32, heads_kv=32, seqlen_q=4096, seqlen_kv=16384, causal=1, causal_offset=12288), False),  # tail-aligned against a long context: tiles are nearly equal
+  (dict(batch=1, heads_q=32, heads_kv=32, seqlen_q=4096, seqlen_kv=16384, causal=1, causal_offset=0), True),       # top-left: the diagonal decides
+  (dict(batch=1, heads_q=32, heads_kv=32, seqlen_q=4096, seqlen_kv=4096), False),                # not causal
+  (dict(batch=1, heads_q=2, heads_kv=2, seqlen_q=4096, seqlen_kv=16384, causal=1, causal_offset=12288), False),    # (an under-filled launch splits the KV axis: no pairing)
+  (dict(batch=2, heads_q=32, heads_kv=8, seqlen_q=8192, seqlen_kv=2048, head_dim=320, causal=1), False),  # config 4 with the causal flag takes the wide-row tile
+])
+def test_paired_row_tile_rule(lib, over, paired):
+  """Which causal prefill launches pair row tiles i and n - 1 - i in one workgroup (ffpa_capi.hip::pick_pair_tiles, profiles/r06_pair_tiles.txt): up to 32 row
+  tiles per head, where the diagonal makes the tiles unequal; the kernel name says so.  FFPA_FLAG_PAIR_TILES / _NO_PAIR_TILES force it where the build exists."""
+  name = ctypes.create_string_buffer(200)
+  p = _params(**over)
+  p.workspace, p.workspace_bytes = 16, 1 << 40
+  assert lib.ffpa_attn_fwd_kernel(ctypes.byref(p), name, len(name)) == 0
+  assert (", PAIR>" in name.value.decode()) == paired, name.value
+  p.flags = hip.FLAG_NO_PAIR_TILES
+  assert lib.ffpa_attn_fwd_kernel(ctypes.byref(p), name, len(name)) == 0 and ", PAIR>" not in name.value.decode()
+  p.flags = hip.FLAG_PAIR_TILES
+  can = bool(over.get("causal")) and over["heads_q"] > 2 and over.get("head_dim", 512) != 320
+  assert lib.ffpa_attn_fwd_kernel(ctypes.byref(p), name, len(name)) == 0 and (", PAIR>" in name.value.decode()) == can, name.value

@@ -47,6 +47,10 @@ CASES = {
   "key_bias_d320": _c(1, 32, 8192, 320, bias="key"), "dense_bias_d320": _c(1, 32, 8192, 320, bias="dense"),
   "key_bias_d1024": _c(1, 32, 8192, 1024, bias="key"), "dense_bias_d1024": _c(1, 32, 8192, 1024, bias="dense"),
   "dropout_d320": _c(1, 32, 8192, 320, dropout=0.1), "dropout_d1024": _c(1, 32, 8192, 1024, dropout=0.1),
+  "causal2k": _c(4, 32, 2048, 512, causal=True), "causal12k": _c(1, 32, 12288, 512, causal=True), "causal_b4_4k": _c(4, 32, 4096, 512, causal=True), "causal_gqa": _c(1, 32, 8192, 512, hkv=8, causal=True),
+  "causal_h8": _c(1, 8, 8192, 512, causal=True), "causal_cross": _c(1, 32, 4096, 512, nkv=16384, causal=True), "d320_causal4k": _c(2, 32, 4096, 320, causal=True), "d320_causal16k": _c(1, 16, 16384, 320, causal=True),
+  "d384_causal": _c(1, 32, 8192, 384, causal=True), "d448_causal": _c(1, 32, 8192, 448, causal=True), "d640_causal": _c(1, 32, 8192, 640, causal=True), "d768_causal": _c(1, 32, 8192, 768, causal=True),
+  "d1024_causal4k": _c(2, 32, 4096, 1024, causal=True), "d1024_causal_h8": _c(1, 8, 8192, 1024, causal=True),
   "n1024": _c(1, 32, 1024, 512), "n2048": _c(1, 32, 2048, 512), "causal4k": _c(1, 32, 4096, 512, causal=True),
   "d320": _c(1, 32, 8192, 320), "d320_causal": _c(1, 32, 8192, 320, causal=True), "d320_n2048": _c(4, 32, 2048, 320), "d320_gqa": _c(2, 32, 8192, 320, hkv=8),
   "d320_b3": _c(3, 32, 8192, 320), "d320_n6k": _c(1, 32, 6144, 320), "d256_b3": _c(3, 32, 8192, 256), "d192_b3": _c(3, 32, 8192, 192), "d128_b3": _c(3, 32, 8192, 128),
@@ -133,7 +137,7 @@ def main():
 
     def run(lib, flags):
       hip._lib = lib
-      kw["flags"] = flags & 0xFFFF
+      kw["flags"] = flags & ~0x10000  # (every library flag; bit 0x10000 is this tool's own)
       kw["merge_in_launch"] = not (flags & 0x10000)
       return hip.forward(q, k, v, bias, c["causal"], c["D"] ** -0.5, **kw)[0]
 

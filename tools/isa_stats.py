@@ -70,6 +70,7 @@ def main():
           hot_scr += sum("scratch_" in l for l in body[a0:b0])
       short = re.sub(r"_ZN4ffpa23ffpa_fwd_split_d_kernelI(\w+?)EEvNS_7FwdArgsE", r"\1", name)
       short = re.sub(r"_ZN4ffpa19ffpa_fwd_m16_kernelI(\w+?)EEvNS_7FwdArgsE", r"m16 \1", short)
+      short = re.sub(r"_ZN4ffpa24ffpa_fwd_m16_pair_kernelI(\w+?)EEvNS_7FwdArgsE", r"m16pair \1", short)
       short = short.replace("DF16b", "bf16 ").replace("DF16_", "fp16 ").replace("Li", " ").replace("ELb", " b").replace("E", "")
       print(f"D={d:>4} {short:<28} vgpr {get('NumVgprs'):>3} agpr {get('NumAgprs'):>3} sgpr {get('NumSgprs'):>3} "
             f"scratch {get('ScratchSize'):>4} B | first..last MFMA: scratch ops {n_scr}, lane spills {n_rl} | inside MFMA loops: scratch {hot_scr}, lane spills {hot_rl} | mfma {len(mf)}")
