@@ -182,6 +182,56 @@ def measured_traffic(workload: str, lib_sha16: str | None):
   return None, None, False
 
 
+def live_traffic(workload: str, timeout_s: float = 150.0):
+  """(bytes, source) or (None, reason): HBM bytes per launch of the dominant kernel MEASURED IN THIS RUN — two short `rocprofv3 --kernel-trace --pmc` passes
+  (FETCH_SIZE, then WRITE_SIZE: they do not fit one pass, MI355X_MICROARCH.md section 'rocprofv3 PMC slots') of this very script with the same workload on the
+  same GPU and library, 1 warm-up + 3 steps each, counters averaged over the kernel's dispatches; FETCH_SIZE is doubled (gfx950 tallies the 128-byte requests of
+  a wide coalesced stream at 64 bytes: the guide's HBM section; WRITE_SIZE as read).  Runs after the timed region, never inside it.  Any failure — no rocprofv3,
+  a pass that times out, counters the profiler does not know — returns (None, why) and the line quotes the committed profile instead."""
+  import csv
+  import glob
+  import re
+  import shutil
+  import signal
+  import subprocess
+  import tempfile
+
+  prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+  if prof is None:
+    return None, "rocprofv3 not found"
+  kernel = re.compile(r"ffpa_fwd_(split_d|m16w?|m16_pair)_kernel")
+  out = tempfile.mkdtemp(prefix="ffpa_bench_pmc_", dir="/tmp")
+  got = {}
+  try:
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+      cmd = [prof, "--kernel-trace", "--output-format", "csv", "--pmc", counter, "-d", out, "-o", counter.lower(), "--", sys.executable, os.path.abspath(__file__),
+             "--workload", workload, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-sdpa", "--no-steady", "--no-ref-protocol", "--no-live-traffic"]
+      pr = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+      try:
+        rc = pr.wait(timeout=timeout_s / 2)
+      except subprocess.TimeoutExpired:
+        os.killpg(pr.pid, signal.SIGKILL)  # (the process group this call started: the profiler and the bench under it)
+        pr.wait()
+        return None, f"rocprofv3 --pmc {counter} did not finish within {timeout_s / 2:g} s"
+      if rc != 0:
+        return None, f"rocprofv3 --pmc {counter} exited with {rc}"
+      vals = []
+      for path in glob.glob(os.path.join(out, "**", f"{counter.lower()}*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(path)):
+          if r.get("Counter_Name") == counter and kernel.search(r.get("Kernel_Name", "")):
+            vals.append(float(r["Counter_Value"]))
+      if not vals:
+        return None, f"no {counter} rows for the kernel in the profiler's output"
+      got[counter] = sum(vals) / len(vals)
+  except Exception as e:  # noqa: BLE001 — informative only
+    return None, f"{type(e).__name__}: {e}"[:200]
+  finally:
+    shutil.rmtree(out, ignore_errors=True)
+  total = int(got["FETCH_SIZE"] * 1024 * 2 + got["WRITE_SIZE"] * 1024)
+  return total, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --workload " + workload +
+                 " --steps 3 --warmup 1` on this GPU and library (FETCH_SIZE KiB x 2: gfx950 counts a wide stream's 128-byte requests as 64; WRITE_SIZE KiB as read; mean over the kernel's dispatches)")
+
+
 class DeviceTelemetry:
   """Shader clock and socket power of the benchmarked GPU, sampled from its sysfs hwmon node by a thread while the timed region runs,
   plus what the device says about itself (CU count, maximum shader clock): the numbers that explain why two boxes of a pool give one
@@ -636,6 +686,7 @@ def main() -> None:
   ap.add_argument("--no-ref-protocol", action="store_true", help="skip the reference bench's own timing protocol (2 warm-ups + 10 iterations)")
   ap.add_argument("--no-gather-extra", action="store_true", help="N > 1: skip the second timed region that adds the all_gather of O")
   ap.add_argument("--gather-extra-timeout", type=float, default=180.0, help="N > 1: seconds the gather leg may take before every rank gives up on it and rank 0 prints the line without it")
+  ap.add_argument("--no-live-traffic", action="store_true", help="N = 1: do not measure roofline.traffic with two rocprofv3 PMC passes of this run (quote the committed profile instead)")
   ap.add_argument("--no-steady", action="store_true", help="N = 1: skip the steady-state leg (the step again after >= 150 ms of continuous load, outside the timed region)")
   ap.add_argument("--sweep", action="store_true", help="the reference bench's case table for --sweep-dims in one process (python -m ffpa_attn.bench)")
   ap.add_argument("--sweep-dims", default="320,512,1024")
@@ -861,6 +912,16 @@ def main() -> None:
   if rank == 0:
     build = build_identity()
     traffic, traffic_src, traffic_stale = measured_traffic(name, build.get("lib_sha16")) if world == 1 else (None, None, False)
+    traffic_live_note = None
+    # (never under a profiler of somebody else's: tools/gpu_round.sh runs this script under rocprofv3 itself — a nested profiler would fight it for the counters)
+    under_profiler = any(k_.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k_ in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "").lower()
+    if world == 1 and not sharded and not args.no_live_traffic and not args.stub_backend and not under_profiler:
+      torch.cuda.synchronize()
+      live, why = live_traffic(name)
+      if live is not None:
+        traffic, traffic_src, traffic_stale = live, why, False
+      else:
+        traffic_live_note = why
     if w["bound"] == "hbm":
       bytes_launch = algorithmic_bytes(w, global_B)
       achieved = bytes_launch / (kernel_ms_avg * 1e-3) / 1e9
@@ -882,6 +943,8 @@ def main() -> None:
         roof["flop_per_clk_per_cu"] = round(achieved * 1e12 / (device["cus"] * device["sclk_mhz_avg"] * 1e6), 1)
         roof["frac_of_mfma_rate_at_measured_clock"] = round(roof["flop_per_clk_per_cu"] / 4096.0, 4)
     roof["traffic_stale"] = bool(traffic_stale)
+    if traffic_live_note is not None:
+      roof["traffic_live_failed"] = traffic_live_note  # (the figure above is then the committed profile's, if its library is this one)
     shape = f"B={global_B} Hq={Hq} Hkv={Hkv} Nq={Nq} Nkv={Nkv} D={D}"
     line = {
       "metric": metric_name(name, w),

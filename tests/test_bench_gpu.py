@@ -35,6 +35,13 @@ def test_bench_line_of_a_short_workload_is_whole():
   assert "model" not in line["config"] and line["config"]["workload"].startswith("cross")
   roof = line["roofline"]
   assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 2500.0 and "traffic" in roof
+  # round 6: the HBM traffic of the dominant kernel is MEASURED in the run (two rocprofv3 PMC passes of the same command behind the timed region) — at least the
+  # compulsory bytes, and nowhere near the operand stream the kernel re-reads from L2 (a counter in the wrong unit would be off by 1024 or more)
+  if "traffic_live_failed" not in roof:
+    assert roof["traffic_source"].startswith("measured in this run") and roof["traffic_stale"] is False
+    assert 0.8 * roof["algorithmic_bytes_per_launch"] <= roof["traffic"] <= 20 * roof["algorithmic_bytes_per_launch"], roof
+  else:
+    assert isinstance(roof["traffic_live_failed"], str) and roof["traffic_live_failed"]
   assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and 0.0 < roof["frac"] < 1.0
   assert roof["kernel"].startswith("ffpa_fwd_m16_kernel<bf16, 512")
   # the step cannot be shorter than its kernel, and the value follows from the step time
@@ -53,7 +60,7 @@ def test_bench_line_of_a_short_workload_is_whole():
 def test_decode_line_is_priced_against_hbm_and_carries_the_graph_replay_leg():
   """The decode workload's roofline is the HBM one; its step is launch-bound from Python, so the line also says what the same step does when it is
   captured into a HIP graph and replayed (one step per graph, and 32 — a token's layers)."""
-  line = _bench("--gpus", "1", "--workload", "decode", "--steps", "10", "--warmup", "3", "--no-sdpa", "--no-cpu-baseline")
+  line = _bench("--gpus", "1", "--workload", "decode", "--steps", "10", "--warmup", "3", "--no-sdpa", "--no-cpu-baseline", "--no-live-traffic")
   roof = line["roofline"]
   assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0 and 0.0 < roof["frac"] < 1.0
   assert roof["kernel"].startswith("ffpa_fwd_split_d_kernel<bf16, 512")
