@@ -227,3 +227,46 @@ def test_deterministic_mode_makes_a_slice_batch_invariant_to_the_bit(hip, monkey
   plan_def = {}
   hip.forward(q[:, :2], k[:, :2], v[:, :2], None, False, 512 ** -0.5, plan_out=plan_def)
   assert plan_def["splits"] > 1
+
+
+def test_decode_step_with_a_device_side_kv_length(hip):
+  """The serving pattern `DecodeStep` is made for: a static-capacity KV cache whose valid length lives ON THE DEVICE — a boolean key mask [1, 1, 1, capacity] and its
+  key ranges (`HIPBackend(kv_bounds=...)`: [first, end, free_lo, free_hi) per 32-row block, a device tensor) — both updated in place between replays: one captured graph
+  serves every length, the split kernel's workgroups past `end` leave at once (HBM bytes follow the valid length, not the capacity), and the result equals the plain
+  call on the same arguments bit for bit and the call on the sliced cache to rounding."""
+  from ffpa_attn_amd import DecodeStep, HIPBackend, ffpa_attn_func
+
+  cap, D = 8192, 512
+  q, k, v = _rand((1, 32, 1, D), seed=101), _rand((1, 32, cap, D), seed=102), _rand((1, 32, cap, D), seed=103)
+  mask = torch.zeros(1, 1, 1, cap, dtype=torch.bool, device=q.device)
+  bounds = torch.zeros(1, 1, 1, 4, dtype=torch.int32, device=q.device)
+  backend = HIPBackend(forward=True, kv_bounds=bounds)
+  step = DecodeStep(forward_backend=backend)
+
+  def set_len(n):
+    mask.zero_()
+    mask[..., :n] = True
+    bounds.copy_(torch.tensor([0, n, 0, n], dtype=torch.int32, device=q.device).view(1, 1, 1, 4))
+
+  for n in (1500, 1501, 4096, 8192, 700):
+    set_len(n)
+    got = step(q, k, v, mask)
+    want_same_args = ffpa_attn_func(q, k, v, attn_mask=mask, forward_backend=backend)
+    want_sliced = ffpa_attn_func(q, k[:, :, :n], v[:, :, :n])
+    assert torch.equal(got, want_same_args), n
+    assert (got.float() - want_sliced.float()).abs().max().item() <= 2e-3, n
+  assert step.captures == 1 and len(step) == 1  # one graph served five lengths
+  # and the bytes follow the length: a step at 700 valid keys is several times cheaper than one at the full capacity
+  def timed(n):
+    set_len(n)
+    for _ in range(5):
+      step(q, k, v, mask)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(50):
+      step(q, k, v, mask)
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / 50
+  t_short, t_full = timed(700), timed(8192)
+  assert t_short < 0.6 * t_full, (t_short, t_full)
