@@ -18,7 +18,19 @@ that matched the key passed in.  The returned tensor is the graph's own output b
 
 Use it where shapes repeat: a static KV cache with the valid length expressed by a mask that lives on the device (the mask's CONTENT may
 change between replays, its address may not), speculative-decoding verification, benchmarks.  A cache that grows by one key per token
-is a new shape per token: every step would be a capture (~ 1 ms) — call ``ffpa_attn_func`` there.
+is a new shape per token: every step would be a capture (~ 1 ms) — call ``ffpa_attn_func`` there, or keep the cache at its CAPACITY and the
+length on the device::
+
+    mask   = torch.zeros(1, 1, 1, capacity, dtype=torch.bool, device=dev)     # True = key holds a token
+    bounds = torch.zeros(1, 1, 1, 4, dtype=torch.int32, device=dev)           # [first, end, free_lo, free_hi) of the mask (hip.mask_kv_bounds' layout)
+    step   = DecodeStep(forward_backend=HIPBackend(forward=True, kv_bounds=bounds))
+    ...
+    mask[..., n] = True; bounds.copy_(torch.tensor([0, n + 1, 0, n + 1], ...))   # per token, in place, on the stream
+    o = step(q, k_cache, v_cache, mask)                                          # ONE graph for every length
+
+The split kernel's workgroups past ``end`` leave at once and keys inside ``[free_lo, free_hi)`` skip the mask read, so the bytes a step streams follow the
+valid length, not the capacity (tests/test_host_path_gpu.py::test_decode_step_with_a_device_side_kv_length: bit-equal to the plain call on the same
+arguments, equal to the call on the sliced cache to rounding, a step at 700 of 8192 keys several times cheaper than at 8192).
 """
 
 from __future__ import annotations
