@@ -113,14 +113,21 @@ def _prune_temps() -> None:
         os.remove(path)
 
 
-def clean_dev() -> None:
-  """Remove what only a development session needs and the round-end snapshot should not carry: variant libraries (build_variant) and their objects."""
+def clean_dev(objects: bool = True) -> None:
+  """Remove what only a development session needs and the round-end snapshot should not carry: variant libraries (build_variant) and their objects — and, with
+  ``objects``, the object files of the main build once both libraries are linked and fresh (20 MB; ``build()`` is gated on the libraries' mtime, and
+  ``build_variant --dims`` rebuilds the objects it finds missing)."""
   import glob
 
   shutil.rmtree(os.path.join(HERE, "variants"), ignore_errors=True)
   for d in glob.glob(os.path.join(OBJ_DIR, "var_*")):
     shutil.rmtree(d, ignore_errors=True)
   _prune_temps()
+  if objects and os.path.exists(LIB_PATH) and os.path.exists(TEST_LIB_PATH):
+    newest = _sources_mtime()
+    if os.path.getmtime(LIB_PATH) >= newest and os.path.getmtime(TEST_LIB_PATH) >= newest:
+      for o in glob.glob(os.path.join(OBJ_DIR, "*.o")):
+        os.remove(o)
 
 
 def build(force: bool = False, jobs: int | None = None, save_temps: bool = True, verbose: bool = True, test_lib: bool = True) -> str:
@@ -208,7 +215,9 @@ def build_variant(tag: str, defs: list[str], jobs: int | None = None, head_dims:
   if same_defs and os.path.exists(lib) and os.path.getmtime(lib) >= newest:
     return lib
   if head_dims:
-    build(verbose=False)  # the untouched head dims come from the main build
+    # the untouched head dims come from the main build (whose objects a round-end clean_dev() may have removed: rebuilt then)
+    missing = [d for d in HEAD_DIMS if d not in head_dims and not os.path.exists(os.path.join(OBJ_DIR, f"ffpa_fwd_d{d}.o"))]
+    build(force=bool(missing), verbose=False)
   tasks, objs = [], []
   for d in HEAD_DIMS:
     if head_dims and d not in head_dims:
