@@ -86,7 +86,7 @@ def install_alias(force: bool = False) -> bool:
   return True
 
 
-__version__ = "0.4.0"  # = the library's ffpa_attn_version() ("ffpa-attn-amd 0.4.0 gfx950"; tests/test_capi.py pins the pair)
+__version__ = "0.5.0"  # = the library's ffpa_attn_version() ("ffpa-attn-amd 0.5.0 gfx950"; tests/test_capi.py pins the pair)
 
 __all__ = [
   "ffpa_attn_func",

@@ -33,6 +33,8 @@ HEAD_DIMS = [64 * i for i in range(1, 17)]
 # head dims whose test-only "safe path" twin kernel (register staging + scalar V gather, used to bisect
 # LDS-DMA / transpose-read problems on hardware) is built into libffpa_attn_hip_test.so — never into the product library.
 SAFE_HEAD_DIMS = {64, 128, 320, 512, 640, 1024}
+# head dims the packed-sequence kernel is built for (FFPA_FOR_EACH_VARLEN_HEAD_DIM, csrc/ffpa_launch.h): the 16x16x32 build's
+VARLEN_HEAD_DIMS = [d for d in HEAD_DIMS if d >= 128]
 
 ARCH = "gfx950"
 CXXFLAGS = [
@@ -167,6 +169,17 @@ def build(force: bool = False, jobs: int | None = None, save_temps: bool = True,
         tasks.append((tobj, [hipcc, *CXXFLAGS, *product, f"-DFFPA_INST_D={d}", "-DFFPA_INST_SAFE=1", "-c", os.path.join(CSRC, "ffpa_fwd_inst.hip"), "-o", tobj], None))
     elif test_lib:
       test_objs.append(obj)
+  # the packed-sequence kernel (ffpa_varlen_inst.hip): a TU of its own per head dim of the 16x16x32 build, so that the dense kernels' objects stay what they were;
+  # its device assembly lands next to the dense TU's (temps_d<D>: the ISA rules read every *.s of a head dim)
+  for d in VARLEN_HEAD_DIMS:
+    obj = os.path.join(OBJ_DIR, f"ffpa_varlen_d{d}.o")
+    objs.append(obj)
+    if test_lib:
+      test_objs.append(obj)
+    if stale(obj):
+      tmp = os.path.join(OBJ_DIR, f"temps_d{d}")
+      os.makedirs(tmp, exist_ok=True)
+      tasks.append((obj, [hipcc, *CXXFLAGS, *product, *extra, f"-DFFPA_INST_D={d}", "-c", os.path.join(CSRC, "ffpa_varlen_inst.hip"), "-o", obj], tmp))
   capi = os.path.join(OBJ_DIR, "ffpa_capi.o")
   objs.append(capi)
   if stale(capi):
@@ -217,7 +230,10 @@ def build_variant(tag: str, defs: list[str], jobs: int | None = None, head_dims:
   if head_dims:
     # the untouched head dims come from the main build (whose objects a round-end clean_dev() may have removed: rebuilt then)
     missing = [d for d in HEAD_DIMS if d not in head_dims and not os.path.exists(os.path.join(OBJ_DIR, f"ffpa_fwd_d{d}.o"))]
+    missing += [d for d in VARLEN_HEAD_DIMS if not os.path.exists(os.path.join(OBJ_DIR, f"ffpa_varlen_d{d}.o"))]
     build(force=bool(missing), verbose=False)
+  elif any(not os.path.exists(os.path.join(OBJ_DIR, f"ffpa_varlen_d{d}.o")) for d in VARLEN_HEAD_DIMS):
+    build(force=True, verbose=False)
   tasks, objs = [], []
   for d in HEAD_DIMS:
     if head_dims and d not in head_dims:
@@ -226,6 +242,7 @@ def build_variant(tag: str, defs: list[str], jobs: int | None = None, head_dims:
     obj = os.path.join(odir, f"ffpa_fwd_d{d}.o")
     objs.append(obj)
     tasks.append([hipcc, *CXXFLAGS, *defs, f"-DFFPA_INST_D={d}", "-c", os.path.join(CSRC, "ffpa_fwd_inst.hip"), "-o", obj])
+  objs += [os.path.join(OBJ_DIR, f"ffpa_varlen_d{d}.o") for d in VARLEN_HEAD_DIMS]  # (the packed-sequence kernels: the main build's, never a variant's)
   capi = os.path.join(odir, "ffpa_capi.o")
   objs.append(capi)
   tasks.append([hipcc, *CXXFLAGS, *defs, "-c", os.path.join(CSRC, "ffpa_capi.hip"), "-o", capi])  # (the plan must see the same tunables as the kernels)

@@ -46,6 +46,18 @@ const DimEntry kDims[] = {
 #undef FFPA_ROW
 };
 
+// the packed-sequence kernel: one launcher per head dim of the 16x16x32 build (ffpa_varlen_inst.hip)
+typedef int (*varlen_fn)(int, const ffpa::FwdArgs&, const ffpa::VarlenArgs&, hipStream_t);
+struct VarlenEntry {
+  int d;
+  varlen_fn launch;
+};
+const VarlenEntry kVarlenDims[] = {
+#define FFPA_ROW(D) {D, &ffpa::launch_varlen_d##D},
+    FFPA_FOR_EACH_VARLEN_HEAD_DIM(FFPA_ROW)
+#undef FFPA_ROW
+};
+
 // Head dims are instantiated in multiples of 64; any multiple of 8 up to 1024 runs on the next instantiation with the
 // columns past the caller's head dim read as zeros and never stored (the reference pads to its compiled multiples on
 // the host, csrc/cuffpa/ffpa_api.cc:123-161).
@@ -806,6 +818,160 @@ int ffpa_attn_fwd_kernel(const ffpa_fwd_params* params, char* buf, size_t n) {
   return FFPA_OK;
 }
 
+// ---- packed sequences (include/ffpa_attn.h: ffpa_varlen_fwd_params)
+namespace {
+
+struct VarlenPlan {
+  const VarlenEntry* ve;
+  int br, bc, nqt;
+  int64_t grid;
+};
+
+// Validation shared by the launch and the queries; fills the plan.  Head dims below the first 16x16x32 instantiation run on it (columns past the
+// caller's head dim read as zeros and are never stored, as in the dense call).
+int varlen_plan(const ffpa_varlen_fwd_params* p, VarlenPlan* out) {
+  if (p == nullptr) return fail(FFPA_ERR_NULL_POINTER, "params is NULL");
+  if (p->struct_size != sizeof(ffpa_varlen_fwd_params) || p->abi_version != FFPA_ATTN_ABI_VERSION)
+    return fail(FFPA_ERR_BAD_ABI, "ffpa_varlen_fwd_params ABI mismatch: size %u (want %zu), version %u (want %d)", p->struct_size,
+                sizeof(ffpa_varlen_fwd_params), p->abi_version, FFPA_ATTN_ABI_VERSION);
+  if (p->dtype != FFPA_DTYPE_BF16 && p->dtype != FFPA_DTYPE_FP16) return fail(FFPA_ERR_BAD_DTYPE, "dtype %d is not bf16(0)/fp16(1)", p->dtype);
+  if (p->batch <= 0 || p->heads_q <= 0 || p->heads_kv <= 0 || p->max_seqlen_q <= 0 || p->max_seqlen_kv < 0)
+    return fail(FFPA_ERR_BAD_SHAPE, "non-positive dimension: batch=%d Hq=%d Hkv=%d max_seqlen_q=%d max_seqlen_kv=%d", p->batch, p->heads_q, p->heads_kv,
+                p->max_seqlen_q, p->max_seqlen_kv);
+  if (p->heads_q % p->heads_kv != 0) return fail(FFPA_ERR_BAD_SHAPE, "num_heads: Hq=%d is not a multiple of Hkv=%d", p->heads_q, p->heads_kv);
+  if (p->head_dim <= 0 || p->head_dim % 8 != 0 || p->head_dim > 1024)
+    return fail(FFPA_ERR_BAD_HEADDIM, "headdim not support! D=%d (supported: multiples of 8 in [8, 1024])", p->head_dim);
+  int dk = kernel_head_dim(p->head_dim);
+  if (dk < FFPA_M16_MIN_D) dk = FFPA_M16_MIN_D;
+  const VarlenEntry* ve = nullptr;
+  for (const VarlenEntry& e : kVarlenDims)
+    if (e.d == dk) ve = &e;
+  if (ve == nullptr) return fail(FFPA_ERR_BAD_HEADDIM, "headdim not support! D=%d", p->head_dim);
+  out->ve = ve;
+  out->br = 128 / (dk <= 512 ? 1 : 2);
+  out->bc = ffpa::m16_block_keys(dk, false);
+  out->nqt = (p->max_seqlen_q + out->br - 1) / out->br;
+  out->grid = (int64_t)p->batch * p->heads_q * out->nqt;
+  if (out->grid > 0x7fffffffLL) return fail(FFPA_ERR_BAD_SHAPE, "grid of %lld workgroups is too large", (long long)out->grid);
+  return FFPA_OK;
+}
+
+int check_strides2(const char* name, const int64_t s[2]) {
+  for (int i = 0; i < 2; ++i) {
+    if (s[i] < 0) return fail(FFPA_ERR_BAD_STRIDE, "%s stride[%d]=%lld is negative", name, i, (long long)s[i]);
+    if (s[i] % 8 != 0) return fail(FFPA_ERR_BAD_STRIDE, "%s stride[%d]=%lld is not a multiple of 8 elements (16 bytes)", name, i, (long long)s[i]);
+  }
+  return FFPA_OK;
+}
+
+}  // namespace
+
+int ffpa_attn_varlen_fwd(const ffpa_varlen_fwd_params* p, void* stream) {
+  VarlenPlan pl;
+  int rc = varlen_plan(p, &pl);
+  if (rc != FFPA_OK) return rc;
+  if (!p->q || !p->k || !p->v || !p->o) return fail(FFPA_ERR_NULL_POINTER, "q/k/v/o must be non-NULL");
+  if (!p->cu_seqlens_q || !p->cu_seqlens_kv) return fail(FFPA_ERR_NULL_POINTER, "cu_seqlens_q / cu_seqlens_kv must be non-NULL");
+  if ((reinterpret_cast<uintptr_t>(p->cu_seqlens_q) & 3u) || (reinterpret_cast<uintptr_t>(p->cu_seqlens_kv) & 3u))
+    return fail(FFPA_ERR_MISALIGNED, "cu_seqlens_q / cu_seqlens_kv must be 4-byte aligned");
+  if (!aligned16(p->q) || !aligned16(p->k) || !aligned16(p->v) || !aligned16(p->o))
+    return fail(FFPA_ERR_MISALIGNED, "q/k/v/o base pointers must be 16-byte aligned");
+  if ((rc = check_strides2("q", p->q_stride)) || (rc = check_strides2("k", p->k_stride)) || (rc = check_strides2("v", p->v_stride)) ||
+      (rc = check_strides2("o", p->o_stride)))
+    return rc;
+  for (const int64_t* st : {p->k_stride, p->v_stride}) {
+    if (st[0] < p->head_dim || st[0] >= (1LL << 24))
+      return fail(FFPA_ERR_BAD_STRIDE, "k/v row stride %lld: rows must not overlap and must be < 2^24 elements apart", (long long)st[0]);
+  }
+  if (p->lse != nullptr && p->lse_stride_head < 0) return fail(FFPA_ERR_BAD_STRIDE, "lse_stride_head is negative");
+  if (!isfinite(p->softmax_scale)) return fail(FFPA_ERR_BAD_SHAPE, "softmax_scale is not finite");
+  if ((rc = check_device()) != FFPA_OK) return rc;
+
+  ffpa::FwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.q = p->q;
+  a.k = p->k;
+  a.v = p->v;
+  a.o = p->o;
+  a.lse = p->lse;
+  // element strides batch / head / row: a sequence's base is its row offset (the kernel adds it), so the batch stride is zero
+  a.sq[1] = p->q_stride[1], a.sq[2] = p->q_stride[0];
+  a.sk[1] = p->k_stride[1], a.sk[2] = p->k_stride[0];
+  a.sv[1] = p->v_stride[1], a.sv[2] = p->v_stride[0];
+  a.so[1] = p->o_stride[1], a.so[2] = p->o_stride[0];
+  a.B = p->batch;
+  a.Hq = p->heads_q;
+  a.Hkv = p->heads_kv;
+  a.Nq = p->max_seqlen_q;   // (the kernel replaces both by the sequence's own)
+  a.Nkv = p->max_seqlen_kv;
+  a.d_valid = p->head_dim;
+  a.group = p->heads_q / p->heads_kv;
+  a.nqt = pl.nqt;
+  a.total_wg = (int)pl.grid;
+  a.causal = p->causal ? 1 : 0;
+  // the 16x16x32 build folds the scale into its exponent (needs scale > 0): a zero scale reaches it as "Q = 0, scale = 1", a negative one as "-Q, |scale|" (ffpa_attn_fwd)
+  a.inv_scale = 1.f;
+  if (p->softmax_scale == 0.f) {
+    a.scale_log2 = 1.4426950408889634f;
+    a.q_mode = 1;
+  } else {
+    const float mag = fabsf(p->softmax_scale);
+    a.scale_log2 = mag * 1.4426950408889634f;
+    a.inv_scale = (float)(1.0 / (double)mag);
+    if (p->softmax_scale < 0.f) a.q_mode = 2;
+  }
+  a.thr = p->rescale_threshold < 0.f ? 8.0f : p->rescale_threshold;
+  a.flags = p->flags & (FFPA_FLAG_NO_XCD_REMAP);
+  a.nsplit = 1;
+  a.tiles_per_split = 0x7fffffff / 2;  // (never the binding limit: the KV axis is not split)
+  a.keep_scale = 1.f;
+  {
+    // XCDs per head: the dense call's rule (ffpa_attn_fwd), priced on the longest sequence the caller announces
+    int g = 1;
+    const unsigned forced = (p->flags >> 8) & 7u;
+    if (forced != 0) {
+      g = 1 << (forced - 1 > 3 ? 3 : forced - 1);
+    } else if ((int64_t)pl.nqt * (p->heads_q / p->heads_kv) >= 64) {
+      const double kv_mib = 2.0 * (double)p->max_seqlen_kv * (double)p->head_dim * 2.0 / 1048576.0;
+      while (g < 8 && (8 / g) * kv_mib > 200.0) g *= 2;
+    }
+    a.xcd_group = g;
+  }
+  a.l2_prefetch = (p->flags & FFPA_FLAG_NO_L2_PREFETCH) ? 0 : ((p->flags & FFPA_FLAG_L2_PREFETCH) || pl.ve->d > 512) ? 1 : 0;
+
+  ffpa::VarlenArgs va;
+  va.cu_q = p->cu_seqlens_q;
+  va.cu_k = p->cu_seqlens_kv;
+  va.lse_stride_h = p->lse_stride_head;
+
+  const int st = pl.ve->launch(p->dtype, a, va, static_cast<hipStream_t>(stream));
+  if (st == -2) return fail(FFPA_ERR_LAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed (is this a gfx950?)");
+  if (st < 0) return fail(FFPA_ERR_LAUNCH, "launch setup failed (%d)", st);
+  if (st != 0) return fail(FFPA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(st)));
+  return FFPA_OK;
+}
+
+int ffpa_attn_varlen_fwd_plan(const ffpa_varlen_fwd_params* params, int out[4]) {
+  VarlenPlan pl;
+  const int rc = varlen_plan(params, &pl);
+  if (rc != FFPA_OK) return rc;
+  if (out == nullptr) return fail(FFPA_ERR_NULL_POINTER, "out is NULL");
+  out[0] = pl.nqt;
+  out[1] = pl.br;
+  out[2] = pl.bc;
+  out[3] = (int)pl.grid;
+  return FFPA_OK;
+}
+
+int ffpa_attn_varlen_fwd_kernel(const ffpa_varlen_fwd_params* params, char* buf, size_t n) {
+  VarlenPlan pl;
+  const int rc = varlen_plan(params, &pl);
+  if (rc != FFPA_OK) return rc;
+  if (buf == nullptr || n == 0) return fail(FFPA_ERR_NULL_POINTER, "buf is NULL");
+  snprintf(buf, n, "ffpa_fwd_m16_varlen_kernel<%s, %d>", params->dtype == FFPA_DTYPE_BF16 ? "bf16" : "fp16", pl.ve->d);
+  return FFPA_OK;
+}
+
 int ffpa_attn_query(int what) {
   switch (what) {
     case FFPA_QUERY_ABI_VERSION: return FFPA_ATTN_ABI_VERSION;
@@ -824,6 +990,7 @@ int ffpa_attn_query(int what) {
     case FFPA_QUERY_DEVICE_CUS: return device_cu_count();
     case FFPA_QUERY_DEVICE_CLOCK_MHZ: return (int)(device_rates().cu_flops / 4096.0 / 1e6);
     case FFPA_QUERY_DEVICE_HBM_GBPS: return (int)(device_rates().hbm_bytes / 1e9);
+    case FFPA_QUERY_VARLEN_AVAILABLE: return 1;
     default: return -1;
   }
 }
@@ -842,9 +1009,9 @@ int ffpa_attn_fwd_tile_config(int head_dim, int* block_rows, int* block_keys, in
 const char* ffpa_attn_last_error(void) { return g_err; }
 
 #ifdef FFPA_PRODUCT_BUILD
-const char* ffpa_attn_version(void) { return "ffpa-attn-amd 0.4.0 gfx950"; }
+const char* ffpa_attn_version(void) { return "ffpa-attn-amd 0.5.0 gfx950"; }
 #else
-const char* ffpa_attn_version(void) { return "ffpa-attn-amd 0.4.0 gfx950 (developer variant: NOT a product build)"; }
+const char* ffpa_attn_version(void) { return "ffpa-attn-amd 0.5.0 gfx950 (developer variant: NOT a product build)"; }
 #endif
 
 }  // extern "C"

@@ -298,7 +298,13 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
   // more keys; for any other mask the order of a head's row tiles does not matter) — so that the launch ends on its short workgroups
   if (a.causal || (MASK && a.kv_bounds != nullptr)) qt = a.nqt - 1 - qt;
 #define FFPA_M16_TILE_DONE return
+#define FFPA_M16_ROW_INV(l) __builtin_amdgcn_rcpf(l)
+#define FFPA_M16_ROW_OUT(x, rh) (T)((x) * inv[rh])
+#define FFPA_M16_LSE_INDEX(row) ((int64_t)b * a.Hq + hq) * a.Nq + (row)
 #include "ffpa_fwd_m16_tile.inc"
+#undef FFPA_M16_LSE_INDEX
+#undef FFPA_M16_ROW_OUT
+#undef FFPA_M16_ROW_INV
 #undef FFPA_M16_TILE_DONE
 }
 
@@ -323,9 +329,64 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_pair_kernel(const FwdArgs a)
   for (int pass = 0; pass < npass; ++pass) {
     const int qt = pass == 0 ? a.nqt - 1 - qt_wg : qt_wg;
 #define FFPA_M16_TILE_DONE continue
+#define FFPA_M16_ROW_INV(l) __builtin_amdgcn_rcpf(l)
+#define FFPA_M16_ROW_OUT(x, rh) (T)((x) * inv[rh])
+#define FFPA_M16_LSE_INDEX(row) ((int64_t)b * a.Hq + hq) * a.Nq + (row)
 #include "ffpa_fwd_m16_tile.inc"
+#undef FFPA_M16_LSE_INDEX
+#undef FFPA_M16_ROW_OUT
+#undef FFPA_M16_ROW_INV
 #undef FFPA_M16_TILE_DONE
   }
+}
+
+// PACKED SEQUENCES (round 6, the reference's ffpa_attn_varlen_func: src/ffpa_attn/ffpa_attn_interface.py:192-279, served there by its CuTe-DSL backend only —
+// src/ffpa_attn/cute/__init__.py:466-575): q [T_q, Hq, D], k / v [T_k, Hkv, D], o [T_q, Hq, D], LSE [Hq, T_q], sequence i owning rows cu_q[i] .. cu_q[i + 1] of q / o and
+// cu_k[i] .. cu_k[i + 1] of k / v.  ONE launch for the whole batch, the boundaries read on the DEVICE (two scalar loads per array and workgroup: no host round trip,
+// so the call captures into a HIP graph): the grid holds ceil(max_seqlen_q / BR) row tiles per (sequence, head); a workgroup looks its sequence up, leaves when its row
+// tile lies past the sequence's last row, and otherwise runs the SAME tile text as the dense kernel on a FwdArgs whose base pointers, lengths and causal offset
+// (tail-aligned per sequence: Nkv_i - Nq_i) are that sequence's — per row the same recurrence, the same bits as a dense launch of that sequence alone (the launch
+// plan's other tiles — wide rows, KV splits, pairs — are not used here).  Rows no key of which is visible (an empty key range; under the causal flag the first
+// Nq_i - Nkv_i rows of a sequence with more queries than keys) come out as O = 0, LSE = -inf: the reference's contract for this entry point
+// (tests/test_ffpa_cute_sm100.py:1117-1183), where the dense kernel keeps SDPA's NaN.
+struct VarlenArgs {
+  const int* cu_q;       // [batch + 1] row offsets into q / o
+  const int* cu_k;       // [batch + 1] row offsets into k / v
+  int64_t lse_stride_h;  // elements between two heads of the LSE tensor (>= T_q)
+};
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void ffpa_fwd_m16_varlen_kernel(const FwdArgs a_in, const VarlenArgs va) {
+  constexpr int MK = 0;  // no attn_bias, no mask ranges: what the reference's packed entry point accepts
+  constexpr bool DROP = false;
+#include "ffpa_fwd_m16_head.inc"
+  int vid = blockIdx.x;
+  if (!(a_in.flags & kFlagNoXcdRemap)) vid = xcd_logical_id(vid, gridDim.x, a_in.xcd_group);
+  const int split = 0;
+  const int bh = vid / a_in.nqt;
+  int qt = vid - bh * a_in.nqt;
+  if (a_in.causal) qt = a_in.nqt - 1 - qt;  // longest rows first
+  const int seq = bh / a_in.Hq;
+  const int q_lo = va.cu_q[seq], k_lo = va.cu_k[seq];
+  const int nq_seq = va.cu_q[seq + 1] - q_lo, nkv_seq = va.cu_k[seq + 1] - k_lo;
+  if (qt * BR >= nq_seq) return;  // (max_seqlen_q sized the grid: this sequence is shorter)
+  FwdArgs a = a_in;  // (batch strides are zero: the launch side)
+  a.Nq = nq_seq;
+  a.Nkv = nkv_seq > 0 ? nkv_seq : 0;
+  a.causal_offset = a.Nkv - nq_seq;
+  a.q = (const T*)a_in.q + (int64_t)q_lo * a_in.sq[2];
+  a.o = (T*)a_in.o + (int64_t)q_lo * a_in.so[2];
+  a.k = (const T*)a_in.k + (int64_t)k_lo * a_in.sk[2];
+  a.v = (const T*)a_in.v + (int64_t)k_lo * a_in.sv[2];
+#define FFPA_M16_TILE_DONE return
+#define FFPA_M16_ROW_INV(l) ((l) > 0.f ? __builtin_amdgcn_rcpf(l) : 0.f)
+#define FFPA_M16_ROW_OUT(x, rh) (l_tot[rh] > 0.f ? (T)((x) * inv[rh]) : (T)0.f)  // (the select BEHIND product + conversion: those stay the dense kernel's one instruction — fp16: v_fma_mixlo, one rounding — and its bits)
+#define FFPA_M16_LSE_INDEX(row) (int64_t)hq * va.lse_stride_h + q_lo + (row)
+#include "ffpa_fwd_m16_tile.inc"
+#undef FFPA_M16_LSE_INDEX
+#undef FFPA_M16_ROW_OUT
+#undef FFPA_M16_ROW_INV
+#undef FFPA_M16_TILE_DONE
 }
 
 }  // namespace ffpa

@@ -31,7 +31,7 @@ _PKG = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_PKG, "libffpa_attn_hip.so")
 TEST_LIB_PATH = os.path.join(_PKG, "libffpa_attn_hip_test.so")  # product kernels + the register-staged SAFE twins (tests only)
 
-ABI_VERSION = 4
+ABI_VERSION = 5  # 5: + the packed-sequence entry points (ffpa_attn_varlen_fwd ...)
 
 # enum ffpa_status (include/ffpa_attn.h)
 _STATUS_EXC = {
@@ -115,6 +115,39 @@ class FfpaFwdParams(ctypes.Structure):
   ]
 
 
+class FfpaVarlenFwdParams(ctypes.Structure):
+  """ctypes mirror of ``struct ffpa_varlen_fwd_params`` (include/ffpa_attn.h): the packed-sequence call."""
+
+  _fields_ = [
+    ("struct_size", ctypes.c_uint32),
+    ("abi_version", ctypes.c_uint32),
+    ("q", ctypes.c_void_p),
+    ("k", ctypes.c_void_p),
+    ("v", ctypes.c_void_p),
+    ("o", ctypes.c_void_p),
+    ("lse", ctypes.c_void_p),
+    ("cu_seqlens_q", ctypes.c_void_p),
+    ("cu_seqlens_kv", ctypes.c_void_p),
+    ("batch", ctypes.c_int32),
+    ("heads_q", ctypes.c_int32),
+    ("heads_kv", ctypes.c_int32),
+    ("head_dim", ctypes.c_int32),
+    ("max_seqlen_q", ctypes.c_int32),
+    ("max_seqlen_kv", ctypes.c_int32),
+    ("q_stride", ctypes.c_int64 * 2),
+    ("k_stride", ctypes.c_int64 * 2),
+    ("v_stride", ctypes.c_int64 * 2),
+    ("o_stride", ctypes.c_int64 * 2),
+    ("lse_stride_head", ctypes.c_int64),
+    ("dtype", ctypes.c_int32),
+    ("causal", ctypes.c_int32),
+    ("softmax_scale", ctypes.c_float),
+    ("rescale_threshold", ctypes.c_float),
+    ("flags", ctypes.c_uint32),
+    ("reserved", ctypes.c_uint32),
+  ]
+
+
 _lib = None
 _debug_lib = None
 _lib_lock = threading.Lock()
@@ -126,6 +159,9 @@ EXPORTS = (
   "ffpa_attn_mask_kv_bounds",
   "ffpa_attn_fwd_plan",
   "ffpa_attn_fwd_kernel",
+  "ffpa_attn_varlen_fwd",
+  "ffpa_attn_varlen_fwd_plan",
+  "ffpa_attn_varlen_fwd_kernel",
   "ffpa_attn_query",
   "ffpa_attn_fwd_tile_config",
   "ffpa_attn_last_error",
@@ -165,6 +201,13 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     if path is None or hasattr(lib, "ffpa_attn_fwd_kernel"):  # (developer A/B runs may load a saved build of an older commit by path)
       lib.ffpa_attn_fwd_kernel.argtypes = [ctypes.POINTER(FfpaFwdParams), ctypes.c_char_p, ctypes.c_size_t]
       lib.ffpa_attn_fwd_kernel.restype = ctypes.c_int
+    if path is None or hasattr(lib, "ffpa_attn_varlen_fwd"):  # (ditto: a saved build from before the packed-sequence entry points)
+      lib.ffpa_attn_varlen_fwd.argtypes = [ctypes.POINTER(FfpaVarlenFwdParams), ctypes.c_void_p]
+      lib.ffpa_attn_varlen_fwd.restype = ctypes.c_int
+      lib.ffpa_attn_varlen_fwd_plan.argtypes = [ctypes.POINTER(FfpaVarlenFwdParams), ctypes.POINTER(ctypes.c_int)]
+      lib.ffpa_attn_varlen_fwd_plan.restype = ctypes.c_int
+      lib.ffpa_attn_varlen_fwd_kernel.argtypes = [ctypes.POINTER(FfpaVarlenFwdParams), ctypes.c_char_p, ctypes.c_size_t]
+      lib.ffpa_attn_varlen_fwd_kernel.restype = ctypes.c_int
     lib.ffpa_attn_query.argtypes = [ctypes.c_int]
     lib.ffpa_attn_query.restype = ctypes.c_int
     lib.ffpa_attn_fwd_tile_config.argtypes = [
@@ -203,6 +246,7 @@ def library_available() -> bool:
 # no mutable global state, every choice travels in ``ffpa_fwd_params`` (SURVEY.md section 8b "Threading").
 _CAPABILITY_QUERIES = {
   "HIP_FWD_AVAILABLE": 1, "CUDA_FWD_AVAILABLE": 1,  # FFPA_QUERY_FWD_AVAILABLE
+  "VARLEN_FWD_AVAILABLE": 11,                        # FFPA_QUERY_VARLEN_AVAILABLE (ffpa_attn_varlen_func: the reference needs its CuTe-DSL backend for it)
   "FP16_AVAILABLE": 5, "DROPOUT_AVAILABLE": 6,       # FFPA_QUERY_FP16_AVAILABLE / _DROPOUT_AVAILABLE
 }
 _CAPABILITY_CONSTANTS = {
@@ -778,3 +822,140 @@ def ffpa_attn_forward_hip(
     float(rescale_threshold),
     kv_bounds,
   )
+
+
+# ----------------------------------------------------------------------------------
+# Packed sequences (ffpa_attn_varlen_func): the launch wrapper and its torch.library op.  Replaces the reference's
+# ffpa_attn::_varlen_fwd_cute (src/ffpa_attn/cute/__init__.py:792-880), which only its CuTe-DSL backend serves.
+# ----------------------------------------------------------------------------------
+def _packed_rows(t: torch.Tensor) -> torch.Tensor:
+  """[T, H, D] with head-dim stride 1, row / head strides multiples of 8 elements, non-overlapping rows and a 16-byte aligned base — else a copy."""
+  ok = t.stride(-1) == 1 and t.stride(0) % 8 == 0 and t.stride(1) % 8 == 0 and t.data_ptr() % 16 == 0
+  if ok and t.size(0) > 1 and t.stride(0) < t.size(2):
+    ok = False
+  return t if ok else t.contiguous()
+
+
+def _varlen_params(q, k, v, o, lse, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, max_seqlen_k: int, causal: bool, softmax_scale: float,
+                   rescale_threshold: float, flags: int) -> FfpaVarlenFwdParams:
+  p = FfpaVarlenFwdParams()
+  p.struct_size = ctypes.sizeof(FfpaVarlenFwdParams)
+  p.abi_version = ABI_VERSION
+  p.q, p.k, p.v, p.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
+  p.lse = lse.data_ptr() if lse is not None else None
+  p.cu_seqlens_q, p.cu_seqlens_kv = cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr()
+  p.batch = cu_seqlens_q.numel() - 1
+  p.heads_q, p.heads_kv, p.head_dim = q.size(1), k.size(1), q.size(2)
+  p.max_seqlen_q, p.max_seqlen_kv = int(max_seqlen_q), int(max_seqlen_k)
+  for name, t in (("q_stride", q), ("k_stride", k), ("v_stride", v), ("o_stride", o)):
+    getattr(p, name)[:] = [t.stride(0), t.stride(1)]
+  p.lse_stride_head = lse.stride(0) if lse is not None else 0
+  p.dtype = _DTYPE[q.dtype]
+  p.causal = 1 if causal else 0
+  p.softmax_scale = float(softmax_scale)
+  p.rescale_threshold = float(rescale_threshold)
+  p.flags = int(flags)
+  return p
+
+
+def varlen_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens_q: torch.Tensor, cu_seqlens_k: torch.Tensor, max_seqlen_q: int,
+                   max_seqlen_k: int, causal: bool, softmax_scale: float, *, rescale_threshold: float = -1.0, return_lse: bool = True, flags: int = 0,
+                   plan_out: "dict | None" = None):
+  """One launch of the packed-sequence kernel: ``q [T_q, Hq, D]``, ``k`` / ``v [T_k, Hkv, D]``, int32 device ``cu_seqlens_*`` ``[B + 1]`` ->
+  ``(o [T_q, Hq, D], lse [Hq, T_q] fp32 | None)``.  Nothing is read back to the host and nothing synchronises: the call captures into a HIP graph.
+  Rows without a visible key: O = 0, LSE = -inf."""
+  if not q.is_cuda:
+    raise NotImplementedError(f"ffpa_attn::_varlen_fwd_hip has no implementation for device '{q.device.type}' (the HIP kernel needs a GPU tensor)")
+  lib = load_library()
+  if q.dtype not in _DTYPE or k.dtype != q.dtype or v.dtype != q.dtype:
+    raise TypeError(f"ffpa_attn::_varlen_fwd_hip only supports fp16/bf16 q/k/v of one dtype, got {q.dtype}, {k.dtype}, {v.dtype}")
+  if q.dim() != 3 or k.dim() != 3 or v.dim() != 3:
+    raise ValueError("ffpa_attn::_varlen_fwd_hip: q/k/v must be 3-D packed [T, H, D] tensors")
+  if k.shape != v.shape or k.size(2) != q.size(2):
+    raise ValueError(f"ffpa_attn::_varlen_fwd_hip: k {tuple(k.shape)} and v {tuple(v.shape)} must share their shape and q's head dim ({q.size(2)})")
+  if k.size(1) == 0 or q.size(1) % k.size(1) != 0:
+    raise ValueError(f"ffpa_attn::_varlen_fwd_hip: query num_heads ({q.size(1)}) must be a multiple of key/value num_heads ({k.size(1)})")
+  for name, cu in (("cu_seqlens_q", cu_seqlens_q), ("cu_seqlens_k", cu_seqlens_k)):
+    if cu.dtype != torch.int32 or cu.dim() != 1 or cu.numel() < 2:
+      raise ValueError(f"ffpa_attn::_varlen_fwd_hip: {name} must be a 1-D int32 tensor of length batch + 1")
+    if cu.device != q.device:
+      raise ValueError(f"ffpa_attn::_varlen_fwd_hip: {name} must be on q's device, got {cu.device} and {q.device}")
+  if cu_seqlens_q.numel() != cu_seqlens_k.numel():
+    raise ValueError("ffpa_attn::_varlen_fwd_hip: cu_seqlens_q and cu_seqlens_k must have one length")
+  if k.device != q.device or v.device != q.device:
+    raise ValueError(f"ffpa_attn::_varlen_fwd_hip: q/k/v must be on one device, got {q.device}, {k.device}, {v.device}")
+  Tq, Hq, D = q.shape
+  Dp = (D + 7) // 8 * 8  # rows must be whole 16-byte slots: only a head dim that is not a multiple of 8 is padded (copies)
+  if Dp != D:
+    pad = (0, Dp - D)
+    q, k, v = (torch.nn.functional.pad(t, pad) for t in (q, k, v))
+  if k.size(0) == 0:
+    # no key row anywhere: every output row is the empty row (O = 0, LSE = -inf).  The C-ABI wants non-NULL bases; nothing is read through them
+    k = v = q.new_zeros((1, k.size(1), Dp))
+  q, k, v = _packed_rows(q), _packed_rows(k), _packed_rows(v)
+  cu_seqlens_q, cu_seqlens_k = cu_seqlens_q.contiguous(), cu_seqlens_k.contiguous()
+  o = torch.empty((Tq, Hq, Dp), dtype=q.dtype, device=q.device)
+  lse = torch.empty((Hq, Tq), dtype=torch.float32, device=q.device) if return_lse else None
+  if Tq == 0 or max_seqlen_q <= 0:
+    return (o[..., :D] if Dp != D else o), lse  # (nothing to compute: no query row in any sequence)
+  p = _varlen_params(q, k, v, o, lse, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal, softmax_scale, rescale_threshold, flags)
+  with torch.cuda.device(q.device):
+    stream = torch.cuda.current_stream(q.device).cuda_stream
+    if plan_out is not None:
+      plan = (ctypes.c_int * 4)()
+      if lib.ffpa_attn_varlen_fwd_plan(ctypes.byref(p), plan) == 0:
+        plan_out.update(row_tiles=plan[0], block_rows=plan[1], block_keys=plan[2], workgroups=plan[3])
+      name = ctypes.create_string_buffer(160)
+      if lib.ffpa_attn_varlen_fwd_kernel(ctypes.byref(p), name, len(name)) == 0:
+        plan_out["kernel"] = name.value.decode()
+    rc = lib.ffpa_attn_varlen_fwd(ctypes.byref(p), ctypes.c_void_p(stream))
+  if rc != 0:
+    raise _STATUS_EXC.get(rc, RuntimeError)(f"ffpa_attn_varlen_fwd: {lib.ffpa_attn_last_error().decode()} (status {rc})")
+  if Dp != D:
+    o = o[..., :D].contiguous()
+  return o, lse
+
+
+def varlen_launch_plan(batch: int, heads_q: int, heads_kv: int, max_seqlen_q: int, max_seqlen_k: int, head_dim: int, *,
+                       dtype: torch.dtype = torch.bfloat16, causal: bool = False) -> dict:
+  """The packed-sequence launch for a shape class, without launching (placeholder pointers): row tiles per (sequence, head), tile, workgroups, kernel name."""
+  lib = load_library()
+  d8 = (int(head_dim) + 7) // 8 * 8
+  p = FfpaVarlenFwdParams()
+  p.struct_size = ctypes.sizeof(FfpaVarlenFwdParams)
+  p.abi_version = ABI_VERSION
+  p.q = p.k = p.v = p.o = p.cu_seqlens_q = p.cu_seqlens_kv = 16
+  p.batch, p.heads_q, p.heads_kv, p.head_dim = int(batch), int(heads_q), int(heads_kv), d8
+  p.max_seqlen_q, p.max_seqlen_kv = int(max_seqlen_q), int(max_seqlen_k)
+  for name, h in (("q_stride", heads_q), ("k_stride", heads_kv), ("v_stride", heads_kv), ("o_stride", heads_q)):
+    getattr(p, name)[:] = [h * d8, d8]
+  p.dtype = _DTYPE[dtype]
+  p.causal = 1 if causal else 0
+  p.softmax_scale = float(head_dim) ** -0.5
+  p.rescale_threshold = -1.0
+  plan = (ctypes.c_int * 4)()
+  rc = lib.ffpa_attn_varlen_fwd_plan(ctypes.byref(p), plan)
+  if rc != 0:
+    raise _STATUS_EXC.get(rc, RuntimeError)(lib.ffpa_attn_last_error().decode())
+  name = ctypes.create_string_buffer(160)
+  lib.ffpa_attn_varlen_fwd_kernel(ctypes.byref(p), name, len(name))
+  return {"row_tiles": plan[0], "block_rows": plan[1], "block_keys": plan[2], "workgroups": plan[3], "kernel": name.value.decode()}
+
+
+torch.library.define(
+  f"{_OP_NAMESPACE}::_varlen_fwd_hip",
+  "(Tensor q, Tensor k, Tensor v, Tensor cu_seqlens_q, Tensor cu_seqlens_k, int max_seqlen_q, int max_seqlen_k, "
+  "float softmax_scale, int causal, float rescale_threshold=-1.0) -> (Tensor o, Tensor softmax_lse)",
+)
+
+
+@torch.library.impl(f"{_OP_NAMESPACE}::_varlen_fwd_hip", "CUDA")  # ROCm tensors dispatch on the CUDA key
+def _varlen_fwd_hip_torch_op(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, softmax_scale, causal, rescale_threshold=-1.0):
+  return varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, bool(causal), softmax_scale,
+                        rescale_threshold=rescale_threshold, return_lse=True)
+
+
+@torch.library.register_fake(f"{_OP_NAMESPACE}::_varlen_fwd_hip")
+def _varlen_fwd_hip_fake(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, softmax_scale, causal, rescale_threshold=-1.0):
+  total_q, heads, head_dim = q.shape
+  return q.new_empty((total_q, heads, head_dim)), q.new_empty((heads, total_q), dtype=torch.float32)

@@ -175,12 +175,21 @@ def ffpa_attn_varlen_func(
   return_lse: bool = False,
   **kwargs: object,
 ):
-  """The reference's packed-THD entry point (``ffpa_attn_interface.py:192-280``), kept under its name and signature so that
-  ``from ffpa_attn import ffpa_attn_varlen_func`` call sites import.  In the reference it is served by the CuTe-DSL backend ONLY and
-  "any unsupported case raises an actionable error immediately — there is no silent fallback to dense / per-sequence paths";
-  CuTe-DSL is NVIDIA-only, so on MI355X every call is the unsupported case.  Unpack the batch and call :func:`ffpa_attn_func`
-  per sequence (what the reference tells callers of unsupported shapes to do)."""
-  raise NotImplementedError(
-    "ffpa_attn_varlen_func is served by the CuTeDSL backend only (NVIDIA SM8x / SM90); it is not available in the MI355X build. "
-    "Unpack the batch with cu_seqlens and call ffpa_attn_func per sequence."
-  )
+  """FFPA variable-length attention over packed sequences (FlashAttention's THD layout) — the reference's entry point under its name and signature
+  (``src/ffpa_attn/ffpa_attn_interface.py:192-279``).  ``q`` is ``[T_q, H_q, D]``, ``k`` / ``v`` are ``[T_k, H_kv, D]``; ``cu_seqlens_q`` /
+  ``cu_seqlens_k`` (int32 device tensors of length ``B + 1`` starting at 0; ``cu_seqlens_k=None`` = self-attention) mark the sequences.
+
+  In the reference the CuTe-DSL backend ALONE serves this call (NVIDIA SM8x / SM90 / SM100; head dims 320 ... 1024).  Here it runs on the MI355X
+  kernel of the dense path — ONE launch for the whole batch, the boundaries read on the device: nothing is copied to the host, the call never
+  synchronises (the reference reads ``cu_seqlens`` back to check ``max_seqlen``) and captures into a HIP graph.  Same checks, same exception classes and
+  texts (``varlen.py``); head dims: any up to 1024.
+
+  ``causal`` = the reference's lower-right (tail-aligned) mask per sequence.  Rows without a visible key — an empty key sequence; the first
+  ``N_q - N_k`` rows of a causal sequence with more queries than keys — come out as ``O = 0`` and ``LSE = -inf``
+  (``tests/test_ffpa_cute_sm100.py:1117-1183``).  ``max_seqlen_q`` must be >= the longest query sequence (rows past it are not computed).
+  ``dropout_p`` must be 0 and every FlashAttention-varlen extension (``window_size``, ``softcap``, ``seqused_k``, ``block_table`` ...) raises
+  ``NotImplementedError``, as in the reference.  Returns ``out [T_q, H_q, D]`` — and ``lse [H_q, T_q]`` fp32 with ``return_lse=True``."""
+  from .varlen import varlen_apply
+
+  return varlen_apply(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p=dropout_p, softmax_scale=softmax_scale,
+                      causal=causal, enable_gqa=enable_gqa, return_lse=return_lse, kwargs=dict(kwargs))

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FFPA_ATTN_ABI_VERSION 4
+#define FFPA_ATTN_ABI_VERSION 5 /* 5: + the packed-sequence entry points (ffpa_attn_varlen_fwd ...) */
 
 /* status codes (0 == success).  The Python host maps them onto the exception
  * classes the reference raises (TORCH_CHECK -> RuntimeError,
@@ -222,6 +222,71 @@ int ffpa_attn_fwd_kernel(const ffpa_fwd_params* params, char* buf, size_t n);
 int ffpa_attn_mask_kv_bounds(const void* bias, int bias_dtype, const int64_t bias_stride[4], int bb, int hb,
                              int nq, int nkv, int32_t* out, void* stream);
 
+/*
+ * PACKED SEQUENCES ("varlen", FlashAttention's THD layout) — the reference's ffpa_attn_varlen_func
+ * (src/ffpa_attn/ffpa_attn_interface.py:192-279), which it serves through its CuTe-DSL backend only
+ * (torch.ops.ffpa_attn._varlen_fwd_cute, src/ffpa_attn/cute/__init__.py:466-575,792-829: NVIDIA SM8x / SM90 / SM100).
+ *
+ *   q  [total_q, Hq,  D]     k, v [total_k, Hkv, D]     o [total_q, Hq, D]     (element strides: row, head; head-dim stride 1)
+ *   lse [Hq, total_q] fp32, natural log, element stride lse_stride_head between heads; may be NULL
+ *   cu_seqlens_q / cu_seqlens_kv: int32 [batch + 1] ON THE DEVICE, non-decreasing, [0] == 0: sequence i owns rows
+ *        cu_seqlens_q[i] .. cu_seqlens_q[i + 1] of q / o and cu_seqlens_kv[i] .. cu_seqlens_kv[i + 1] of k / v.
+ *
+ * ONE launch for the whole batch; the boundaries are read by the kernel (nothing is copied to the host, the call never
+ * synchronises and captures into a HIP graph): the grid holds ceil(max_seqlen_q / block rows) row tiles per (sequence,
+ * head), workgroups whose tile lies past their sequence's last row leave at once.  max_seqlen_q must be >= every
+ * sequence's query length (rows past it would not be computed); max_seqlen_kv is only a hint for the launch side.
+ * Per sequence the arithmetic is the dense call's (same tile, same recurrence: bit-identical to ffpa_attn_fwd on that
+ * sequence alone under FFPA_FLAG_DETERMINISTIC).  causal = the reference's tail-aligned mask PER SEQUENCE: row r of
+ * sequence i sees key j iff j <= r + (Nkv_i - Nq_i).  Rows without a visible key (an empty key range; the first
+ * Nq_i - Nkv_i rows of a causal sequence with more queries than keys) get O = 0 and LSE = -inf — the contract the
+ * reference's tests pin for this entry point (tests/test_ffpa_cute_sm100.py:1117-1183) — where ffpa_attn_fwd keeps
+ * SDPA's NaN.  No attn_bias, no dropout (the reference rejects both here: cute/__init__.py:76-139).
+ */
+typedef struct ffpa_varlen_fwd_params {
+  uint32_t struct_size; /* sizeof(ffpa_varlen_fwd_params), checked */
+  uint32_t abi_version; /* FFPA_ATTN_ABI_VERSION                    */
+
+  const void* q;
+  const void* k;
+  const void* v;
+  void* o;
+  float* lse; /* optional */
+  const int32_t* cu_seqlens_q;  /* device, [batch + 1] */
+  const int32_t* cu_seqlens_kv; /* device, [batch + 1] */
+
+  int32_t batch;          /* sequences */
+  int32_t heads_q;        /* Hq  */
+  int32_t heads_kv;       /* Hkv */
+  int32_t head_dim;       /* D: any multiple of 8 in [8, 1024] */
+  int32_t max_seqlen_q;   /* >= the longest query sequence */
+  int32_t max_seqlen_kv;  /* >= the longest key sequence (launch-side hint) */
+
+  int64_t q_stride[2]; /* elements: row, head */
+  int64_t k_stride[2];
+  int64_t v_stride[2];
+  int64_t o_stride[2];
+  int64_t lse_stride_head; /* elements between two heads of lse (>= total_q); ignored when lse == NULL */
+
+  int32_t dtype;  /* enum ffpa_dtype */
+  int32_t causal; /* 0 / 1: tail-aligned per sequence */
+
+  float softmax_scale;     /* > 0 or < 0 or 0: as ffpa_fwd_params */
+  float rescale_threshold; /* as ffpa_fwd_params: < 0 => 8.0 */
+  uint32_t flags;          /* FFPA_FLAG_NO_XCD_REMAP, FFPA_FLAG_L2_PREFETCH / _NO_L2_PREFETCH, FFPA_FLAG_XCD_GROUP(); others ignored */
+  uint32_t reserved;       /* 0 */
+} ffpa_varlen_fwd_params;
+
+/* Launch the packed-sequence forward on `stream` of the CURRENT device.  Asynchronous; returns an ffpa_status. */
+int ffpa_attn_varlen_fwd(const ffpa_varlen_fwd_params* params, void* stream);
+
+/* Its launch plan: out[0] = row tiles per (sequence, head) in the grid, out[1] = query rows per workgroup, out[2] = keys per tile,
+ * out[3] = workgroups of the launch.  Returns an ffpa_status. */
+int ffpa_attn_varlen_fwd_plan(const ffpa_varlen_fwd_params* params, int out[4]);
+
+/* The kernel it runs, as text ("ffpa_fwd_m16_varlen_kernel<bf16, 512>").  Returns an ffpa_status. */
+int ffpa_attn_varlen_fwd_kernel(const ffpa_varlen_fwd_params* params, char* buf, size_t n);
+
 /* Capability / build queries.  Replaces the module attributes
  * CUDA_FWD_AVAILABLE, F16_ACC_AVAILABLE, ... (csrc/cuffpa/ffpa_api.cc:283-305). */
 enum ffpa_query {
@@ -239,7 +304,8 @@ enum ffpa_query {
      not per SKU constant */
   FFPA_QUERY_DEVICE_CUS = 8,        /* compute units */
   FFPA_QUERY_DEVICE_CLOCK_MHZ = 9,  /* engine clock */
-  FFPA_QUERY_DEVICE_HBM_GBPS = 10   /* HBM peak (4 transfers x memory clock x bus width: HBM3 / HBM3E) */
+  FFPA_QUERY_DEVICE_HBM_GBPS = 10,  /* HBM peak (4 transfers x memory clock x bus width: HBM3 / HBM3E) */
+  FFPA_QUERY_VARLEN_AVAILABLE = 11  /* 1 if ffpa_attn_varlen_fwd's kernels are in this build */
 };
 int ffpa_attn_query(int what);
 

@@ -1,0 +1,305 @@
+"""Packed sequences on the GPU (`pytest -m gpu`): ffpa_attn_varlen_func / ffpa_attn_varlen_fwd — ONE launch for the batch — against
+
+* the pinned CPU oracle, sequence by sequence (the recurrence the dense path is pinned to: tests/test_oracle.py);
+* the dense kernel on each sequence alone, BIT FOR BIT (the packed kernel runs the dense kernel's tile text on per-sequence arguments: under
+  FFPA_FLAG_DETERMINISTIC — no KV splits, no wide-row tile — a dense launch of one sequence computes the same bits: LSE in both dtypes, O in bf16;
+  fp16 O up to the compiler's one-or-two-roundings choice in the very last instruction);
+* PyTorch SDPA per sequence at the reference's tolerance;
+
+over the shape list of the reference's own packed-sequence test (tests/test_ffpa_cute_sm100.py:1085-1157: uneven lengths, Nq < Nkv and Nq > Nkv under the
+tail-aligned causal mask, zero-length key / query sequences, residues around the row tile, GQA / MQA, 70 sequences with empty ones in between) and its
+contract for rows without a visible key: O = 0 and LSE = -inf exactly, with no K / V byte read (:1160-1183)."""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_fwd_gpu import TOL, _check_vs_oracle, _close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+  if not torch.cuda.is_available():
+    pytest.fail("these tests need a GPU; run with -m 'not gpu' on CPU boxes")
+  from ffpa_attn_amd import hip as h
+
+  h.load_library()  # fail loudly if the extension is missing: there is no fallback
+  return h
+
+
+def _cu(lens):
+  return torch.tensor([0, *np.cumsum(lens).tolist()], dtype=torch.int32, device="cuda")
+
+
+def _make(lens_q, lens_k, hq, hkv, d, dtype, seed=0, scale=1.0):
+  g = torch.Generator(device="cuda").manual_seed(seed)
+  tq, tk = int(sum(lens_q)), int(sum(lens_k))
+  q = torch.randn((tq, hq, d), dtype=dtype, device="cuda", generator=g) * scale
+  k = torch.randn((tk, hkv, d), dtype=dtype, device="cuda", generator=g) * scale
+  v = torch.randn((tk, hkv, d), dtype=dtype, device="cuda", generator=g) * scale
+  return q, k, v
+
+
+def _seq(t, a, b):
+  """rows [a, b) of a packed [T, H, D] tensor as the dense layout [1, H, n, D] (a view)"""
+  return t[a:b].transpose(0, 1).unsqueeze(0)
+
+
+def _check_packed(hip, q, k, v, lens_q, lens_k, causal, out, lse, *, oracle=True, dense_bits=True, sdpa=True, name=""):
+  """out / lse of one packed call against the three references, sequence by sequence."""
+  hq, d = q.size(1), q.size(2)
+  assert out.shape == q.shape and out.dtype == q.dtype and lse.shape == (hq, q.size(0)) and lse.dtype == torch.float32
+  bq, bk = np.cumsum([0, *lens_q]), np.cumsum([0, *lens_k])
+  scale = 1.0 / math.sqrt(d)
+  bc = hip.varlen_launch_plan(len(lens_q), hq, k.size(1), max(max(lens_q), 1), max(max(lens_k), 1), d)["block_keys"]
+  for i, (nq, nk) in enumerate(zip(lens_q, lens_k)):
+    qs, qe, ks, ke = int(bq[i]), int(bq[i + 1]), int(bk[i]), int(bk[i + 1])
+    if nq == 0:
+      continue
+    o_i, l_i = _seq(out, qs, qe), lse[:, qs:qe].unsqueeze(0)
+    dead = nq if nk == 0 else (max(0, nq - nk) if causal else 0)  # rows without a visible key: the first Nq - Nkv of a causal sequence
+    if dead:
+      assert torch.all(o_i[:, :, :dead] == 0), f"{name} seq {i}: rows without a visible key must be exactly 0"
+      assert torch.all(l_i[:, :, :dead] == -float("inf")), f"{name} seq {i}: their LSE must be exactly -inf"
+    if dead == nq:
+      continue
+    assert torch.isfinite(o_i[:, :, dead:].float()).all() and torch.isfinite(l_i[:, :, dead:]).all(), f"{name} seq {i}"
+    q_i, k_i, v_i = _seq(q, qs, qe), _seq(k, ks, ke), _seq(v, ks, ke)
+    if oracle:
+      _check_vs_oracle(o_i, l_i, q_i, k_i, v_i, causal=causal, causal_offset=nk - nq, rows=(dead, nq), block_keys=bc, name=f"{name} seq {i} vs oracle")
+    if dense_bits and nq > 32:  # (dense launches of <= 32 rows run the short-query tiles: another kernel, equal to rounding only)
+      o_d, l_d = hip.forward(q_i, k_i, v_i, None, causal, scale, flags=hip.FLAG_DETERMINISTIC)
+      assert torch.equal(l_d[:, :, dead:], l_i[:, :, dead:]), f"{name} seq {i}: LSE differs from the dense kernel's bits"
+      if q.dtype == torch.bfloat16:
+        assert torch.equal(o_d[:, :, dead:], o_i[:, :, dead:]), f"{name} seq {i}: O differs from the dense kernel's bits"
+      else:
+        # fp16: the accumulators are the same bits; the LAST instruction — O * (1 / l) rounded to fp16 — is hipcc's choice per element between
+        # v_fma_mixlo_f16 (one rounding) and v_mul_f32 + v_cvt_f16_f32 (two), and it chooses differently in the two kernels: where the fp32
+        # product lands on an fp16 rounding midpoint (~ 2^-13 of the elements) the results differ by one fp16 spacing
+        a, b = o_d[:, :, dead:].float(), o_i[:, :, dead:].float()
+        diff = (a - b).abs()
+        spacing = torch.maximum(a.abs(), b.abs()).clamp_min(2.0 ** -14) * 2.0 ** -10
+        assert torch.all(diff <= spacing), f"{name} seq {i}: fp16 O differs from the dense kernel's by more than one spacing ({diff.max().item():.3e})"
+        assert (diff > 0).float().mean().item() <= 2e-3, f"{name} seq {i}: {(diff > 0).float().mean().item():.2e} of the fp16 outputs differ from the dense kernel's"
+    if sdpa:
+      live = slice(dead, nq)
+      mask = None
+      if causal:
+        rows = torch.arange(nq, device="cuda").view(-1, 1)
+        cols = torch.arange(nk, device="cuda").view(1, -1)
+        mask = (cols <= rows + (nk - nq))[live]
+      ref = F.scaled_dot_product_attention(q_i[:, :, live], k_i, v_i, attn_mask=mask, enable_gqa=hq != k.size(1))
+      _close(o_i[:, :, live], ref, q.dtype, f"{name} seq {i} vs SDPA")
+
+
+REFERENCE_SHAPES = [  # tests/test_ffpa_cute_sm100.py:1089-1114 (data: lengths and head counts)
+  pytest.param([130, 512, 7, 1024], None, 4, 4, id="uneven_equal"),
+  pytest.param([64, 200, 1], [512, 333, 1024], 4, 4, id="cross_sq_lt_sk"),
+  pytest.param([512, 700, 300], [64, 129, 1], 4, 4, id="cross_sq_gt_sk"),
+  pytest.param([128, 256], [0, 256], 2, 2, id="zero_len_k"),
+  pytest.param([0, 256, 130], [64, 256, 130], 2, 2, id="zero_len_q"),
+  pytest.param([1, 127, 128, 129, 255], None, 2, 2, id="residue_m"),
+  pytest.param([777], None, 2, 2, id="single_seq"),
+  pytest.param([255, 1024], None, 8, 2, id="gqa_4to1"),
+  pytest.param([300, 129], None, 8, 1, id="mqa_8to1"),
+  pytest.param([(0 if i % 7 == 0 else 40 + 9 * i) for i in range(70)], None, 2, 2, id="batch70_with_zeros"),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("lens_q, lens_k, hq, hkv", REFERENCE_SHAPES)
+def test_packed_call_matches_oracle_dense_bits_and_sdpa_per_sequence(hip, lens_q, lens_k, hq, hkv, causal, dtype):
+  from ffpa_attn_amd import ffpa_attn_varlen_func
+
+  lens_k = lens_q if lens_k is None else lens_k
+  d = 512
+  q, k, v = _make(lens_q, lens_k, hq, hkv, d, dtype, scale=0.25)  # (the reference test's randn / 4)
+  cu_q, cu_k = _cu(lens_q), _cu(lens_k)
+  out, lse = ffpa_attn_varlen_func(q, k, v, cu_q, cu_k, max(lens_q), max(lens_k), causal=causal, enable_gqa=hq != hkv, return_lse=True)
+  big = len(lens_q) > 8  # (the 70-sequence case: the oracle on a sample of its sequences only — it is a CPU loop)
+  _check_packed(hip, q, k, v, lens_q, lens_k, causal, out, lse, oracle=not big, name=f"D{d}")
+  if big:
+    keep = [3, 8, 22, 41, 69]
+    for i in keep:
+      qs, qe = int(sum(lens_q[:i])), int(sum(lens_q[: i + 1]))
+      _check_vs_oracle(_seq(out, qs, qe), lse[:, qs:qe].unsqueeze(0), _seq(q, qs, qe), _seq(k, qs, qe), _seq(v, qs, qe), causal=causal,
+                       causal_offset=0, block_keys=64, name=f"batch70 seq {i}")
+
+
+@pytest.mark.parametrize("d", [64, 72, 128, 192, 256, 320, 384, 448, 576, 640, 768, 1024])
+def test_every_head_dim_of_the_packed_kernel(hip, d):
+  """every instantiation (128 ... 1024; smaller and in-between head dims run on the next one with their missing columns read as zeros): ragged lengths,
+  causal, GQA."""
+  lens_q, lens_k = [200, 33, 129, 64], [264, 33, 300, 17]
+  for dtype, causal in ((torch.bfloat16, True), (torch.float16, False)):
+    q, k, v = _make(lens_q, lens_k, 4, 2, d, dtype, seed=d)
+    out, lse = hip.varlen_forward(q, k, v, _cu(lens_q), _cu(lens_k), max(lens_q), max(lens_k), causal, 1.0 / math.sqrt(d))
+    # (the dense call serves D = 64 with its 32x32x16 kernel: another mapping, equal to rounding only — from 72 up both run the 16x16x32 tile)
+    _check_packed(hip, q, k, v, lens_q, lens_k, causal, out, lse, sdpa=d <= 512, dense_bits=d > 64, name=f"D{d} {dtype} causal={causal}")
+
+
+def test_head_dim_that_is_not_a_multiple_of_8_is_padded_by_copies(hip):
+  lens = [100, 260]
+  q, k, v = _make(lens, lens, 2, 2, 100, torch.bfloat16)
+  out, lse = hip.varlen_forward(q, k, v, _cu(lens), _cu(lens), 260, 260, True, 0.1)
+  assert out.shape == (360, 2, 100) and out.is_contiguous()
+  _check_packed(hip, q, k, v, lens, lens, True, out, lse, dense_bits=False, sdpa=False, name="D100")
+  for i, (a, b) in enumerate(((0, 100), (100, 360))):
+    ref = F.scaled_dot_product_attention(_seq(q, a, b), _seq(k, a, b), _seq(v, a, b), is_causal=True, scale=0.1)
+    _close(_seq(out, a, b), ref, torch.bfloat16, f"D100 seq {i}")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_rows_without_a_visible_key_read_no_kv(hip, dtype):
+  """tests/test_ffpa_cute_sm100.py:1160-1183: every key sequence is empty and the K / V buffers are NaN — O = 0 and LSE = -inf must come from the mask,
+  not from arithmetic on data that should never have been loaded.  And the mixed form: one live sequence between two empty ones, NaN rows around its keys."""
+  from ffpa_attn_amd import ffpa_attn_varlen_func
+
+  lens_q, d = [130, 256, 1], 512
+  cu_q, cu_k = _cu(lens_q), _cu([0, 0, 0])
+  q = torch.randn(sum(lens_q), 2, d, device="cuda", dtype=dtype)
+  k = torch.full((0, 2, d), float("nan"), device="cuda", dtype=dtype)
+  out, lse = ffpa_attn_varlen_func(q, k, k.clone(), cu_q, cu_k, max(lens_q), 1, causal=True, return_lse=True)
+  assert torch.all(out == 0) and torch.all(lse == -float("inf"))
+  # a live sequence whose neighbours' key rows are NaN: a read past the sequence's own keys would poison it
+  lens_k = [64, 200, 64]
+  q, k, v = _make(lens_q, lens_k, 2, 2, d, dtype)
+  k[:64], k[264:], v[:64], v[264:] = float("nan"), float("nan"), float("nan"), float("nan")
+  out, lse = ffpa_attn_varlen_func(q, k, v, cu_q, _cu(lens_k), max(lens_q), max(lens_k), return_lse=True)
+  mid = _seq(out, 130, 386)
+  assert torch.isfinite(mid.float()).all() and torch.isfinite(lse[:, 130:386]).all()
+  ref = F.scaled_dot_product_attention(_seq(q, 130, 386), _seq(k, 64, 264), _seq(v, 64, 264))
+  _close(mid, ref, dtype, "live sequence between NaN neighbours")
+
+
+def test_zero_copy_strided_views_and_oversized_max_seqlen(hip):
+  """q / k / v as slices of one packed qkv buffer [T, 3, H, D] (row stride 3 H D) and an output that is written into a dense tensor: nothing is copied
+  (strides are part of the call); max_seqlen_q larger than every sequence only adds workgroups that leave at once."""
+  lens = [300, 45, 512]
+  t, h, d = sum(lens), 4, 320
+  g = torch.Generator(device="cuda").manual_seed(5)
+  qkv = torch.randn((t, 3, h, d), dtype=torch.bfloat16, device="cuda", generator=g)
+  q, k, v = qkv[:, 0], qkv[:, 1], qkv[:, 2]
+  assert not q.is_contiguous()
+  cu = _cu(lens)
+  out, lse = hip.varlen_forward(q, k, v, cu, cu, 512, 512, True, d ** -0.5)
+  out2, lse2 = hip.varlen_forward(q.contiguous(), k.contiguous(), v.contiguous(), cu, cu, 4096, 8192, True, d ** -0.5)
+  assert torch.equal(out, out2) and torch.equal(lse, lse2)
+  _check_packed(hip, q, k, v, lens, lens, True, out, lse, name="strided")
+
+
+def test_softmax_scale_conventions_and_exact_recurrence(hip):
+  """scale None = 1 / sqrt(D); a negative and a zero scale reach the kernel as (-Q, |scale|) / (Q = 0): as on the dense path; rescale_threshold = 0 is
+  the exact recurrence (equal to the lazy one to rounding)."""
+  from ffpa_attn_amd import ffpa_attn_varlen_func
+
+  lens = [150, 70]
+  q, k, v = _make(lens, lens, 2, 2, 512, torch.bfloat16)
+  cu = _cu(lens)
+  base = ffpa_attn_varlen_func(q, k, v, cu, None, 150, 150)
+  assert torch.equal(base, ffpa_attn_varlen_func(q, k, v, cu, cu, 150, 150, softmax_scale=512 ** -0.5))
+  neg = ffpa_attn_varlen_func(q, k, v, cu, cu, 150, 150, softmax_scale=-(512 ** -0.5))
+  assert torch.equal(neg, ffpa_attn_varlen_func(-q, k, v, cu, cu, 150, 150))
+  zero = ffpa_attn_varlen_func(q, k, v, cu, cu, 150, 150, softmax_scale=0.0)
+  for a, b in ((0, 150), (150, 220)):
+    _close(_seq(zero, a, b), _seq(v, a, b).float().mean(dim=2, keepdim=True).expand(-1, -1, b - a, -1), torch.bfloat16, "scale 0 = mean of V")
+  exact = ffpa_attn_varlen_func(q, k, v, cu, cu, 150, 150, rescale_threshold=0.0)
+  _close(exact, base, torch.bfloat16, "exact vs lazy recurrence")
+
+
+def test_packed_call_captures_into_a_hip_graph_and_follows_the_device_side_boundaries(hip):
+  """No host read, no synchronisation: the call captures as it is, and a replay follows cu_seqlens written IN PLACE (same totals, other boundaries)."""
+  lens_a, lens_b = [100, 300, 112], [256, 0, 256]
+  q, k, v = _make(lens_a, lens_a, 4, 4, 512, torch.bfloat16)
+  cu = _cu(lens_a)
+  side = torch.cuda.Stream()
+  side.wait_stream(torch.cuda.current_stream())
+  with torch.cuda.stream(side):
+    hip.varlen_forward(q, k, v, cu, cu, 512, 512, True, 512 ** -0.5)  # (warm-up: the kernel attribute is set outside the capture)
+  torch.cuda.current_stream().wait_stream(side)
+  g = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(g):
+    out, lse = hip.varlen_forward(q, k, v, cu, cu, 512, 512, True, 512 ** -0.5)
+  for lens in (lens_a, lens_b, lens_a):
+    cu.copy_(_cu(lens))
+    g.replay()
+    torch.cuda.synchronize()
+    eager, eager_lse = hip.varlen_forward(q, k, v, cu, cu, 512, 512, True, 512 ** -0.5)
+    assert torch.equal(out, eager) and torch.equal(lse, eager_lse)
+    _check_packed(hip, q, k, v, lens, lens, True, out, lse, oracle=False, name=f"replay {lens}")
+
+
+def test_backward_of_the_packed_call_matches_per_sequence_sdpa():
+  """tests/test_ffpa_cute_sm80.py:269-…: autograd through the packed call against SDPA per sequence; here the backward is the dense path's SDPA-backward
+  hookup per sequence on the saved O / LSE.  Includes a causal sequence with more queries than keys (its first rows get zero gradients)."""
+  from ffpa_attn_amd import ffpa_attn_varlen_func
+
+  lens_q, lens_k, h, d = [96, 40, 130], [96, 72, 50], 2, 320
+  q, k, v = _make(lens_q, lens_k, h, h, d, torch.bfloat16, scale=0.5)
+  for causal in (False, True):
+    qa, ka, va = (t.clone().requires_grad_(True) for t in (q, k, v))
+    out = ffpa_attn_varlen_func(qa, ka, va, _cu(lens_q), _cu(lens_k), max(lens_q), max(lens_k), causal=causal)
+    go = torch.randn_like(out)
+    out.backward(go)
+    qr, kr, vr = (t.clone().float().requires_grad_(True) for t in (q, k, v))
+    bq, bk = np.cumsum([0, *lens_q]), np.cumsum([0, *lens_k])
+    refs = []
+    for i, (nq, nk) in enumerate(zip(lens_q, lens_k)):
+      qs, qe, ks, ke = int(bq[i]), int(bq[i + 1]), int(bk[i]), int(bk[i + 1])
+      mask = None
+      if causal:
+        mask = torch.arange(nk, device="cuda").view(1, -1) <= torch.arange(nq, device="cuda").view(-1, 1) + (nk - nq)
+      o = F.scaled_dot_product_attention(_seq(qr, qs, qe), _seq(kr, ks, ke), _seq(vr, ks, ke), attn_mask=mask)
+      o = torch.nan_to_num(o, nan=0.0)  # rows without a visible key: the packed contract is O = 0 (their gradients vanish)
+      refs.append(o[0].transpose(0, 1))
+    ref = torch.cat(refs, dim=0)
+    _close(out, ref.to(out.dtype), torch.bfloat16, f"forward causal={causal}")
+    ref.backward(go.float())
+    for name, got, want in (("dq", qa.grad, qr.grad), ("dk", ka.grad, kr.grad), ("dv", va.grad, vr.grad)):
+      want = torch.nan_to_num(want, nan=0.0)
+      err = (got.float() - want).abs().max().item()
+      assert err <= 3e-2 * max(1.0, want.abs().max().item()), f"{name} causal={causal}: {err:.3e}"
+
+
+def test_op_registration_of_the_packed_call(hip):
+  """ffpa_attn::_varlen_fwd_hip through torch.library's own checks (schema, fake implementation, dispatch) and through torch.compile."""
+  from ffpa_attn_amd import ffpa_attn_varlen_func
+
+  lens = [70, 130]
+  q, k, v = _make(lens, lens, 2, 2, 320, torch.bfloat16)
+  cu = _cu(lens)
+  torch.library.opcheck(torch.ops.ffpa_attn._varlen_fwd_hip.default, (q, k, v, cu, cu, 130, 130, 320 ** -0.5, 1),
+                        test_utils=("test_schema", "test_faketensor"))
+  eager = ffpa_attn_varlen_func(q, k, v, cu, cu, 130, 130, causal=True)
+  compiled = torch.compile(lambda a, b, c: ffpa_attn_varlen_func(a, b, c, cu, cu, 130, 130, causal=True) * 2.0)(q, k, v)
+  assert torch.equal(compiled, eager * 2.0)
+
+
+def test_c_abi_of_the_packed_call_on_raw_pointers(hip):
+  """The boundary itself: ffpa_attn_varlen_fwd on a hand-filled parameter block (no torch types behind the pointers' back), stream given explicitly."""
+  import ctypes
+
+  lens = [190, 66]
+  q, k, v = _make(lens, lens, 4, 1, 256, torch.float16)
+  cu = _cu(lens)
+  o = torch.full_like(q, float("nan"))
+  lse = torch.full((4, 256), float("nan"), dtype=torch.float32, device="cuda")
+  lib = hip.load_library()
+  p = hip.FfpaVarlenFwdParams()
+  p.struct_size, p.abi_version = ctypes.sizeof(hip.FfpaVarlenFwdParams), hip.ABI_VERSION
+  p.q, p.k, p.v, p.o, p.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr()
+  p.cu_seqlens_q = p.cu_seqlens_kv = cu.data_ptr()
+  p.batch, p.heads_q, p.heads_kv, p.head_dim, p.max_seqlen_q, p.max_seqlen_kv = 2, 4, 1, 256, 190, 190
+  p.q_stride[:], p.k_stride[:], p.v_stride[:], p.o_stride[:] = [4 * 256, 256], [256, 256], [256, 256], [4 * 256, 256]
+  p.lse_stride_head, p.dtype, p.causal, p.softmax_scale, p.rescale_threshold = 256, 1, 1, 1.0 / 16, -1.0
+  s = torch.cuda.Stream()
+  s.wait_stream(torch.cuda.current_stream())
+  assert lib.ffpa_attn_varlen_fwd(ctypes.byref(p), ctypes.c_void_p(s.cuda_stream)) == 0, lib.ffpa_attn_last_error()
+  s.synchronize()
+  _check_packed(hip, q, k, v, lens, lens, True, o, lse, name="C-ABI")

@@ -47,7 +47,7 @@ def main():
     path = isa_files(d)
     if not path:
       continue
-    for name, body in kernels(path[0]):
+    for name, body in (kb for pth in sorted(path) for kb in kernels(pth)):  # (every TU of the head dim: the dense kernels' and the packed-sequence kernel's)
       text = "".join(body)
       get = lambda k: (re.search(rf"; {k}: (\d+)", text) or [None, "?"])[1]
       mf = [i for i, l in enumerate(body) if "v_mfma" in l]
@@ -71,6 +71,7 @@ def main():
       short = re.sub(r"_ZN4ffpa23ffpa_fwd_split_d_kernelI(\w+?)EEvNS_7FwdArgsE", r"\1", name)
       short = re.sub(r"_ZN4ffpa19ffpa_fwd_m16_kernelI(\w+?)EEvNS_7FwdArgsE", r"m16 \1", short)
       short = re.sub(r"_ZN4ffpa24ffpa_fwd_m16_pair_kernelI(\w+?)EEvNS_7FwdArgsE", r"m16pair \1", short)
+      short = re.sub(r"_ZN4ffpa26ffpa_fwd_m16_varlen_kernelI(\w+?)EEvNS_7FwdArgsENS_10VarlenArgsE", r"m16varlen \1", short)
       short = short.replace("DF16b", "bf16 ").replace("DF16_", "fp16 ").replace("Li", " ").replace("ELb", " b").replace("E", "")
       print(f"D={d:>4} {short:<28} vgpr {get('NumVgprs'):>3} agpr {get('NumAgprs'):>3} sgpr {get('NumSgprs'):>3} "
             f"scratch {get('ScratchSize'):>4} B | first..last MFMA: scratch ops {n_scr}, lane spills {n_rl} | inside MFMA loops: scratch {hot_scr}, lane spills {hot_rl} | mfma {len(mf)}")
