@@ -86,6 +86,9 @@ WORKLOADS = {
   "dropout": _w(1, 32, 32, 8192, 8192, 512, dropout=0.1, note="reference bench case 'dropout' (p = 0.1, in-kernel Philox)"),
   "non_aligned": _w(1, 8, 8, 8191, 8191, 512, note="reference bench case 'non-aligned' (N-1, H/4 heads)"),
   "decode": _w(1, 32, 32, 1, 8192, 512, bound="hbm", note="reference bench case 'decode-attn' (Nq = 1: split-KV kernel + LSE merge; HBM-bound)"),
+  # packed sequences (ffpa_attn_varlen_func: the reference's CuTe-DSL-only entry point, one launch here): 8 causal self-attention sequences, 16384 tokens
+  "varlen": _w(8, 32, 8, 4864, 4864, 512, causal=True, via="varlen", lens=(4096, 512, 2048, 1024, 3072, 256, 4864, 512),
+               note="packed THD batch through ffpa_attn_varlen_func: 8 causal sequences of 256 ... 4864 tokens (16384 in all), GQA 32 / 8, one launch"),
 }
 
 
@@ -199,7 +202,7 @@ def live_traffic(workload: str, timeout_s: float = 150.0):
   prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
   if prof is None:
     return None, "rocprofv3 not found"
-  kernel = re.compile(r"ffpa_fwd_(split_d|m16w?|m16_pair)_kernel")
+  kernel = re.compile(r"ffpa_fwd_(split_d|m16w?|m16_pair|m16_varlen)_kernel")
   out = tempfile.mkdtemp(prefix="ffpa_bench_pmc_", dir="/tmp")
   got = {}
   try:
@@ -462,6 +465,155 @@ def accuracy(w: dict, q, k, v, mask, scale: float) -> dict:
   return res
 
 
+def varlen_main(args) -> None:
+  """`--workload varlen` (N = 1): the packed-sequence call — ffpa_attn_varlen_func -> ffpa_attn::_varlen_fwd_hip -> ffpa_attn_varlen_fwd -> ONE launch of
+  ffpa_fwd_m16_varlen_kernel — under the same contract as the dense workloads: W warm-ups, exactly K timed steps between synchronises, HIP events per
+  step, the MFMA roofline of the kernel with its HBM traffic measured in the run, the reference's CPU path beside it.  Next to the contract figure: the
+  same batch as a per-sequence loop of dense calls (what the reference tells callers without its CuTe-DSL backend to do) and SDPA per sequence."""
+  import math
+
+  from ffpa_attn_amd import ffpa_attn_varlen_func, hip
+
+  name = "varlen"
+  w = WORKLOADS[name]
+  lens, Hq, Hkv, D = list(w["lens"]), w["Hq"], w["Hkv"], w["D"]
+  dev = torch.device("cuda", 0)
+  torch.cuda.set_device(dev)
+  hip.load_library()
+  total = sum(lens)
+  torch.manual_seed(0)
+  q = torch.randn(total, Hq, D, dtype=torch.bfloat16, device=dev)
+  k = torch.randn(total, Hkv, D, dtype=torch.bfloat16, device=dev)
+  v = torch.randn(total, Hkv, D, dtype=torch.bfloat16, device=dev)
+  bounds = [0]
+  for n in lens:
+    bounds.append(bounds[-1] + n)
+  cu = torch.tensor(bounds, dtype=torch.int32, device=dev)
+  max_len = max(lens)
+  flops = 4 * Hq * D * sum(n * (n + 1) // 2 for n in lens)  # the reference's model (cli/_flops.py:37-53) per sequence: causal self-attention sees n (n + 1) / 2 pairs
+  alg_bytes = 2 * D * total * (2 * Hq + 2 * Hkv) + 4 * Hq * total
+
+  def step():
+    return ffpa_attn_varlen_func(q, k, v, cu, cu, max_len, max_len, causal=True, enable_gqa=True)
+
+  def seq(t, i):
+    return t[bounds[i]:bounds[i + 1]].transpose(0, 1).unsqueeze(0)  # [n, H, D] -> [1, H, n, D], a view
+
+  def step_loop():  # the same batch, one dense call per sequence (zero-copy views: the C-ABI honours strides)
+    return [ffpa_attn_func(seq(q, i), seq(k, i), seq(v, i), is_causal=True, enable_gqa=True) for i in range(len(lens))]
+
+  telemetry = DeviceTelemetry(0)
+
+  def timed(fn):
+    for _ in range(args.warmup):
+      fn()
+    torch.cuda.synchronize()
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    telemetry.start()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+      starts[i].record()
+      fn()
+      ends[i].record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    telemetry.stop()
+    return elapsed, sorted(a.elapsed_time(b) for a, b in zip(starts, ends))
+
+  elapsed, kernel_ms = timed(step)
+  device = telemetry.summary()
+  kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
+  value = flops * args.steps / elapsed / 1e12
+  steady = None
+  if not args.no_steady:
+    n_pre, n_timed = max(20, int(150.0 / kernel_ms_avg)), max(20, min(400, int(60.0 / kernel_ms_avg)))
+    for _ in range(n_pre):
+      step()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(n_timed):
+      step()
+    ev1.record()
+    torch.cuda.synchronize()
+    ss_ms = ev0.elapsed_time(ev1) / n_timed
+    steady = {"ms_per_step": round(ss_ms, 4), "tflops": round(flops / ss_ms / 1e9, 2), "launches": n_timed, "after_launches": n_pre,
+              "what": "the same step back to back after >= 150 ms of continuous load, one HIP event pair around the launches; outside the timed region"}
+  plan = hip.varlen_launch_plan(len(lens), Hq, Hkv, max_len, max_len, D, causal=True)
+  build = build_identity()
+  traffic, traffic_src, traffic_stale = measured_traffic(name, build.get("lib_sha16"))
+  note = None
+  under_profiler = any(k_.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k_ in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "").lower()
+  if not args.no_live_traffic and not under_profiler:
+    torch.cuda.synchronize()
+    live, why = live_traffic(name)
+    if live is not None:
+      traffic, traffic_src, traffic_stale = live, why, False
+    else:
+      note = why
+  achieved = flops / (kernel_ms_avg * 1e-3) / 1e12
+  roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
+          "traffic": traffic, "traffic_source": traffic_src, "kernel": plan["kernel"], "kernel_ms_avg": round(kernel_ms_avg, 4),
+          "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 4), "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
+          "workgroups": plan["workgroups"], "traffic_stale": bool(traffic_stale)}
+  if note is not None:
+    roof["traffic_live_failed"] = note
+  if device.get("peak_tflops_from_device"):
+    roof["frac_of_device_peak"] = round(achieved / device["peak_tflops_from_device"], 4)
+  line = {
+    "metric": f"attention fwd TFLOPS + max-abs-err vs SDPA, bf16 packed sequences {lens} Hq={Hq}/Hkv={Hkv} D={D} causal [varlen]",
+    "value": round(value, 2), "unit": "TFLOPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+    "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+    "config": {"workload": f"varlen: {w['note']}; T={total} Hq={Hq} Hkv={Hkv} D={D} bf16", "global_batch": len(lens), "seq_len": max_len, "parallelism": "single GPU",
+               "flops_model": "4*Hq*D*sum_i n_i (n_i + 1) / 2", "step": "ffpa_attn_varlen_func"},
+    "roofline": roof, "device": device, "steady_state": steady, "build": build,
+    "plan": {k_: plan[k_] for k_ in ("row_tiles", "block_rows", "block_keys", "workgroups")},
+  }
+  # the same batch as a loop of dense calls, one per sequence — and its outputs against the packed call's (same tile, same recurrence: the bits where the
+  # dense plan is the plain tile; rounding where it pairs / splits / takes another tile)
+  out = step()
+  if not args.no_sdpa:  # (--no-sdpa: no comparison legs at all — what the profiler passes of tools/gpu_round.sh run, so that their kernel list is this kernel's alone)
+    loop_elapsed, _ = timed(step_loop)
+    loop_out = step_loop()
+    diff = max((out[bounds[i]:bounds[i + 1]].float() - loop_out[i][0].transpose(0, 1).float()).abs().max().item() for i in range(len(lens)))
+    line["per_sequence_loop"] = {"ms_per_step": round(loop_elapsed / args.steps * 1e3, 4), "tflops": round(flops * args.steps / loop_elapsed / 1e12, 2), "launches_per_step": len(lens),
+                                 "max_abs_diff_vs_packed": round(diff, 6), "packed_speedup": round(loop_elapsed / elapsed, 3),
+                                 "what": "ffpa_attn_func(is_causal=True) per sequence on zero-copy views of the packed tensors (each call its own launch plan); same W / K"}
+    try:
+      sd = lambda: [torch.nn.functional.scaled_dot_product_attention(seq(q, i), seq(k, i), seq(v, i), is_causal=True, enable_gqa=True) for i in range(len(lens))]  # noqa: E731
+      ref = sd()
+      err = max((out[bounds[i]:bounds[i + 1]].float() - ref[i][0].transpose(0, 1).float()).abs().max().item() for i in range(len(lens)))
+      torch.cuda.synchronize()
+      t1 = time.perf_counter()
+      for _ in range(3):
+        sd()
+      torch.cuda.synchronize()
+      sdpa_s = (time.perf_counter() - t1) / 3
+      line.update(max_abs_err_vs_sdpa=round(err, 6), sdpa_gpu_ms=round(sdpa_s * 1e3, 4), sdpa_gpu_tflops=round(flops / sdpa_s / 1e12, 2),
+                  speedup_vs_sdpa_gpu=round(sdpa_s / (elapsed / args.steps), 3), sdpa_call="F.scaled_dot_product_attention(is_causal=True, enable_gqa=True) per sequence")
+    except Exception as e:  # noqa: BLE001 — informative only
+      line["sdpa_error"] = str(e)[:200]
+  if not args.no_cpu_baseline:
+    # the reference's CPU path for a packed batch: it has none (the CuTe-DSL backend is GPU-only) — what it tells such callers to do is the dense call per
+    # sequence, which falls back to torch CPU SDPA: timed on the THREE shortest sequences (a bounded sample)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sample = sorted(range(len(lens)), key=lambda i: lens[i])[:3]
+    cq, ck, cv = q.cpu(), k.cpu(), v.cpu()
+    run = lambda: [torch._C._nn.scaled_dot_product_attention(seq(cq, i), seq(ck, i), seq(cv, i), is_causal=True, enable_gqa=True) for i in sample]  # noqa: E731
+    run()
+    best = float("inf")
+    for _ in range(2):
+      t0 = time.perf_counter()
+      run()
+      best = min(best, time.perf_counter() - t0)
+    sflops = 4 * Hq * D * sum(lens[i] * (lens[i] + 1) // 2 for i in sample)
+    line["cpu_baseline"] = {"value": round(sflops / best / 1e12, 4), "unit": "TFLOPS", "cores": torch.get_num_threads(), "kind": "reference",
+                            "sample": f"torch CPU SDPA per sequence (what the reference's dense entry point falls back to; its packed entry point has no CPU path) on the "
+                                      f"three shortest sequences {[lens[i] for i in sample]}, Hq={Hq} Hkv={Hkv} D={D} bf16 causal, best of 2 after 1 warm-up, {best * 1e3:.1f} ms per pass"}
+  print(json.dumps(line), flush=True)
+
+
 def stub_main(args, world: int, rank: int) -> None:
   """(tests) The launch / barrier / max-over-ranks / one-JSON-line plumbing of this script on CPU over `--stub-backend` (gloo), with a
   short sleep standing in for the step: what tests/test_bench_spawn.py runs at world size 2.  Not a benchmark."""
@@ -710,6 +862,10 @@ def main() -> None:
     sys.exit("bench.py needs a GPU (the HIP kernel has no CPU fallback)")
   if args.sweep:
     return sweep_main(args)
+  if args.workload == "varlen":
+    if world != 1:
+      sys.exit("bench.py: --workload varlen is a single-GPU workload")
+    return varlen_main(args)
   torch.cuda.set_device(local_rank)
   dev = torch.device("cuda", local_rank)
   dist = None

@@ -363,10 +363,15 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_varlen_kernel(const FwdArgs 
   int vid = blockIdx.x;
   if (!(a_in.flags & kFlagNoXcdRemap)) vid = xcd_logical_id(vid, gridDim.x, a_in.xcd_group);
   const int split = 0;
-  const int bh = vid / a_in.nqt;
-  int qt = vid - bh * a_in.nqt;
+  // HEAD-major order of the (sequence, head) pairs: the XCD remap hands every XCD a contiguous range of them (all row tiles of a pair on one XCD: its K / V
+  // stream stays in one L2), and sequences differ in length by orders of magnitude — sequence-major (the dense order) would give one XCD the longest sequence
+  // and another the shortest (measured: 400 vs 960 TFLOPS on the bench's 256 ... 4864-token batch); head-major gives every XCD the same heads of EVERY
+  // sequence, and under GQA the heads of one KV group sit side by side
+  const int pair = vid / a_in.nqt;
+  int qt = vid - pair * a_in.nqt;
   if (a_in.causal) qt = a_in.nqt - 1 - qt;  // longest rows first
-  const int seq = bh / a_in.Hq;
+  const int seq = pair % a_in.B;
+  const int bh = seq * a_in.Hq + pair / a_in.B;
   const int q_lo = va.cu_q[seq], k_lo = va.cu_k[seq];
   const int nq_seq = va.cu_q[seq + 1] - q_lo, nkv_seq = va.cu_k[seq + 1] - k_lo;
   if (qt * BR >= nq_seq) return;  // (max_seqlen_q sized the grid: this sequence is shorter)

@@ -94,6 +94,23 @@ def test_prefill_builds_have_no_scratch_inside_their_mfma_loops(capsys, monkeypa
 
 
 @pytest.mark.skipif(not TEMPS, reason="no --save-temps assembly in csrc/build")
+def test_packed_sequence_kernels_keep_their_mfma_loops_free_of_spill_code(capsys, monkeypatch):
+  """ffpa_fwd_m16_varlen_kernel (one per head dim 128 ... 1024 and dtype; a TU of its own next to the dense one): the dense tile text on per-sequence
+  arguments — the sequence's lengths and base pointers live in scalar registers, the register file is as full as the dense kernel's (256 + 256), and the
+  one or two values the allocator parks in scratch are written in front of the KV loop and read back behind it: never inside an MFMA loop."""
+  import re
+
+  lines = [l for l in _stats(monkeypatch, capsys, 128, 192, 256, 320, 384, 448, 512, 576, 640, 704, 768, 832, 896, 960, 1024) if " m16varlen " in l]
+  assert len(lines) == 15 * 2, len(lines)
+  for l in lines:
+    assert "inside MFMA loops: scratch 0, lane spills 0" in l, l
+    assert int(re.search(r"first\.\.last MFMA: scratch ops (\d+)", l).group(1)) == 0, l
+    assert int(re.search(r"scratch\s+(\d+) B", l).group(1)) <= 64, l
+  d512 = [l for l in lines if "bf16  512" in l]
+  assert len(d512) == 1 and "vgpr 256 agpr 256" in d512[0] and "mfma 256" in d512[0], d512
+
+
+@pytest.mark.skipif(not TEMPS, reason="no --save-temps assembly in csrc/build")
 def test_the_isa_check_fails_on_a_planted_hazard(tmp_path, capsys):
   """build() keeps only the gzip-compressed device assembly of every TU — and its ISA check must still bite: a copy of one TU's assembly with a VALU
   write to an asm MFMA's operand planted right in front of it, an early reader of an asm MFMA's result, and an M0 write outside the DMA asm are all

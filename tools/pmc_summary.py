@@ -46,7 +46,7 @@ def trace_stats(src, kernel, warmup, steps=None):
 
 def main():
   argv = sys.argv[1:]
-  kernel = r"ffpa_fwd_(split_d|m16w?)_kernel"  # (regex) the prefill kernels: 32x32x16-MFMA build / 16x16x32-MFMA build (+ its wide-row tile)
+  kernel = r"ffpa_fwd_(split_d|m16w?|m16_pair|m16_varlen)_kernel"  # (regex) the prefill kernels: 32x32x16-MFMA build / 16x16x32-MFMA build (+ its wide-row tile, its paired-tile and packed-sequence kernels)
   if "--kernel" in argv:
     i = argv.index("--kernel")
     kernel = argv[i + 1]
@@ -143,6 +143,8 @@ def main():
           d["operand_stream_bytes_per_" + k] = stream / m(k)
       if d["kernel_ms_mean_under_pmc"]:
         d["operand_stream_TBps_under_pmc"] = stream / (d["kernel_ms_mean_under_pmc"] * 1e-3) / 1e12
+    elif (line.get("roofline") or {}).get("algorithmic_bytes_per_launch"):  # (the packed-sequence workload: no single B / Nq / Nkv — the line carries the figure)
+      d["algorithmic_bytes_Q+K+V+O+LSE"] = line["roofline"]["algorithmic_bytes_per_launch"]
   res["derived"] = d
   json.dump(res, open(out, "w"), indent=1)
   print(json.dumps(d, indent=1))
