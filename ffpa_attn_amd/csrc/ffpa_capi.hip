@@ -943,6 +943,9 @@ int ffpa_attn_varlen_fwd(const ffpa_varlen_fwd_params* p, void* stream) {
   va.cu_q = p->cu_seqlens_q;
   va.cu_k = p->cu_seqlens_kv;
   va.lse_stride_h = p->lse_stride_head;
+  // eight XCDs: Hq / 8 consecutive heads per chunk puts the same heads of every sequence on every XCD (balance) and, under GQA, heads that share a K / V
+  // stream next to each other (ffpa_fwd_m16_varlen_kernel); head counts that are not a multiple of 8 fall back to head-major order
+  va.head_chunk = (p->heads_q % 8 == 0) ? p->heads_q / 8 : 1;
 
   const int st = pl.ve->launch(p->dtype, a, va, static_cast<hipStream_t>(stream));
   if (st == -2) return fail(FFPA_ERR_LAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed (is this a gfx950?)");

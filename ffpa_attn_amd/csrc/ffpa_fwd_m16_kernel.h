@@ -353,6 +353,7 @@ struct VarlenArgs {
   const int* cu_q;       // [batch + 1] row offsets into q / o
   const int* cu_k;       // [batch + 1] row offsets into k / v
   int64_t lse_stride_h;  // elements between two heads of the LSE tensor (>= T_q)
+  int head_chunk;        // consecutive query heads that walk a sequence side by side (the workgroup order below): a divisor of Hq
 };
 
 template <typename T, int D>
@@ -363,15 +364,20 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_varlen_kernel(const FwdArgs 
   int vid = blockIdx.x;
   if (!(a_in.flags & kFlagNoXcdRemap)) vid = xcd_logical_id(vid, gridDim.x, a_in.xcd_group);
   const int split = 0;
-  // HEAD-major order of the (sequence, head) pairs: the XCD remap hands every XCD a contiguous range of them (all row tiles of a pair on one XCD: its K / V
-  // stream stays in one L2), and sequences differ in length by orders of magnitude — sequence-major (the dense order) would give one XCD the longest sequence
-  // and another the shortest (measured: 400 vs 960 TFLOPS on the bench's 256 ... 4864-token batch); head-major gives every XCD the same heads of EVERY
-  // sequence, and under GQA the heads of one KV group sit side by side
-  const int pair = vid / a_in.nqt;
-  int qt = vid - pair * a_in.nqt;
+  // Order of the (sequence, head) pairs: head CHUNK-major, then sequence, then the head inside its chunk (va.head_chunk consecutive heads: Hq / 8 when that is
+  // whole, else 1).  The XCD remap hands every XCD a contiguous range of pairs (all row tiles of a pair on one XCD: its K / V stream stays in one L2), and
+  // sequences differ in length by orders of magnitude — sequence-major (the dense order) gives one XCD the longest sequence and another the shortest (measured:
+  // 400 vs 960 TFLOPS on the bench's 256 ... 4864-token batch).  Chunk-major gives every XCD the same heads of EVERY sequence; and the heads of a chunk — under
+  // GQA heads of ONE KV group — walk the same sequence side by side, so that the group's K / V stream is fetched once per L2, not once per head
+  // ... side by side at the level of ROW TILES: (chunk, sequence, row tile, head in chunk) — a head's tiles alone fill an XCD's 32 CUs for a whole round, so heads
+  // that merely follow each other stream the sequence's K / V once each (measured: no fewer HBM bytes than head-major order); interleaved per tile, the same row
+  // tile of the chunk's heads runs at the same time on the same keys
+  const int per_seq = a_in.nqt * va.head_chunk, per_chunk = a_in.B * per_seq;
+  const int chunk = vid / per_chunk, in_chunk = vid - chunk * per_chunk;
+  const int seq = in_chunk / per_seq, in_seq = in_chunk - seq * per_seq;
+  int qt = in_seq / va.head_chunk;
   if (a_in.causal) qt = a_in.nqt - 1 - qt;  // longest rows first
-  const int seq = pair % a_in.B;
-  const int bh = seq * a_in.Hq + pair / a_in.B;
+  const int bh = seq * a_in.Hq + chunk * va.head_chunk + (in_seq - (in_seq / va.head_chunk) * va.head_chunk);
   const int q_lo = va.cu_q[seq], k_lo = va.cu_k[seq];
   const int nq_seq = va.cu_q[seq + 1] - q_lo, nkv_seq = va.cu_k[seq + 1] - k_lo;
   if (qt * BR >= nq_seq) return;  // (max_seqlen_q sized the grid: this sequence is shorter)

@@ -303,3 +303,35 @@ def test_c_abi_of_the_packed_call_on_raw_pointers(hip):
   assert lib.ffpa_attn_varlen_fwd(ctypes.byref(p), ctypes.c_void_p(s.cuda_stream)) == 0, lib.ffpa_attn_last_error()
   s.synchronize()
   _check_packed(hip, q, k, v, lens, lens, True, o, lse, name="C-ABI")
+
+
+def test_randomized_packed_batches(hip):
+  """Random batches (1 ... 12 sequences of 0 ... 700 tokens, independent query / key lengths, MHA / GQA / MQA, causal or not, both dtypes, a head dim of every
+  tile family) against the dense kernel's bits and SDPA per sequence, and the oracle on one sequence of each batch.  FFPA_VARLEN_FUZZ=a:b picks the seeds."""
+  import os
+
+  lo, hi = (int(x) for x in os.environ.get("FFPA_VARLEN_FUZZ", "0:48").split(":"))
+  for seed in range(lo, hi):
+    rng = np.random.default_rng(1000 + seed)
+    nseq = int(rng.integers(1, 13))
+    lens_q = [int(x) for x in rng.choice([0, 1, 7, 31, 33, 64, 127, 128, 129, 200, 333, 512, 700], size=nseq)]
+    lens_k = lens_q if rng.random() < 0.4 else [int(x) for x in rng.choice([0, 1, 17, 64, 65, 128, 255, 256, 300, 640], size=nseq)]
+    if sum(lens_q) == 0:
+      lens_q[0] = 40
+    hkv = int(rng.choice([1, 2, 4]))
+    hq = hkv * int(rng.choice([1, 2, 4]))
+    d = int(rng.choice([128, 256, 320, 512, 640, 1024]))
+    dtype = torch.bfloat16 if rng.random() < 0.6 else torch.float16
+    causal = bool(rng.random() < 0.5)
+    q, k, v = _make(lens_q, lens_k, hq, hkv, d, dtype, seed=seed)
+    mq, mk = max(lens_q), max(max(lens_k), 1)
+    out, lse = hip.varlen_forward(q, k, v, _cu(lens_q), _cu(lens_k), mq + int(rng.integers(0, 200)), mk, causal, 1.0 / math.sqrt(d))
+    name = f"fuzz seed {seed}: lens_q={lens_q} lens_k={lens_k} Hq={hq} Hkv={hkv} D={d} {dtype} causal={causal}"
+    _check_packed(hip, q, k, v, lens_q, lens_k, causal, out, lse, oracle=False, sdpa=d <= 512, name=name)
+    live = [i for i, (a, b) in enumerate(zip(lens_q, lens_k)) if a > 0 and b > 0 and not (causal and a > b)]
+    if live:
+      i = live[seed % len(live)]
+      qs, ks = int(sum(lens_q[:i])), int(sum(lens_k[:i]))
+      bc = hip.varlen_launch_plan(nseq, hq, hkv, mq, mk, d)["block_keys"]
+      _check_vs_oracle(_seq(out, qs, qs + lens_q[i]), lse[:, qs:qs + lens_q[i]].unsqueeze(0), _seq(q, qs, qs + lens_q[i]), _seq(k, ks, ks + lens_k[i]),
+                       _seq(v, ks, ks + lens_k[i]), causal=causal, causal_offset=lens_k[i] - lens_q[i], block_keys=bc, name=name + f" seq {i} vs oracle")

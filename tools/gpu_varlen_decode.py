@@ -1,0 +1,64 @@
+"""Packed DECODE-like batches through ffpa_attn_varlen_func: one query token per sequence, ragged KV lengths — what continuous batching produces.
+The packed kernel runs its 128-row prefill tile on them (one workgroup per (sequence, head) walks that sequence's keys): this prints what that
+sustains next to (a) the same batch as a loop of dense decode calls (split-KV kernels, one launch pair per sequence) and (b) the HBM bytes the
+batch has to read.  Developer tool (tools/visits/): python tools/gpu_varlen_decode.py"""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from ffpa_attn_amd import ffpa_attn_varlen_func, hip  # noqa: E402
+
+
+def timeit(fn, reps=30, warm=5):
+  for _ in range(warm):
+    fn()
+  torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(reps):
+    fn()
+  e1.record()
+  torch.cuda.synchronize()
+  return e0.elapsed_time(e1) / reps
+
+
+def main():
+  torch.manual_seed(0)
+  rng = np.random.default_rng(0)
+  for nseq, hq, hkv, d, nq in ((32, 32, 32, 512, 1), (32, 32, 8, 512, 1), (8, 32, 32, 512, 1), (64, 32, 8, 320, 1), (16, 32, 8, 512, 16)):
+    lens_k = [int(x) for x in rng.integers(1024, 16384, size=nseq)]
+    lens_q = [nq] * nseq
+    tq, tk = sum(lens_q), sum(lens_k)
+    q = torch.randn(tq, hq, d, dtype=torch.bfloat16, device="cuda")
+    k = torch.randn(tk, hkv, d, dtype=torch.bfloat16, device="cuda")
+    v = torch.randn(tk, hkv, d, dtype=torch.bfloat16, device="cuda")
+    cu_q = torch.tensor([0, *np.cumsum(lens_q).tolist()], dtype=torch.int32, device="cuda")
+    cu_k = torch.tensor([0, *np.cumsum(lens_k).tolist()], dtype=torch.int32, device="cuda")
+    bq, bk = np.cumsum([0, *lens_q]), np.cumsum([0, *lens_k])
+    gqa = hq != hkv
+
+    def packed():
+      return ffpa_attn_varlen_func(q, k, v, cu_q, cu_k, nq, max(lens_k), causal=True, enable_gqa=gqa)
+
+    def seq(t, a, b):
+      return t[a:b].transpose(0, 1).unsqueeze(0)
+
+    def loop():
+      # (the op, not ffpa_attn_func: the public entry point sends 8 <= Nq < 512 to SDPA like the reference does — whose is_causal is top-left aligned)
+      return [hip.ffpa_attn_forward_hip(seq(q, bq[i], bq[i + 1]), seq(k, bk[i], bk[i + 1]), seq(v, bk[i], bk[i + 1]), None, causal=True, softmax_scale=d ** -0.5)[0] for i in range(nseq)]
+
+    o = packed()
+    ref = loop()
+    err = max((o[bq[i]:bq[i + 1]].float() - ref[i][0].transpose(0, 1).float()).abs().max().item() for i in range(nseq))
+    t_p, t_l = timeit(packed), timeit(loop, reps=5, warm=2)
+    kv_bytes = 2 * tk * hkv * d * 2
+    print(f"VARLENDECODE {nseq} seqs x Nq {nq}, KV {min(lens_k)} ... {max(lens_k)} (sum {tk}), Hq {hq} Hkv {hkv} D {d}: packed {t_p * 1e3:8.1f} us = {kv_bytes / t_p / 1e9:6.2f} TB/s of K + V | "
+          f"loop of {nseq} dense decode calls {t_l * 1e3:8.1f} us = {kv_bytes / t_l / 1e9:6.2f} TB/s | max abs diff {err:.2e}", flush=True)
+
+
+if __name__ == "__main__":
+  main()
