@@ -824,6 +824,7 @@ namespace {
 struct VarlenPlan {
   const VarlenEntry* ve;
   int br, bc, nqt;
+  int pack;  // > 0: decode batch under GQA — the query heads of a KV group are the rows of the tile (VarlenArgs::pack)
   int64_t grid;
 };
 
@@ -850,8 +851,12 @@ int varlen_plan(const ffpa_varlen_fwd_params* p, VarlenPlan* out) {
   out->ve = ve;
   out->br = 128 / (dk <= 512 ? 1 : 2);
   out->bc = ffpa::m16_block_keys(dk, false);
-  out->nqt = (p->max_seqlen_q + out->br - 1) / out->br;
-  out->grid = (int64_t)p->batch * p->heads_q * out->nqt;
+  // decode batches (at most one query token per sequence) under GQA: the group's heads ride in the rows of ONE tile per (sequence, KV head) — the K / V stream
+  // of a group is read once, not once per query head.  (More tokens per sequence would need rows (token, head) that are not evenly spaced in a THD tensor.)
+  const int group = p->heads_q / p->heads_kv;
+  out->pack = (p->max_seqlen_q == 1 && group > 1 && group <= out->br && !(p->flags & FFPA_FLAG_NO_PACK_GQA)) ? group : 0;
+  out->nqt = out->pack ? 1 : (p->max_seqlen_q + out->br - 1) / out->br;
+  out->grid = (int64_t)p->batch * (out->pack ? p->heads_kv : p->heads_q) * out->nqt;
   if (out->grid > 0x7fffffffLL) return fail(FFPA_ERR_BAD_SHAPE, "grid of %lld workgroups is too large", (long long)out->grid);
   return FFPA_OK;
 }
@@ -946,6 +951,18 @@ int ffpa_attn_varlen_fwd(const ffpa_varlen_fwd_params* p, void* stream) {
   // eight XCDs: Hq / 8 consecutive heads per chunk puts the same heads of every sequence on every XCD (balance) and, under GQA, heads that share a K / V
   // stream next to each other (ffpa_fwd_m16_varlen_kernel); head counts that are not a multiple of 8 fall back to head-major order
   va.head_chunk = (p->heads_q % 8 == 0) ? p->heads_q / 8 : 1;
+  va.pack = pl.pack;
+  va.q_tok_stride = p->q_stride[0];
+  va.o_tok_stride = p->o_stride[0];
+  if (pl.pack) {
+    // FwdArgs describes Hkv heads of `pack` rows: head stride = one KV group, row stride = one query head
+    a.Hq = p->heads_kv;
+    a.group = 1;
+    a.sq[1] = p->q_stride[1] * pl.pack, a.sq[2] = p->q_stride[1];
+    a.so[1] = p->o_stride[1] * pl.pack, a.so[2] = p->o_stride[1];
+    a.causal = 0;
+    va.head_chunk = (p->heads_kv % 8 == 0) ? p->heads_kv / 8 : 1;
+  }
 
   const int st = pl.ve->launch(p->dtype, a, va, static_cast<hipStream_t>(stream));
   if (st == -2) return fail(FFPA_ERR_LAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed (is this a gfx950?)");
@@ -971,7 +988,7 @@ int ffpa_attn_varlen_fwd_kernel(const ffpa_varlen_fwd_params* params, char* buf,
   const int rc = varlen_plan(params, &pl);
   if (rc != FFPA_OK) return rc;
   if (buf == nullptr || n == 0) return fail(FFPA_ERR_NULL_POINTER, "buf is NULL");
-  snprintf(buf, n, "ffpa_fwd_m16_varlen_kernel<%s, %d>", params->dtype == FFPA_DTYPE_BF16 ? "bf16" : "fp16", pl.ve->d);
+  snprintf(buf, n, "ffpa_fwd_m16_varlen_kernel<%s, %d>%s", params->dtype == FFPA_DTYPE_BF16 ? "bf16" : "fp16", pl.ve->d, pl.pack ? " (GQA heads packed into rows)" : "");
   return FFPA_OK;
 }
 

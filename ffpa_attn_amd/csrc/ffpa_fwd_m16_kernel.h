@@ -354,6 +354,12 @@ struct VarlenArgs {
   const int* cu_k;       // [batch + 1] row offsets into k / v
   int64_t lse_stride_h;  // elements between two heads of the LSE tensor (>= T_q)
   int head_chunk;        // consecutive query heads that walk a sequence side by side (the workgroup order below): a divisor of Hq
+  // DECODE batches (one query token per sequence at most) under GQA: pack > 0 = the `pack` query heads of a KV group are the ROWS of the tile — FwdArgs then
+  // describes Hkv "heads" (head stride = one KV group, row stride = one query head) and a sequence has pack rows per token: the group's K / V stream is
+  // read by ONE workgroup instead of `pack` (the reference's pack_gqa, src/ffpa_attn/cute/__init__.py:792-829; the dense path packs the same way for
+  // Nq <= 7: hip/__init__.py).  A token's base address is its row offset times the TOKEN stride below, not the (head) row stride.  0 = rows are tokens.
+  int pack;
+  int64_t q_tok_stride, o_tok_stride;  // elements between two tokens of q / o
 };
 
 template <typename T, int D>
@@ -379,20 +385,21 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_varlen_kernel(const FwdArgs 
   if (a_in.causal) qt = a_in.nqt - 1 - qt;  // longest rows first
   const int bh = seq * a_in.Hq + chunk * va.head_chunk + (in_seq - (in_seq / va.head_chunk) * va.head_chunk);
   const int q_lo = va.cu_q[seq], k_lo = va.cu_k[seq];
-  const int nq_seq = va.cu_q[seq + 1] - q_lo, nkv_seq = va.cu_k[seq + 1] - k_lo;
+  const int ntok_seq = va.cu_q[seq + 1] - q_lo, nkv_seq = va.cu_k[seq + 1] - k_lo;
+  const int nq_seq = va.pack ? (ntok_seq > 0 ? va.pack : 0) : ntok_seq;  // (packed decode: the rows of a sequence are the group's heads of its one token)
   if (qt * BR >= nq_seq) return;  // (max_seqlen_q sized the grid: this sequence is shorter)
   FwdArgs a = a_in;  // (batch strides are zero: the launch side)
   a.Nq = nq_seq;
   a.Nkv = nkv_seq > 0 ? nkv_seq : 0;
-  a.causal_offset = a.Nkv - nq_seq;
-  a.q = (const T*)a_in.q + (int64_t)q_lo * a_in.sq[2];
-  a.o = (T*)a_in.o + (int64_t)q_lo * a_in.so[2];
+  a.causal_offset = a.Nkv - nq_seq;  // (packed decode runs without the causal flag: a single token sees every key of its sequence)
+  a.q = (const T*)a_in.q + (int64_t)q_lo * va.q_tok_stride;
+  a.o = (T*)a_in.o + (int64_t)q_lo * va.o_tok_stride;
   a.k = (const T*)a_in.k + (int64_t)k_lo * a_in.sk[2];
   a.v = (const T*)a_in.v + (int64_t)k_lo * a_in.sv[2];
 #define FFPA_M16_TILE_DONE return
 #define FFPA_M16_ROW_INV(l) ((l) > 0.f ? __builtin_amdgcn_rcpf(l) : 0.f)
 #define FFPA_M16_ROW_OUT(x, rh) (l_tot[rh] > 0.f ? (T)((x) * inv[rh]) : (T)0.f)  // (the select BEHIND product + conversion: those stay the dense kernel's one instruction — fp16: v_fma_mixlo, one rounding — and its bits)
-#define FFPA_M16_LSE_INDEX(row) (int64_t)hq * va.lse_stride_h + q_lo + (row)
+#define FFPA_M16_LSE_INDEX(row) (va.pack ? (int64_t)(hq * va.pack + (row)) * va.lse_stride_h + q_lo : (int64_t)hq * va.lse_stride_h + q_lo + (row))
 #include "ffpa_fwd_m16_tile.inc"
 #undef FFPA_M16_LSE_INDEX
 #undef FFPA_M16_ROW_OUT

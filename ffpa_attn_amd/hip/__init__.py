@@ -59,6 +59,7 @@ FLAG_WIDE_TILE = 0x1000     # bench / test: prefill launches take the wide-row t
 FLAG_NO_WIDE_TILE = 0x2000  # bench / test: never
 FLAG_PAIR_TILES = 0x8000      # bench / test: causal prefill launches pair row tiles i and n - 1 - i in one workgroup (default: the library decides)
 FLAG_NO_PAIR_TILES = 0x20000  # bench / test: never
+FLAG_NO_PACK_GQA = 0x40000  # bench / test, packed-sequence call: decode batches under GQA keep one workgroup per QUERY head (default: a KV group's heads are the rows of one tile)
 FLAG_DETERMINISTIC = 0x4000  # batch-invariant bits: no prefill KV splits, no wide-row tile, short-query splits by the KV length alone (FFPA_HIP_DETERMINISTIC=1 sets it on every call)
 
 
@@ -917,7 +918,7 @@ def varlen_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens
 
 
 def varlen_launch_plan(batch: int, heads_q: int, heads_kv: int, max_seqlen_q: int, max_seqlen_k: int, head_dim: int, *,
-                       dtype: torch.dtype = torch.bfloat16, causal: bool = False) -> dict:
+                       dtype: torch.dtype = torch.bfloat16, causal: bool = False, flags: int = 0) -> dict:
   """The packed-sequence launch for a shape class, without launching (placeholder pointers): row tiles per (sequence, head), tile, workgroups, kernel name."""
   lib = load_library()
   d8 = (int(head_dim) + 7) // 8 * 8
@@ -933,6 +934,7 @@ def varlen_launch_plan(batch: int, heads_q: int, heads_kv: int, max_seqlen_q: in
   p.causal = 1 if causal else 0
   p.softmax_scale = float(head_dim) ** -0.5
   p.rescale_threshold = -1.0
+  p.flags = int(flags)
   plan = (ctypes.c_int * 4)()
   rc = lib.ffpa_attn_varlen_fwd_plan(ctypes.byref(p), plan)
   if rc != 0:

@@ -77,6 +77,7 @@ enum ffpa_bias_dtype {
                                              launches never split the KV axis and never take the wide-row tile (128-row tiles, one pass per row), short-query launches
                                              split by the KV length alone (a fixed number of KV tiles per range).  Costs what the launch-size rules would have gained
                                              (under-filled / ragged-round prefill launches: up to ~ 20 %).  Python: FFPA_HIP_DETERMINISTIC=1 sets it on every call. */
+#define FFPA_FLAG_NO_PACK_GQA      0x40000u /* bench / test, ffpa_attn_varlen_fwd: decode batches (max_seqlen_q == 1) under GQA keep one workgroup per QUERY head (default: the heads of a KV group are packed into the rows of one tile) */
 #define FFPA_FLAG_XCD_GROUP(log2p1) ((unsigned)(log2p1) << 8) /* bench-only: bits 8..10 = 1 + log2 of the XCDs that share a head's row tiles (1 -> 1, 2 -> 2, 3 -> 4, 4 -> 8); 0 = the launch side decides */
 
 /*
@@ -236,6 +237,8 @@ int ffpa_attn_mask_kv_bounds(const void* bias, int bias_dtype, const int64_t bia
  * synchronises and captures into a HIP graph): the grid holds ceil(max_seqlen_q / block rows) row tiles per (sequence,
  * head), workgroups whose tile lies past their sequence's last row leave at once.  max_seqlen_q must be >= every
  * sequence's query length (rows past it would not be computed); max_seqlen_kv is only a hint for the launch side.
+ * Decode batches — max_seqlen_q == 1 — under GQA run with the query heads of a KV group packed into the rows of one tile per
+ * (sequence, KV head): the group's K / V are read once (the reference's pack_gqa, cute/__init__.py:792-829).
  * Per sequence the arithmetic is the dense call's (same tile, same recurrence: bit-identical to ffpa_attn_fwd on that
  * sequence alone under FFPA_FLAG_DETERMINISTIC).  causal = the reference's tail-aligned mask PER SEQUENCE: row r of
  * sequence i sees key j iff j <= r + (Nkv_i - Nq_i).  Rows without a visible key (an empty key range; the first
@@ -273,7 +276,7 @@ typedef struct ffpa_varlen_fwd_params {
 
   float softmax_scale;     /* > 0 or < 0 or 0: as ffpa_fwd_params */
   float rescale_threshold; /* as ffpa_fwd_params: < 0 => 8.0 */
-  uint32_t flags;          /* FFPA_FLAG_NO_XCD_REMAP, FFPA_FLAG_L2_PREFETCH / _NO_L2_PREFETCH, FFPA_FLAG_XCD_GROUP(); others ignored */
+  uint32_t flags;          /* FFPA_FLAG_NO_XCD_REMAP, FFPA_FLAG_L2_PREFETCH / _NO_L2_PREFETCH, FFPA_FLAG_XCD_GROUP(), FFPA_FLAG_NO_PACK_GQA; others ignored */
   uint32_t reserved;       /* 0 */
 } ffpa_varlen_fwd_params;
 

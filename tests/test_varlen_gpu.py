@@ -335,3 +335,27 @@ def test_randomized_packed_batches(hip):
       bc = hip.varlen_launch_plan(nseq, hq, hkv, mq, mk, d)["block_keys"]
       _check_vs_oracle(_seq(out, qs, qs + lens_q[i]), lse[:, qs:qs + lens_q[i]].unsqueeze(0), _seq(q, qs, qs + lens_q[i]), _seq(k, ks, ks + lens_k[i]),
                        _seq(v, ks, ks + lens_k[i]), causal=causal, causal_offset=lens_k[i] - lens_q[i], block_keys=bc, name=name + f" seq {i} vs oracle")
+
+
+@pytest.mark.parametrize("hq, hkv, d, dtype", [(32, 8, 512, torch.bfloat16), (16, 2, 320, torch.float16), (8, 1, 1024, torch.bfloat16), (24, 8, 128, torch.bfloat16)])
+def test_decode_batches_pack_the_heads_of_a_kv_group_into_rows(hip, hq, hkv, d, dtype):
+  """One query token per sequence (continuous-batching decode) under GQA: the launch runs one workgroup per (sequence, KV head) with the group's query heads
+  as the rows of its tile (the reference's pack_gqa) — per row the same arithmetic: bit-identical to the unpacked launch (FLAG_NO_PACK_GQA), O and LSE; against
+  SDPA per sequence; sequences without a token or without keys in between."""
+  lens_k = [700, 0, 64, 1300, 129, 2048, 1, 333]
+  lens_q = [1, 1, 0, 1, 1, 1, 1, 1]
+  q, k, v = _make(lens_q, lens_k, hq, hkv, d, dtype, seed=hq + d)
+  cu_q, cu_k = _cu(lens_q), _cu(lens_k)
+  plan = {}
+  out, lse = hip.varlen_forward(q, k, v, cu_q, cu_k, 1, max(lens_k), True, d ** -0.5, plan_out=plan)
+  assert plan["workgroups"] == len(lens_q) * hkv and "packed into rows" in plan["kernel"], plan
+  plan_u = {}
+  out_u, lse_u = hip.varlen_forward(q, k, v, cu_q, cu_k, 1, max(lens_k), True, d ** -0.5, flags=hip.FLAG_NO_PACK_GQA, plan_out=plan_u)
+  assert plan_u["workgroups"] == len(lens_q) * hq
+  assert torch.equal(out, out_u) and torch.equal(lse, lse_u)
+  _check_packed(hip, q, k, v, lens_q, lens_k, True, out, lse, oracle=False, dense_bits=False, sdpa=d <= 512, name=f"packed decode Hq{hq}/Hkv{hkv} D{d}")
+  # the oracle on the longest sequence
+  i = 5
+  qs, ks = sum(lens_q[:i]), sum(lens_k[:i])
+  _check_vs_oracle(_seq(out, qs, qs + 1), lse[:, qs:qs + 1].unsqueeze(0), _seq(q, qs, qs + 1), _seq(k, ks, ks + lens_k[i]), _seq(v, ks, ks + lens_k[i]),
+                   causal=True, causal_offset=lens_k[i] - 1, block_keys=plan["block_keys"], name="packed decode vs oracle")
