@@ -877,8 +877,8 @@ int ffpa_attn_varlen_fwd(const ffpa_varlen_fwd_params* p, void* stream) {
   if (rc != FFPA_OK) return rc;
   if (!p->q || !p->k || !p->v || !p->o) return fail(FFPA_ERR_NULL_POINTER, "q/k/v/o must be non-NULL");
   if (!p->cu_seqlens_q || !p->cu_seqlens_kv) return fail(FFPA_ERR_NULL_POINTER, "cu_seqlens_q / cu_seqlens_kv must be non-NULL");
-  if ((reinterpret_cast<uintptr_t>(p->cu_seqlens_q) & 3u) || (reinterpret_cast<uintptr_t>(p->cu_seqlens_kv) & 3u))
-    return fail(FFPA_ERR_MISALIGNED, "cu_seqlens_q / cu_seqlens_kv must be 4-byte aligned");
+  if ((reinterpret_cast<uintptr_t>(p->cu_seqlens_q) & 3u) || (reinterpret_cast<uintptr_t>(p->cu_seqlens_kv) & 3u) || (reinterpret_cast<uintptr_t>(p->seqused_kv) & 3u))
+    return fail(FFPA_ERR_MISALIGNED, "cu_seqlens_q / cu_seqlens_kv / seqused_kv must be 4-byte aligned");
   if (!aligned16(p->q) || !aligned16(p->k) || !aligned16(p->v) || !aligned16(p->o))
     return fail(FFPA_ERR_MISALIGNED, "q/k/v/o base pointers must be 16-byte aligned");
   if ((rc = check_strides2("q", p->q_stride)) || (rc = check_strides2("k", p->k_stride)) || (rc = check_strides2("v", p->v_stride)) ||
@@ -952,6 +952,7 @@ int ffpa_attn_varlen_fwd(const ffpa_varlen_fwd_params* p, void* stream) {
   // stream next to each other (ffpa_fwd_m16_varlen_kernel); head counts that are not a multiple of 8 fall back to head-major order
   va.head_chunk = (p->heads_q % 8 == 0) ? p->heads_q / 8 : 1;
   va.pack = pl.pack;
+  va.used_k = p->seqused_kv;
   va.q_tok_stride = p->q_stride[0];
   va.o_tok_stride = p->o_stride[0];
   if (pl.pack) {

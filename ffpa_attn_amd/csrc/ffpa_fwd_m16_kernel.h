@@ -360,6 +360,8 @@ struct VarlenArgs {
   // Nq <= 7: hip/__init__.py).  A token's base address is its row offset times the TOKEN stride below, not the (head) row stride.  0 = rows are tokens.
   int pack;
   int64_t q_tok_stride, o_tok_stride;  // elements between two tokens of q / o
+  const int* used_k;     // optional [batch]: sequence i uses only the first used_k[i] of its key rows (a KV cache of fixed capacity per sequence whose valid
+                         // length lives on the device: FlashAttention's seqused_k / cache_seqlens); NULL = all of cu_k[i] .. cu_k[i + 1]
 };
 
 template <typename T, int D>
@@ -385,7 +387,12 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_varlen_kernel(const FwdArgs 
   if (a_in.causal) qt = a_in.nqt - 1 - qt;  // longest rows first
   const int bh = seq * a_in.Hq + chunk * va.head_chunk + (in_seq - (in_seq / va.head_chunk) * va.head_chunk);
   const int q_lo = va.cu_q[seq], k_lo = va.cu_k[seq];
-  const int ntok_seq = va.cu_q[seq + 1] - q_lo, nkv_seq = va.cu_k[seq + 1] - k_lo;
+  const int ntok_seq = va.cu_q[seq + 1] - q_lo;
+  int nkv_seq = va.cu_k[seq + 1] - k_lo;
+  if (va.used_k != nullptr) {
+    const int used = va.used_k[seq];
+    nkv_seq = nkv_seq < used ? nkv_seq : used;
+  }
   const int nq_seq = va.pack ? (ntok_seq > 0 ? va.pack : 0) : ntok_seq;  // (packed decode: the rows of a sequence are the group's heads of its one token)
   if (qt * BR >= nq_seq) return;  // (max_seqlen_q sized the grid: this sequence is shorter)
   FwdArgs a = a_in;  // (batch strides are zero: the launch side)

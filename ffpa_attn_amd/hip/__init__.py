@@ -129,6 +129,7 @@ class FfpaVarlenFwdParams(ctypes.Structure):
     ("lse", ctypes.c_void_p),
     ("cu_seqlens_q", ctypes.c_void_p),
     ("cu_seqlens_kv", ctypes.c_void_p),
+    ("seqused_kv", ctypes.c_void_p),
     ("batch", ctypes.c_int32),
     ("heads_q", ctypes.c_int32),
     ("heads_kv", ctypes.c_int32),
@@ -838,13 +839,14 @@ def _packed_rows(t: torch.Tensor) -> torch.Tensor:
 
 
 def _varlen_params(q, k, v, o, lse, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, max_seqlen_k: int, causal: bool, softmax_scale: float,
-                   rescale_threshold: float, flags: int) -> FfpaVarlenFwdParams:
+                   rescale_threshold: float, flags: int, seqused_k=None) -> FfpaVarlenFwdParams:
   p = FfpaVarlenFwdParams()
   p.struct_size = ctypes.sizeof(FfpaVarlenFwdParams)
   p.abi_version = ABI_VERSION
   p.q, p.k, p.v, p.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
   p.lse = lse.data_ptr() if lse is not None else None
   p.cu_seqlens_q, p.cu_seqlens_kv = cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr()
+  p.seqused_kv = seqused_k.data_ptr() if seqused_k is not None else None
   p.batch = cu_seqlens_q.numel() - 1
   p.heads_q, p.heads_kv, p.head_dim = q.size(1), k.size(1), q.size(2)
   p.max_seqlen_q, p.max_seqlen_kv = int(max_seqlen_q), int(max_seqlen_k)
@@ -861,10 +863,15 @@ def _varlen_params(q, k, v, o, lse, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: in
 
 def varlen_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens_q: torch.Tensor, cu_seqlens_k: torch.Tensor, max_seqlen_q: int,
                    max_seqlen_k: int, causal: bool, softmax_scale: float, *, rescale_threshold: float = -1.0, return_lse: bool = True, flags: int = 0,
-                   plan_out: "dict | None" = None):
+                   plan_out: "dict | None" = None, seqused_k: "torch.Tensor | None" = None):
   """One launch of the packed-sequence kernel: ``q [T_q, Hq, D]``, ``k`` / ``v [T_k, Hkv, D]``, int32 device ``cu_seqlens_*`` ``[B + 1]`` ->
   ``(o [T_q, Hq, D], lse [Hq, T_q] fp32 | None)``.  Nothing is read back to the host and nothing synchronises: the call captures into a HIP graph.
-  Rows without a visible key: O = 0, LSE = -inf."""
+  Rows without a visible key: O = 0, LSE = -inf.
+
+  ``seqused_k`` (int32 device ``[B]``, this build's extension at the op level — the public ``ffpa_attn_varlen_func`` rejects it like the reference's): sequence i
+  uses only the first ``seqused_k[i]`` of its key rows — a KV cache of fixed capacity per sequence (``k`` / ``v`` = the cache viewed as ``[B * capacity, Hkv, D]``,
+  ``cu_seqlens_k`` = multiples of the capacity) whose valid lengths live on the device: ONE captured graph serves every length, a replay follows lengths written
+  in place, and with one token per sequence under GQA the group's heads are packed into the rows of one tile (FlashAttention's ``cache_seqlens`` decode)."""
   if not q.is_cuda:
     raise NotImplementedError(f"ffpa_attn::_varlen_fwd_hip has no implementation for device '{q.device.type}' (the HIP kernel needs a GPU tensor)")
   lib = load_library()
@@ -883,6 +890,10 @@ def varlen_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens
       raise ValueError(f"ffpa_attn::_varlen_fwd_hip: {name} must be on q's device, got {cu.device} and {q.device}")
   if cu_seqlens_q.numel() != cu_seqlens_k.numel():
     raise ValueError("ffpa_attn::_varlen_fwd_hip: cu_seqlens_q and cu_seqlens_k must have one length")
+  if seqused_k is not None:
+    if seqused_k.dtype != torch.int32 or seqused_k.dim() != 1 or seqused_k.numel() != cu_seqlens_k.numel() - 1 or seqused_k.device != q.device:
+      raise ValueError("ffpa_attn::_varlen_fwd_hip: seqused_k must be a 1-D int32 tensor of length batch on q's device")
+    seqused_k = seqused_k.contiguous()
   if k.device != q.device or v.device != q.device:
     raise ValueError(f"ffpa_attn::_varlen_fwd_hip: q/k/v must be on one device, got {q.device}, {k.device}, {v.device}")
   Tq, Hq, D = q.shape
@@ -899,7 +910,7 @@ def varlen_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens
   lse = torch.empty((Hq, Tq), dtype=torch.float32, device=q.device) if return_lse else None
   if Tq == 0 or max_seqlen_q <= 0:
     return (o[..., :D] if Dp != D else o), lse  # (nothing to compute: no query row in any sequence)
-  p = _varlen_params(q, k, v, o, lse, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal, softmax_scale, rescale_threshold, flags)
+  p = _varlen_params(q, k, v, o, lse, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal, softmax_scale, rescale_threshold, flags, seqused_k)
   with torch.cuda.device(q.device):
     stream = torch.cuda.current_stream(q.device).cuda_stream
     if plan_out is not None:
@@ -947,17 +958,17 @@ def varlen_launch_plan(batch: int, heads_q: int, heads_kv: int, max_seqlen_q: in
 torch.library.define(
   f"{_OP_NAMESPACE}::_varlen_fwd_hip",
   "(Tensor q, Tensor k, Tensor v, Tensor cu_seqlens_q, Tensor cu_seqlens_k, int max_seqlen_q, int max_seqlen_k, "
-  "float softmax_scale, int causal, float rescale_threshold=-1.0) -> (Tensor o, Tensor softmax_lse)",
+  "float softmax_scale, int causal, float rescale_threshold=-1.0, Tensor? seqused_k=None) -> (Tensor o, Tensor softmax_lse)",
 )
 
 
 @torch.library.impl(f"{_OP_NAMESPACE}::_varlen_fwd_hip", "CUDA")  # ROCm tensors dispatch on the CUDA key
-def _varlen_fwd_hip_torch_op(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, softmax_scale, causal, rescale_threshold=-1.0):
+def _varlen_fwd_hip_torch_op(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, softmax_scale, causal, rescale_threshold=-1.0, seqused_k=None):
   return varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, bool(causal), softmax_scale,
-                        rescale_threshold=rescale_threshold, return_lse=True)
+                        rescale_threshold=rescale_threshold, return_lse=True, seqused_k=seqused_k)
 
 
 @torch.library.register_fake(f"{_OP_NAMESPACE}::_varlen_fwd_hip")
-def _varlen_fwd_hip_fake(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, softmax_scale, causal, rescale_threshold=-1.0):
+def _varlen_fwd_hip_fake(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, softmax_scale, causal, rescale_threshold=-1.0, seqused_k=None):
   total_q, heads, head_dim = q.shape
   return q.new_empty((total_q, heads, head_dim)), q.new_empty((heads, total_q), dtype=torch.float32)

@@ -257,6 +257,9 @@ typedef struct ffpa_varlen_fwd_params {
   float* lse; /* optional */
   const int32_t* cu_seqlens_q;  /* device, [batch + 1] */
   const int32_t* cu_seqlens_kv; /* device, [batch + 1] */
+  const int32_t* seqused_kv;    /* optional, device, [batch]: sequence i uses only its first seqused_kv[i] key rows (clamped to its range) — a KV cache of
+                                   fixed capacity per sequence (cu_seqlens_kv = multiples of the capacity) whose valid lengths live on the device and change
+                                   between HIP-graph replays; FlashAttention's seqused_k / cache_seqlens.  NULL = every key row of the range */
 
   int32_t batch;          /* sequences */
   int32_t heads_q;        /* Hq  */

@@ -359,3 +359,49 @@ def test_decode_batches_pack_the_heads_of_a_kv_group_into_rows(hip, hq, hkv, d, 
   qs, ks = sum(lens_q[:i]), sum(lens_k[:i])
   _check_vs_oracle(_seq(out, qs, qs + 1), lse[:, qs:qs + 1].unsqueeze(0), _seq(q, qs, qs + 1), _seq(k, ks, ks + lens_k[i]), _seq(v, ks, ks + lens_k[i]),
                    causal=True, causal_offset=lens_k[i] - 1, block_keys=plan["block_keys"], name="packed decode vs oracle")
+
+
+def test_static_capacity_kv_cache_with_device_side_lengths(hip):
+  """seqused_k (the op-level extension): a KV cache of fixed capacity per sequence, viewed as packed rows, whose valid lengths live on the device — equal, bit for
+  bit, to the call on the tightly packed valid rows; ONE captured graph follows lengths rewritten in place; decode under GQA runs packed (one workgroup per
+  (sequence, KV head)).  Rows of the cache past a sequence's length are NaN: nothing may read them."""
+  b, cap, hq, hkv, d = 6, 1536, 16, 4, 512
+  g = torch.Generator(device="cuda").manual_seed(11)
+  cache_k = torch.randn((b, cap, hkv, d), dtype=torch.bfloat16, device="cuda", generator=g)
+  cache_v = torch.randn((b, cap, hkv, d), dtype=torch.bfloat16, device="cuda", generator=g)
+  q = torch.randn((b, hq, d), dtype=torch.bfloat16, device="cuda", generator=g)  # one token per sequence
+  cu_q = _cu([1] * b)
+  cu_k = torch.arange(0, (b + 1) * cap, cap, dtype=torch.int32, device="cuda")
+  used = torch.zeros(b, dtype=torch.int32, device="cuda")
+
+  def poisoned(lens):
+    k, v = cache_k.clone(), cache_v.clone()
+    for i, n in enumerate(lens):
+      k[i, n:], v[i, n:] = float("nan"), float("nan")
+    return k.view(b * cap, hkv, d), v.view(b * cap, hkv, d)
+
+  graph = out = lse = None
+  kk, vv = poisoned([cap] * b)
+  for lens in ([1536, 1, 700, 64, 0, 1000], [5, 1536, 129, 640, 33, 1]):
+    kp, vp = poisoned(lens)
+    kk.copy_(kp), vv.copy_(vp)
+    used.copy_(torch.tensor(lens, dtype=torch.int32))
+    if graph is None:
+      plan = {}
+      hip.varlen_forward(q, kk, vv, cu_q, cu_k, 1, cap, True, d ** -0.5, seqused_k=used, plan_out=plan)  # (warm-up outside the capture)
+      assert plan["workgroups"] == b * hkv and "packed into rows" in plan["kernel"]
+      graph = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(graph):
+        out, lse = hip.varlen_forward(q, kk, vv, cu_q, cu_k, 1, cap, True, d ** -0.5, seqused_k=used)
+    graph.replay()
+    torch.cuda.synchronize()
+    tight_k = torch.cat([cache_k[i, :n] for i, n in enumerate(lens)]).contiguous()
+    tight_v = torch.cat([cache_v[i, :n] for i, n in enumerate(lens)]).contiguous()
+    ref, ref_lse = hip.varlen_forward(q, tight_k, tight_v, cu_q, _cu(lens), 1, max(lens), True, d ** -0.5)
+    assert torch.equal(out, ref) and torch.equal(lse, ref_lse), lens
+    _check_packed(hip, q, tight_k, tight_v, [1] * b, lens, True, out, lse, oracle=False, dense_bits=False, name=f"cache lens {lens}")
+  # the public entry point keeps the reference's refusal of this option
+  from ffpa_attn_amd import ffpa_attn_varlen_func
+
+  with pytest.raises(NotImplementedError, match="unsupported options: seqused_k"):
+    ffpa_attn_varlen_func(q, kk, vv, cu_q, cu_k, 1, cap, seqused_k=used)
