@@ -81,6 +81,8 @@ struct Plan {
   int bias_raw;  // FwdArgs.bias_cache_raw
   int bias_lds;  // FwdArgs.bias_lds: > 0 bytes of the key-bias row cache, < 0 -(bytes of the bias-tile staging areas), 0 neither
   int pair;      // 1: row tiles i and nqt - 1 - i share a workgroup (FwdArgs.pair_tiles): the grid holds (nqt + 1) / 2 workgroups per (batch, head)
+  int chunk;     // > 1: a causal GQA launch in the HEAD-CHUNK order — (head chunk, batch, row tile, head in chunk), chunks of this many heads of one KV group: the same row
+                 //      tile of the group's heads runs at the same time on the same keys (ffpa_fwd_m16_varlen_kernel in its dense mode: the packed-sequence kernel's order)
   size_t ws_bytes;
 };
 
@@ -443,6 +445,27 @@ bool pick_pair_tiles(const ffpa_fwd_params* p, const Plan& pl) {
   return pl.nqt <= kT.pair_max_row_tiles && 2 * lo <= hi;
 }
 
+// Heads that walk a sequence side by side in the head-chunk order: the largest divisor of the KV group's size that leaves a multiple of eight chunks (every XCD
+// then owns whole chunks of every batch element / sequence: balance); 1 = plain head-major order.
+int pick_head_chunk(int heads_q, int group) {
+  for (int c = group; c > 1; --c)
+    if (group % c == 0 && heads_q % c == 0 && (heads_q / c) % 8 == 0) return c;
+  return 1;
+}
+
+// Causal GQA launches in the head-chunk order (round 6: found on the packed-sequence kernel, whose order it is).  A head's row tiles alone fill an XCD for a round,
+// so in the dense order the heads of a KV group stream the group's K / V one after the other; interleaved per row tile they stream it together.  Same tile, same
+// bits; interleaved same-run A/B of the two orders on dense shapes (tools/gpu_dense_vs_packed.py, profiles/r06_head_chunks.txt): Hq 32 / Hkv 8 N 8192 causal D 512
+// + 3.2 %, D 1024 + 4.3 %, D 320 + 2.8 %, B 2 N 4096 + 1.2 %, B 4 N 2048 + 1.8 % (over the paired-tile launch); non-causal +- 0; MHA - 3.7 % with chunks of 4 heads
+// (four K / V streams at once instead of one) -> chunks never span KV groups.  Builds without bias / mask ranges / dropout; every row must see a key (the kernel's
+// empty-row contract is the packed call's: 0, not SDPA's NaN).
+int pick_dense_head_chunk(const ffpa_fwd_params* p, const Plan& pl, int dk) {
+  if (!pl.m16 || pl.wide || pl.splits != 1 || pl.mk != 0 || !p->causal || p->causal_offset < 0 || p->causal_row_mod != 0 || p->dropout_p > 0.f || dk < FFPA_M16_MIN_D) return 1;
+  if (p->flags & (FFPA_FLAG_NO_HEAD_CHUNKS | FFPA_FLAG_DEBUG_SAFE_PATH | FFPA_FLAG_PAIR_TILES)) return 1;
+  if (p->lse != nullptr && (int64_t)p->batch * p->heads_q * p->seqlen_q >= (1LL << 31)) return 1;
+  return pick_head_chunk(p->heads_q, p->heads_q / p->heads_kv);
+}
+
 // Launch plan: tile variant -> wide-row tile? -> KV splits (rules above) -> build and bias placement -> scratch.
 Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
   Plan pl = {};
@@ -461,7 +484,8 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
   pl.m16 = (pl.variant == 0 && !(p->flags & FFPA_FLAG_DEBUG_SAFE_PATH) && c.dk >= FFPA_M16_MIN_D) ? 1 : 0;
   if (pl.m16) pick_m16_build(p, de, pl, c.dk);
   pick_small_d_bias_tiles(p, de, pl);
-  pl.pair = pick_pair_tiles(p, pl) ? 1 : 0;
+  pl.chunk = pick_dense_head_chunk(p, pl, c.dk);
+  pl.pair = (pl.chunk <= 1 && pick_pair_tiles(p, pl)) ? 1 : 0;
   pl.tiles_per_split = (pl.nt + pl.splits - 1) / pl.splits;
   if (pl.tiles_per_split < 1) pl.tiles_per_split = 1;
   pl.splits = (pl.nt + pl.tiles_per_split - 1) / pl.tiles_per_split;
@@ -705,7 +729,19 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
     a.tickets = pl.variant == 1 ? p->split_tickets : nullptr;
   }
 
-  int st = de->launch(p->dtype, safe, pl.wide ? 3 : pl.variant, a, static_cast<hipStream_t>(stream));
+  int st;
+  if (pl.chunk > 1) {
+    // the packed-sequence kernel in its dense mode (no boundary arrays): this launch's FwdArgs as they are, that kernel's workgroup order
+    ffpa::VarlenArgs va;
+    memset(&va, 0, sizeof(va));
+    va.lse_stride_h = p->seqlen_q;
+    va.head_chunk = pl.chunk;
+    st = -3;
+    for (const VarlenEntry& e : kVarlenDims)
+      if (e.d == kernel_head_dim(p->head_dim)) st = e.launch(p->dtype, a, va, static_cast<hipStream_t>(stream));
+  } else {
+    st = de->launch(p->dtype, safe, pl.wide ? 3 : pl.variant, a, static_cast<hipStream_t>(stream));
+  }
   if (st == 0 && pl.splits > 1 && a.tickets == nullptr) {
     const unsigned rows = (unsigned)((int64_t)p->batch * p->heads_q * p->seqlen_q);
     if (p->dtype == FFPA_DTYPE_BF16)
@@ -808,6 +844,8 @@ int ffpa_attn_fwd_kernel(const ffpa_fwd_params* params, char* buf, size_t n) {
   const char* merge = pl.splits > 1 ? ((params->split_tickets != nullptr && pl.variant == 1) ? " (in-launch split merge)" : " + ffpa_fwd_merge_kernel") : "";
   if (pl.wide) {
     snprintf(buf, n, "ffpa_fwd_m16w_kernel<%s, %d, RH=%d, MK=%d>%s", dt, de->d, pl.br / 64, pl.mk, merge);
+  } else if (pl.chunk > 1) {
+    snprintf(buf, n, "ffpa_fwd_m16_varlen_kernel<%s, %d> (dense launch, head chunks of %d)", dt, de->d, pl.chunk);
   } else if (pl.m16) {
     snprintf(buf, n, "ffpa_fwd_m16_kernel<%s, %d, MK=%d, DROP=%d%s>%s", dt, de->d, pl.mk, drop, pl.pair ? ", PAIR" : "", merge);
   } else {
@@ -948,9 +986,9 @@ int ffpa_attn_varlen_fwd(const ffpa_varlen_fwd_params* p, void* stream) {
   va.cu_q = p->cu_seqlens_q;
   va.cu_k = p->cu_seqlens_kv;
   va.lse_stride_h = p->lse_stride_head;
-  // eight XCDs: Hq / 8 consecutive heads per chunk puts the same heads of every sequence on every XCD (balance) and, under GQA, heads that share a K / V
-  // stream next to each other (ffpa_fwd_m16_varlen_kernel); head counts that are not a multiple of 8 fall back to head-major order
-  va.head_chunk = (p->heads_q % 8 == 0) ? p->heads_q / 8 : 1;
+  // heads of one KV group that walk a sequence side by side (ffpa_fwd_m16_varlen_kernel; pick_head_chunk: whole chunks per XCD, never across KV groups — MHA and
+  // head counts that do not divide into eight chunks run plain head-major order)
+  va.head_chunk = pick_head_chunk(p->heads_q, p->heads_q / p->heads_kv);
   va.pack = pl.pack;
   va.used_k = p->seqused_kv;
   va.q_tok_stride = p->q_stride[0];
@@ -962,7 +1000,7 @@ int ffpa_attn_varlen_fwd(const ffpa_varlen_fwd_params* p, void* stream) {
     a.sq[1] = p->q_stride[1] * pl.pack, a.sq[2] = p->q_stride[1];
     a.so[1] = p->o_stride[1] * pl.pack, a.so[2] = p->o_stride[1];
     a.causal = 0;
-    va.head_chunk = (p->heads_kv % 8 == 0) ? p->heads_kv / 8 : 1;
+    va.head_chunk = 1;  // (the rows of a tile ARE the group: KV heads share nothing)
   }
 
   const int st = pl.ve->launch(p->dtype, a, va, static_cast<hipStream_t>(stream));

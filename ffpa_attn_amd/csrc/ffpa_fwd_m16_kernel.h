@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_pair_kernel(const FwdArgs a)
 // Nq_i - Nkv_i rows of a sequence with more queries than keys) come out as O = 0, LSE = -inf: the reference's contract for this entry point
 // (tests/test_ffpa_cute_sm100.py:1117-1183), where the dense kernel keeps SDPA's NaN.
 struct VarlenArgs {
-  const int* cu_q;       // [batch + 1] row offsets into q / o
+  const int* cu_q;       // [batch + 1] row offsets into q / o.  NULL = a DENSE launch that only borrows this kernel's workgroup order (see the kernel)
   const int* cu_k;       // [batch + 1] row offsets into k / v
   int64_t lse_stride_h;  // elements between two heads of the LSE tensor (>= T_q)
   int head_chunk;        // consecutive query heads that walk a sequence side by side (the workgroup order below): a divisor of Hq
@@ -386,23 +386,32 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_varlen_kernel(const FwdArgs 
   int qt = in_seq / va.head_chunk;
   if (a_in.causal) qt = a_in.nqt - 1 - qt;  // longest rows first
   const int bh = seq * a_in.Hq + chunk * va.head_chunk + (in_seq - (in_seq / va.head_chunk) * va.head_chunk);
-  const int q_lo = va.cu_q[seq], k_lo = va.cu_k[seq];
-  const int ntok_seq = va.cu_q[seq + 1] - q_lo;
-  int nkv_seq = va.cu_k[seq + 1] - k_lo;
-  if (va.used_k != nullptr) {
-    const int used = va.used_k[seq];
-    nkv_seq = nkv_seq < used ? nkv_seq : used;
+  FwdArgs a = a_in;
+  int q_lo;  // packed: the sequence's first row of q / o (LSE [Hq, T_q]: its column); dense: the batch element's first LSE row
+  if (va.cu_q == nullptr) {
+    // DENSE launches in this kernel's workgroup order (ffpa_attn_fwd -> ffpa_capi.hip: causal + GQA, no bias, no dropout, every row sees a key): the
+    // arguments are the dense call's as they are — "sequence" = batch element, batch strides live —, only the order of the workgroups is this kernel's
+    q_lo = seq * a_in.Hq * a_in.Nq;
+  } else {
+    q_lo = va.cu_q[seq];
+    const int k_lo = va.cu_k[seq];
+    const int ntok_seq = va.cu_q[seq + 1] - q_lo;
+    int nkv_seq = va.cu_k[seq + 1] - k_lo;
+    if (va.used_k != nullptr) {
+      const int used = va.used_k[seq];
+      nkv_seq = nkv_seq < used ? nkv_seq : used;
+    }
+    const int nq_seq = va.pack ? (ntok_seq > 0 ? va.pack : 0) : ntok_seq;  // (packed decode: the rows of a sequence are the group's heads of its one token)
+    if (qt * BR >= nq_seq) return;  // (max_seqlen_q sized the grid: this sequence is shorter)
+    // (batch strides are zero: the launch side)
+    a.Nq = nq_seq;
+    a.Nkv = nkv_seq > 0 ? nkv_seq : 0;
+    a.causal_offset = a.Nkv - nq_seq;  // (packed decode runs without the causal flag: a single token sees every key of its sequence)
+    a.q = (const T*)a_in.q + (int64_t)q_lo * va.q_tok_stride;
+    a.o = (T*)a_in.o + (int64_t)q_lo * va.o_tok_stride;
+    a.k = (const T*)a_in.k + (int64_t)k_lo * a_in.sk[2];
+    a.v = (const T*)a_in.v + (int64_t)k_lo * a_in.sv[2];
   }
-  const int nq_seq = va.pack ? (ntok_seq > 0 ? va.pack : 0) : ntok_seq;  // (packed decode: the rows of a sequence are the group's heads of its one token)
-  if (qt * BR >= nq_seq) return;  // (max_seqlen_q sized the grid: this sequence is shorter)
-  FwdArgs a = a_in;  // (batch strides are zero: the launch side)
-  a.Nq = nq_seq;
-  a.Nkv = nkv_seq > 0 ? nkv_seq : 0;
-  a.causal_offset = a.Nkv - nq_seq;  // (packed decode runs without the causal flag: a single token sees every key of its sequence)
-  a.q = (const T*)a_in.q + (int64_t)q_lo * va.q_tok_stride;
-  a.o = (T*)a_in.o + (int64_t)q_lo * va.o_tok_stride;
-  a.k = (const T*)a_in.k + (int64_t)k_lo * a_in.sk[2];
-  a.v = (const T*)a_in.v + (int64_t)k_lo * a_in.sv[2];
 #define FFPA_M16_TILE_DONE return
 #define FFPA_M16_ROW_INV(l) ((l) > 0.f ? __builtin_amdgcn_rcpf(l) : 0.f)
 #define FFPA_M16_ROW_OUT(x, rh) (l_tot[rh] > 0.f ? (T)((x) * inv[rh]) : (T)0.f)  // (the select BEHIND product + conversion: those stay the dense kernel's one instruction — fp16: v_fma_mixlo, one rounding — and its bits)

@@ -77,6 +77,7 @@ enum ffpa_bias_dtype {
                                              launches never split the KV axis and never take the wide-row tile (128-row tiles, one pass per row), short-query launches
                                              split by the KV length alone (a fixed number of KV tiles per range).  Costs what the launch-size rules would have gained
                                              (under-filled / ragged-round prefill launches: up to ~ 20 %).  Python: FFPA_HIP_DETERMINISTIC=1 sets it on every call. */
+#define FFPA_FLAG_NO_HEAD_CHUNKS   0x80000u /* bench / test, ffpa_attn_fwd: causal GQA prefill launches keep the (batch, head, row tile) workgroup order (default: the launch side takes the head-chunk order — the same row tile of a KV group's heads at the same time — where its rule applies; same bits either way) */
 #define FFPA_FLAG_NO_PACK_GQA      0x40000u /* bench / test, ffpa_attn_varlen_fwd: decode batches (max_seqlen_q == 1) under GQA keep one workgroup per QUERY head (default: the heads of a KV group are packed into the rows of one tile) */
 #define FFPA_FLAG_XCD_GROUP(log2p1) ((unsigned)(log2p1) << 8) /* bench-only: bits 8..10 = 1 + log2 of the XCDs that share a head's row tiles (1 -> 1, 2 -> 2, 3 -> 4, 4 -> 8); 0 = the launch side decides */
 

@@ -477,3 +477,36 @@ def test_paired_row_tile_rule(lib, over, paired):
   p.flags = hip.FLAG_PAIR_TILES
   can = bool(over.get("causal")) and over["heads_q"] > 2 and over.get("head_dim", 512) != 320
   assert lib.ffpa_attn_fwd_kernel(ctypes.byref(p), name, len(name)) == 0 and (", PAIR>" in name.value.decode()) == can, name.value
+
+
+@pytest.mark.parametrize("over, chunk", [
+  (dict(batch=1, heads_q=32, heads_kv=8, seqlen_q=8192, seqlen_kv=8192, causal=1, causal_offset=0), 4),      # a KV group per chunk, eight chunks: one per XCD
+  (dict(batch=4, heads_q=32, heads_kv=8, seqlen_q=2048, seqlen_kv=2048, causal=1, causal_offset=0), 4),      # (16 row tiles per head: the chunk order, not the paired tiles)
+  (dict(batch=1, heads_q=64, heads_kv=8, seqlen_q=4096, seqlen_kv=4096, causal=1, causal_offset=0), 8),
+  (dict(batch=1, heads_q=32, heads_kv=4, seqlen_q=8192, seqlen_kv=8192, causal=1, causal_offset=0), 4),      # groups of 8: two chunks of 4 per group (eight chunks in all)
+  (dict(batch=1, heads_q=32, heads_kv=8, seqlen_q=8192, seqlen_kv=8192, head_dim=1024, causal=1, causal_offset=0), 4),
+  (dict(batch=1, heads_q=32, heads_kv=8, seqlen_q=4096, seqlen_kv=16384, causal=1, causal_offset=12288), 4),  # tail-aligned against a longer context
+  (dict(batch=1, heads_q=32, heads_kv=32, seqlen_q=8192, seqlen_kv=8192, causal=1, causal_offset=0), 1),     # MHA: heads share nothing (measured - 3.7 % with chunks)
+  (dict(batch=1, heads_q=32, heads_kv=8, seqlen_q=8192, seqlen_kv=8192), 1),                                 # not causal: measured +- 0
+  (dict(batch=1, heads_q=12, heads_kv=4, seqlen_q=8192, seqlen_kv=8192, causal=1, causal_offset=0), 1),      # 12 heads do not make eight chunks
+  (dict(batch=1, heads_q=32, heads_kv=8, seqlen_q=8192, seqlen_kv=4096, causal=1, causal_offset=-4096), 1),  # rows without a visible key: the dense kernel's NaN contract
+  (dict(batch=1, heads_q=32, heads_kv=8, seqlen_q=8192, seqlen_kv=8192, causal=1, causal_offset=0, dropout_p=0.1), 1),
+  (dict(batch=2, heads_q=32, heads_kv=8, seqlen_q=8192, seqlen_kv=2048, head_dim=320, causal=1, causal_offset=0), 1),  # config 4 with the causal flag: the wide-row tile
+  (dict(batch=1, heads_q=32, heads_kv=8, seqlen_q=16, seqlen_kv=8192, causal=1, causal_offset=8176), 1),     # short-query launch
+])
+def test_head_chunk_order_rule(lib, over, chunk):
+  """Which dense launches run in the head-chunk workgroup order (ffpa_capi.hip::pick_dense_head_chunk; profiles/r06_head_chunks.txt): causal + GQA, the build
+  without bias / mask ranges / dropout, every row sees a key, and the KV groups divide into a multiple of eight chunks.  The kernel name says so;
+  FFPA_FLAG_NO_HEAD_CHUNKS keeps the (batch, head, row tile) order.  (Same tile, same bits either way: tests/test_m16_gpu.py.)"""
+  name = ctypes.create_string_buffer(200)
+  p = _params(**over)
+  p.workspace, p.workspace_bytes = 16, 1 << 40
+  assert lib.ffpa_attn_fwd_kernel(ctypes.byref(p), name, len(name)) == 0
+  got = name.value.decode()
+  d = over.get("head_dim", 512)
+  if chunk > 1:
+    assert got == f"ffpa_fwd_m16_varlen_kernel<bf16, {d}> (dense launch, head chunks of {chunk})", got
+  else:
+    assert "varlen" not in got, got
+  p.flags = hip.FLAG_NO_HEAD_CHUNKS
+  assert lib.ffpa_attn_fwd_kernel(ctypes.byref(p), name, len(name)) == 0 and "varlen" not in name.value.decode()

@@ -485,3 +485,38 @@ def test_paired_row_tiles_are_bit_identical_to_unpaired(hip, shape):
   ref = torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=keep, enable_gqa=Hq != Hkv)
   o1, _ = hip.forward(q, k, v, None, True, D ** -0.5, causal_offset=off, flags=hip.FLAG_PAIR_TILES)
   assert (o1.float() - ref.float()).abs().max().item() <= 2e-2
+
+
+@pytest.mark.parametrize("shape", [
+  dict(B=1, Hq=32, Hkv=8, Nq=2048, Nkv=2048, D=512, dtype=torch.bfloat16),
+  dict(B=3, Hq=16, Hkv=2, Nq=777, Nkv=777, D=320, dtype=torch.float16),       # chunks of 2 (groups of 8 in eight chunks), ragged tail, odd batch
+  dict(B=1, Hq=64, Hkv=8, Nq=640, Nkv=1900, D=1024, dtype=torch.bfloat16),     # tail-aligned against a longer context, split-D tiles
+  dict(B=2, Hq=32, Hkv=8, Nq=1024, Nkv=1024, D=128, dtype=torch.bfloat16),
+])
+def test_head_chunk_order_computes_the_same_bits(shape):
+  """Causal GQA launches run in the head-chunk workgroup order (the packed-sequence kernel's, in its dense mode: ffpa_capi.hip::pick_dense_head_chunk): the
+  same tile text on the same arguments — LSE (both dtypes) and O (bf16) bit-identical to the (batch, head, row tile) order (FFPA_FLAG_NO_HEAD_CHUNKS), fp16 O up
+  to the compiler's last-instruction rounding choice; the plan says which ran."""
+  from ffpa_attn_amd import hip
+
+  B, Hq, Hkv, Nq, Nkv, D, dtype = (shape[k] for k in ("B", "Hq", "Hkv", "Nq", "Nkv", "D", "dtype"))
+  g = torch.Generator(device="cuda").manual_seed(Nq + D)
+  q = torch.randn((B, Hq, Nq, D), dtype=dtype, device="cuda", generator=g)
+  k = torch.randn((B, Hkv, Nkv, D), dtype=dtype, device="cuda", generator=g)
+  v = torch.randn((B, Hkv, Nkv, D), dtype=dtype, device="cuda", generator=g)
+  plan, plan_off = {}, {}
+  o, lse = hip.forward(q, k, v, None, True, D ** -0.5, plan_out=plan, num_splits=1)
+  o2, lse2 = hip.forward(q, k, v, None, True, D ** -0.5, flags=hip.FLAG_NO_HEAD_CHUNKS | hip.FLAG_NO_PAIR_TILES, plan_out=plan_off, num_splits=1)
+  assert "head chunks of" in plan["kernel"] and "varlen" not in plan_off["kernel"], (plan, plan_off)
+  assert torch.equal(lse, lse2)
+  if dtype == torch.bfloat16:
+    assert torch.equal(o, o2)
+  else:
+    # fp16: the same accumulators; the very last instruction (O / l rounded to fp16) is hipcc's per-element choice between v_fma_mixlo_f16 (one rounding) and
+    # v_mul_f32 + v_cvt (two), made differently in the two kernels: ~ 2^-13 of the elements differ by one fp16 spacing (tests/test_varlen_gpu.py)
+    diff = (o.float() - o2.float()).abs()
+    assert torch.all(diff <= torch.maximum(o.float().abs(), o2.float().abs()).clamp_min(2.0 ** -14) * 2.0 ** -10) and (diff > 0).float().mean().item() <= 2e-3
+  # strided inputs ([B, N, H, D] storage) through the same route
+  qs, ks, vs = (t.transpose(1, 2).contiguous().transpose(1, 2) for t in (q, k, v))
+  o3, lse3 = hip.forward(qs, ks, vs, None, True, D ** -0.5, num_splits=1)
+  assert torch.equal(o, o3) and torch.equal(lse, lse3)
