@@ -82,6 +82,7 @@ WORKLOADS = {
   "cfg2_causal": _w(1, 32, 32, 8192, 8192, 512, causal=True, note="reference bench case 'causal'"),
   "cross": _w(1, 32, 32, 1024, 8192, 512, note="reference bench case 'cross-attn' (Nq = 1024)"),
   "gqa": _w(1, 32, 8, 8192, 8192, 512, note="reference bench case 'gqa' (Hkv = H/4)"),
+  "gqa_causal": _w(1, 32, 8, 8192, 8192, 512, causal=True, note="the reference bench's 'gqa' and 'causal' cases together (LLM-style prefill): the launch the head-chunk workgroup order is for"),
   "attn_mask": _w(1, 32, 32, 8192, 8192, 512, mask="key_bias", note="reference bench case 'attn-mask': additive [1,1,1,Nkv] randn*0.25 (cli/_runner_fwd.py:75-81)"),
   "dropout": _w(1, 32, 32, 8192, 8192, 512, dropout=0.1, note="reference bench case 'dropout' (p = 0.1, in-kernel Philox)"),
   "non_aligned": _w(1, 8, 8, 8191, 8191, 512, note="reference bench case 'non-aligned' (N-1, H/4 heads)"),
