@@ -47,7 +47,7 @@ const DimEntry kDims[] = {
 };
 
 // the packed-sequence kernel: one launcher per head dim of the 16x16x32 build (ffpa_varlen_inst.hip)
-typedef int (*varlen_fn)(int, const ffpa::FwdArgs&, const ffpa::VarlenArgs&, hipStream_t);
+typedef int (*varlen_fn)(int, int, const ffpa::FwdArgs&, const ffpa::VarlenArgs&, hipStream_t);
 struct VarlenEntry {
   int d;
   varlen_fn launch;
@@ -738,7 +738,7 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
     va.head_chunk = pl.chunk;
     st = -3;
     for (const VarlenEntry& e : kVarlenDims)
-      if (e.d == kernel_head_dim(p->head_dim)) st = e.launch(p->dtype, a, va, static_cast<hipStream_t>(stream));
+      if (e.d == kernel_head_dim(p->head_dim)) st = e.launch(p->dtype, 0, a, va, static_cast<hipStream_t>(stream));
   } else {
     st = de->launch(p->dtype, safe, pl.wide ? 3 : pl.variant, a, static_cast<hipStream_t>(stream));
   }
@@ -863,6 +863,7 @@ struct VarlenPlan {
   const VarlenEntry* ve;
   int br, bc, nqt;
   int pack;  // > 0: decode batch under GQA — the query heads of a KV group are the rows of the tile (VarlenArgs::pack)
+  int nt;    // 1: the build whose K / V pieces carry the non-temporal hint
   int64_t grid;
 };
 
@@ -895,6 +896,18 @@ int varlen_plan(const ffpa_varlen_fwd_params* p, VarlenPlan* out) {
   out->pack = (p->max_seqlen_q == 1 && group > 1 && group <= out->br && !(p->flags & FFPA_FLAG_NO_PACK_GQA)) ? group : 0;
   out->nqt = out->pack ? 1 : (p->max_seqlen_q + out->br - 1) / out->br;
   out->grid = (int64_t)p->batch * (out->pack ? p->heads_kv : p->heads_q) * out->nqt;
+  // The non-temporal K / V fetch (the dense short-query launches' rule, ffpa_attn_fwd): every K / V byte is read by ONE workgroup — one row tile per (sequence,
+  // head), and MHA or packed GQA rows — and the batch's K + V do not fit the 256 MiB Infinity Cache.  The launch side sees only max_seqlen_kv, not the lengths: it
+  // prices a ragged batch at half of batch x max (>= 272 MiB of that).  LDS-DMA from HBM: 5.9 TB/s without the hint, 7.3 with it (profiles/r04_kv_stream.txt);
+  // packed decode batches: profiles/r06_varlen.txt.  FFPA_FLAG_KV_STREAM / _NO_KV_STREAM force either.
+  {
+    const bool one_reader = out->nqt == 1 && (out->pack > 0 || group == 1);
+    const int64_t kv_bound = 2LL * p->batch * p->heads_kv * (int64_t)p->max_seqlen_kv * p->head_dim * 2;
+    bool nt = one_reader && kv_bound / 2 >= (272LL << 20);
+    if (p->flags & FFPA_FLAG_KV_STREAM) nt = true;
+    if (p->flags & FFPA_FLAG_NO_KV_STREAM) nt = false;
+    out->nt = nt ? 1 : 0;
+  }
   if (out->grid > 0x7fffffffLL) return fail(FFPA_ERR_BAD_SHAPE, "grid of %lld workgroups is too large", (long long)out->grid);
   return FFPA_OK;
 }
@@ -1003,7 +1016,7 @@ int ffpa_attn_varlen_fwd(const ffpa_varlen_fwd_params* p, void* stream) {
     va.head_chunk = 1;  // (the rows of a tile ARE the group: KV heads share nothing)
   }
 
-  const int st = pl.ve->launch(p->dtype, a, va, static_cast<hipStream_t>(stream));
+  const int st = pl.ve->launch(p->dtype, pl.nt, a, va, static_cast<hipStream_t>(stream));
   if (st == -2) return fail(FFPA_ERR_LAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed (is this a gfx950?)");
   if (st < 0) return fail(FFPA_ERR_LAUNCH, "launch setup failed (%d)", st);
   if (st != 0) return fail(FFPA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(st)));
@@ -1027,7 +1040,8 @@ int ffpa_attn_varlen_fwd_kernel(const ffpa_varlen_fwd_params* params, char* buf,
   const int rc = varlen_plan(params, &pl);
   if (rc != FFPA_OK) return rc;
   if (buf == nullptr || n == 0) return fail(FFPA_ERR_NULL_POINTER, "buf is NULL");
-  snprintf(buf, n, "ffpa_fwd_m16_varlen_kernel<%s, %d>%s", params->dtype == FFPA_DTYPE_BF16 ? "bf16" : "fp16", pl.ve->d, pl.pack ? " (GQA heads packed into rows)" : "");
+  snprintf(buf, n, "ffpa_fwd_m16_varlen_kernel<%s, %d%s>%s", params->dtype == FFPA_DTYPE_BF16 ? "bf16" : "fp16", pl.ve->d, pl.nt ? ", NT" : "",
+           pl.pack ? " (GQA heads packed into rows)" : "");
   return FFPA_OK;
 }
 

@@ -245,6 +245,23 @@ __device__ __forceinline__ void lds_dma_16_at(u32x4 rsrc, uint32_t lds_base, uin
                : "memory", "scc" FFPA_M0_CLOBBER);
 }
 
+// ... and with the non-temporal hint, chosen at compile time: what the packed-sequence kernel's decode-batch build issues (ffpa_fwd_m16_kernel.h: the tile text names
+// its DMA form through a macro of the enclosing kernel; the dense kernels name lds_dma_16_at itself)
+template <bool NT>
+struct LdsDma16 {
+  template <int LCONST>
+  static __device__ __forceinline__ void at(u32x4 rsrc, uint32_t lds_base, uint32_t voff, uint32_t soff) {
+    if constexpr (NT) {
+      asm volatile("s_add_u32 m0, %0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds"
+                   :
+                   : "s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff), "n"(LCONST)
+                   : "memory", "scc" FFPA_M0_CLOBBER);
+    } else {
+      lds_dma_16_at<LCONST>(rsrc, lds_base, voff, soff);
+    }
+  }
+};
+
 // Row-uniform form (one LDS image row == whole pieces: D = 512).  Everything but the per-lane swizzled
 // column offset `voff` is scalar: destination = lds_base + LCONST (+ IMM), source row offset `row_off` inside
 // the tile, and IMM advances source and destination together for the second KiB of a 2 KiB row.  No VALU;

@@ -34,6 +34,8 @@
 //   * anything else (odd strides, boolean masks next to dropout) is read element by element from global memory (slow, rare).
 #pragma once
 
+#include <type_traits>
+
 #include "ffpa_fwd_kernel.h"
 
 #ifndef FFPA_M16_MIN_D
@@ -224,6 +226,30 @@ struct Mfma16<_Float16> {
   }
 };
 
+// The same wrappers with the NON-TEMPORAL hint on the riding piece (the packed-sequence kernel's decode-batch build: K / V bytes that ONE workgroup reads once).
+template <typename T>
+struct Mfma16Nt;
+#define FFPA_MFMA16_NT(TYPE, SUFFIX)                                                                                                                        \
+  template <>                                                                                                                                              \
+  struct Mfma16Nt<TYPE> : Mfma16<TYPE> {                                                                                                                   \
+    typedef Elem<TYPE>::v8 v8;                                                                                                                             \
+    template <int KIND, int LCONST>                                                                                                                        \
+    static __device__ __forceinline__ void with_dma(f32x4& d, v8 a, v8 b, u32x4 rsrc, uint32_t lds_base, uint32_t voff, uint32_t soff) {                  \
+      if constexpr (KIND == 0)                                                                                                                             \
+        asm volatile("s_add_u32 m0, %3, %7\n\tv_mfma_f32_16x16x32_" SUFFIX " %0, %1, %2, 0\n\tbuffer_load_dwordx4 %4, %5, %6 offen nt lds"                \
+                     : "=&v"(d) : "v"(a), "v"(b), "s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff), "n"(LCONST) : "memory", "scc" FFPA_M0_CLOBBER);          \
+      else if constexpr (KIND == 1)                                                                                                                        \
+        asm volatile("s_add_u32 m0, %3, %7\n\tv_mfma_f32_16x16x32_" SUFFIX " %0, %1, %2, %0\n\tbuffer_load_dwordx4 %4, %5, %6 offen nt lds"               \
+                     : "+v"(d) : "v"(a), "v"(b), "s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff), "n"(LCONST) : "memory", "scc" FFPA_M0_CLOBBER);           \
+      else                                                                                                                                                 \
+        asm volatile("s_add_u32 m0, %3, %7\n\tv_mfma_f32_16x16x32_" SUFFIX " %0, %1, %2, %0\n\tbuffer_load_dwordx4 %4, %5, %6 offen nt lds"               \
+                     : "+a"(d) : "v"(a), "v"(b), "s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff), "n"(LCONST) : "memory", "scc" FFPA_M0_CLOBBER);           \
+    }                                                                                                                                                      \
+  };
+FFPA_MFMA16_NT(__bf16, "bf16")
+FFPA_MFMA16_NT(_Float16, "f16")
+#undef FFPA_MFMA16_NT
+
 // A query row lives in the 4 lanes n, n + 16, n + 32, n + 48, and every lane carries a value for two rows (n and 16 + n).
 // Both 4-lane reductions together in three register swaps (no LDS crossbar): v_permlane32_swap pairs row n's halves in lanes
 // 0 .. 31 and row 16 + n's in lanes 32 .. 63, v_permlane16_swap folds the remaining lane ^ 16 step, and a last
@@ -286,6 +312,8 @@ __device__ __forceinline__ int m16_v_swizzle(int key) {
 // prefill.cuh:398-546) — of the bias-free kernel (MK = 0: nothing but the Philox code rides along) and of the additive-bias kernel.
 template <typename T, int D, int MK = 0, bool DROP = false>
 __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
+#define FFPA_M16_MFMA Mfma16<T>
+#define FFPA_M16_DMA16 lds_dma_16_at
 #include "ffpa_fwd_m16_head.inc"
   // workgroup -> (batch, head, row tile, split): as ffpa_fwd_split_d_kernel (all row tiles of a head on one XCD)
   int vid = blockIdx.x;
@@ -306,6 +334,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 #undef FFPA_M16_ROW_OUT
 #undef FFPA_M16_ROW_INV
 #undef FFPA_M16_TILE_DONE
+#undef FFPA_M16_DMA16
+#undef FFPA_M16_MFMA
 }
 
 // PAIRED ROW TILES (round 6: launches under the causal flag, FwdArgs::pair_tiles): workgroup i of a head walks row tile nqt - 1 - i (its long one) and then
@@ -317,6 +347,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 template <typename T, int D, bool DROP = false>
 __global__ __launch_bounds__(256) void ffpa_fwd_m16_pair_kernel(const FwdArgs a) {
   constexpr int MK = 0;  // the builds without a bias: what a launch under the causal flag runs
+#define FFPA_M16_MFMA Mfma16<T>
+#define FFPA_M16_DMA16 lds_dma_16_at
 #include "ffpa_fwd_m16_head.inc"
   int vid = blockIdx.x;
   if (!(a.flags & kFlagNoXcdRemap)) vid = xcd_logical_id(vid, gridDim.x, a.xcd_group);
@@ -337,6 +369,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_pair_kernel(const FwdArgs a)
 #undef FFPA_M16_ROW_OUT
 #undef FFPA_M16_ROW_INV
 #undef FFPA_M16_TILE_DONE
+#undef FFPA_M16_DMA16
+#undef FFPA_M16_MFMA
   }
 }
 
@@ -364,10 +398,14 @@ struct VarlenArgs {
                          // length lives on the device: FlashAttention's seqused_k / cache_seqlens); NULL = all of cu_k[i] .. cu_k[i + 1]
 };
 
-template <typename T, int D>
+// NT: the decode-batch build — every K / V piece carries the non-temporal hint (each byte has ONE reader and the batch's K + V do not fit the caches: the launch
+// side's rule, ffpa_capi.hip; LDS-DMA from HBM 5.9 -> 7.3 TB/s with it, profiles/r04_kv_stream.txt) — otherwise the same kernel.
+template <typename T, int D, bool NT = false>
 __global__ __launch_bounds__(256) void ffpa_fwd_m16_varlen_kernel(const FwdArgs a_in, const VarlenArgs va) {
   constexpr int MK = 0;  // no attn_bias, no mask ranges: what the reference's packed entry point accepts
   constexpr bool DROP = false;
+#define FFPA_M16_MFMA std::conditional_t<NT, Mfma16Nt<T>, Mfma16<T>>
+#define FFPA_M16_DMA16 LdsDma16<NT>::template at
 #include "ffpa_fwd_m16_head.inc"
   int vid = blockIdx.x;
   if (!(a_in.flags & kFlagNoXcdRemap)) vid = xcd_logical_id(vid, gridDim.x, a_in.xcd_group);
@@ -421,6 +459,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_varlen_kernel(const FwdArgs 
 #undef FFPA_M16_ROW_OUT
 #undef FFPA_M16_ROW_INV
 #undef FFPA_M16_TILE_DONE
+#undef FFPA_M16_DMA16
+#undef FFPA_M16_MFMA
 }
 
 }  // namespace ffpa

@@ -280,7 +280,7 @@ typedef struct ffpa_varlen_fwd_params {
 
   float softmax_scale;     /* > 0 or < 0 or 0: as ffpa_fwd_params */
   float rescale_threshold; /* as ffpa_fwd_params: < 0 => 8.0 */
-  uint32_t flags;          /* FFPA_FLAG_NO_XCD_REMAP, FFPA_FLAG_L2_PREFETCH / _NO_L2_PREFETCH, FFPA_FLAG_XCD_GROUP(), FFPA_FLAG_NO_PACK_GQA; others ignored */
+  uint32_t flags;          /* FFPA_FLAG_NO_XCD_REMAP, FFPA_FLAG_L2_PREFETCH / _NO_L2_PREFETCH, FFPA_FLAG_XCD_GROUP(), FFPA_FLAG_NO_PACK_GQA, FFPA_FLAG_KV_STREAM / _NO_KV_STREAM; others ignored */
   uint32_t reserved;       /* 0 */
 } ffpa_varlen_fwd_params;
 

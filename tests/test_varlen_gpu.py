@@ -361,6 +361,22 @@ def test_decode_batches_pack_the_heads_of_a_kv_group_into_rows(hip, hq, hkv, d, 
                    causal=True, causal_offset=lens_k[i] - 1, block_keys=plan["block_keys"], name="packed decode vs oracle")
 
 
+@pytest.mark.parametrize("hq, hkv, d, dtype, nq", [(32, 8, 512, torch.bfloat16, 1), (8, 8, 320, torch.float16, 1), (4, 1, 1024, torch.bfloat16, 1), (8, 8, 128, torch.bfloat16, 37)])
+def test_decode_batches_with_the_non_temporal_kv_fetch_are_bit_identical(hip, hq, hkv, d, dtype, nq):
+  """The NT build of the packed kernel (K / V pieces carry the non-temporal hint: the launch side takes it for decode batches whose K + V have one reader per byte and
+  do not fit the caches) computes the same bits as the plain build — the hint changes where a line lives, not what it holds.  Forced either way here (the batch is small)."""
+  lens_k = [700, 0, 64, 1300, 129, 2048, 1, 333]
+  lens_q = [nq, nq, 0, nq, nq, nq, 1, nq]
+  q, k, v = _make(lens_q, lens_k, hq, hkv, d, dtype, seed=hq + d + 1)
+  cu_q, cu_k = _cu(lens_q), _cu(lens_k)
+  pa, pb = {}, {}
+  out_a, lse_a = hip.varlen_forward(q, k, v, cu_q, cu_k, nq, max(lens_k), True, d ** -0.5, flags=hip.FLAG_KV_STREAM, plan_out=pa)
+  out_b, lse_b = hip.varlen_forward(q, k, v, cu_q, cu_k, nq, max(lens_k), True, d ** -0.5, flags=hip.FLAG_NO_KV_STREAM, plan_out=pb)
+  assert ", NT>" in pa["kernel"] and ", NT>" not in pb["kernel"], (pa, pb)
+  assert torch.equal(out_a, out_b) and torch.equal(lse_a, lse_b)
+  _check_packed(hip, q, k, v, lens_q, lens_k, True, out_a, lse_a, oracle=False, dense_bits=False, sdpa=d <= 512, name=f"NT packed decode Hq{hq}/Hkv{hkv} D{d}")
+
+
 def test_static_capacity_kv_cache_with_device_side_lengths(hip):
   """seqused_k (the op-level extension): a KV cache of fixed capacity per sequence, viewed as packed rows, whose valid lengths live on the device — equal, bit for
   bit, to the call on the tightly packed valid rows; ONE captured graph follows lengths rewritten in place; decode under GQA runs packed (one workgroup per

@@ -51,11 +51,24 @@ def main():
       # (the op, not ffpa_attn_func: the public entry point sends 8 <= Nq < 512 to SDPA like the reference does — whose is_causal is top-left aligned)
       return [hip.ffpa_attn_forward_hip(seq(q, bq[i], bq[i + 1]), seq(k, bk[i], bk[i + 1]), seq(v, bk[i], bk[i + 1]), None, causal=True, softmax_scale=d ** -0.5)[0] for i in range(nseq)]
 
+    def packed_flags(flags):
+      return lambda: hip.varlen_forward(q, k, v, cu_q, cu_k, nq, max(lens_k), True, d ** -0.5, flags=flags)
+
     o = packed()
     ref = loop()
     err = max((o[bq[i]:bq[i + 1]].float() - ref[i][0].transpose(0, 1).float()).abs().max().item() for i in range(nseq))
     t_p, t_l = timeit(packed), timeit(loop, reps=5, warm=2)
     kv_bytes = 2 * tk * hkv * d * 2
+    # the non-temporal K / V fetch, interleaved A/B of the two builds (the default launch above takes one of them by the launch side's rule)
+    plan = {}
+    hip.varlen_forward(q, k, v, cu_q, cu_k, nq, max(lens_k), True, d ** -0.5, plan_out=plan)
+    ab = {"plain": [], "nt": []}
+    for _ in range(3):
+      ab["plain"].append(timeit(packed_flags(hip.FLAG_NO_KV_STREAM)))
+      ab["nt"].append(timeit(packed_flags(hip.FLAG_KV_STREAM)))
+    same = all(torch.equal(a, b) for a, b in zip(packed_flags(hip.FLAG_NO_KV_STREAM)(), packed_flags(hip.FLAG_KV_STREAM)()))
+    print(f"VARLENDECODE_NT default = {plan['kernel']} | plain {min(ab['plain']) * 1e3:8.1f} us = {kv_bytes / min(ab['plain']) / 1e9:5.2f} TB/s | NT {min(ab['nt']) * 1e3:8.1f} us = "
+          f"{kv_bytes / min(ab['nt']) / 1e9:5.2f} TB/s ({(min(ab['plain']) / min(ab['nt']) - 1) * 100:+.1f} %) | bit-identical {same}", flush=True)
     print(f"VARLENDECODE {nseq} seqs x Nq {nq}, KV {min(lens_k)} ... {max(lens_k)} (sum {tk}), Hq {hq} Hkv {hkv} D {d}: packed {t_p * 1e3:8.1f} us = {kv_bytes / t_p / 1e9:6.2f} TB/s of K + V | "
           f"loop of {nseq} dense decode calls {t_l * 1e3:8.1f} us = {kv_bytes / t_l / 1e9:6.2f} TB/s | max abs diff {err:.2e}", flush=True)
 
