@@ -17,6 +17,7 @@
 #include "ffpa_attn.h"
 #include "ffpa_fwd_kernel.h"
 #include "ffpa_fwd_m16_kernel.h"  // (FFPA_M16_MIN_D: the head dims whose prefill launches run the 16x16x32 build)
+#include "ffpa_varlen_merge.h"   // (stage 2 of a KV-split packed-sequence launch)
 #include "ffpa_launch.h"
 
 namespace {
@@ -166,6 +167,11 @@ struct PlanTunables {
   int short_one_per_cu_min_d, short_one_per_cu_lds;  // short-query tiles that want ONE workgroup per CU: head dims from here up, or tiles above this much LDS (profiles/r03_decode_splits.txt)
   int det_tiles_per_split;     // FFPA_FLAG_DETERMINISTIC: KV tiles per split range of a short-query launch (a function of the KV length alone)
   int pair_max_row_tiles;      // causal launches pair row tiles i and n - 1 - i in one workgroup up to this many row tiles per head (profiles/r06_pair_tiles.txt)
+  // KV splits of the packed-sequence call (varlen_plan; profiles/r06_varlen_splits.txt): a batch of several sequences is ragged, and ranges beyond "one workgroup per
+  // slot" even out what the longest sequence would otherwise run alone — up to this many workgroups per slot, at least this many KV tiles of the longest sequence per
+  // range, and partials (written + read back) of at most this fraction of the K + V bytes the launch side can estimate
+  int varlen_balance_wgs, varlen_balance_min_tiles;
+  double varlen_partial_frac;
 };
 constexpr PlanTunables kPlanGfx950 = {
     5.0e12 / 9.8304e12, 4.0e12 / 9.8304e12, 5.0e12 / 8.0e12,
@@ -177,6 +183,8 @@ constexpr PlanTunables kPlanGfx950 = {
     320, 80 * 1024,
     16,
     32,
+    4, 16,
+    0.02,
 };
 constexpr const PlanTunables& kT = kPlanGfx950;
 
@@ -864,7 +872,9 @@ struct VarlenPlan {
   int br, bc, nqt;
   int pack;  // > 0: decode batch under GQA — the query heads of a KV group are the rows of the tile (VarlenArgs::pack)
   int nt;    // 1: the build whose K / V pieces carry the non-temporal hint
-  int64_t grid;
+  int splits;        // KV ranges per sequence (1 = the KV axis is not split)
+  size_t ws_bytes;   // scratch the split launch uses
+  int64_t grid;      // workgroups of the launch (all ranges)
 };
 
 // Validation shared by the launch and the queries; fills the plan.  Head dims below the first 16x16x32 instantiation run on it (columns past the
@@ -908,6 +918,49 @@ int varlen_plan(const ffpa_varlen_fwd_params* p, VarlenPlan* out) {
     if (p->flags & FFPA_FLAG_NO_KV_STREAM) nt = false;
     out->nt = nt ? 1 : 0;
   }
+  // KV SPLITS (ABI 6).  A launch of one row tile per (sequence, head) — decode, speculative decoding, chunked prefill — splits every sequence's KV range over `splits`
+  // workgroups (the sequence's own tiles / splits per range, computed on the device) + ffpa_varlen_merge_kernel.  The launch side sees max_seqlen_kv only.  Two
+  // reasons, measured on packed decode batches (tools/gpu_varlen_splits.py, profiles/r06_varlen_splits.txt):
+  //   (a) FILL the chip — the dense short-query launches' rule (pick_splits): one workgroup per CU for head dims >= 320 (a tile pair is 128 KiB of LDS there), else
+  //       two; at least kT.min_tiles_short KV tiles of the longest sequence per range.  8 sequences x 8 KV heads = 64 workgroups: 649 -> 212 us with 4 ranges;
+  //   (b) BALANCE a ragged batch — several sequences differ in length and the longest one's workgroups finish last: up to kT.varlen_balance_wgs workgroups per slot
+  //       in ranges of at least kT.varlen_balance_min_tiles tiles (256 pairs x 4 ranges: 877 -> 728 us; 64 x 8: 181 us), as long as the partials stay a small
+  //       fraction of the K + V bytes (64 query rows per sequence: 4 ranges 248 us, 16 ranges 293 us).
+  out->splits = 1;
+  out->ws_bytes = 0;
+  if (out->nqt == 1 && p->total_q > 0 && p->workspace != nullptr && p->num_splits != 1 && !(p->flags & FFPA_FLAG_DETERMINISTIC)) {
+    const int64_t cus = device_cu_count();
+    const int64_t max_tiles = ((int64_t)p->max_seqlen_kv + out->bc - 1) / out->bc;
+    int64_t want = 1;
+    if ((p->flags & FFPA_FLAG_FORCE_SPLITS) && p->num_splits > 1) {
+      want = p->num_splits < max_tiles ? p->num_splits : max_tiles;  // (sweeps and tests: exactly n, down to one tile per range)
+    } else {
+      const int64_t slots = (dk >= kT.short_one_per_cu_min_d ? 1 : 2) * cus;
+      int64_t fill = 2 * out->grid <= slots ? slots / out->grid : 1;
+      if (fill > max_tiles / kT.min_tiles_short) fill = max_tiles / kT.min_tiles_short;
+      int64_t balance = 1;
+      if (p->batch > 1 && out->grid < kT.varlen_balance_wgs * slots) {
+        balance = kT.varlen_balance_wgs * slots / out->grid;
+        if (balance > max_tiles / kT.varlen_balance_min_tiles) balance = max_tiles / kT.varlen_balance_min_tiles;
+        // partials: splits x Hq x total_q x D x 4 B, written and read back; K + V: every pair streams its sequence — priced at 0.6 x the longest (a ragged batch)
+        const double kv_bytes = (double)out->grid * 0.6 * (double)p->max_seqlen_kv * dk * 4.0;
+        const double per_split_rw = 2.0 * (double)p->heads_q * (double)p->total_q * dk * 4.0;
+        const int64_t afford = (int64_t)(kT.varlen_partial_frac * kv_bytes / per_split_rw);
+        if (balance > afford) balance = afford;
+      }
+      want = fill > balance ? fill : balance;
+      if (want < 1) want = 1;
+      if (p->num_splits > 1 && want > p->num_splits) want = p->num_splits;
+    }
+    if (want > ffpa::kMergeMaxSplits) want = ffpa::kMergeMaxSplits;
+    const size_t per_split = (size_t)p->heads_q * (size_t)p->total_q * ((size_t)dk + 1) * sizeof(float);
+    if ((uint64_t)want * per_split > p->workspace_bytes) want = (int64_t)(p->workspace_bytes / per_split);
+    if (want > 1 && out->grid * want <= 0x7fffffffLL) {
+      out->splits = (int)want;
+      out->ws_bytes = (size_t)want * per_split;
+      out->grid *= want;
+    }
+  }
   if (out->grid > 0x7fffffffLL) return fail(FFPA_ERR_BAD_SHAPE, "grid of %lld workgroups is too large", (long long)out->grid);
   return FFPA_OK;
 }
@@ -941,6 +994,8 @@ int ffpa_attn_varlen_fwd(const ffpa_varlen_fwd_params* p, void* stream) {
   }
   if (p->lse != nullptr && p->lse_stride_head < 0) return fail(FFPA_ERR_BAD_STRIDE, "lse_stride_head is negative");
   if (!isfinite(p->softmax_scale)) return fail(FFPA_ERR_BAD_SHAPE, "softmax_scale is not finite");
+  if (p->total_q < 0) return fail(FFPA_ERR_BAD_SHAPE, "total_q=%d is negative", p->total_q);
+  if (p->workspace != nullptr && !aligned16(p->workspace)) return fail(FFPA_ERR_MISALIGNED, "workspace must be 16-byte aligned");
   if ((rc = check_device()) != FFPA_OK) return rc;
 
   ffpa::FwdArgs a;
@@ -1016,14 +1071,32 @@ int ffpa_attn_varlen_fwd(const ffpa_varlen_fwd_params* p, void* stream) {
     va.head_chunk = 1;  // (the rows of a tile ARE the group: KV heads share nothing)
   }
 
-  const int st = pl.ve->launch(p->dtype, pl.nt, a, va, static_cast<hipStream_t>(stream));
+  va.ws_head_rows = va.ws_split_rows = 0;
+  if (pl.splits > 1) {
+    // partials [split, query head, token, Dk] fp32 + their LSE [split, query head, token]; the kernel finds a range's tiles from its sequence's own length
+    a.nsplit = pl.splits;
+    a.ws_o = static_cast<float*>(p->workspace);
+    a.ws_lse = a.ws_o + (size_t)pl.splits * p->heads_q * p->total_q * pl.ve->d;
+    va.ws_head_rows = p->total_q;
+    va.ws_split_rows = (int64_t)p->heads_q * p->total_q;
+  }
+
+  int st = pl.ve->launch(p->dtype, pl.nt, a, va, static_cast<hipStream_t>(stream));
+  if (st == 0 && pl.splits > 1) {
+    const dim3 grid((unsigned)((int64_t)p->heads_q * p->total_q), (unsigned)(p->head_dim + 255) / 256);
+    if (p->dtype == FFPA_DTYPE_BF16)
+      hipLaunchKernelGGL(ffpa::ffpa_varlen_merge_kernel<__bf16>, grid, dim3(64), 0, static_cast<hipStream_t>(stream), a, va, pl.ve->d, p->batch, p->o_stride[1]);
+    else
+      hipLaunchKernelGGL(ffpa::ffpa_varlen_merge_kernel<_Float16>, grid, dim3(64), 0, static_cast<hipStream_t>(stream), a, va, pl.ve->d, p->batch, p->o_stride[1]);
+    st = (int)hipGetLastError();
+  }
   if (st == -2) return fail(FFPA_ERR_LAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed (is this a gfx950?)");
   if (st < 0) return fail(FFPA_ERR_LAUNCH, "launch setup failed (%d)", st);
   if (st != 0) return fail(FFPA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(st)));
   return FFPA_OK;
 }
 
-int ffpa_attn_varlen_fwd_plan(const ffpa_varlen_fwd_params* params, int out[4]) {
+int ffpa_attn_varlen_fwd_plan(const ffpa_varlen_fwd_params* params, int out[5]) {
   VarlenPlan pl;
   const int rc = varlen_plan(params, &pl);
   if (rc != FFPA_OK) return rc;
@@ -1032,7 +1105,19 @@ int ffpa_attn_varlen_fwd_plan(const ffpa_varlen_fwd_params* params, int out[4]) 
   out[1] = pl.br;
   out[2] = pl.bc;
   out[3] = (int)pl.grid;
+  out[4] = pl.splits;
   return FFPA_OK;
+}
+
+size_t ffpa_attn_varlen_fwd_workspace_bytes(const ffpa_varlen_fwd_params* params) {
+  if (params == nullptr || params->struct_size != sizeof(ffpa_varlen_fwd_params)) return 0;
+  // size for the split count the heuristic would pick with unlimited scratch
+  ffpa_varlen_fwd_params q = *params;
+  q.workspace = reinterpret_cast<void*>(16);
+  q.workspace_bytes = ~0ull;
+  VarlenPlan pl;
+  if (varlen_plan(&q, &pl) != FFPA_OK) return 0;
+  return pl.ws_bytes;
 }
 
 int ffpa_attn_varlen_fwd_kernel(const ffpa_varlen_fwd_params* params, char* buf, size_t n) {
@@ -1040,8 +1125,8 @@ int ffpa_attn_varlen_fwd_kernel(const ffpa_varlen_fwd_params* params, char* buf,
   const int rc = varlen_plan(params, &pl);
   if (rc != FFPA_OK) return rc;
   if (buf == nullptr || n == 0) return fail(FFPA_ERR_NULL_POINTER, "buf is NULL");
-  snprintf(buf, n, "ffpa_fwd_m16_varlen_kernel<%s, %d%s>%s", params->dtype == FFPA_DTYPE_BF16 ? "bf16" : "fp16", pl.ve->d, pl.nt ? ", NT" : "",
-           pl.pack ? " (GQA heads packed into rows)" : "");
+  snprintf(buf, n, "ffpa_fwd_m16_varlen_kernel<%s, %d%s>%s%s", params->dtype == FFPA_DTYPE_BF16 ? "bf16" : "fp16", pl.ve->d, pl.nt ? ", NT" : "",
+           pl.pack ? " (GQA heads packed into rows)" : "", pl.splits > 1 ? " + ffpa_varlen_merge_kernel" : "");
   return FFPA_OK;
 }
 

@@ -329,7 +329,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 #define FFPA_M16_ROW_INV(l) __builtin_amdgcn_rcpf(l)
 #define FFPA_M16_ROW_OUT(x, rh) (T)((x) * inv[rh])
 #define FFPA_M16_LSE_INDEX(row) ((int64_t)b * a.Hq + hq) * a.Nq + (row)
+#define FFPA_M16_WS_ROW(row) ((((int64_t)split * a.B + b) * a.Hq + hq) * a.Nq + (row))
 #include "ffpa_fwd_m16_tile.inc"
+#undef FFPA_M16_WS_ROW
 #undef FFPA_M16_LSE_INDEX
 #undef FFPA_M16_ROW_OUT
 #undef FFPA_M16_ROW_INV
@@ -364,7 +366,9 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_pair_kernel(const FwdArgs a)
 #define FFPA_M16_ROW_INV(l) __builtin_amdgcn_rcpf(l)
 #define FFPA_M16_ROW_OUT(x, rh) (T)((x) * inv[rh])
 #define FFPA_M16_LSE_INDEX(row) ((int64_t)b * a.Hq + hq) * a.Nq + (row)
+#define FFPA_M16_WS_ROW(row) ((((int64_t)split * a.B + b) * a.Hq + hq) * a.Nq + (row))
 #include "ffpa_fwd_m16_tile.inc"
+#undef FFPA_M16_WS_ROW
 #undef FFPA_M16_LSE_INDEX
 #undef FFPA_M16_ROW_OUT
 #undef FFPA_M16_ROW_INV
@@ -396,6 +400,11 @@ struct VarlenArgs {
   int64_t q_tok_stride, o_tok_stride;  // elements between two tokens of q / o
   const int* used_k;     // optional [batch]: sequence i uses only the first used_k[i] of its key rows (a KV cache of fixed capacity per sequence whose valid
                          // length lives on the device: FlashAttention's seqused_k / cache_seqlens); NULL = all of cu_k[i] .. cu_k[i + 1]
+  // KV SPLITS (FwdArgs::nsplit > 1, launches of one row tile per (sequence, head) only): workgroup (pair, split) walks KV tiles [split * tps, (split + 1) * tps) of ITS
+  // sequence, tps = ceil(tiles of that sequence / nsplit) computed here on the device, and stores a normalised fp32 partial + LSE to FwdArgs::ws_o / ws_lse at row
+  // split * ws_split_rows + head * ws_head_rows + token (ffpa_varlen_merge_kernel, ffpa_varlen_merge.h, combines them: the reference's decode stage 2)
+  int64_t ws_head_rows;   // total_q
+  int64_t ws_split_rows;  // query heads x total_q
 };
 
 // NT: the decode-batch build — every K / V piece carries the non-temporal hint (each byte has ONE reader and the batch's K + V do not fit the caches: the launch
@@ -409,7 +418,12 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_varlen_kernel(const FwdArgs 
 #include "ffpa_fwd_m16_head.inc"
   int vid = blockIdx.x;
   if (!(a_in.flags & kFlagNoXcdRemap)) vid = xcd_logical_id(vid, gridDim.x, a_in.xcd_group);
-  const int split = 0;
+  int split = 0;
+  if (a_in.nsplit > 1) {  // (the KV ranges of a pair are neighbours in the launch order: one XCD, one after the other)
+    const int pair = vid / a_in.nsplit;
+    split = vid - pair * a_in.nsplit;
+    vid = pair;
+  }
   // Order of the (sequence, head) pairs: head CHUNK-major, then sequence, then the head inside its chunk (va.head_chunk consecutive heads: Hq / 8 when that is
   // whole, else 1).  The XCD remap hands every XCD a contiguous range of pairs (all row tiles of a pair on one XCD: its K / V stream stays in one L2), and
   // sequences differ in length by orders of magnitude — sequence-major (the dense order) gives one XCD the longest sequence and another the shortest (measured:
@@ -445,6 +459,10 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_varlen_kernel(const FwdArgs 
     a.Nq = nq_seq;
     a.Nkv = nkv_seq > 0 ? nkv_seq : 0;
     a.causal_offset = a.Nkv - nq_seq;  // (packed decode runs without the causal flag: a single token sees every key of its sequence)
+    if (a_in.nsplit > 1) {
+      const int tiles = (a.Nkv + BC - 1) / BC;
+      a.tiles_per_split = (tiles + a_in.nsplit - 1) / a_in.nsplit;  // (a sequence shorter than nsplit tiles leaves ranges empty: dead partials, weight 0 in the merge)
+    }
     a.q = (const T*)a_in.q + (int64_t)q_lo * va.q_tok_stride;
     a.o = (T*)a_in.o + (int64_t)q_lo * va.o_tok_stride;
     a.k = (const T*)a_in.k + (int64_t)k_lo * a_in.sk[2];
@@ -454,7 +472,10 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_varlen_kernel(const FwdArgs 
 #define FFPA_M16_ROW_INV(l) ((l) > 0.f ? __builtin_amdgcn_rcpf(l) : 0.f)
 #define FFPA_M16_ROW_OUT(x, rh) (l_tot[rh] > 0.f ? (T)((x) * inv[rh]) : (T)0.f)  // (the select BEHIND product + conversion: those stay the dense kernel's one instruction — fp16: v_fma_mixlo, one rounding — and its bits)
 #define FFPA_M16_LSE_INDEX(row) (va.pack ? (int64_t)(hq * va.pack + (row)) * va.lse_stride_h + q_lo : (int64_t)hq * va.lse_stride_h + q_lo + (row))
+// (the KV-split workspace of the packed call: [split, query head, token] rows — ffpa_varlen_merge_kernel reads them back by (head, token))
+#define FFPA_M16_WS_ROW(row) ((int64_t)split * va.ws_split_rows + (va.pack ? (int64_t)(hq * va.pack + (row)) * va.ws_head_rows + q_lo : (int64_t)hq * va.ws_head_rows + q_lo + (row)))
 #include "ffpa_fwd_m16_tile.inc"
+#undef FFPA_M16_WS_ROW
 #undef FFPA_M16_LSE_INDEX
 #undef FFPA_M16_ROW_OUT
 #undef FFPA_M16_ROW_INV

@@ -31,7 +31,7 @@ _PKG = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_PKG, "libffpa_attn_hip.so")
 TEST_LIB_PATH = os.path.join(_PKG, "libffpa_attn_hip_test.so")  # product kernels + the register-staged SAFE twins (tests only)
 
-ABI_VERSION = 5  # 5: + the packed-sequence entry points (ffpa_attn_varlen_fwd ...)
+ABI_VERSION = 6  # 5: + the packed-sequence entry points (ffpa_attn_varlen_fwd ...); 6: + KV splits inside the packed call
 
 # enum ffpa_status (include/ffpa_attn.h)
 _STATUS_EXC = {
@@ -148,6 +148,10 @@ class FfpaVarlenFwdParams(ctypes.Structure):
     ("rescale_threshold", ctypes.c_float),
     ("flags", ctypes.c_uint32),
     ("reserved", ctypes.c_uint32),
+    ("workspace", ctypes.c_void_p),
+    ("workspace_bytes", ctypes.c_uint64),
+    ("num_splits", ctypes.c_int32),
+    ("total_q", ctypes.c_int32),
   ]
 
 
@@ -165,6 +169,7 @@ EXPORTS = (
   "ffpa_attn_varlen_fwd",
   "ffpa_attn_varlen_fwd_plan",
   "ffpa_attn_varlen_fwd_kernel",
+  "ffpa_attn_varlen_fwd_workspace_bytes",
   "ffpa_attn_query",
   "ffpa_attn_fwd_tile_config",
   "ffpa_attn_last_error",
@@ -209,6 +214,8 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
       lib.ffpa_attn_varlen_fwd.restype = ctypes.c_int
       lib.ffpa_attn_varlen_fwd_plan.argtypes = [ctypes.POINTER(FfpaVarlenFwdParams), ctypes.POINTER(ctypes.c_int)]
       lib.ffpa_attn_varlen_fwd_plan.restype = ctypes.c_int
+      lib.ffpa_attn_varlen_fwd_workspace_bytes.argtypes = [ctypes.POINTER(FfpaVarlenFwdParams)]
+      lib.ffpa_attn_varlen_fwd_workspace_bytes.restype = ctypes.c_size_t
       lib.ffpa_attn_varlen_fwd_kernel.argtypes = [ctypes.POINTER(FfpaVarlenFwdParams), ctypes.c_char_p, ctypes.c_size_t]
       lib.ffpa_attn_varlen_fwd_kernel.restype = ctypes.c_int
     lib.ffpa_attn_query.argtypes = [ctypes.c_int]
@@ -840,7 +847,7 @@ def _packed_rows(t: torch.Tensor) -> torch.Tensor:
 
 
 def _varlen_params(q, k, v, o, lse, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, max_seqlen_k: int, causal: bool, softmax_scale: float,
-                   rescale_threshold: float, flags: int, seqused_k=None) -> FfpaVarlenFwdParams:
+                   rescale_threshold: float, flags: int, seqused_k=None, num_splits: int = 0) -> FfpaVarlenFwdParams:
   p = FfpaVarlenFwdParams()
   p.struct_size = ctypes.sizeof(FfpaVarlenFwdParams)
   p.abi_version = ABI_VERSION
@@ -858,13 +865,31 @@ def _varlen_params(q, k, v, o, lse, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: in
   p.causal = 1 if causal else 0
   p.softmax_scale = float(softmax_scale)
   p.rescale_threshold = float(rescale_threshold)
-  p.flags = int(flags)
+  p.flags = int(flags) | (FLAG_DETERMINISTIC if os.environ.get("FFPA_HIP_DETERMINISTIC", "0").lower() not in ("0", "", "off", "false", "no") else 0)
+  p.num_splits = int(num_splits)
+  p.total_q = q.size(0)
   return p
+
+
+# Scratch of a KV-split packed launch: a function of the shape class (ffpa_capi.hip varlen_plan), asked once per class
+_VARLEN_SCRATCH: "dict[tuple, int]" = {}
+
+
+def _varlen_scratch(lib, p: "FfpaVarlenFwdParams", device_index: int) -> int:
+  if p.num_splits == 1 or p.flags & FLAG_DETERMINISTIC:
+    return 0
+  key = (id(lib), device_index, p.dtype, p.batch, p.heads_q, p.heads_kv, p.head_dim, p.max_seqlen_q, p.max_seqlen_kv, p.total_q, p.flags, p.num_splits, os.environ.get("FFPA_HIP_FAKE_CUS"))
+  hit = _VARLEN_SCRATCH.get(key)
+  if hit is None:
+    if len(_VARLEN_SCRATCH) >= 512:
+      _VARLEN_SCRATCH.clear()
+    hit = _VARLEN_SCRATCH[key] = int(lib.ffpa_attn_varlen_fwd_workspace_bytes(ctypes.byref(p)))
+  return hit
 
 
 def varlen_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens_q: torch.Tensor, cu_seqlens_k: torch.Tensor, max_seqlen_q: int,
                    max_seqlen_k: int, causal: bool, softmax_scale: float, *, rescale_threshold: float = -1.0, return_lse: bool = True, flags: int = 0,
-                   plan_out: "dict | None" = None, seqused_k: "torch.Tensor | None" = None):
+                   plan_out: "dict | None" = None, seqused_k: "torch.Tensor | None" = None, num_splits: int = 0):
   """One launch of the packed-sequence kernel: ``q [T_q, Hq, D]``, ``k`` / ``v [T_k, Hkv, D]``, int32 device ``cu_seqlens_*`` ``[B + 1]`` ->
   ``(o [T_q, Hq, D], lse [Hq, T_q] fp32 | None)``.  Nothing is read back to the host and nothing synchronises: the call captures into a HIP graph.
   Rows without a visible key: O = 0, LSE = -inf.
@@ -872,7 +897,11 @@ def varlen_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens
   ``seqused_k`` (int32 device ``[B]``, this build's extension at the op level — the public ``ffpa_attn_varlen_func`` rejects it like the reference's): sequence i
   uses only the first ``seqused_k[i]`` of its key rows — a KV cache of fixed capacity per sequence (``k`` / ``v`` = the cache viewed as ``[B * capacity, Hkv, D]``,
   ``cu_seqlens_k`` = multiples of the capacity) whose valid lengths live on the device: ONE captured graph serves every length, a replay follows lengths written
-  in place, and with one token per sequence under GQA the group's heads are packed into the rows of one tile (FlashAttention's ``cache_seqlens`` decode)."""
+  in place, and with one token per sequence under GQA the group's heads are packed into the rows of one tile (FlashAttention's ``cache_seqlens`` decode).
+
+  ``num_splits``: 0 = the library decides (launches of one row tile per (sequence, head) that leave most of the chip idle — a decode batch of a few long
+  sequences — split every sequence's KV range over several workgroups and merge fp32 partials in a second kernel of the same call: equal to the unsplit launch
+  to rounding, not to the bit), 1 = never, n = at most n.  ``FFPA_HIP_DETERMINISTIC=1`` / ``FLAG_DETERMINISTIC``: never."""
   if not q.is_cuda:
     raise NotImplementedError(f"ffpa_attn::_varlen_fwd_hip has no implementation for device '{q.device.type}' (the HIP kernel needs a GPU tensor)")
   lib = load_library()
@@ -911,14 +940,20 @@ def varlen_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens
   lse = torch.empty((Hq, Tq), dtype=torch.float32, device=q.device) if return_lse else None
   if Tq == 0 or max_seqlen_q <= 0:
     return (o[..., :D] if Dp != D else o), lse  # (nothing to compute: no query row in any sequence)
-  p = _varlen_params(q, k, v, o, lse, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal, softmax_scale, rescale_threshold, flags, seqused_k)
+  p = _varlen_params(q, k, v, o, lse, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal, softmax_scale, rescale_threshold, flags, seqused_k, num_splits)
   with torch.cuda.device(q.device):
     stream = torch.cuda.current_stream(q.device).cuda_stream
+    ws_bytes = _varlen_scratch(lib, p, q.device.index or 0)
+    workspace = None
+    if ws_bytes:
+      workspace = _workspace(q.device, stream, ws_bytes)  # (held in a local until the launch below has been enqueued)
+      p.workspace = workspace.data_ptr()
+      p.workspace_bytes = ws_bytes
     if plan_out is not None:
-      plan = (ctypes.c_int * 4)()
+      plan = (ctypes.c_int * 5)()
       if lib.ffpa_attn_varlen_fwd_plan(ctypes.byref(p), plan) == 0:
-        plan_out.update(row_tiles=plan[0], block_rows=plan[1], block_keys=plan[2], workgroups=plan[3])
-      name = ctypes.create_string_buffer(160)
+        plan_out.update(row_tiles=plan[0], block_rows=plan[1], block_keys=plan[2], workgroups=plan[3], splits=plan[4])
+      name = ctypes.create_string_buffer(200)
       if lib.ffpa_attn_varlen_fwd_kernel(ctypes.byref(p), name, len(name)) == 0:
         plan_out["kernel"] = name.value.decode()
     rc = lib.ffpa_attn_varlen_fwd(ctypes.byref(p), ctypes.c_void_p(stream))
@@ -930,8 +965,10 @@ def varlen_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens
 
 
 def varlen_launch_plan(batch: int, heads_q: int, heads_kv: int, max_seqlen_q: int, max_seqlen_k: int, head_dim: int, *,
-                       dtype: torch.dtype = torch.bfloat16, causal: bool = False, flags: int = 0) -> dict:
-  """The packed-sequence launch for a shape class, without launching (placeholder pointers): row tiles per (sequence, head), tile, workgroups, kernel name."""
+                       dtype: torch.dtype = torch.bfloat16, causal: bool = False, flags: int = 0, total_q: int = 0, num_splits: int = 0) -> dict:
+  """The packed-sequence launch for a shape class, without launching (placeholder pointers): row tiles per (sequence, head), tile, workgroups, KV ranges per
+  sequence, kernel name.  ``total_q`` (rows of q) > 0: the plan of a call that hands the library its scratch (``varlen_forward`` does) — KV splits included;
+  0: the plan without scratch (never split)."""
   lib = load_library()
   d8 = (int(head_dim) + 7) // 8 * 8
   p = FfpaVarlenFwdParams()
@@ -947,13 +984,20 @@ def varlen_launch_plan(batch: int, heads_q: int, heads_kv: int, max_seqlen_q: in
   p.softmax_scale = float(head_dim) ** -0.5
   p.rescale_threshold = -1.0
   p.flags = int(flags)
-  plan = (ctypes.c_int * 4)()
+  p.num_splits = int(num_splits)
+  p.total_q = int(total_q)
+  if total_q > 0:
+    p.workspace, p.workspace_bytes = 16, 0xFFFFFFFFFFFFFFFF
+  plan = (ctypes.c_int * 5)()
   rc = lib.ffpa_attn_varlen_fwd_plan(ctypes.byref(p), plan)
   if rc != 0:
     raise _STATUS_EXC.get(rc, RuntimeError)(lib.ffpa_attn_last_error().decode())
-  name = ctypes.create_string_buffer(160)
+  name = ctypes.create_string_buffer(200)
   lib.ffpa_attn_varlen_fwd_kernel(ctypes.byref(p), name, len(name))
-  return {"row_tiles": plan[0], "block_rows": plan[1], "block_keys": plan[2], "workgroups": plan[3], "kernel": name.value.decode()}
+  out = {"row_tiles": plan[0], "block_rows": plan[1], "block_keys": plan[2], "workgroups": plan[3], "kernel": name.value.decode()}
+  if total_q > 0:
+    out["splits"] = plan[4]
+  return out
 
 
 torch.library.define(

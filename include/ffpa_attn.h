@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FFPA_ATTN_ABI_VERSION 5 /* 5: + the packed-sequence entry points (ffpa_attn_varlen_fwd ...) */
+#define FFPA_ATTN_ABI_VERSION 6 /* 5: + the packed-sequence entry points (ffpa_attn_varlen_fwd ...); 6: + KV splits inside the packed call (its workspace fields, ffpa_attn_varlen_fwd_workspace_bytes, plan out[4]) */
 
 /* status codes (0 == success).  The Python host maps them onto the exception
  * classes the reference raises (TORCH_CHECK -> RuntimeError,
@@ -280,16 +280,31 @@ typedef struct ffpa_varlen_fwd_params {
 
   float softmax_scale;     /* > 0 or < 0 or 0: as ffpa_fwd_params */
   float rescale_threshold; /* as ffpa_fwd_params: < 0 => 8.0 */
-  uint32_t flags;          /* FFPA_FLAG_NO_XCD_REMAP, FFPA_FLAG_L2_PREFETCH / _NO_L2_PREFETCH, FFPA_FLAG_XCD_GROUP(), FFPA_FLAG_NO_PACK_GQA, FFPA_FLAG_KV_STREAM / _NO_KV_STREAM; others ignored */
+  uint32_t flags;          /* FFPA_FLAG_NO_XCD_REMAP, FFPA_FLAG_L2_PREFETCH / _NO_L2_PREFETCH, FFPA_FLAG_XCD_GROUP(), FFPA_FLAG_NO_PACK_GQA, FFPA_FLAG_KV_STREAM / _NO_KV_STREAM, FFPA_FLAG_DETERMINISTIC, FFPA_FLAG_FORCE_SPLITS; others ignored */
   uint32_t reserved;       /* 0 */
+
+  /* KV SPLITS (ABI 6): batches whose (sequence, head) pairs leave most of the chip idle — a decode batch of a few long sequences: 8 sequences x 8 KV heads
+   * are 64 workgroups for 256 CUs — split every sequence's KV range over num_splits workgroups (each sequence by ITS OWN length, read on the device:
+   * ceil(tiles_i / splits) KV tiles per range), which write normalised fp32 partials + LSE to the workspace; a second kernel of the same call merges them
+   * (the reference's decode stage 2, csrc/cuffpa/native/sm_80/split_kv.cuh:329-455).  Still nothing read on the host, still graph-capturable (two nodes).
+   * Only launches with ONE row tile per (sequence, head) split (max_seqlen_q <= block rows: decode, speculative decoding, chunked prefill), and only with a
+   * workspace: size from ffpa_attn_varlen_fwd_workspace_bytes().  A split launch's bits equal the unsplit launch's to fp32-merge rounding, not to the bit:
+   * FFPA_FLAG_DETERMINISTIC or num_splits = 1 keeps one range per sequence. */
+  void* workspace;          /* device scratch, 16-byte aligned; NULL => no split */
+  uint64_t workspace_bytes;
+  int32_t num_splits;       /* 0 = library heuristic, 1 = never split, n = at most n (with FFPA_FLAG_FORCE_SPLITS: exactly n where the key length allows) */
+  int32_t total_q;          /* rows of q / o (= cu_seqlens_q[batch]); 0 => no split (the partials are laid out [split, Hq, total_q, D]) */
 } ffpa_varlen_fwd_params;
 
 /* Launch the packed-sequence forward on `stream` of the CURRENT device.  Asynchronous; returns an ffpa_status. */
 int ffpa_attn_varlen_fwd(const ffpa_varlen_fwd_params* params, void* stream);
 
+/* Scratch bytes the packed call wants for the KV split count its heuristic would pick with unlimited scratch (0 = it would not split). */
+size_t ffpa_attn_varlen_fwd_workspace_bytes(const ffpa_varlen_fwd_params* params);
+
 /* Its launch plan: out[0] = row tiles per (sequence, head) in the grid, out[1] = query rows per workgroup, out[2] = keys per tile,
- * out[3] = workgroups of the launch.  Returns an ffpa_status. */
-int ffpa_attn_varlen_fwd_plan(const ffpa_varlen_fwd_params* params, int out[4]);
+ * out[3] = workgroups of the launch (all KV ranges), out[4] = KV ranges per sequence given params->workspace_bytes (ABI 6).  Returns an ffpa_status. */
+int ffpa_attn_varlen_fwd_plan(const ffpa_varlen_fwd_params* params, int out[5]);
 
 /* The kernel it runs, as text ("ffpa_fwd_m16_varlen_kernel<bf16, 512>").  Returns an ffpa_status. */
 int ffpa_attn_varlen_fwd_kernel(const ffpa_varlen_fwd_params* params, char* buf, size_t n);

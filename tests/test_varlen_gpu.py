@@ -50,9 +50,13 @@ def _seq(t, a, b):
   return t[a:b].transpose(0, 1).unsqueeze(0)
 
 
-def _check_packed(hip, q, k, v, lens_q, lens_k, causal, out, lse, *, oracle=True, dense_bits=True, sdpa=True, name=""):
-  """out / lse of one packed call against the three references, sequence by sequence."""
+def _check_packed(hip, q, k, v, lens_q, lens_k, causal, out, lse, *, oracle=True, dense_bits=True, sdpa=True, name="", max_q=None, max_k=None):
+  """out / lse of one packed call against the three references, sequence by sequence.  (max_q / max_k: what the call announced, if not the longest sequence —
+  a launch that split its KV ranges merged fp32 partials: equal to the dense kernel to rounding, so the bit comparison is skipped for it.)"""
   hq, d = q.size(1), q.size(2)
+  if dense_bits:
+    plan = hip.varlen_launch_plan(len(lens_q), hq, k.size(1), max(max_q or max(lens_q), 1), max(max_k or max(lens_k), 1), d, dtype=q.dtype, causal=causal, total_q=q.size(0))
+    dense_bits = plan["splits"] == 1
   assert out.shape == q.shape and out.dtype == q.dtype and lse.shape == (hq, q.size(0)) and lse.dtype == torch.float32
   bq, bk = np.cumsum([0, *lens_q]), np.cumsum([0, *lens_k])
   scale = 1.0 / math.sqrt(d)
@@ -325,9 +329,10 @@ def test_randomized_packed_batches(hip):
     causal = bool(rng.random() < 0.5)
     q, k, v = _make(lens_q, lens_k, hq, hkv, d, dtype, seed=seed)
     mq, mk = max(lens_q), max(max(lens_k), 1)
-    out, lse = hip.varlen_forward(q, k, v, _cu(lens_q), _cu(lens_k), mq + int(rng.integers(0, 200)), mk, causal, 1.0 / math.sqrt(d))
+    mq_said = mq + int(rng.integers(0, 200))
+    out, lse = hip.varlen_forward(q, k, v, _cu(lens_q), _cu(lens_k), mq_said, mk, causal, 1.0 / math.sqrt(d))
     name = f"fuzz seed {seed}: lens_q={lens_q} lens_k={lens_k} Hq={hq} Hkv={hkv} D={d} {dtype} causal={causal}"
-    _check_packed(hip, q, k, v, lens_q, lens_k, causal, out, lse, oracle=False, sdpa=d <= 512, name=name)
+    _check_packed(hip, q, k, v, lens_q, lens_k, causal, out, lse, oracle=False, sdpa=d <= 512, name=name, max_q=mq_said, max_k=mk)
     live = [i for i, (a, b) in enumerate(zip(lens_q, lens_k)) if a > 0 and b > 0 and not (causal and a > b)]
     if live:
       i = live[seed % len(live)]
@@ -347,10 +352,10 @@ def test_decode_batches_pack_the_heads_of_a_kv_group_into_rows(hip, hq, hkv, d, 
   q, k, v = _make(lens_q, lens_k, hq, hkv, d, dtype, seed=hq + d)
   cu_q, cu_k = _cu(lens_q), _cu(lens_k)
   plan = {}
-  out, lse = hip.varlen_forward(q, k, v, cu_q, cu_k, 1, max(lens_k), True, d ** -0.5, plan_out=plan)
+  out, lse = hip.varlen_forward(q, k, v, cu_q, cu_k, 1, max(lens_k), True, d ** -0.5, plan_out=plan, num_splits=1)  # (one KV range per sequence: the bits below)
   assert plan["workgroups"] == len(lens_q) * hkv and "packed into rows" in plan["kernel"], plan
   plan_u = {}
-  out_u, lse_u = hip.varlen_forward(q, k, v, cu_q, cu_k, 1, max(lens_k), True, d ** -0.5, flags=hip.FLAG_NO_PACK_GQA, plan_out=plan_u)
+  out_u, lse_u = hip.varlen_forward(q, k, v, cu_q, cu_k, 1, max(lens_k), True, d ** -0.5, flags=hip.FLAG_NO_PACK_GQA, plan_out=plan_u, num_splits=1)
   assert plan_u["workgroups"] == len(lens_q) * hq
   assert torch.equal(out, out_u) and torch.equal(lse, lse_u)
   _check_packed(hip, q, k, v, lens_q, lens_k, True, out, lse, oracle=False, dense_bits=False, sdpa=d <= 512, name=f"packed decode Hq{hq}/Hkv{hkv} D{d}")
@@ -359,6 +364,56 @@ def test_decode_batches_pack_the_heads_of_a_kv_group_into_rows(hip, hq, hkv, d, 
   qs, ks = sum(lens_q[:i]), sum(lens_k[:i])
   _check_vs_oracle(_seq(out, qs, qs + 1), lse[:, qs:qs + 1].unsqueeze(0), _seq(q, qs, qs + 1), _seq(k, ks, ks + lens_k[i]), _seq(v, ks, ks + lens_k[i]),
                    causal=True, causal_offset=lens_k[i] - 1, block_keys=plan["block_keys"], name="packed decode vs oracle")
+
+
+def _same_to_merge_rounding(out, lse, ref, ref_lse, name):
+  """A KV-split launch against the one-range launch of the same batch: the same softmax, combined from normalised fp32 partials.  Not the same bits: every range
+  runs the recurrence from ITS first tile (its own stale row max under the lazy-rescale convention), so P = exp2(s - m) is rounded to 16 bits at another position
+  of its binade — the P-rounding noise of two runs, not of one: per element one output spacing + 2^-8 (bf16) / 2^-11 (fp16) of the row's largest |O|.  LSE within fp32
+  rounding of the exp / log pair; rows without a visible key exactly 0 / -inf in both."""
+  dead = ref_lse == -float("inf")
+  assert torch.equal(lse == -float("inf"), dead), name
+  assert torch.allclose(lse[~dead], ref_lse[~dead], rtol=0, atol=2e-5), f"{name}: LSE differs by {(lse[~dead] - ref_lse[~dead]).abs().max().item():.3e}"
+  a, b = out.float(), ref.float()
+  assert torch.isfinite(a).all(), name
+  bf = out.dtype == torch.bfloat16
+  spacing = torch.maximum(a.abs(), b.abs()).clamp_min(2.0 ** -14) * (2.0 ** -7 if bf else 2.0 ** -10)
+  allow = spacing + b.abs().amax(dim=-1, keepdim=True) * (2.0 ** -8 if bf else 2.0 ** -11)
+  diff = (a - b).abs()
+  assert torch.all(diff <= allow), f"{name}: O differs from the one-range launch by {(diff / allow).max().item():.2f} x the allowance"
+  assert (diff / allow).mean().item() < 0.15, f"{name}: mean difference {(diff / allow).mean().item():.3f} of the allowance"
+  assert torch.all(a[dead.t().unsqueeze(-1).expand_as(a)] == 0), name
+
+
+@pytest.mark.parametrize("hq, hkv, d, dtype, nq, splits", [
+  (32, 8, 512, torch.bfloat16, 1, 0), (32, 8, 512, torch.bfloat16, 1, 3), (8, 8, 320, torch.float16, 1, 5), (4, 1, 1024, torch.bfloat16, 1, 16), (16, 4, 128, torch.bfloat16, 1, 2),
+  (8, 8, 512, torch.bfloat16, 37, 4), (8, 2, 256, torch.float16, 100, 7), (8, 2, 640, torch.bfloat16, 64, 0), (4, 4, 512, torch.bfloat16, 128, 64),
+])
+def test_kv_splits_inside_the_packed_launch(hip, hq, hkv, d, dtype, nq, splits):
+  """Batches of one row tile per (sequence, head) that leave most of the chip idle split every sequence's KV range over several workgroups — each sequence by ITS OWN
+  length, read on the device — and merge fp32 partials in a second kernel of the same call.  Left to the library (splits = 0) and forced (FLAG_FORCE_SPLITS: 2 ... 64
+  ranges, more ranges than some sequences have KV tiles; ranges without a key; sequences without a key or a token) against the one-range launch of the same batch (to
+  merge rounding), SDPA per sequence and the oracle on the longest sequence; the empty-row contract holds through the merge."""
+  lens_k = [2900, 0, 64, 1300, 129, 4096, 1, 33, 640]  # (33 < Nq: the first Nq - 33 rows of that sequence see no key under the causal flag)
+  lens_q = [nq, nq, 0, nq, max(1, nq // 2), nq, 1, nq, nq]
+  q, k, v = _make(lens_q, lens_k, hq, hkv, d, dtype, seed=hq + d + nq)
+  cu_q, cu_k = _cu(lens_q), _cu(lens_k)
+  p1, ps = {}, {}
+  ref, ref_lse = hip.varlen_forward(q, k, v, cu_q, cu_k, nq, max(lens_k), True, d ** -0.5, num_splits=1, plan_out=p1)
+  out, lse = hip.varlen_forward(q, k, v, cu_q, cu_k, nq, max(lens_k), True, d ** -0.5, num_splits=splits, flags=hip.FLAG_FORCE_SPLITS if splits else 0, plan_out=ps)
+  assert p1["splits"] == 1 and "merge" not in p1["kernel"]
+  tiles = -(-max(lens_k) // ps["block_keys"])
+  assert ps["splits"] == (min(splits, tiles) if splits else ps["splits"]) and ps["splits"] > 1 and ps["workgroups"] == p1["workgroups"] * ps["splits"], (p1, ps)
+  assert ps["kernel"].endswith("+ ffpa_varlen_merge_kernel"), ps
+  _same_to_merge_rounding(out, lse, ref, ref_lse, f"splits {ps['splits']} Hq{hq}/Hkv{hkv} D{d} Nq{nq}")
+  _check_packed(hip, q, k, v, lens_q, lens_k, True, out, lse, oracle=False, dense_bits=False, sdpa=d <= 512, name=f"KV splits {ps['splits']} Hq{hq}/Hkv{hkv} D{d} Nq{nq}")
+  i = 5
+  qs, ks = sum(lens_q[:i]), sum(lens_k[:i])
+  _check_vs_oracle(_seq(out, qs, qs + nq), lse[:, qs:qs + nq].unsqueeze(0), _seq(q, qs, qs + nq), _seq(k, ks, ks + lens_k[i]), _seq(v, ks, ks + lens_k[i]),
+                   causal=True, causal_offset=lens_k[i] - nq, block_keys=ps["block_keys"], name="KV splits vs oracle")
+  # the deterministic flag keeps one range per sequence: the one-range launch's bits
+  det, det_lse = hip.varlen_forward(q, k, v, cu_q, cu_k, nq, max(lens_k), True, d ** -0.5, flags=hip.FLAG_DETERMINISTIC)
+  assert torch.equal(det, ref) and torch.equal(det_lse, ref_lse)
 
 
 @pytest.mark.parametrize("hq, hkv, d, dtype, nq", [(32, 8, 512, torch.bfloat16, 1), (8, 8, 320, torch.float16, 1), (4, 1, 1024, torch.bfloat16, 1), (8, 8, 128, torch.bfloat16, 37)])
@@ -377,7 +432,8 @@ def test_decode_batches_with_the_non_temporal_kv_fetch_are_bit_identical(hip, hq
   _check_packed(hip, q, k, v, lens_q, lens_k, True, out_a, lse_a, oracle=False, dense_bits=False, sdpa=d <= 512, name=f"NT packed decode Hq{hq}/Hkv{hkv} D{d}")
 
 
-def test_static_capacity_kv_cache_with_device_side_lengths(hip):
+@pytest.mark.parametrize("num_splits", [1, 0])
+def test_static_capacity_kv_cache_with_device_side_lengths(hip, num_splits):
   """seqused_k (the op-level extension): a KV cache of fixed capacity per sequence, viewed as packed rows, whose valid lengths live on the device — equal, bit for
   bit, to the call on the tightly packed valid rows; ONE captured graph follows lengths rewritten in place; decode under GQA runs packed (one workgroup per
   (sequence, KV head)).  Rows of the cache past a sequence's length are NaN: nothing may read them."""
@@ -404,17 +460,21 @@ def test_static_capacity_kv_cache_with_device_side_lengths(hip):
     used.copy_(torch.tensor(lens, dtype=torch.int32))
     if graph is None:
       plan = {}
-      hip.varlen_forward(q, kk, vv, cu_q, cu_k, 1, cap, True, d ** -0.5, seqused_k=used, plan_out=plan)  # (warm-up outside the capture)
-      assert plan["workgroups"] == b * hkv and "packed into rows" in plan["kernel"]
+      hip.varlen_forward(q, kk, vv, cu_q, cu_k, 1, cap, True, d ** -0.5, seqused_k=used, plan_out=plan, num_splits=num_splits)  # (warm-up outside the capture)
+      # (24 workgroups for 256 CUs: left to itself the launch splits every sequence's KV range — by its length on the device — and the graph holds two kernels)
+      assert plan["workgroups"] == b * hkv * plan["splits"] and "packed into rows" in plan["kernel"] and (plan["splits"] == 1) == (num_splits == 1), plan
       graph = torch.cuda.CUDAGraph()
       with torch.cuda.graph(graph):
-        out, lse = hip.varlen_forward(q, kk, vv, cu_q, cu_k, 1, cap, True, d ** -0.5, seqused_k=used)
+        out, lse = hip.varlen_forward(q, kk, vv, cu_q, cu_k, 1, cap, True, d ** -0.5, seqused_k=used, num_splits=num_splits)
     graph.replay()
     torch.cuda.synchronize()
     tight_k = torch.cat([cache_k[i, :n] for i, n in enumerate(lens)]).contiguous()
     tight_v = torch.cat([cache_v[i, :n] for i, n in enumerate(lens)]).contiguous()
-    ref, ref_lse = hip.varlen_forward(q, tight_k, tight_v, cu_q, _cu(lens), 1, max(lens), True, d ** -0.5)
-    assert torch.equal(out, ref) and torch.equal(lse, ref_lse), lens
+    ref, ref_lse = hip.varlen_forward(q, tight_k, tight_v, cu_q, _cu(lens), 1, max(lens), True, d ** -0.5, num_splits=1)
+    if num_splits == 1:
+      assert torch.equal(out, ref) and torch.equal(lse, ref_lse), lens
+    else:
+      _same_to_merge_rounding(out, lse, ref, ref_lse, f"cache lens {lens}")
     _check_packed(hip, q, tight_k, tight_v, [1] * b, lens, True, out, lse, oracle=False, dense_bits=False, name=f"cache lens {lens}")
   # the public entry point keeps the reference's refusal of this option
   from ffpa_attn_amd import ffpa_attn_varlen_func
