@@ -900,10 +900,12 @@ int varlen_plan(const ffpa_varlen_fwd_params* p, VarlenPlan* out) {
   out->ve = ve;
   out->br = 128 / (dk <= 512 ? 1 : 2);
   out->bc = ffpa::m16_block_keys(dk, false);
-  // decode batches (at most one query token per sequence) under GQA: the group's heads ride in the rows of ONE tile per (sequence, KV head) — the K / V stream
-  // of a group is read once, not once per query head.  (More tokens per sequence would need rows (token, head) that are not evenly spaced in a THD tensor.)
+  // short query sequences under GQA — decode (one token per sequence), speculative decoding / multi-token prediction / small prefill chunks (a few) —: the group's
+  // heads x the sequence's tokens ride in the rows of ONE tile per (sequence, KV head), head-major (VarlenArgs::pack) — the K / V stream of a group is read once, not
+  // once per query head, and the tile's MFMA rows are `group` times better used.  Packed when every sequence's rows fit one tile: group x max_seqlen_q <= block rows.
+  // Measured (tools/gpu_varlen_decode.py, profiles/r06_varlen_pack_tokens.txt): 16 sequences x 16 tokens, Hq 32 / Hkv 8, D 512: 2.2 -> 4.7 TB/s of K + V; 2.1 ... 5.2 x one workgroup per query head on five shapes, bit-identical.
   const int group = p->heads_q / p->heads_kv;
-  out->pack = (p->max_seqlen_q == 1 && group > 1 && group <= out->br && !(p->flags & FFPA_FLAG_NO_PACK_GQA)) ? group : 0;
+  out->pack = (group > 1 && (int64_t)group * p->max_seqlen_q <= out->br && !(p->flags & FFPA_FLAG_NO_PACK_GQA)) ? group : 0;
   out->nqt = out->pack ? 1 : (p->max_seqlen_q + out->br - 1) / out->br;
   out->grid = (int64_t)p->batch * (out->pack ? p->heads_kv : p->heads_q) * out->nqt;
   // The non-temporal K / V fetch (the dense short-query launches' rule, ffpa_attn_fwd): every K / V byte is read by ONE workgroup — one row tile per (sequence,
@@ -1067,7 +1069,7 @@ int ffpa_attn_varlen_fwd(const ffpa_varlen_fwd_params* p, void* stream) {
     a.group = 1;
     a.sq[1] = p->q_stride[1] * pl.pack, a.sq[2] = p->q_stride[1];
     a.so[1] = p->o_stride[1] * pl.pack, a.so[2] = p->o_stride[1];
-    a.causal = 0;
+    if (p->max_seqlen_q == 1) a.causal = 0;  // (a single token sees every key of its sequence; more tokens: the kernel sets causal_row_mod per sequence)
     va.head_chunk = 1;  // (the rows of a tile ARE the group: KV heads share nothing)
   }
 

@@ -330,7 +330,11 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_kernel(const FwdArgs a) {
 #define FFPA_M16_ROW_OUT(x, rh) (T)((x) * inv[rh])
 #define FFPA_M16_LSE_INDEX(row) ((int64_t)b * a.Hq + hq) * a.Nq + (row)
 #define FFPA_M16_WS_ROW(row) ((((int64_t)split * a.B + b) * a.Hq + hq) * a.Nq + (row))
+#define FFPA_M16_Q_ROW_OFF(row) ((int64_t)(row) * a.sq[2])
+#define FFPA_M16_O_ROW_OFF(row) ((int64_t)(row) * a.so[2])
 #include "ffpa_fwd_m16_tile.inc"
+#undef FFPA_M16_O_ROW_OFF
+#undef FFPA_M16_Q_ROW_OFF
 #undef FFPA_M16_WS_ROW
 #undef FFPA_M16_LSE_INDEX
 #undef FFPA_M16_ROW_OUT
@@ -367,7 +371,11 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_pair_kernel(const FwdArgs a)
 #define FFPA_M16_ROW_OUT(x, rh) (T)((x) * inv[rh])
 #define FFPA_M16_LSE_INDEX(row) ((int64_t)b * a.Hq + hq) * a.Nq + (row)
 #define FFPA_M16_WS_ROW(row) ((((int64_t)split * a.B + b) * a.Hq + hq) * a.Nq + (row))
+#define FFPA_M16_Q_ROW_OFF(row) ((int64_t)(row) * a.sq[2])
+#define FFPA_M16_O_ROW_OFF(row) ((int64_t)(row) * a.so[2])
 #include "ffpa_fwd_m16_tile.inc"
+#undef FFPA_M16_O_ROW_OFF
+#undef FFPA_M16_Q_ROW_OFF
 #undef FFPA_M16_WS_ROW
 #undef FFPA_M16_LSE_INDEX
 #undef FFPA_M16_ROW_OUT
@@ -392,10 +400,12 @@ struct VarlenArgs {
   const int* cu_k;       // [batch + 1] row offsets into k / v
   int64_t lse_stride_h;  // elements between two heads of the LSE tensor (>= T_q)
   int head_chunk;        // consecutive query heads that walk a sequence side by side (the workgroup order below): a divisor of Hq
-  // DECODE batches (one query token per sequence at most) under GQA: pack > 0 = the `pack` query heads of a KV group are the ROWS of the tile — FwdArgs then
-  // describes Hkv "heads" (head stride = one KV group, row stride = one query head) and a sequence has pack rows per token: the group's K / V stream is
-  // read by ONE workgroup instead of `pack` (the reference's pack_gqa, src/ffpa_attn/cute/__init__.py:792-829; the dense path packs the same way for
-  // Nq <= 7: hip/__init__.py).  A token's base address is its row offset times the TOKEN stride below, not the (head) row stride.  0 = rows are tokens.
+  // SHORT query sequences under GQA (decode: one token per sequence; speculative decoding / multi-token prediction / small prefill chunks: a few): pack > 0 = the
+  // `pack` query heads of a KV group x the sequence's tokens are the ROWS of ONE tile, head-major — row r of sequence i is (head r / ntok_i, token r % ntok_i), the
+  // layout the dense path's host-side packing produces (FwdArgs::causal_row_mod = ntok_i: the causal limit of row r is r % ntok_i + causal_offset).  FwdArgs then
+  // describes Hkv "heads" (head stride = one KV group, row stride = one query head): the group's K / V stream is read by ONE workgroup instead of `pack` (the
+  // reference's pack_gqa, src/ffpa_attn/cute/__init__.py:792-829; the dense path packs the same way for Nq <= 7: hip/__init__.py).  A token's address is its row
+  // offset times the TOKEN stride below, not the (head) row stride.  The launch side packs when pack x max_seqlen_q rows fit one tile.  0 = rows are tokens.
   int pack;
   int64_t q_tok_stride, o_tok_stride;  // elements between two tokens of q / o
   const int* used_k;     // optional [batch]: sequence i uses only the first used_k[i] of its key rows (a KV cache of fixed capacity per sequence whose valid
@@ -440,6 +450,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_varlen_kernel(const FwdArgs 
   const int bh = seq * a_in.Hq + chunk * va.head_chunk + (in_seq - (in_seq / va.head_chunk) * va.head_chunk);
   FwdArgs a = a_in;
   int q_lo;  // packed: the sequence's first row of q / o (LSE [Hq, T_q]: its column); dense: the batch element's first LSE row
+  int ntok = 1;  // tokens of this sequence (>= 1): packed rows are (row / ntok, row % ntok) = (head of the group, token)
   if (va.cu_q == nullptr) {
     // DENSE launches in this kernel's workgroup order (ffpa_attn_fwd -> ffpa_capi.hip: causal + GQA, no bias, no dropout, every row sees a key): the
     // arguments are the dense call's as they are — "sequence" = batch element, batch strides live —, only the order of the workgroups is this kernel's
@@ -453,12 +464,14 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_varlen_kernel(const FwdArgs 
       const int used = va.used_k[seq];
       nkv_seq = nkv_seq < used ? nkv_seq : used;
     }
-    const int nq_seq = va.pack ? (ntok_seq > 0 ? va.pack : 0) : ntok_seq;  // (packed decode: the rows of a sequence are the group's heads of its one token)
+    ntok = ntok_seq > 0 ? ntok_seq : 1;
+    const int nq_seq = va.pack ? va.pack * ntok_seq : ntok_seq;  // (packed: the rows of a sequence are (head of the group, token), head-major)
     if (qt * BR >= nq_seq) return;  // (max_seqlen_q sized the grid: this sequence is shorter)
     // (batch strides are zero: the launch side)
     a.Nq = nq_seq;
     a.Nkv = nkv_seq > 0 ? nkv_seq : 0;
-    a.causal_offset = a.Nkv - nq_seq;  // (packed decode runs without the causal flag: a single token sees every key of its sequence)
+    a.causal_offset = a.Nkv - ntok_seq;  // (tail-aligned per sequence; a single packed token runs without the causal flag — it sees every key of its sequence)
+    if (va.pack) a.causal_row_mod = ntok_seq;
     if (a_in.nsplit > 1) {
       const int tiles = (a.Nkv + BC - 1) / BC;
       a.tiles_per_split = (tiles + a_in.nsplit - 1) / a_in.nsplit;  // (a sequence shorter than nsplit tiles leaves ranges empty: dead partials, weight 0 in the merge)
@@ -471,10 +484,15 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_varlen_kernel(const FwdArgs 
 #define FFPA_M16_TILE_DONE return
 #define FFPA_M16_ROW_INV(l) ((l) > 0.f ? __builtin_amdgcn_rcpf(l) : 0.f)
 #define FFPA_M16_ROW_OUT(x, rh) (l_tot[rh] > 0.f ? (T)((x) * inv[rh]) : (T)0.f)  // (the select BEHIND product + conversion: those stay the dense kernel's one instruction — fp16: v_fma_mixlo, one rounding — and its bits)
-#define FFPA_M16_LSE_INDEX(row) (va.pack ? (int64_t)(hq * va.pack + (row)) * va.lse_stride_h + q_lo : (int64_t)hq * va.lse_stride_h + q_lo + (row))
+#define FFPA_M16_LSE_INDEX(row) (va.pack ? (int64_t)(hq * va.pack + (row) / ntok) * va.lse_stride_h + q_lo + (row) % ntok : (int64_t)hq * va.lse_stride_h + q_lo + (row))
 // (the KV-split workspace of the packed call: [split, query head, token] rows — ffpa_varlen_merge_kernel reads them back by (head, token))
-#define FFPA_M16_WS_ROW(row) ((int64_t)split * va.ws_split_rows + (va.pack ? (int64_t)(hq * va.pack + (row)) * va.ws_head_rows + q_lo : (int64_t)hq * va.ws_head_rows + q_lo + (row)))
+#define FFPA_M16_WS_ROW(row) ((int64_t)split * va.ws_split_rows + (va.pack ? (int64_t)(hq * va.pack + (row) / ntok) * va.ws_head_rows + q_lo + (row) % ntok : (int64_t)hq * va.ws_head_rows + q_lo + (row)))
+// (packed rows: a.sq[2] / a.so[2] are the HEAD strides of q / o, a token is q_tok_stride / o_tok_stride further; rows are tokens: ntok-independent)
+#define FFPA_M16_Q_ROW_OFF(row) (va.pack ? (int64_t)((row) / ntok) * a.sq[2] + (int64_t)((row) % ntok) * va.q_tok_stride : (int64_t)(row) * a.sq[2])
+#define FFPA_M16_O_ROW_OFF(row) (va.pack ? (int64_t)((row) / ntok) * a.so[2] + (int64_t)((row) % ntok) * va.o_tok_stride : (int64_t)(row) * a.so[2])
 #include "ffpa_fwd_m16_tile.inc"
+#undef FFPA_M16_O_ROW_OFF
+#undef FFPA_M16_Q_ROW_OFF
 #undef FFPA_M16_WS_ROW
 #undef FFPA_M16_LSE_INDEX
 #undef FFPA_M16_ROW_OUT

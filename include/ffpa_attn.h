@@ -78,7 +78,7 @@ enum ffpa_bias_dtype {
                                              split by the KV length alone (a fixed number of KV tiles per range).  Costs what the launch-size rules would have gained
                                              (under-filled / ragged-round prefill launches: up to ~ 20 %).  Python: FFPA_HIP_DETERMINISTIC=1 sets it on every call. */
 #define FFPA_FLAG_NO_HEAD_CHUNKS   0x80000u /* bench / test, ffpa_attn_fwd: causal GQA prefill launches keep the (batch, head, row tile) workgroup order (default: the launch side takes the head-chunk order — the same row tile of a KV group's heads at the same time — where its rule applies; same bits either way) */
-#define FFPA_FLAG_NO_PACK_GQA      0x40000u /* bench / test, ffpa_attn_varlen_fwd: decode batches (max_seqlen_q == 1) under GQA keep one workgroup per QUERY head (default: the heads of a KV group are packed into the rows of one tile) */
+#define FFPA_FLAG_NO_PACK_GQA      0x40000u /* bench / test, ffpa_attn_varlen_fwd: short query sequences under GQA (group x max_seqlen_q rows fit one tile: decode, speculative decoding) keep one workgroup per QUERY head (default: the heads of a KV group x the tokens are packed into the rows of one tile) */
 #define FFPA_FLAG_XCD_GROUP(log2p1) ((unsigned)(log2p1) << 8) /* bench-only: bits 8..10 = 1 + log2 of the XCDs that share a head's row tiles (1 -> 1, 2 -> 2, 3 -> 4, 4 -> 8); 0 = the launch side decides */
 
 /*
@@ -238,8 +238,9 @@ int ffpa_attn_mask_kv_bounds(const void* bias, int bias_dtype, const int64_t bia
  * synchronises and captures into a HIP graph): the grid holds ceil(max_seqlen_q / block rows) row tiles per (sequence,
  * head), workgroups whose tile lies past their sequence's last row leave at once.  max_seqlen_q must be >= every
  * sequence's query length (rows past it would not be computed); max_seqlen_kv is only a hint for the launch side.
- * Decode batches — max_seqlen_q == 1 — under GQA run with the query heads of a KV group packed into the rows of one tile per
- * (sequence, KV head): the group's K / V are read once (the reference's pack_gqa, cute/__init__.py:792-829).
+ * Short query sequences under GQA — decode (max_seqlen_q == 1), speculative decoding, small prefill chunks: (Hq / Hkv) x max_seqlen_q rows
+ * fit one tile — run with the query heads of a KV group x the sequence's tokens packed into the rows of one tile per (sequence, KV head):
+ * the group's K / V are read once (the reference's pack_gqa, cute/__init__.py:792-829).
  * Per sequence the arithmetic is the dense call's (same tile, same recurrence: bit-identical to ffpa_attn_fwd on that
  * sequence alone under FFPA_FLAG_DETERMINISTIC).  causal = the reference's tail-aligned mask PER SEQUENCE: row r of
  * sequence i sees key j iff j <= r + (Nkv_i - Nq_i).  Rows without a visible key (an empty key range; the first

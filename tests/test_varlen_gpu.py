@@ -366,10 +366,41 @@ def test_decode_batches_pack_the_heads_of_a_kv_group_into_rows(hip, hq, hkv, d, 
                    causal=True, causal_offset=lens_k[i] - 1, block_keys=plan["block_keys"], name="packed decode vs oracle")
 
 
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("hq, hkv, d, dtype, nq", [(32, 8, 512, torch.bfloat16, 16), (16, 2, 320, torch.float16, 5), (8, 2, 1024, torch.bfloat16, 16), (24, 8, 128, torch.bfloat16, 42),
+                                                   (8, 4, 512, torch.bfloat16, 64), (6, 1, 256, torch.float16, 2)])
+def test_short_sequences_pack_heads_and_tokens_into_the_rows_of_one_tile(hip, hq, hkv, d, dtype, nq, causal):
+  """A few query tokens per sequence under GQA (speculative decoding, multi-token prediction, small prefill chunks): group x max_seqlen_q rows fit one tile, and the
+  launch runs one workgroup per (sequence, KV head) whose rows are (head of the group, token), head-major — per row the same arithmetic: bit-identical to the unpacked
+  launch (FLAG_NO_PACK_GQA), O and LSE; ragged token counts (1 ... Nq, none), more tokens than keys under the causal flag (rows without a visible key), no keys."""
+  lens_k = [700, 0, 64, 1300, 129, 2048, 1, 333, 3]
+  lens_q = [nq, nq, 0, max(1, nq - 1), 1, nq, min(nq, 3), max(1, nq // 2), nq]
+  q, k, v = _make(lens_q, lens_k, hq, hkv, d, dtype, seed=hq + d + nq)
+  cu_q, cu_k = _cu(lens_q), _cu(lens_k)
+  plan, plan_u = {}, {}
+  out, lse = hip.varlen_forward(q, k, v, cu_q, cu_k, nq, max(lens_k), causal, d ** -0.5, plan_out=plan, num_splits=1)
+  assert plan["workgroups"] == len(lens_q) * hkv and "packed into rows" in plan["kernel"], plan
+  out_u, lse_u = hip.varlen_forward(q, k, v, cu_q, cu_k, nq, max(lens_k), causal, d ** -0.5, flags=hip.FLAG_NO_PACK_GQA, plan_out=plan_u, num_splits=1)
+  assert plan_u["workgroups"] == len(lens_q) * hq and "packed into rows" not in plan_u["kernel"], plan_u
+  assert torch.equal(lse, lse_u), (lse - lse_u).abs().max()
+  assert torch.equal(out, out_u)
+  _check_packed(hip, q, k, v, lens_q, lens_k, causal, out, lse, oracle=False, dense_bits=False, sdpa=d <= 512, name=f"packed tokens Hq{hq}/Hkv{hkv} D{d} Nq{nq}")
+  i = 5
+  qs, ks = sum(lens_q[:i]), sum(lens_k[:i])
+  _check_vs_oracle(_seq(out, qs, qs + nq), lse[:, qs:qs + nq].unsqueeze(0), _seq(q, qs, qs + nq), _seq(k, ks, ks + lens_k[i]), _seq(v, ks, ks + lens_k[i]),
+                   causal=causal, causal_offset=lens_k[i] - nq, block_keys=plan["block_keys"], name="packed tokens vs oracle")
+  # ... and with its KV ranges split (the library's own count for this batch): to merge rounding
+  ps = {}
+  out_s, lse_s = hip.varlen_forward(q, k, v, cu_q, cu_k, nq, max(lens_k), causal, d ** -0.5, plan_out=ps)
+  assert ps["splits"] > 1 and "packed into rows" in ps["kernel"], ps
+  _same_to_merge_rounding(out_s, lse_s, out, lse, f"packed tokens + {ps['splits']} KV ranges")
+
+
 def _same_to_merge_rounding(out, lse, ref, ref_lse, name):
   """A KV-split launch against the one-range launch of the same batch: the same softmax, combined from normalised fp32 partials.  Not the same bits: every range
   runs the recurrence from ITS first tile (its own stale row max under the lazy-rescale convention), so P = exp2(s - m) is rounded to 16 bits at another position
-  of its binade — the P-rounding noise of two runs, not of one: per element one output spacing + 2^-8 (bf16) / 2^-11 (fp16) of the row's largest |O|.  LSE within fp32
+  of its binade — the P-rounding noise of two runs, not of one (per run ~ 2^-9 |v| / sqrt(effective keys) rms per element, the row's largest |O| ~ 2.5 / sqrt(effective
+  keys); the worst of 10^5 elements at 4 sigma of the difference of two runs: 2^-8 x 1.1): per element one output spacing + 2^-7 (bf16) / 2^-10 (fp16) of the row's largest |O|.  LSE within fp32
   rounding of the exp / log pair; rows without a visible key exactly 0 / -inf in both."""
   dead = ref_lse == -float("inf")
   assert torch.equal(lse == -float("inf"), dead), name
@@ -378,16 +409,17 @@ def _same_to_merge_rounding(out, lse, ref, ref_lse, name):
   assert torch.isfinite(a).all(), name
   bf = out.dtype == torch.bfloat16
   spacing = torch.maximum(a.abs(), b.abs()).clamp_min(2.0 ** -14) * (2.0 ** -7 if bf else 2.0 ** -10)
-  allow = spacing + b.abs().amax(dim=-1, keepdim=True) * (2.0 ** -8 if bf else 2.0 ** -11)
+  allow = spacing + b.abs().amax(dim=-1, keepdim=True) * (2.0 ** -7 if bf else 2.0 ** -10)
   diff = (a - b).abs()
   assert torch.all(diff <= allow), f"{name}: O differs from the one-range launch by {(diff / allow).max().item():.2f} x the allowance"
-  assert (diff / allow).mean().item() < 0.15, f"{name}: mean difference {(diff / allow).mean().item():.3f} of the allowance"
+  assert (diff / allow).mean().item() < 0.1, f"{name}: mean difference {(diff / allow).mean().item():.3f} of the allowance"
   assert torch.all(a[dead.t().unsqueeze(-1).expand_as(a)] == 0), name
 
 
 @pytest.mark.parametrize("hq, hkv, d, dtype, nq, splits", [
   (32, 8, 512, torch.bfloat16, 1, 0), (32, 8, 512, torch.bfloat16, 1, 3), (8, 8, 320, torch.float16, 1, 5), (4, 1, 1024, torch.bfloat16, 1, 16), (16, 4, 128, torch.bfloat16, 1, 2),
   (8, 8, 512, torch.bfloat16, 37, 4), (8, 2, 256, torch.float16, 100, 7), (8, 2, 640, torch.bfloat16, 64, 0), (4, 4, 512, torch.bfloat16, 128, 64),
+  (32, 8, 512, torch.bfloat16, 16, 5), (8, 2, 1024, torch.float16, 9, 0),
 ])
 def test_kv_splits_inside_the_packed_launch(hip, hq, hkv, d, dtype, nq, splits):
   """Batches of one row tile per (sequence, head) that leave most of the chip idle split every sequence's KV range over several workgroups — each sequence by ITS OWN

@@ -29,7 +29,7 @@ def timeit(fn, reps=30, warm=5):
 def main():
   torch.manual_seed(0)
   rng = np.random.default_rng(0)
-  for nseq, hq, hkv, d, nq in ((32, 32, 32, 512, 1), (32, 32, 8, 512, 1), (8, 32, 32, 512, 1), (64, 32, 8, 320, 1), (16, 32, 8, 512, 16)):
+  for nseq, hq, hkv, d, nq in ((32, 32, 32, 512, 1), (32, 32, 8, 512, 1), (8, 32, 32, 512, 1), (64, 32, 8, 320, 1), (16, 32, 8, 512, 16), (32, 32, 8, 512, 4), (64, 64, 8, 128, 8), (16, 16, 2, 1024, 8)):
     lens_k = [int(x) for x in rng.integers(1024, 16384, size=nseq)]
     lens_q = [nq] * nseq
     tq, tk = sum(lens_q), sum(lens_k)
@@ -67,6 +67,16 @@ def main():
       ab["plain"].append(timeit(packed_flags(hip.FLAG_NO_KV_STREAM)))
       ab["nt"].append(timeit(packed_flags(hip.FLAG_KV_STREAM)))
     same = all(torch.equal(a, b) for a, b in zip(packed_flags(hip.FLAG_NO_KV_STREAM)(), packed_flags(hip.FLAG_KV_STREAM)()))
+    if gqa:
+      # the rows of a tile: (head of the KV group, token) packed — or one workgroup per query head (FLAG_NO_PACK_GQA)
+      pk = {"packed": [], "per head": []}
+      for _ in range(3):
+        pk["packed"].append(timeit(packed_flags(0)))
+        pk["per head"].append(timeit(packed_flags(hip.FLAG_NO_PACK_GQA)))
+      same = all(torch.equal(a, b) for a, b in zip(hip.varlen_forward(q, k, v, cu_q, cu_k, nq, max(lens_k), True, d ** -0.5, num_splits=1),
+                                                   hip.varlen_forward(q, k, v, cu_q, cu_k, nq, max(lens_k), True, d ** -0.5, num_splits=1, flags=hip.FLAG_NO_PACK_GQA)))
+      print(f"VARLENDECODE_PACK rows = (head of the group, token): {min(pk['packed']) * 1e3:8.1f} us = {kv_bytes / min(pk['packed']) / 1e9:5.2f} TB/s | one workgroup per query head "
+            f"{min(pk['per head']) * 1e3:8.1f} us = {kv_bytes / min(pk['per head']) / 1e9:5.2f} TB/s ({min(pk['per head']) / min(pk['packed']):.2f} x) | bit-identical (one KV range) {same}", flush=True)
     print(f"VARLENDECODE_NT default = {plan['kernel']} | plain {min(ab['plain']) * 1e3:8.1f} us = {kv_bytes / min(ab['plain']) / 1e9:5.2f} TB/s | NT {min(ab['nt']) * 1e3:8.1f} us = "
           f"{kv_bytes / min(ab['nt']) / 1e9:5.2f} TB/s ({(min(ab['plain']) / min(ab['nt']) - 1) * 100:+.1f} %) | bit-identical {same}", flush=True)
     print(f"VARLENDECODE {nseq} seqs x Nq {nq}, KV {min(lens_k)} ... {max(lens_k)} (sum {tk}), Hq {hq} Hkv {hkv} D {d}: packed {t_p * 1e3:8.1f} us = {kv_bytes / t_p / 1e9:6.2f} TB/s of K + V | "
