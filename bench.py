@@ -90,6 +90,10 @@ WORKLOADS = {
   # packed sequences (ffpa_attn_varlen_func: the reference's CuTe-DSL-only entry point, one launch here): 8 causal self-attention sequences, 16384 tokens
   "varlen": _w(8, 32, 8, 4864, 4864, 512, causal=True, via="varlen", lens=(4096, 512, 2048, 1024, 3072, 256, 4864, 512),
                note="packed THD batch through ffpa_attn_varlen_func: 8 causal sequences of 256 ... 4864 tokens (16384 in all), GQA 32 / 8, one launch"),
+  # ... and a packed DECODE batch (continuous batching: one new token per sequence against ragged KV lengths): HBM-bound, K + V streamed once
+  "varlen_decode": _w(32, 32, 8, 1, 16384, 512, causal=True, via="varlen_decode", bound="hbm", kv_range=(1024, 16384),
+                      note="packed decode batch through the packed-sequence call: 32 sequences x 1 token against ragged KV lengths 1024 ... 16384 (seeded), GQA 32 / 8: heads of a KV "
+                           "group packed into tile rows, KV ranges split + merged, non-temporal K / V fetch; HBM-bound"),
 }
 
 
@@ -464,6 +468,146 @@ def accuracy(w: dict, q, k, v, mask, scale: float) -> dict:
   res["sdpa_gpu_ms"] = round(sdpa_s * 1e3, 4)
   res["sdpa_call"] = "F.scaled_dot_product_attention(" + ", ".join(f"{a}={'<mask>' if a == 'attn_mask' else b}" for a, b in sdpa_kw.items()) + ")"
   return res
+
+
+def varlen_decode_main(args) -> None:
+  """`--workload varlen_decode` (N = 1): a packed DECODE batch — one query token per sequence, ragged KV lengths, GQA — through the packed-sequence op
+  (hip.varlen_forward = ffpa_attn::_varlen_fwd_hip -> ffpa_attn_varlen_fwd: ffpa_fwd_m16_varlen_kernel with the heads of a KV group in the rows of one tile and
+  every sequence's KV range split by its own length + ffpa_varlen_merge_kernel).  Same contract as the dense `decode` workload: W warm-ups, exactly K timed
+  steps between synchronises, HIP events per step; the roofline is HBM's (every K / V byte once: algorithmic bytes / step time).  Beside it: the same call with one
+  KV range per sequence, with one workgroup per QUERY head, and the batch as a loop of dense decode calls."""
+  import numpy as np
+
+  from ffpa_attn_amd import hip
+
+  name = "varlen_decode"
+  w = WORKLOADS[name]
+  nseq, Hq, Hkv, D = w["B"], w["Hq"], w["Hkv"], w["D"]
+  dev = torch.device("cuda", 0)
+  torch.cuda.set_device(dev)
+  hip.load_library()
+  lens = [int(x) for x in np.random.default_rng(0).integers(w["kv_range"][0], w["kv_range"][1], size=nseq)]
+  tk = sum(lens)
+  torch.manual_seed(0)
+  q = torch.randn(nseq, Hq, D, dtype=torch.bfloat16, device=dev)
+  k = torch.randn(tk, Hkv, D, dtype=torch.bfloat16, device=dev)
+  v = torch.randn(tk, Hkv, D, dtype=torch.bfloat16, device=dev)
+  cu_q = torch.arange(0, nseq + 1, dtype=torch.int32, device=dev)
+  bk = [0]
+  for n in lens:
+    bk.append(bk[-1] + n)
+  cu_k = torch.tensor(bk, dtype=torch.int32, device=dev)
+  scale = D ** -0.5
+  flops = 4 * Hq * D * tk  # every token sees every key of its sequence
+  alg_bytes = 2 * D * (2 * tk * Hkv + 2 * nseq * Hq) + 4 * Hq * nseq  # K + V once, q, o, LSE
+
+  def step(**kw):
+    return hip.varlen_forward(q, k, v, cu_q, cu_k, 1, max(lens), True, scale, **kw)
+
+  telemetry = DeviceTelemetry(0)
+
+  def timed(fn, telem=False):
+    for _ in range(args.warmup):
+      fn()
+    torch.cuda.synchronize()
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    if telem:
+      telemetry.start()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+      starts[i].record()
+      fn()
+      ends[i].record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if telem:
+      telemetry.stop()
+    return elapsed, sorted(a.elapsed_time(b) for a, b in zip(starts, ends))
+
+  elapsed, kernel_ms = timed(step, telem=True)
+  device = telemetry.summary()
+  kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
+  plan = {}
+  out, lse = step(plan_out=plan)
+  steady = None
+  if not args.no_steady:
+    n_pre, n_timed = max(20, int(150.0 / kernel_ms_avg)), max(20, min(400, int(60.0 / kernel_ms_avg)))
+    for _ in range(n_pre):
+      step()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(n_timed):
+      step()
+    ev1.record()
+    torch.cuda.synchronize()
+    ss_ms = ev0.elapsed_time(ev1) / n_timed
+    steady = {"ms_per_step": round(ss_ms, 4), "gbps": round(alg_bytes / ss_ms / 1e6, 1), "frac_of_hbm_peak": round(alg_bytes / ss_ms / 1e6 / HBM_PEAK_GBPS, 4), "launches": n_timed,
+              "after_launches": n_pre, "what": "the same step back to back after >= 150 ms of continuous load, one HIP event pair around the launches; outside the timed region"}
+  build = build_identity()
+  traffic, traffic_src, traffic_stale = measured_traffic(name, build.get("lib_sha16"))
+  note = None
+  under_profiler = any(k_.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k_ in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "").lower()
+  if not args.no_live_traffic and not under_profiler:
+    torch.cuda.synchronize()
+    live, why = live_traffic(name)
+    if live is not None:
+      traffic, traffic_src, traffic_stale = live, why, False
+    else:
+      note = why
+  achieved = alg_bytes / (kernel_ms_avg * 1e-3) / 1e9
+  roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+          "traffic_source": traffic_src, "kernel": plan["kernel"], "kernel_ms_avg": round(kernel_ms_avg, 4), "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 4),
+          "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes, "workgroups": plan["workgroups"], "traffic_stale": bool(traffic_stale),
+          "what": "HIP events around one step (the split kernel + its merge kernel); traffic: the split kernel's dispatches"}
+  if note is not None:
+    roof["traffic_live_failed"] = note
+  line = {
+    "metric": f"attention fwd TFLOPS + max-abs-err vs SDPA, bf16 packed decode batch {nseq} x 1 token, KV {min(lens)} ... {max(lens)} (sum {tk}) Hq={Hq}/Hkv={Hkv} D={D} [varlen_decode]",
+    "value": round(flops * args.steps / elapsed / 1e12, 3), "unit": "TFLOPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+    "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+    "config": {"workload": f"varlen_decode: {w['note']}; T_k={tk} Hq={Hq} Hkv={Hkv} D={D} bf16", "global_batch": nseq, "seq_len": 1, "parallelism": "single GPU",
+               "flops_model": "4*Hq*D*sum_i nkv_i", "step": "hip.varlen_forward (ffpa_attn::_varlen_fwd_hip)"},
+    "roofline": roof, "device": device, "steady_state": steady, "build": build,
+    "plan": {k_: plan[k_] for k_ in ("row_tiles", "block_rows", "block_keys", "workgroups", "splits")},
+  }
+  if not args.no_sdpa:  # (the comparison legs; --no-sdpa: none of them — the profiler passes)
+    legs = {}
+    for what, kw in (("one_kv_range", dict(num_splits=1)), ("one_workgroup_per_query_head", dict(flags=hip.FLAG_NO_PACK_GQA)), ("no_nt_hint", dict(flags=hip.FLAG_NO_KV_STREAM))):
+      el, _ = timed(lambda kw=kw: step(**kw))
+      pl = {}
+      step(plan_out=pl, **kw)
+      legs[what] = {"ms_per_step": round(el / args.steps * 1e3, 4), "gbps": round(alg_bytes * args.steps / el / 1e9, 1), "kernel": pl["kernel"], "splits": pl["splits"], "workgroups": pl["workgroups"],
+                    "library_speedup": round(el / elapsed, 3)}
+    line["other_launches"] = legs
+
+    def seq(t, a, b):
+      return t[a:b].transpose(0, 1).unsqueeze(0)
+
+    def loop():
+      return [hip.ffpa_attn_forward_hip(seq(q, i, i + 1), seq(k, bk[i], bk[i + 1]), seq(v, bk[i], bk[i + 1]), None, causal=True, softmax_scale=scale)[0] for i in range(nseq)]
+
+    el, _ = timed(loop)
+    ref = loop()
+    diff = max((out[i:i + 1].float() - ref[i][0].transpose(0, 1).float()).abs().max().item() for i in range(nseq))
+    line["per_sequence_loop"] = {"ms_per_step": round(el / args.steps * 1e3, 4), "gbps": round(alg_bytes * args.steps / el / 1e9, 1), "launches_per_step": 2 * nseq,
+                                 "max_abs_diff_vs_packed": round(diff, 6), "packed_speedup": round(el / elapsed, 3),
+                                 "what": "the dense decode call (split-KV kernel + merge) per sequence on zero-copy views of the packed tensors; same W / K"}
+    try:
+      sd = lambda: [torch.nn.functional.scaled_dot_product_attention(seq(q, i, i + 1), seq(k, bk[i], bk[i + 1]), seq(v, bk[i], bk[i + 1]), enable_gqa=True) for i in range(nseq)]  # noqa: E731
+      ref = sd()
+      err = max((out[i:i + 1].float() - ref[i][0].transpose(0, 1).float()).abs().max().item() for i in range(nseq))
+      torch.cuda.synchronize()
+      t1 = time.perf_counter()
+      for _ in range(3):
+        sd()
+      torch.cuda.synchronize()
+      sdpa_s = (time.perf_counter() - t1) / 3
+      line.update(max_abs_err_vs_sdpa=round(err, 6), sdpa_gpu_ms=round(sdpa_s * 1e3, 4), speedup_vs_sdpa_gpu=round(sdpa_s / (elapsed / args.steps), 3),
+                  sdpa_call="F.scaled_dot_product_attention(enable_gqa=True) per sequence")
+    except Exception as e:  # noqa: BLE001 — informative only
+      line["sdpa_error"] = str(e)[:200]
+  print(json.dumps(line))
 
 
 def varlen_main(args) -> None:
@@ -863,10 +1007,10 @@ def main() -> None:
     sys.exit("bench.py needs a GPU (the HIP kernel has no CPU fallback)")
   if args.sweep:
     return sweep_main(args)
-  if args.workload == "varlen":
+  if args.workload in ("varlen", "varlen_decode"):
     if world != 1:
-      sys.exit("bench.py: --workload varlen is a single-GPU workload")
-    return varlen_main(args)
+      sys.exit(f"bench.py: --workload {args.workload} is a single-GPU workload")
+    return varlen_main(args) if args.workload == "varlen" else varlen_decode_main(args)
   torch.cuda.set_device(local_rank)
   dev = torch.device("cuda", local_rank)
   dist = None

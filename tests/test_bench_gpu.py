@@ -71,3 +71,20 @@ def test_decode_line_is_priced_against_hbm_and_carries_the_graph_replay_leg():
     assert leg["ms_per_step"] > 0 and abs(leg["gbps"] - roof["bytes_per_launch"] / leg["ms_per_step"] / 1e6) / leg["gbps"] < 0.01 and 0.0 < leg["frac_of_hbm_peak"] < 1.0
   # no host work per step: a replayed step cannot be slower than the step launched from Python by more than timer noise
   assert g["steps_per_graph_32"]["ms_per_step"] <= line["ms_per_step"] * 1.10
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_packed_decode_line_is_priced_against_hbm_and_names_its_launch():
+  """`--workload varlen_decode`: a packed decode batch (one token per sequence, ragged KV lengths, GQA) — the HBM roofline of one step, the launch the library
+  picked (heads packed into tile rows, KV ranges split and merged, the non-temporal fetch) and the same call without each of them beside it."""
+  line = _bench("--gpus", "1", "--workload", "varlen_decode", "--steps", "4", "--warmup", "2", "--no-live-traffic")
+  for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
+              "device", "steady_state", "build", "plan", "other_launches", "per_sequence_loop"):
+    assert key in line, key
+  roof = line["roofline"]
+  assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0 and 0.05 < roof["frac"] < 1.0
+  assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["kernel_ms_avg"] * 1e-3) / 1e9) <= 0.01 * roof["achieved"]
+  assert "packed into rows" in roof["kernel"] and line["plan"]["workgroups"] == 32 * 8 * line["plan"]["splits"]
+  legs = line["other_launches"]
+  assert legs["one_kv_range"]["splits"] == 1 and legs["one_workgroup_per_query_head"]["workgroups"] % (32 * 32) == 0 and ", NT>" not in legs["no_nt_hint"]["kernel"]
+  assert line["per_sequence_loop"]["max_abs_diff_vs_packed"] < 4e-3 and line["max_abs_err_vs_sdpa"] < 1e-2

@@ -396,6 +396,67 @@ def test_short_sequences_pack_heads_and_tokens_into_the_rows_of_one_tile(hip, hq
   _same_to_merge_rounding(out_s, lse_s, out, lse, f"packed tokens + {ps['splits']} KV ranges")
 
 
+def test_randomized_short_query_batches(hip):
+  """Random decode-like batches — 1 ... 24 sequences of 0 ... 40 query tokens against 0 ... 6000 keys, MHA / GQA / MQA, a head dim of every tile family, causal or
+  not, optional device-side KV lengths over a roomier cache — through every launch form the plan can take (rows packed or per head, one KV range or the library's
+  count or a forced one, the non-temporal fetch on or off): the packed / NT forms bit-identical to the plain one at one KV range, split launches equal to it to merge
+  rounding, all of it against SDPA per sequence.  FFPA_VARLEN_FUZZ_SHORT=a:b picks the seeds."""
+  import os
+
+  lo, hi = (int(x) for x in os.environ.get("FFPA_VARLEN_FUZZ_SHORT", "0:40").split(":"))
+  for seed in range(lo, hi):
+    rng = np.random.default_rng(7000 + seed)
+    nseq = int(rng.integers(1, 25))
+    mq = int(rng.choice([1, 1, 1, 2, 3, 4, 8, 16, 40]))
+    lens_q = [int(rng.integers(0, mq + 1)) if rng.random() < 0.3 else mq for _ in range(nseq)]
+    lens_k = [int(x) for x in rng.choice([0, 1, 17, 64, 65, 300, 640, 1500, 3000, 6000], size=nseq)]
+    if sum(lens_q) == 0:
+      lens_q[0] = mq
+    hkv = int(rng.choice([1, 2, 4]))
+    hq = hkv * int(rng.choice([1, 2, 4, 8]))
+    d = int(rng.choice([128, 256, 320, 512, 640, 1024]))
+    dtype = torch.bfloat16 if rng.random() < 0.6 else torch.float16
+    causal = bool(rng.random() < 0.6)
+    q, k, v = _make(lens_q, lens_k, hq, hkv, d, dtype, seed=seed)
+    cu_q, cu_k, mk = _cu(lens_q), _cu(lens_k), max(max(lens_k), 1)
+    used = None
+    if rng.random() < 0.3 and sum(lens_k) > 0:
+      # a roomier cache: every sequence's range holds `slack` more rows than it uses (NaN: nothing may read them)
+      slack = int(rng.integers(1, 200))
+      kk = torch.full((sum(lens_k) + slack * nseq, hkv, d), float("nan"), dtype=dtype, device="cuda")
+      vv = kk.clone()
+      roomy, pos, src = [0], 0, 0
+      for n in lens_k:
+        kk[pos:pos + n], vv[pos:pos + n] = k[src:src + n], v[src:src + n]
+        pos, src = pos + n + slack, src + n
+        roomy.append(pos)
+      used = torch.tensor(lens_k, dtype=torch.int32, device="cuda")
+      k_call, v_call, cu_call, mk_call = kk, vv, torch.tensor(roomy, dtype=torch.int32, device="cuda"), mk + slack
+    else:
+      k_call, v_call, cu_call, mk_call = k, v, cu_k, mk
+    name = f"short fuzz seed {seed}: lens_q={lens_q} lens_k={lens_k} Hq={hq} Hkv={hkv} D={d} {dtype} causal={causal} seqused={used is not None}"
+
+    def run(**kw):
+      return hip.varlen_forward(q, k_call, v_call, cu_q, cu_call, mq, mk_call, causal, 1.0 / math.sqrt(d), seqused_k=used, **kw)
+
+    base, base_lse = run(num_splits=1, flags=hip.FLAG_NO_PACK_GQA | hip.FLAG_NO_KV_STREAM)
+    _check_packed(hip, q, k, v, lens_q, lens_k, causal, base, base_lse, oracle=False, dense_bits=False, sdpa=d <= 512, name=name)
+    for flags in (0, hip.FLAG_KV_STREAM, hip.FLAG_NO_PACK_GQA | hip.FLAG_KV_STREAM):
+      o, l = run(num_splits=1, flags=flags)
+      assert torch.equal(o, base) and torch.equal(l, base_lse), f"{name}: flags {flags:#x} at one KV range differ from the plain launch"
+    plan = {}
+    o, l = run(plan_out=plan)
+    if plan["splits"] > 1:
+      _same_to_merge_rounding(o, l, base, base_lse, f"{name}: the library's {plan['splits']} KV ranges")
+    else:
+      assert torch.equal(o, base) and torch.equal(l, base_lse), name
+    forced = int(rng.choice([2, 3, 5, 8, 13]))
+    plan = {}
+    o, l = run(num_splits=forced, flags=hip.FLAG_FORCE_SPLITS | (hip.FLAG_NO_PACK_GQA if rng.random() < 0.3 else 0), plan_out=plan)
+    if plan["row_tiles"] == 1 and plan["splits"] > 1:
+      _same_to_merge_rounding(o, l, base, base_lse, f"{name}: {plan['splits']} forced KV ranges")
+
+
 def _same_to_merge_rounding(out, lse, ref, ref_lse, name):
   """A KV-split launch against the one-range launch of the same batch: the same softmax, combined from normalised fp32 partials.  Not the same bits: every range
   runs the recurrence from ITS first tile (its own stale row max under the lazy-rescale convention), so P = exp2(s - m) is rounded to 16 bits at another position
