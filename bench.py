@@ -558,7 +558,7 @@ def varlen_decode_main(args) -> None:
   achieved = alg_bytes / (kernel_ms_avg * 1e-3) / 1e9
   roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
           "traffic_source": traffic_src, "kernel": plan["kernel"], "kernel_ms_avg": round(kernel_ms_avg, 4), "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 4),
-          "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes, "workgroups": plan["workgroups"], "traffic_stale": bool(traffic_stale),
+          "bytes_per_launch": alg_bytes, "algorithmic_bytes_per_launch": alg_bytes, "workgroups": plan["workgroups"], "traffic_stale": bool(traffic_stale),
           "what": "HIP events around one step (the split kernel + its merge kernel); traffic: the split kernel's dispatches"}
   if note is not None:
     roof["traffic_live_failed"] = note

@@ -473,6 +473,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_varlen_kernel(const FwdArgs 
     a.causal_offset = a.Nkv - ntok_seq;  // (tail-aligned per sequence; a single packed token runs without the causal flag — it sees every key of its sequence)
     if (va.pack) a.causal_row_mod = ntok_seq;
     if (a_in.nsplit > 1) {
+      if ((int64_t)q_lo + ntok_seq > va.ws_head_rows) return;  // (a caller whose total_q is smaller than its boundaries say: nothing is stored outside the scratch it sized)
       const int tiles = (a.Nkv + BC - 1) / BC;
       a.tiles_per_split = (tiles + a_in.nsplit - 1) / a_in.nsplit;  // (a sequence shorter than nsplit tiles leaves ranges empty: dead partials, weight 0 in the merge)
     }

@@ -294,7 +294,8 @@ typedef struct ffpa_varlen_fwd_params {
   void* workspace;          /* device scratch, 16-byte aligned; NULL => no split */
   uint64_t workspace_bytes;
   int32_t num_splits;       /* 0 = library heuristic, 1 = never split, n = at most n (with FFPA_FLAG_FORCE_SPLITS: exactly n where the key length allows) */
-  int32_t total_q;          /* rows of q / o (= cu_seqlens_q[batch]); 0 => no split (the partials are laid out [split, Hq, total_q, D]) */
+  int32_t total_q;          /* rows of q / o (>= cu_seqlens_q[batch]); 0 => no split (the partials are laid out [split, Hq, total_q, D]; a sequence whose rows
+                               lie past total_q is skipped by a split launch — never stored outside the scratch) */
 } ffpa_varlen_fwd_params;
 
 /* Launch the packed-sequence forward on `stream` of the CURRENT device.  Asynchronous; returns an ffpa_status. */

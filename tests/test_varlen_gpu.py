@@ -309,6 +309,44 @@ def test_c_abi_of_the_packed_call_on_raw_pointers(hip):
   _check_packed(hip, q, k, v, lens, lens, True, o, lse, name="C-ABI")
 
 
+def test_c_abi_kv_splits_stay_inside_the_scratch_the_caller_sized(hip):
+  """ABI 6 on raw pointers: the caller's scratch (ffpa_attn_varlen_fwd_workspace_bytes for ITS total_q) is all a split launch writes — a parameter block whose total_q
+  is smaller than the boundaries on the device say (a caller's bug the host side cannot see) loses the sequences past it, not memory: the words behind the scratch
+  keep their pattern, the sequences inside total_q are right; with the honest total_q the same call is whole."""
+  import ctypes
+
+  lens_q, lens_k = [3, 2, 4, 3], [900, 1500, 700, 1100]
+  q, k, v = _make(lens_q, lens_k, 8, 2, 512, torch.bfloat16, seed=5)
+  cu_q, cu_k = _cu(lens_q), _cu(lens_k)
+  lib = hip.load_library()
+  ref, ref_lse = hip.varlen_forward(q, k, v, cu_q, cu_k, 4, 1500, True, 512 ** -0.5, num_splits=1)
+  for total_q in (12, 5):
+    o = torch.full_like(q, float("nan"))
+    lse = torch.full((8, 12), float("nan"), dtype=torch.float32, device="cuda")
+    p = hip.FfpaVarlenFwdParams()
+    p.struct_size, p.abi_version = ctypes.sizeof(hip.FfpaVarlenFwdParams), hip.ABI_VERSION
+    p.q, p.k, p.v, p.o, p.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr()
+    p.cu_seqlens_q, p.cu_seqlens_kv = cu_q.data_ptr(), cu_k.data_ptr()
+    p.batch, p.heads_q, p.heads_kv, p.head_dim, p.max_seqlen_q, p.max_seqlen_kv = 4, 8, 2, 512, 4, 1500
+    p.q_stride[:], p.k_stride[:], p.v_stride[:], p.o_stride[:] = [8 * 512, 512], [2 * 512, 512], [2 * 512, 512], [8 * 512, 512]
+    p.lse_stride_head, p.dtype, p.causal, p.softmax_scale, p.rescale_threshold = 12, 0, 1, 512 ** -0.5, -1.0
+    p.total_q, p.num_splits, p.flags = total_q, 5, hip.FLAG_FORCE_SPLITS
+    want = lib.ffpa_attn_varlen_fwd_workspace_bytes(ctypes.byref(p))
+    assert want == 5 * 8 * total_q * (512 + 1) * 4
+    guard = 1 << 20
+    ws = torch.full(((want + guard) // 4,), 1.5, dtype=torch.float32, device="cuda")
+    p.workspace, p.workspace_bytes = ws.data_ptr(), want
+    plan = (ctypes.c_int * 5)()
+    assert lib.ffpa_attn_varlen_fwd_plan(ctypes.byref(p), plan) == 0 and plan[4] == 5 and plan[3] == 4 * 2 * 5, list(plan)
+    assert lib.ffpa_attn_varlen_fwd(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0, lib.ffpa_attn_last_error()
+    torch.cuda.synchronize()
+    assert torch.all(ws[want // 4:] == 1.5), f"total_q = {total_q}: the launch wrote behind the scratch"
+    rows = 12 if total_q == 12 else 5  # (sequences 0 and 1 end at row 5; sequence 2 — rows 5 .. 9 — does not fit a scratch of 5 rows per head)
+    _same_to_merge_rounding(o[:rows], lse[:, :rows].contiguous(), ref[:rows], ref_lse[:, :rows].contiguous(), f"C-ABI splits, total_q = {total_q}")
+    if total_q == 5:
+      assert torch.isnan(o[5:].float()).all() and torch.isnan(lse[:, 5:]).all(), "rows past total_q must not be written"
+
+
 def test_randomized_packed_batches(hip):
   """Random batches (1 ... 12 sequences of 0 ... 700 tokens, independent query / key lengths, MHA / GQA / MQA, causal or not, both dtypes, a head dim of every
   tile family) against the dense kernel's bits and SDPA per sequence, and the oracle on one sequence of each batch.  FFPA_VARLEN_FUZZ=a:b picks the seeds."""
