@@ -172,7 +172,6 @@ struct PlanTunables {
   // range, and partials (written + read back) of at most this fraction of the K + V bytes the launch side can estimate
   int varlen_balance_wgs, varlen_balance_min_tiles;
   double varlen_partial_frac;
-  int varlen_pair_max_row_tiles;  // packed causal launches pair row tiles per sequence up to this many row tiles of the LONGEST sequence (profiles/r06_varlen_pair_tiles.txt)
 };
 constexpr PlanTunables kPlanGfx950 = {
     5.0e12 / 9.8304e12, 4.0e12 / 9.8304e12, 5.0e12 / 8.0e12,
@@ -186,7 +185,6 @@ constexpr PlanTunables kPlanGfx950 = {
     32,
     4, 16,
     0.02,
-    0,
 };
 constexpr const PlanTunables& kT = kPlanGfx950;
 
@@ -874,7 +872,6 @@ struct VarlenPlan {
   int br, bc, nqt;
   int pack;  // > 0: decode batch under GQA — the query heads of a KV group are the rows of the tile (VarlenArgs::pack)
   int nt;    // 1: the build whose K / V pieces carry the non-temporal hint
-  int pair;  // 1: the paired-row-tile build (causal launches of several row tiles per head): the grid holds ceil(nqt / 2) slots per (sequence, head)
   int splits;        // KV ranges per sequence (1 = the KV axis is not split)
   size_t ws_bytes;   // scratch the split launch uses
   int64_t grid;      // workgroups of the launch (all ranges)
@@ -964,16 +961,6 @@ int varlen_plan(const ffpa_varlen_fwd_params* p, VarlenPlan* out) {
       out->splits = (int)want;
       out->ws_bytes = (size_t)want * per_split;
       out->grid *= want;
-    }
-  }
-  // PAIRED ROW TILES (ffpa_fwd_m16_varlen_kernel<.., PAIR>): under the causal flag slot j of a sequence walks row tile nqt_i - 1 - j and then tile j — per sequence
-  // the dense path's pairing (pick_pair_tiles): equal work for all workgroups of a sequence, half the workgroups (and half the empty ones of a ragged batch), the
-  // same bits.  The tile counts are per sequence and live on the device; the launch side knows the longest one.  Measured: profiles/r06_varlen_pair_tiles.txt.
-  out->pair = 0;
-  if (p->causal && out->nqt >= 2 && out->splits == 1 && out->pack == 0 && !(p->flags & FFPA_FLAG_NO_PAIR_TILES)) {
-    if ((p->flags & FFPA_FLAG_PAIR_TILES) || out->nqt <= kT.varlen_pair_max_row_tiles) {
-      out->pair = 1;
-      out->grid = (int64_t)p->batch * p->heads_q * ((out->nqt + 1) / 2);
     }
   }
   if (out->grid > 0x7fffffffLL) return fail(FFPA_ERR_BAD_SHAPE, "grid of %lld workgroups is too large", (long long)out->grid);
@@ -1096,7 +1083,7 @@ int ffpa_attn_varlen_fwd(const ffpa_varlen_fwd_params* p, void* stream) {
     va.ws_split_rows = (int64_t)p->heads_q * p->total_q;
   }
 
-  int st = pl.ve->launch(p->dtype, pl.pair ? 2 : pl.nt, a, va, static_cast<hipStream_t>(stream));
+  int st = pl.ve->launch(p->dtype, pl.nt, a, va, static_cast<hipStream_t>(stream));
   if (st == 0 && pl.splits > 1) {
     const dim3 grid((unsigned)((int64_t)p->heads_q * p->total_q), (unsigned)(p->head_dim + 255) / 256);
     if (p->dtype == FFPA_DTYPE_BF16)
@@ -1140,7 +1127,7 @@ int ffpa_attn_varlen_fwd_kernel(const ffpa_varlen_fwd_params* params, char* buf,
   const int rc = varlen_plan(params, &pl);
   if (rc != FFPA_OK) return rc;
   if (buf == nullptr || n == 0) return fail(FFPA_ERR_NULL_POINTER, "buf is NULL");
-  snprintf(buf, n, "ffpa_fwd_m16_varlen_kernel<%s, %d%s>%s%s", params->dtype == FFPA_DTYPE_BF16 ? "bf16" : "fp16", pl.ve->d, pl.pair ? ", PAIR" : (pl.nt ? ", NT" : ""),
+  snprintf(buf, n, "ffpa_fwd_m16_varlen_kernel<%s, %d%s>%s%s", params->dtype == FFPA_DTYPE_BF16 ? "bf16" : "fp16", pl.ve->d, pl.nt ? ", NT" : "",
            pl.pack ? " (GQA heads packed into rows)" : "", pl.splits > 1 ? " + ffpa_varlen_merge_kernel" : "");
   return FFPA_OK;
 }

@@ -419,10 +419,7 @@ struct VarlenArgs {
 
 // NT: the decode-batch build — every K / V piece carries the non-temporal hint (each byte has ONE reader and the batch's K + V do not fit the caches: the launch
 // side's rule, ffpa_capi.hip; LDS-DMA from HBM 5.9 -> 7.3 TB/s with it, profiles/r04_kv_stream.txt) — otherwise the same kernel.
-// PAIR: the paired-row-tile build (ffpa_fwd_m16_pair_kernel's idea per SEQUENCE, packed calls under the causal flag): the grid holds ceil(nqt / 2) workgroup slots per
-// (sequence, head); slot j of a sequence of nqt_i row tiles walks tile nqt_i - 1 - j and then tile j — nqt_i + 1 diagonal-bounded tiles' worth of KV steps for every
-// workgroup of that sequence, half the workgroups, the same bits per row.  A build of its own so that the one-tile builds stay what they were.
-template <typename T, int D, bool NT = false, bool PAIR = false>
+template <typename T, int D, bool NT = false>
 __global__ __launch_bounds__(256) void ffpa_fwd_m16_varlen_kernel(const FwdArgs a_in, const VarlenArgs va) {
   constexpr int MK = 0;  // no attn_bias, no mask ranges: what the reference's packed entry point accepts
   constexpr bool DROP = false;
@@ -445,14 +442,11 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_varlen_kernel(const FwdArgs 
   // ... side by side at the level of ROW TILES: (chunk, sequence, row tile, head in chunk) — a head's tiles alone fill an XCD's 32 CUs for a whole round, so heads
   // that merely follow each other stream the sequence's K / V once each (measured: no fewer HBM bytes than head-major order); interleaved per tile, the same row
   // tile of the chunk's heads runs at the same time on the same keys
-  const int slots = PAIR ? (a_in.nqt + 1) >> 1 : a_in.nqt;  // row-tile slots per (sequence, head) in the grid
-  const int per_seq = slots * va.head_chunk, per_chunk = a_in.B * per_seq;
+  const int per_seq = a_in.nqt * va.head_chunk, per_chunk = a_in.B * per_seq;
   const int chunk = vid / per_chunk, in_chunk = vid - chunk * per_chunk;
   const int seq = in_chunk / per_seq, in_seq = in_chunk - seq * per_seq;
-  const int slot = in_seq / va.head_chunk;
-  int qt0 = slot;  // the one-tile builds' row tile
-  if (!PAIR && a_in.causal) qt0 = a_in.nqt - 1 - qt0;  // longest rows first
-  int nqt_seq = a_in.nqt;  // row tiles of THIS sequence (PAIR)
+  int qt = in_seq / va.head_chunk;
+  if (a_in.causal) qt = a_in.nqt - 1 - qt;  // longest rows first
   const int bh = seq * a_in.Hq + chunk * va.head_chunk + (in_seq - (in_seq / va.head_chunk) * va.head_chunk);
   FwdArgs a = a_in;
   int q_lo;  // packed: the sequence's first row of q / o (LSE [Hq, T_q]: its column); dense: the batch element's first LSE row
@@ -472,12 +466,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_varlen_kernel(const FwdArgs 
     }
     ntok = ntok_seq > 0 ? ntok_seq : 1;
     const int nq_seq = va.pack ? va.pack * ntok_seq : ntok_seq;  // (packed: the rows of a sequence are (head of the group, token), head-major)
-    if constexpr (PAIR) {
-      nqt_seq = (nq_seq + BR - 1) / BR;
-      if (2 * slot >= nqt_seq) return;  // (slots 0 .. ceil(nqt_seq / 2) - 1 hold work: this sequence has fewer tile pairs than the grid's slots; without a row: none)
-    } else {
-      if (qt0 * BR >= nq_seq) return;  // (max_seqlen_q sized the grid: this sequence is shorter)
-    }
+    if (qt * BR >= nq_seq) return;  // (max_seqlen_q sized the grid: this sequence is shorter)
     // (batch strides are zero: the launch side)
     a.Nq = nq_seq;
     a.Nkv = nkv_seq > 0 ? nkv_seq : 0;
@@ -493,6 +482,7 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_varlen_kernel(const FwdArgs 
     a.k = (const T*)a_in.k + (int64_t)k_lo * a_in.sk[2];
     a.v = (const T*)a_in.v + (int64_t)k_lo * a_in.sv[2];
   }
+#define FFPA_M16_TILE_DONE return
 #define FFPA_M16_ROW_INV(l) ((l) > 0.f ? __builtin_amdgcn_rcpf(l) : 0.f)
 #define FFPA_M16_ROW_OUT(x, rh) (l_tot[rh] > 0.f ? (T)((x) * inv[rh]) : (T)0.f)  // (the select BEHIND product + conversion: those stay the dense kernel's one instruction — fp16: v_fma_mixlo, one rounding — and its bits)
 #define FFPA_M16_LSE_INDEX(row) (va.pack ? (int64_t)(hq * va.pack + (row) / ntok) * va.lse_stride_h + q_lo + (row) % ntok : (int64_t)hq * va.lse_stride_h + q_lo + (row))
@@ -501,26 +491,14 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_varlen_kernel(const FwdArgs 
 // (packed rows: a.sq[2] / a.so[2] are the HEAD strides of q / o, a token is q_tok_stride / o_tok_stride further; rows are tokens: ntok-independent)
 #define FFPA_M16_Q_ROW_OFF(row) (va.pack ? (int64_t)((row) / ntok) * a.sq[2] + (int64_t)((row) % ntok) * va.q_tok_stride : (int64_t)(row) * a.sq[2])
 #define FFPA_M16_O_ROW_OFF(row) (va.pack ? (int64_t)((row) / ntok) * a.so[2] + (int64_t)((row) % ntok) * va.o_tok_stride : (int64_t)(row) * a.so[2])
-  if constexpr (PAIR) {
-    const int npass = 2 * slot != nqt_seq - 1 ? 2 : 1;  // (an odd tile count: the middle tile is its own partner)
-    for (int pass = 0; pass < npass; ++pass) {
-      const int qt = pass == 0 ? nqt_seq - 1 - slot : slot;
-#define FFPA_M16_TILE_DONE continue
 #include "ffpa_fwd_m16_tile.inc"
-#undef FFPA_M16_TILE_DONE
-    }
-  } else {
-    const int qt = qt0;
-#define FFPA_M16_TILE_DONE return
-#include "ffpa_fwd_m16_tile.inc"
-#undef FFPA_M16_TILE_DONE
-  }
 #undef FFPA_M16_O_ROW_OFF
 #undef FFPA_M16_Q_ROW_OFF
 #undef FFPA_M16_WS_ROW
 #undef FFPA_M16_LSE_INDEX
 #undef FFPA_M16_ROW_OUT
 #undef FFPA_M16_ROW_INV
+#undef FFPA_M16_TILE_DONE
 #undef FFPA_M16_DMA16
 #undef FFPA_M16_MFMA
 }

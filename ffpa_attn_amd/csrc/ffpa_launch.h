@@ -21,7 +21,7 @@ struct VarlenArgs;
 #define FFPA_FOR_EACH_VARLEN_HEAD_DIM(X) \
   X(128) X(192) X(256) X(320) X(384) X(448) X(512) \
   X(576) X(640) X(704) X(768) X(832) X(896) X(960) X(1024)
-#define FFPA_DECL(D) int launch_varlen_d##D(int dtype, int build, const FwdArgs& a, const VarlenArgs& va, hipStream_t stream);
+#define FFPA_DECL(D) int launch_varlen_d##D(int dtype, int nt, const FwdArgs& a, const VarlenArgs& va, hipStream_t stream);
 FFPA_FOR_EACH_VARLEN_HEAD_DIM(FFPA_DECL)
 #undef FFPA_DECL
 

@@ -14,11 +14,11 @@
 
 namespace ffpa {
 
-template <typename T, int D, bool NT, bool PAIR>
+template <typename T, int D, bool NT>
 static int launch_varlen(const FwdArgs& a, const VarlenArgs& va, hipStream_t stream) {
   constexpr int BC = m16_block_keys(D, false);
   constexpr int LDS = 2 * BC * D * 2 + m16_exchange_bytes(D, 0);
-  auto kern = ffpa_fwd_m16_varlen_kernel<T, D, NT, PAIR>;
+  auto kern = ffpa_fwd_m16_varlen_kernel<T, D, NT>;
   static std::atomic<bool> attr_done[64];  // write-once per device (setting the attribute twice is harmless)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return -1;
@@ -36,15 +36,10 @@ static int launch_varlen(const FwdArgs& a, const VarlenArgs& va, hipStream_t str
 #define FFPA_CAT2(a, b) a##b
 #define FFPA_CAT(a, b) FFPA_CAT2(a, b)
 
-// build: 0 = one row tile per workgroup, 1 = the same with the non-temporal hint on its K / V pieces (launches of one row tile per (sequence, head)), 2 = paired
-// row tiles (causal launches of several row tiles per head) — ffpa_capi.hip decides per launch
-int FFPA_CAT(launch_varlen_d, FFPA_INST_D)(int dtype, int build, const FwdArgs& a, const VarlenArgs& va, hipStream_t stream) {
-  if (dtype == 0)
-    return build == 1 ? launch_varlen<__bf16, FFPA_INST_D, true, false>(a, va, stream)
-                      : (build == 2 ? launch_varlen<__bf16, FFPA_INST_D, false, true>(a, va, stream) : launch_varlen<__bf16, FFPA_INST_D, false, false>(a, va, stream));
-  if (dtype == 1)
-    return build == 1 ? launch_varlen<_Float16, FFPA_INST_D, true, false>(a, va, stream)
-                      : (build == 2 ? launch_varlen<_Float16, FFPA_INST_D, false, true>(a, va, stream) : launch_varlen<_Float16, FFPA_INST_D, false, false>(a, va, stream));
+// nt: the decode-batch build (K / V pieces with the non-temporal hint: ffpa_capi.hip decides per launch)
+int FFPA_CAT(launch_varlen_d, FFPA_INST_D)(int dtype, int nt, const FwdArgs& a, const VarlenArgs& va, hipStream_t stream) {
+  if (dtype == 0) return nt ? launch_varlen<__bf16, FFPA_INST_D, true>(a, va, stream) : launch_varlen<__bf16, FFPA_INST_D, false>(a, va, stream);
+  if (dtype == 1) return nt ? launch_varlen<_Float16, FFPA_INST_D, true>(a, va, stream) : launch_varlen<_Float16, FFPA_INST_D, false>(a, va, stream);
   return -4;
 }
 
