@@ -519,6 +519,7 @@ def _same_to_merge_rounding(out, lse, ref, ref_lse, name):
   (32, 8, 512, torch.bfloat16, 1, 0), (32, 8, 512, torch.bfloat16, 1, 3), (8, 8, 320, torch.float16, 1, 5), (4, 1, 1024, torch.bfloat16, 1, 16), (16, 4, 128, torch.bfloat16, 1, 2),
   (8, 8, 512, torch.bfloat16, 37, 4), (8, 2, 256, torch.float16, 100, 7), (8, 2, 640, torch.bfloat16, 64, 0), (4, 4, 512, torch.bfloat16, 128, 64),
   (32, 8, 512, torch.bfloat16, 16, 5), (8, 2, 1024, torch.float16, 9, 0),
+  (8, 2, 72, torch.bfloat16, 1, 3), (8, 2, 200, torch.float16, 4, 0), (4, 4, 328, torch.bfloat16, 20, 6),  # head dims between the kernels' (128 / 256 / 384 run them: partial rows of the KERNEL's width)
 ])
 def test_kv_splits_inside_the_packed_launch(hip, hq, hkv, d, dtype, nq, splits):
   """Batches of one row tile per (sequence, head) that leave most of the chip idle split every sequence's KV range over several workgroups — each sequence by ITS OWN
