@@ -51,6 +51,17 @@ def _allows_small_d(backend: Backend, head_dim: int) -> bool:
   return bool(env) and (_env_flag(env) or _env_flag("FFPA_HIP_ALLOW_SMALL_D"))
 
 
+def _allows_short_seq(backend: Backend, Nq: int, Nkv: int, is_causal: bool) -> bool:
+  """Opt-in routing of SHORT sequences (8 <= Nq < 512 or Nkv < 512) to the HIP kernel: ``FFPA_HIP_ALLOW_SHORT_SEQ=1`` — the analogue of the small-D switches above for
+  the reference's other two length thresholds (functional.py:717-724), which are tuned for GPUs whose SDPA has a flash kernel for such calls; on MI355X SDPA serves a
+  large head dim through its math / efficient backends (4 ... 10 x slower than this kernel: chunked prefill of 128 ... 511 rows against a long context).  Off by default
+  — the dispatch decisions are the reference's — and never for a call whose answer would change: under ``is_causal`` SDPA masks top-left, this kernel tail-aligned,
+  the two agree only for Nq == Nkv."""
+  if backend.name not in ("hip", "cuda", "triton") or not _env_flag("FFPA_HIP_ALLOW_SHORT_SEQ"):
+    return False
+  return (not is_causal) or Nq == Nkv
+
+
 @dataclass
 class AttentionMeta:
   is_causal: bool = False
@@ -93,9 +104,9 @@ class FFPAAttnMeta:
     return cls(forward_meta=fwd, backward_meta=bwd)
 
   # ------------------------------------------------------------------ fallback predicate
-  def fallback(self, query: torch.Tensor, key: torch.Tensor, attn_mask, dropout_p: float) -> bool:
+  def fallback(self, query: torch.Tensor, key: torch.Tensor, attn_mask, dropout_p: float, is_causal: bool = False) -> bool:
     """True when the call must go to ``torch._C._nn.scaled_dot_product_attention``
-    (functional.py:676-724)."""
+    (functional.py:676-724).  ``is_causal`` (not an argument of the reference's method) only matters under ``FFPA_HIP_ALLOW_SHORT_SEQ=1``."""
     assert query.dim() == 4, "Expected query shape [B, Nh_q, Nq, D]"
     assert key.dim() == 4, "Expected key shape [B, Nh_kv, Nkv, D]"
     _, _, Nq, D = query.shape
@@ -106,11 +117,11 @@ class FFPAAttnMeta:
       return True
     if fwd.name == "cutedsl":
       return True  # no CuTe-DSL hardware here (reference: cute_forward_available() is False)
+    short = (8 <= Nq < 512 or Nkv < 512) and not _allows_short_seq(fwd, Nq, Nkv, is_causal)
     reasons = [
       D <= SMALL_HEAD_DIM_MAX and not _allows_small_d(fwd, D),
       D > MAX_HEAD_DIM,
-      8 <= Nq < 512,
-      Nkv < 512,
+      short,
     ]
     return any(reasons)  # (large-D CPU tensors reach the op and raise NotImplementedError, like the reference)
 

@@ -142,7 +142,7 @@ def ffpa_attn_func(
   function cannot recurse — tests/test_monkey_patch.py:65-69 in the reference).
   """
   meta = FFPAAttnMeta.from_kwargs(**kwargs)
-  if meta.fallback(query, key, attn_mask, dropout_p):
+  if meta.fallback(query, key, attn_mask, dropout_p, is_causal=is_causal):
     return torch._C._nn.scaled_dot_product_attention(
       query,
       key,

@@ -92,6 +92,24 @@ def test_small_d_opt_in_env(monkeypatch):
   assert FFPAAttnMeta.from_kwargs().fallback(q32, q32, None, 0.0)  # below 64 never reaches the kernel
 
 
+def test_short_sequence_opt_in_env(monkeypatch):
+  """FFPA_HIP_ALLOW_SHORT_SEQ=1: the reference's two length thresholds (8 <= Nq < 512, Nkv < 512: functional.py:717-724) stop sending a large-D call to SDPA —
+  unless its answer would change (is_causal with Nq != Nkv: SDPA masks top-left, the kernel tail-aligned).  Off by default: the reference's decisions."""
+  q = torch.empty((1, 8, 128, 512), dtype=torch.bfloat16, device="meta")
+  k = torch.empty((1, 8, 4096, 512), dtype=torch.bfloat16, device="meta")
+  ks = torch.empty((1, 8, 128, 512), dtype=torch.bfloat16, device="meta")
+  meta = FFPAAttnMeta.from_kwargs()
+  assert meta.fallback(q, k, None, 0.0) and meta.fallback(q, ks, None, 0.0, is_causal=True)
+  monkeypatch.setenv("FFPA_HIP_ALLOW_SHORT_SEQ", "1")
+  assert not meta.fallback(q, k, None, 0.0)                   # chunked prefill: 128 rows against 4096 keys
+  assert not meta.fallback(q, ks, None, 0.0)                  # Nkv < 512
+  assert not meta.fallback(q, ks, None, 0.0, is_causal=True)  # Nq == Nkv: both conventions mask the same pairs
+  assert meta.fallback(q, k, None, 0.0, is_causal=True)       # top-left vs tail-aligned: SDPA keeps it
+  assert FFPAAttnMeta.from_kwargs(backend="sdpa").fallback(q, k, None, 0.0)
+  small = torch.empty((1, 8, 128, 128), dtype=torch.bfloat16, device="meta")
+  assert meta.fallback(small, small, None, 0.0)  # the head-dim rule is another switch
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------------
 # Source compatibility of the Backend objects: tests/golden/backend_golden.json holds what the REFERENCE's dataclasses do with each
 # constructor call (functional.py:176-470; generated by tests/golden/make_golden.py from the imported reference): the kwargs that

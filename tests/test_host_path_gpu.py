@@ -270,3 +270,56 @@ def test_decode_step_with_a_device_side_kv_length(hip):
     return s.elapsed_time(e) / 50
   t_short, t_full = timed(700), timed(8192)
   assert t_short < 0.6 * t_full, (t_short, t_full)
+
+
+def test_short_sequence_opt_in_routes_to_the_kernel_with_sdpas_answers(hip, monkeypatch):
+  """FFPA_HIP_ALLOW_SHORT_SEQ=1 (functional.py `_allows_short_seq`): calls the reference's length thresholds hand to SDPA — 8 <= Nq < 512, Nkv < 512 — reach the HIP
+  kernel instead, with the answers the default route gives (SDPA here): chunked prefill rows against a long context, plain and under a boolean mask and GQA; a short
+  causal self-attention (Nq == Nkv: both causal conventions agree); `is_causal` with Nq != Nkv stays with SDPA (top-left there, tail-aligned here)."""
+  import time
+
+  import torch.nn.functional as F
+
+  from ffpa_attn_amd import ffpa_attn_func
+
+  calls = []
+  real = hip.forward
+
+  def counting(*a, **k):
+    calls.append(1)
+    return real(*a, **k)
+
+  monkeypatch.setattr(hip, "forward", counting)
+  g = torch.Generator(device="cuda").manual_seed(3)
+  mk = lambda *shape: torch.randn(shape, dtype=torch.bfloat16, device="cuda", generator=g)  # noqa: E731
+  q, k, v = mk(2, 8, 128, 512), mk(2, 2, 4096, 512), mk(2, 2, 4096, 512)
+  mask = torch.rand((1, 1, 128, 4096), device="cuda", generator=g) > 0.3
+  qs, ks, vs = mk(2, 8, 256, 512), mk(2, 8, 256, 512), mk(2, 8, 256, 512)
+  cases = [("chunk vs context, GQA", (q, k, v), dict(enable_gqa=True)), ("... under a boolean mask", (q, k, v), dict(enable_gqa=True, attn_mask=mask)),
+           ("short causal self-attention", (qs, ks, vs), dict(is_causal=True)), ("short keys", (qs, ks[:, :, :100], vs[:, :, :100]), dict())]
+  monkeypatch.delenv("FFPA_HIP_ALLOW_SHORT_SEQ", raising=False)
+  default = [ffpa_attn_func(*t, **kw) for _, t, kw in cases]
+  assert not calls  # the reference's decisions: SDPA
+  monkeypatch.setenv("FFPA_HIP_ALLOW_SHORT_SEQ", "1")
+  for (name, t, kw), ref in zip(cases, default):
+    n = len(calls)
+    out = ffpa_attn_func(*t, **kw)
+    assert len(calls) == n + 1, f"{name}: the kernel did not run"
+    assert torch.allclose(out.float(), ref.float(), atol=2e-2, rtol=2e-2), f"{name}: {(out.float() - ref.float()).abs().max().item():.3e}"
+    assert (out.float() - ref.float()).abs().max().item() <= 1e-2, name
+  n = len(calls)
+  out = ffpa_attn_func(q, k.repeat_interleave(4, 1), v.repeat_interleave(4, 1), is_causal=True)  # Nq != Nkv under is_causal: SDPA's top-left mask, SDPA's call
+  assert len(calls) == n
+  assert torch.equal(out, F.scaled_dot_product_attention(q, k.repeat_interleave(4, 1), v.repeat_interleave(4, 1), is_causal=True))
+  # what the switch is for (informative: printed with -s)
+  def timed(fn, reps=10):
+    fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps):
+      fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+  t_k = timed(lambda: ffpa_attn_func(q, k, v, enable_gqa=True))
+  monkeypatch.delenv("FFPA_HIP_ALLOW_SHORT_SEQ")
+  t_s = timed(lambda: ffpa_attn_func(q, k, v, enable_gqa=True))
+  print(f"SHORTSEQ B2 Hq8/Hkv2 Nq128 Nkv4096 D512: kernel {t_k:.3f} ms, default route (SDPA) {t_s:.3f} ms ({t_s / t_k:.1f} x)")
