@@ -160,7 +160,7 @@ def _piece_plan_chunks(qu: torch.Tensor, ku: torch.Tensor, chunks: int, kwargs: 
     causal = bool(kw.pop("is_causal", False))
     kw.pop("scale", None)
     meta = FFPAAttnMeta.from_kwargs(**kw)
-    if meta.fallback(qu, ku, mask, dropout_p):
+    if meta.fallback(qu, ku, mask, dropout_p, is_causal=causal):
       return chunks
     g, nq, d = qu.shape[1:]
     # the launch hip.forward makes of a piece: packed GQA heads for short queries, the prefill-split opt-out of the environment
