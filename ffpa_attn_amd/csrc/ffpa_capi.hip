@@ -928,14 +928,41 @@ int varlen_plan(const ffpa_varlen_fwd_params* p, VarlenPlan* out) {
   //   (b) BALANCE a ragged batch — several sequences differ in length and the longest one's workgroups finish last: up to kT.varlen_balance_wgs workgroups per slot
   //       in ranges of at least kT.varlen_balance_min_tiles tiles (256 pairs x 4 ranges: 877 -> 728 us; 64 x 8: 181 us), as long as the partials stay a small
   //       fraction of the K + V bytes (64 query rows per sequence: 4 ranges 248 us, 16 ranges 293 us).
+  //   (c) PREFILL launches (several row tiles per head) that leave most of the chip idle — chunked prefill of one long sequence with a few heads per GPU: 8 heads x
+  //       8 row tiles are 64 workgroups — take the dense path's under-filled rule (pick_splits): fill the slots, at least kT.min_tiles_prefill KV tiles per
+  //       range; under the causal flag every row tile shares out the tiles up to ITS diagonal (the kernel), and the launch side prices the average row tile
+  //       (max_seqlen_kv - max_seqlen_q / 2 keys).  64 workgroups x 4 ranges: 679 -> 242 us (392 -> 1100 TFLOPS); 16 x 16: 2600 -> 231 us.
   out->splits = 1;
   out->ws_bytes = 0;
-  if (out->nqt == 1 && p->total_q > 0 && p->workspace != nullptr && p->num_splits != 1 && !(p->flags & FFPA_FLAG_DETERMINISTIC)) {
+  if (p->total_q > 0 && p->workspace != nullptr && p->num_splits != 1 && !(p->flags & FFPA_FLAG_DETERMINISTIC)) {
     const int64_t cus = device_cu_count();
     const int64_t max_tiles = ((int64_t)p->max_seqlen_kv + out->bc - 1) / out->bc;
     int64_t want = 1;
     if ((p->flags & FFPA_FLAG_FORCE_SPLITS) && p->num_splits > 1) {
       want = p->num_splits < max_tiles ? p->num_splits : max_tiles;  // (sweeps and tests: exactly n, down to one tile per range)
+    } else if (out->nqt > 1) {
+      // (c): slots as in (a); the workgroups that find rows — the grid is sized by max_seqlen_q, a ragged batch's short sequences leave theirs at once — are at
+      // least heads x ceil(total_q / block rows) (exact when the lengths are whole tiles; a range too many costs little, one too few a lot: 2 sequences of 1024 /
+      // 256 rows, 8 heads: 2 ranges 361 us, 3 270, 4 277).  A causal launch that fills the slots only once and whose longest row tile walks >= 1.5 x the average
+      // one (a whole prompt: 1 ... n tiles) takes two ranges: the second half of the long rows fills the slots the short ones leave (8 heads x 4096 x 4096:
+      // 187 -> 168 us; D = 128: 78 -> 70).  profiles/r06_varlen_prefill_splits.txt
+      const int64_t slots = (dk >= kT.short_one_per_cu_min_d ? 1 : 2) * cus;
+      int64_t live = (int64_t)p->heads_q * (((int64_t)p->total_q + out->br - 1) / out->br);
+      if (live > out->grid) live = out->grid;
+      if (live < 1) live = 1;
+      if (2 * live <= slots) want = slots / live;
+      double avg_tiles = (double)max_tiles;
+      if (p->causal) {
+        const double mq = p->max_seqlen_q < p->max_seqlen_kv ? p->max_seqlen_q : p->max_seqlen_kv;  // (rows past the keys see none)
+        avg_tiles = ((double)p->max_seqlen_kv - 0.5 * mq) / out->bc;
+        if (want == 1 && live <= slots && (double)max_tiles >= 1.5 * avg_tiles) want = 2;
+      }
+      const int64_t cap = (int64_t)(avg_tiles / kT.min_tiles_prefill);
+      if (want > cap) want = cap;
+      if (want < 1) want = 1;
+      if (p->num_splits > 1 && want > p->num_splits) want = p->num_splits;
+      const double per_split = (double)p->heads_q * (double)p->total_q * ((double)dk + 1.0) * sizeof(float);
+      if ((double)want * per_split > kT.max_auto_ws_bytes) want = (int64_t)(kT.max_auto_ws_bytes / per_split);
     } else {
       const int64_t slots = (dk >= kT.short_one_per_cu_min_d ? 1 : 2) * cus;
       int64_t fill = 2 * out->grid <= slots ? slots / out->grid : 1;

@@ -410,8 +410,8 @@ struct VarlenArgs {
   int64_t q_tok_stride, o_tok_stride;  // elements between two tokens of q / o
   const int* used_k;     // optional [batch]: sequence i uses only the first used_k[i] of its key rows (a KV cache of fixed capacity per sequence whose valid
                          // length lives on the device: FlashAttention's seqused_k / cache_seqlens); NULL = all of cu_k[i] .. cu_k[i + 1]
-  // KV SPLITS (FwdArgs::nsplit > 1, launches of one row tile per (sequence, head) only): workgroup (pair, split) walks KV tiles [split * tps, (split + 1) * tps) of ITS
-  // sequence, tps = ceil(tiles of that sequence / nsplit) computed here on the device, and stores a normalised fp32 partial + LSE to FwdArgs::ws_o / ws_lse at row
+  // KV SPLITS (FwdArgs::nsplit > 1: launches of one row tile per (sequence, head), and prefill launches that leave most of the chip idle): workgroup (pair, row tile,
+  // split) walks KV tiles [split * tps, (split + 1) * tps) of ITS sequence, tps = ceil(tiles that row tile of that sequence can see / nsplit) computed here on the device, and stores a normalised fp32 partial + LSE to FwdArgs::ws_o / ws_lse at row
   // split * ws_split_rows + head * ws_head_rows + token (ffpa_varlen_merge_kernel, ffpa_varlen_merge.h, combines them: the reference's decode stage 2)
   int64_t ws_head_rows;   // total_q
   int64_t ws_split_rows;  // query heads x total_q
@@ -474,8 +474,16 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_varlen_kernel(const FwdArgs 
     if (va.pack) a.causal_row_mod = ntok_seq;
     if (a_in.nsplit > 1) {
       if ((int64_t)q_lo + ntok_seq > va.ws_head_rows) return;  // (a caller whose total_q is smaller than its boundaries say: nothing is stored outside the scratch it sized)
-      const int tiles = (a.Nkv + BC - 1) / BC;
-      a.tiles_per_split = (tiles + a_in.nsplit - 1) / a_in.nsplit;  // (a sequence shorter than nsplit tiles leaves ranges empty: dead partials, weight 0 in the merge)
+      int tiles = (a.Nkv + BC - 1) / BC;
+      if (a.causal) {
+        // under the causal flag a row tile walks the KV tiles up to ITS diagonal (the tile text's clamp, restated): those are what its ranges share out —
+        // every row tile of an under-filled prefill launch splits its own visible keys evenly (one-row-tile launches: all keys of the sequence, as before)
+        const int last_row = a.causal_row_mod ? a.causal_row_mod - 1 : qt * BR + BR - 1;
+        const int64_t last = (int64_t)last_row + a.causal_offset;
+        const int ntc = last < 0 ? 0 : (int)(last / BC) + 1;
+        tiles = tiles < ntc ? tiles : ntc;
+      }
+      a.tiles_per_split = (tiles + a_in.nsplit - 1) / a_in.nsplit;  // (fewer tiles than ranges leaves ranges empty: dead partials, weight 0 in the merge)
     }
     a.q = (const T*)a_in.q + (int64_t)q_lo * va.q_tok_stride;
     a.o = (T*)a_in.o + (int64_t)q_lo * va.o_tok_stride;

@@ -878,7 +878,7 @@ _VARLEN_SCRATCH: "dict[tuple, int]" = {}
 def _varlen_scratch(lib, p: "FfpaVarlenFwdParams", device_index: int) -> int:
   if p.num_splits == 1 or p.flags & FLAG_DETERMINISTIC:
     return 0
-  key = (id(lib), device_index, p.dtype, p.batch, p.heads_q, p.heads_kv, p.head_dim, p.max_seqlen_q, p.max_seqlen_kv, p.total_q, p.flags, p.num_splits, os.environ.get("FFPA_HIP_FAKE_CUS"))
+  key = (id(lib), device_index, p.dtype, p.batch, p.heads_q, p.heads_kv, p.head_dim, p.max_seqlen_q, p.max_seqlen_kv, p.total_q, p.causal, p.flags, p.num_splits, os.environ.get("FFPA_HIP_FAKE_CUS"))
   hit = _VARLEN_SCRATCH.get(key)
   if hit is None:
     if len(_VARLEN_SCRATCH) >= 512:
@@ -899,9 +899,9 @@ def varlen_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens
   ``cu_seqlens_k`` = multiples of the capacity) whose valid lengths live on the device: ONE captured graph serves every length, a replay follows lengths written
   in place, and with one token per sequence under GQA the group's heads are packed into the rows of one tile (FlashAttention's ``cache_seqlens`` decode).
 
-  ``num_splits``: 0 = the library decides (launches of one row tile per (sequence, head) that leave most of the chip idle — a decode batch of a few long
-  sequences — split every sequence's KV range over several workgroups and merge fp32 partials in a second kernel of the same call: equal to the unsplit launch
-  to rounding, not to the bit), 1 = never, n = at most n.  ``FFPA_HIP_DETERMINISTIC=1`` / ``FLAG_DETERMINISTIC``: never."""
+  ``num_splits``: 0 = the library decides (launches that leave most of the chip idle — a decode batch of a few long sequences, a prefill chunk of one long
+  prompt with a few heads per GPU — split every row tile's KV range over several workgroups and merge fp32 partials in a second kernel of the same call: equal
+  to the unsplit launch to rounding, not to the bit), 1 = never, n = at most n.  ``FFPA_HIP_DETERMINISTIC=1`` / ``FLAG_DETERMINISTIC``: never."""
   if not q.is_cuda:
     raise NotImplementedError(f"ffpa_attn::_varlen_fwd_hip has no implementation for device '{q.device.type}' (the HIP kernel needs a GPU tensor)")
   lib = load_library()

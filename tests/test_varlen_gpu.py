@@ -50,13 +50,14 @@ def _seq(t, a, b):
   return t[a:b].transpose(0, 1).unsqueeze(0)
 
 
-def _check_packed(hip, q, k, v, lens_q, lens_k, causal, out, lse, *, oracle=True, dense_bits=True, sdpa=True, name="", max_q=None, max_k=None):
+def _check_packed(hip, q, k, v, lens_q, lens_k, causal, out, lse, *, oracle=True, dense_bits=True, sdpa=True, name="", max_q=None, max_k=None, split=None):
   """out / lse of one packed call against the three references, sequence by sequence.  (max_q / max_k: what the call announced, if not the longest sequence —
   a launch that split its KV ranges merged fp32 partials: equal to the dense kernel to rounding, so the bit comparison is skipped for it.)"""
   hq, d = q.size(1), q.size(2)
-  if dense_bits:
-    plan = hip.varlen_launch_plan(len(lens_q), hq, k.size(1), max(max_q or max(lens_q), 1), max(max_k or max(lens_k), 1), d, dtype=q.dtype, causal=causal, total_q=q.size(0))
-    dense_bits = plan["splits"] == 1
+  # (a launch that leaves most of the chip idle splits its KV ranges: fp32 partials + merge — the oracle check then carries the P-rounding noise of several walks)
+  if split is None:  # (None: what the library does by itself for this shape class)
+    split = hip.varlen_launch_plan(len(lens_q), hq, k.size(1), max(max_q or max(lens_q), 1), max(max_k or max(lens_k), 1), d, dtype=q.dtype, causal=causal, total_q=q.size(0))["splits"] > 1
+  dense_bits = dense_bits and not split
   assert out.shape == q.shape and out.dtype == q.dtype and lse.shape == (hq, q.size(0)) and lse.dtype == torch.float32
   bq, bk = np.cumsum([0, *lens_q]), np.cumsum([0, *lens_k])
   scale = 1.0 / math.sqrt(d)
@@ -75,7 +76,7 @@ def _check_packed(hip, q, k, v, lens_q, lens_k, causal, out, lse, *, oracle=True
     assert torch.isfinite(o_i[:, :, dead:].float()).all() and torch.isfinite(l_i[:, :, dead:]).all(), f"{name} seq {i}"
     q_i, k_i, v_i = _seq(q, qs, qe), _seq(k, ks, ke), _seq(v, ks, ke)
     if oracle:
-      _check_vs_oracle(o_i, l_i, q_i, k_i, v_i, causal=causal, causal_offset=nk - nq, rows=(dead, nq), block_keys=bc, name=f"{name} seq {i} vs oracle")
+      _check_vs_oracle(o_i, l_i, q_i, k_i, v_i, causal=causal, causal_offset=nk - nq, rows=(dead, nq), block_keys=bc, name=f"{name} seq {i} vs oracle", split=split)
     if dense_bits and nq > 32:  # (dense launches of <= 32 rows run the short-query tiles: another kernel, equal to rounding only)
       o_d, l_d = hip.forward(q_i, k_i, v_i, None, causal, scale, flags=hip.FLAG_DETERMINISTIC)
       assert torch.equal(l_d[:, :, dead:], l_i[:, :, dead:]), f"{name} seq {i}: LSE differs from the dense kernel's bits"
@@ -128,6 +129,10 @@ def test_packed_call_matches_oracle_dense_bits_and_sdpa_per_sequence(hip, lens_q
   out, lse = ffpa_attn_varlen_func(q, k, v, cu_q, cu_k, max(lens_q), max(lens_k), causal=causal, enable_gqa=hq != hkv, return_lse=True)
   big = len(lens_q) > 8  # (the 70-sequence case: the oracle on a sample of its sequences only — it is a CPU loop)
   _check_packed(hip, q, k, v, lens_q, lens_k, causal, out, lse, oracle=not big, name=f"D{d}")
+  if hip.varlen_launch_plan(len(lens_q), hq, hkv, max(lens_q), max(max(lens_k), 1), d, dtype=dtype, causal=causal, total_q=q.size(0))["splits"] > 1:
+    # (these few-head batches leave most of the chip idle: the library split their KV ranges.  The one-range launch of the same batch keeps the dense kernel's bits)
+    one, one_lse = hip.varlen_forward(q, k, v, cu_q, cu_k, max(lens_q), max(lens_k), causal, d ** -0.5, num_splits=1)
+    _check_packed(hip, q, k, v, lens_q, lens_k, causal, one, one_lse, oracle=not big, sdpa=False, split=False, name=f"D{d}, one KV range")
   if big:
     keep = [3, 8, 22, 41, 69]
     for i in keep:
@@ -192,10 +197,15 @@ def test_zero_copy_strided_views_and_oversized_max_seqlen(hip):
   q, k, v = qkv[:, 0], qkv[:, 1], qkv[:, 2]
   assert not q.is_contiguous()
   cu = _cu(lens)
-  out, lse = hip.varlen_forward(q, k, v, cu, cu, 512, 512, True, d ** -0.5)
-  out2, lse2 = hip.varlen_forward(q.contiguous(), k.contiguous(), v.contiguous(), cu, cu, 4096, 8192, True, d ** -0.5)
+  out, lse = hip.varlen_forward(q, k, v, cu, cu, 512, 512, True, d ** -0.5, num_splits=1)
+  out2, lse2 = hip.varlen_forward(q.contiguous(), k.contiguous(), v.contiguous(), cu, cu, 4096, 8192, True, d ** -0.5, num_splits=1)
   assert torch.equal(out, out2) and torch.equal(lse, lse2)
   _check_packed(hip, q, k, v, lens, lens, True, out, lse, name="strided")
+  # left to the library, this launch (4 heads x 7 row tiles with rows) splits its KV ranges — by the announced maxima, which are part of the shape class: equal to
+  # the one-range launch to merge rounding
+  for mq, mk in ((512, 512), (4096, 8192)):
+    out3, lse3 = hip.varlen_forward(q, k, v, cu, cu, mq, mk, True, d ** -0.5)
+    _same_to_merge_rounding(out3, lse3, out, lse, f"strided, max_seqlen {mq} / {mk}")
 
 
 def test_softmax_scale_conventions_and_exact_recurrence(hip):
@@ -546,6 +556,39 @@ def test_kv_splits_inside_the_packed_launch(hip, hq, hkv, d, dtype, nq, splits):
   # the deterministic flag keeps one range per sequence: the one-range launch's bits
   det, det_lse = hip.varlen_forward(q, k, v, cu_q, cu_k, nq, max(lens_k), True, d ** -0.5, flags=hip.FLAG_DETERMINISTIC)
   assert torch.equal(det, ref) and torch.equal(det_lse, ref_lse)
+
+
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("hq, hkv, d, dtype, splits", [
+  (4, 4, 512, torch.bfloat16, 0), (4, 4, 512, torch.bfloat16, 3), (8, 2, 320, torch.float16, 5), (2, 1, 1024, torch.bfloat16, 4), (4, 2, 128, torch.bfloat16, 7), (2, 2, 200, torch.float16, 2),
+  (2, 2, 512, torch.bfloat16, 64),
+])
+def test_kv_splits_of_under_filled_prefill_launches(hip, hq, hkv, d, dtype, splits, causal):
+  """PREFILL launches (several row tiles per head) that leave most of the chip idle — a chunk of a long prompt with a few heads per GPU — split the KV range of every
+  row tile: under the causal flag the tiles up to ITS diagonal (the kernel restates the tile text's clamp), each sequence by its own lengths.  Left to the library
+  (splits = 0) and forced (more ranges than the short row tiles have KV tiles: empty ranges; sequences with more rows than keys: rows without a visible key; a
+  sequence without keys) against the one-range launch (to merge rounding), SDPA per sequence and the oracle on one sequence."""
+  lens_q = [700, 130, 0, 300, 64, 513]
+  lens_k = [5000, 130, 77, 100, 2048, 0 if splits == 3 else 1900]
+  q, k, v = _make(lens_q, lens_k, hq, hkv, d, dtype, seed=hq + d + splits)
+  cu_q, cu_k = _cu(lens_q), _cu(lens_k)
+  p1, ps = {}, {}
+  ref, ref_lse = hip.varlen_forward(q, k, v, cu_q, cu_k, max(lens_q), max(lens_k), causal, d ** -0.5, num_splits=1, plan_out=p1)
+  out, lse = hip.varlen_forward(q, k, v, cu_q, cu_k, max(lens_q), max(lens_k), causal, d ** -0.5, num_splits=splits, flags=hip.FLAG_FORCE_SPLITS if splits else 0, plan_out=ps)
+  assert p1["splits"] == 1 and "merge" not in p1["kernel"] and p1["row_tiles"] > 1
+  tiles = -(-max(lens_k) // ps["block_keys"])
+  assert ps["splits"] == (min(splits, tiles) if splits else ps["splits"]) and ps["splits"] > 1 and ps["workgroups"] == p1["workgroups"] * ps["splits"], (p1, ps)
+  assert ps["kernel"].endswith("+ ffpa_varlen_merge_kernel"), ps
+  name = f"prefill KV splits {ps['splits']} Hq{hq}/Hkv{hkv} D{d} {'causal' if causal else 'full'}"
+  _same_to_merge_rounding(out, lse, ref, ref_lse, name)
+  _check_packed(hip, q, k, v, lens_q, lens_k, causal, out, lse, oracle=False, dense_bits=False, sdpa=d <= 512, name=name)
+  i = 0
+  _check_vs_oracle(_seq(out, 0, lens_q[i]), lse[:, :lens_q[i]].unsqueeze(0), _seq(q, 0, lens_q[i]), _seq(k, 0, lens_k[i]), _seq(v, 0, lens_k[i]),
+                   causal=causal, causal_offset=lens_k[i] - lens_q[i], rows=(0, 256), block_keys=ps["block_keys"], name=name + " vs oracle", split=True)
+  det, det_lse = hip.varlen_forward(q, k, v, cu_q, cu_k, max(lens_q), max(lens_k), causal, d ** -0.5, flags=hip.FLAG_DETERMINISTIC)
+  assert torch.equal(det, ref) and torch.equal(det_lse, ref_lse)
+  env, env_lse = hip.varlen_forward(q, k, v, cu_q, cu_k, max(lens_q), max(lens_k), causal, d ** -0.5, num_splits=1)
+  assert torch.equal(env, ref) and torch.equal(env_lse, ref_lse)
 
 
 @pytest.mark.parametrize("hq, hkv, d, dtype, nq", [(32, 8, 512, torch.bfloat16, 1), (8, 8, 320, torch.float16, 1), (4, 1, 1024, torch.bfloat16, 1), (8, 8, 128, torch.bfloat16, 37)])
