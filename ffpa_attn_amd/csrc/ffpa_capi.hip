@@ -84,6 +84,7 @@ struct Plan {
   int pair;      // 1: row tiles i and nqt - 1 - i share a workgroup (FwdArgs.pair_tiles): the grid holds (nqt + 1) / 2 workgroups per (batch, head)
   int chunk;     // > 1: a causal GQA launch in the HEAD-CHUNK order — (head chunk, batch, row tile, head in chunk), chunks of this many heads of one KV group: the same row
                  //      tile of the group's heads runs at the same time on the same keys (ffpa_fwd_m16_varlen_kernel in its dense mode: the packed-sequence kernel's order)
+  int tile_ranges;  // 1: a causal launch whose KV splits are PER ROW TILE — every row tile shares out the KV tiles up to its own diagonal (the same kernel's dense mode)
   size_t ws_bytes;
 };
 
@@ -172,6 +173,10 @@ struct PlanTunables {
   // range, and partials (written + read back) of at most this fraction of the K + V bytes the launch side can estimate
   int varlen_balance_wgs, varlen_balance_min_tiles;
   double varlen_partial_frac;
+  // per-row-tile KV ranges of dense causal launches of one round (pick_tile_ranges; profiles/r06_tile_ranges.txt): keys a range of the average row tile keeps at
+  // least (head dims <= 512 / the split-D tiles), and the head dim below which the launch takes three ranges instead of two (two workgroups fit a CU there)
+  double tile_ranges_min_keys, tile_ranges_min_keys_splitd;
+  int tile_ranges_three_below_d;
 };
 constexpr PlanTunables kPlanGfx950 = {
     5.0e12 / 9.8304e12, 4.0e12 / 9.8304e12, 5.0e12 / 8.0e12,
@@ -185,6 +190,8 @@ constexpr PlanTunables kPlanGfx950 = {
     32,
     4, 16,
     0.02,
+    640.0, 2048.0,
+    256,
 };
 constexpr const PlanTunables& kT = kPlanGfx950;
 
@@ -474,6 +481,34 @@ int pick_dense_head_chunk(const ffpa_fwd_params* p, const Plan& pl, int dk) {
   return pick_head_chunk(p->heads_q, p->heads_q / p->heads_kv);
 }
 
+// PER-ROW-TILE KV ranges for causal launches of ONE ROUND of workgroups (CUs / 2 < workgroups <= CUs: a whole prompt with a few heads per GPU — 8 heads x 4096
+// tokens are 256 row tiles).  Longest first, the round ends on a few long row tiles while the short ones' CUs idle; uniform KV ranges (the dense kernel's) do not help —
+// a short row tile sees nothing of the later ranges, the long ones still walk the first range whole: 2 ranges - 15 %, tools/gpu_prefill_splits.py c_* —, ranges of
+// every row tile's OWN visible keys do (the packed-sequence kernel computes them on the device: its dense mode): 8 heads x 4096 x 4096 D 512 187 -> 165 us against
+// 199 us of the paired-tile launch, D 128 85 -> 70 us (profiles/r06_tile_ranges.txt).  Taken when the longest row tile walks >= 1.5 x the average one and a range
+// of the average one keeps enough keys (below).  The builds the dense mode has (pick_dense_head_chunk); fp32 partials + merge: equal to the one-range launch
+// to rounding — FFPA_FLAG_DETERMINISTIC / num_splits = 1 / FFPA_FLAG_NO_TILE_RANGES keep one range.
+int pick_tile_ranges(const ffpa_fwd_params* p, const Plan& pl, const PlanCtx& c) {
+  if (!pl.m16 || pl.wide || pl.splits != 1 || pl.mk != 0 || !p->causal || p->causal_offset < 0 || p->causal_row_mod != 0 || p->dropout_p > 0.f || c.dk < FFPA_M16_MIN_D) return 0;
+  if (p->flags & (FFPA_FLAG_NO_TILE_RANGES | FFPA_FLAG_DEBUG_SAFE_PATH | FFPA_FLAG_PAIR_TILES | FFPA_FLAG_DETERMINISTIC)) return 0;
+  if (p->workspace == nullptr || p->num_splits == 1 || pl.nqt < 2) return 0;
+  if ((int64_t)p->batch * p->heads_q * p->seqlen_q >= (1LL << 31)) return 0;
+  int64_t want = 0;
+  if ((p->flags & FFPA_FLAG_TILE_RANGES) && (p->flags & FFPA_FLAG_FORCE_SPLITS) && p->num_splits > 1) {
+    want = p->num_splits < pl.nt ? p->num_splits : pl.nt;  // (sweeps and tests: exactly n)
+  } else if (c.priced && 2 * c.base > c.cus && c.base <= c.cus && (double)c.nt_visible >= 1.5 * c.nt_eff) {
+    // a range of the average row tile keeps at least tile_ranges_min_keys keys (the partials and their merge: measured neutral at 512 keys per range — 16 heads x
+    // 2048 x 2048 - 1 % —, + 22 % at 750, + 15 ... 33 % at 1024; the split-D tiles - 4 % at 1024, + 8 % at 2048); small tiles (two workgroups per CU) take three
+    const double avg_keys = c.nt_eff * pl.bc, min_keys = c.dk > 512 ? kT.tile_ranges_min_keys_splitd : kT.tile_ranges_min_keys;
+    for (int64_t w = c.dk < kT.tile_ranges_three_below_d ? 3 : 2; w >= 2 && want == 0; --w)
+      if (avg_keys / (double)w >= min_keys) want = w;
+  }
+  if (want > ffpa::kMergeMaxSplits) want = ffpa::kMergeMaxSplits;
+  const size_t per_split = (size_t)p->batch * p->heads_q * p->seqlen_q * ((size_t)c.dk + 1) * sizeof(float);
+  if ((uint64_t)want * per_split > p->workspace_bytes) want = (int64_t)(p->workspace_bytes / per_split);
+  return want > 1 ? (int)want : 0;
+}
+
 // Launch plan: tile variant -> wide-row tile? -> KV splits (rules above) -> build and bias placement -> scratch.
 Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
   Plan pl = {};
@@ -487,16 +522,21 @@ Plan make_plan(const ffpa_fwd_params* p, const DimEntry* de) {
   pl.nqt = (p->seqlen_q + pl.br - 1) / pl.br;
   pl.nt = (p->seqlen_kv + pl.bc - 1) / pl.bc;
   const PlanCtx c = plan_context(p, de, &pl, cus);
-  const int64_t want = pick_splits(c);
+  const int64_t want = (p->flags & FFPA_FLAG_TILE_RANGES) ? 0 : pick_splits(c);  // (the flag: this launch's ranges are per row tile or none — pick_tile_ranges below)
   pl.splits = want > 0 ? (int)clamp_splits(c, want) : 1;
   pl.m16 = (pl.variant == 0 && !(p->flags & FFPA_FLAG_DEBUG_SAFE_PATH) && c.dk >= FFPA_M16_MIN_D) ? 1 : 0;
   if (pl.m16) pick_m16_build(p, de, pl, c.dk);
   pick_small_d_bias_tiles(p, de, pl);
   pl.chunk = pick_dense_head_chunk(p, pl, c.dk);
+  if (const int ranges = pick_tile_ranges(p, pl, c)) {
+    pl.tile_ranges = 1;
+    pl.splits = ranges;
+    if (pl.chunk < 1) pl.chunk = 1;
+  }
   pl.pair = (pl.chunk <= 1 && pick_pair_tiles(p, pl)) ? 1 : 0;
   pl.tiles_per_split = (pl.nt + pl.splits - 1) / pl.splits;
   if (pl.tiles_per_split < 1) pl.tiles_per_split = 1;
-  pl.splits = (pl.nt + pl.tiles_per_split - 1) / pl.tiles_per_split;
+  if (!pl.tile_ranges) pl.splits = (pl.nt + pl.tiles_per_split - 1) / pl.tiles_per_split;  // (per-row-tile ranges: the kernel sizes them, every count is exact)
   if (pl.splits < 1) pl.splits = 1;
   pl.ws_bytes = pl.splits > 1 ? (size_t)pl.splits * p->batch * p->heads_q * p->seqlen_q * ((size_t)c.dk + 1) * sizeof(float) : 0;
   return pl;
@@ -738,12 +778,15 @@ int ffpa_attn_fwd(const ffpa_fwd_params* p, void* stream) {
   }
 
   int st;
-  if (pl.chunk > 1) {
-    // the packed-sequence kernel in its dense mode (no boundary arrays): this launch's FwdArgs as they are, that kernel's workgroup order
+  if (pl.chunk > 1 || pl.tile_ranges) {
+    // the packed-sequence kernel in its dense mode (no boundary arrays): this launch's FwdArgs as they are, that kernel's workgroup order — and, with KV ranges,
+    // its per-row-tile ranges into the dense call's workspace rows [split, batch, head, row]
     ffpa::VarlenArgs va;
     memset(&va, 0, sizeof(va));
     va.lse_stride_h = p->seqlen_q;
-    va.head_chunk = pl.chunk;
+    va.head_chunk = pl.chunk > 1 ? pl.chunk : 1;
+    va.ws_head_rows = p->seqlen_q;
+    va.ws_split_rows = (int64_t)p->batch * p->heads_q * p->seqlen_q;
     st = -3;
     for (const VarlenEntry& e : kVarlenDims)
       if (e.d == kernel_head_dim(p->head_dim)) st = e.launch(p->dtype, 0, a, va, static_cast<hipStream_t>(stream));
@@ -852,6 +895,8 @@ int ffpa_attn_fwd_kernel(const ffpa_fwd_params* params, char* buf, size_t n) {
   const char* merge = pl.splits > 1 ? ((params->split_tickets != nullptr && pl.variant == 1) ? " (in-launch split merge)" : " + ffpa_fwd_merge_kernel") : "";
   if (pl.wide) {
     snprintf(buf, n, "ffpa_fwd_m16w_kernel<%s, %d, RH=%d, MK=%d>%s", dt, de->d, pl.br / 64, pl.mk, merge);
+  } else if (pl.tile_ranges) {
+    snprintf(buf, n, "ffpa_fwd_m16_varlen_kernel<%s, %d> (dense launch, head chunks of %d, KV ranges per row tile)%s", dt, de->d, pl.chunk > 1 ? pl.chunk : 1, merge);
   } else if (pl.chunk > 1) {
     snprintf(buf, n, "ffpa_fwd_m16_varlen_kernel<%s, %d> (dense launch, head chunks of %d)", dt, de->d, pl.chunk);
   } else if (pl.m16) {

@@ -455,6 +455,8 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_varlen_kernel(const FwdArgs 
     // DENSE launches in this kernel's workgroup order (ffpa_attn_fwd -> ffpa_capi.hip: causal + GQA, no bias, no dropout, every row sees a key): the
     // arguments are the dense call's as they are — "sequence" = batch element, batch strides live —, only the order of the workgroups is this kernel's
     q_lo = seq * a_in.Hq * a_in.Nq;
+    // (KV ranges in this mode: a causal launch of one round of workgroups whose long row tiles would run alone at the end — ffpa_capi.hip pick_tile_ranges; the
+    // workspace rows are the dense call's [split, batch, head, row]: ws_head_rows = Nq, ws_split_rows = B x Hq x Nq, merged by ffpa_fwd_merge_kernel)
   } else {
     q_lo = va.cu_q[seq];
     const int k_lo = va.cu_k[seq];
@@ -472,23 +474,23 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_varlen_kernel(const FwdArgs 
     a.Nkv = nkv_seq > 0 ? nkv_seq : 0;
     a.causal_offset = a.Nkv - ntok_seq;  // (tail-aligned per sequence; a single packed token runs without the causal flag — it sees every key of its sequence)
     if (va.pack) a.causal_row_mod = ntok_seq;
-    if (a_in.nsplit > 1) {
-      if ((int64_t)q_lo + ntok_seq > va.ws_head_rows) return;  // (a caller whose total_q is smaller than its boundaries say: nothing is stored outside the scratch it sized)
-      int tiles = (a.Nkv + BC - 1) / BC;
-      if (a.causal) {
-        // under the causal flag a row tile walks the KV tiles up to ITS diagonal (the tile text's clamp, restated): those are what its ranges share out —
-        // every row tile of an under-filled prefill launch splits its own visible keys evenly (one-row-tile launches: all keys of the sequence, as before)
-        const int last_row = a.causal_row_mod ? a.causal_row_mod - 1 : qt * BR + BR - 1;
-        const int64_t last = (int64_t)last_row + a.causal_offset;
-        const int ntc = last < 0 ? 0 : (int)(last / BC) + 1;
-        tiles = tiles < ntc ? tiles : ntc;
-      }
-      a.tiles_per_split = (tiles + a_in.nsplit - 1) / a_in.nsplit;  // (fewer tiles than ranges leaves ranges empty: dead partials, weight 0 in the merge)
-    }
+    if (a_in.nsplit > 1 && (int64_t)q_lo + ntok_seq > va.ws_head_rows) return;  // (a caller whose total_q is smaller than its boundaries say: nothing is stored outside the scratch it sized)
     a.q = (const T*)a_in.q + (int64_t)q_lo * va.q_tok_stride;
     a.o = (T*)a_in.o + (int64_t)q_lo * va.o_tok_stride;
     a.k = (const T*)a_in.k + (int64_t)k_lo * a_in.sk[2];
     a.v = (const T*)a_in.v + (int64_t)k_lo * a_in.sv[2];
+  }
+  if (a_in.nsplit > 1) {
+    int tiles = (a.Nkv + BC - 1) / BC;
+    if (a.causal) {
+      // under the causal flag a row tile walks the KV tiles up to ITS diagonal (the tile text's clamp, restated): those are what its ranges share out —
+      // every row tile of an under-filled prefill launch splits its own visible keys evenly (one-row-tile launches: all keys of the sequence, as before)
+      const int last_row = a.causal_row_mod ? a.causal_row_mod - 1 : qt * BR + BR - 1;
+      const int64_t last = (int64_t)last_row + a.causal_offset;
+      const int ntc = last < 0 ? 0 : (int)(last / BC) + 1;
+      tiles = tiles < ntc ? tiles : ntc;
+    }
+    a.tiles_per_split = (tiles + a_in.nsplit - 1) / a_in.nsplit;  // (fewer tiles than ranges leaves ranges empty: dead partials, weight 0 in the merge)
   }
 #define FFPA_M16_TILE_DONE return
 #define FFPA_M16_ROW_INV(l) ((l) > 0.f ? __builtin_amdgcn_rcpf(l) : 0.f)

@@ -164,7 +164,7 @@ def test_underfilled_prefill_plan_splits_the_kv_axis(lib):
   (dict(heads_q=7, heads_kv=7, seqlen_q=4096, seqlen_kv=8192), 1),      # 224
   (dict(heads_q=3, heads_kv=3, seqlen_q=4096, seqlen_kv=8192, head_dim=1024), 1),  # 192 workgroups of 64 rows
   (dict(heads_q=5, heads_kv=5, seqlen_q=4096, seqlen_kv=2048), 1),      # short context (measured - 20 %)
-  (dict(heads_q=5, heads_kv=5, seqlen_q=4096, seqlen_kv=4096, causal=1), 1),
+  (dict(heads_q=5, heads_kv=5, seqlen_q=4096, seqlen_kv=4096, causal=1, causal_offset=0), 2),  # (uniform ranges lose under the causal flag; PER-ROW-TILE ranges: + 33 % — test_causal_tile_range_rule)
   # under-filled (workgroups <= CUs / 2): CUs / workgroups splits fill one round; a count that makes two rounds of shorter workgroups is taken at 5 % predicted
   (dict(heads_q=3, heads_kv=3, seqlen_q=4096, seqlen_kv=8192), 2),      # 96 workgroups: 2 x 96 = 192 of 256 CUs; five ranges measured + 2 % — inside the margin
   (dict(heads_q=3, heads_kv=3, seqlen_q=4096, seqlen_kv=16384), 5),     # ... on 16384 keys 5 x 96 = 480 = two rounds of a fifth: + 6 ... 8 %
@@ -510,3 +510,58 @@ def test_head_chunk_order_rule(lib, over, chunk):
     assert "varlen" not in got, got
   p.flags = hip.FLAG_NO_HEAD_CHUNKS
   assert lib.ffpa_attn_fwd_kernel(ctypes.byref(p), name, len(name)) == 0 and "varlen" not in name.value.decode()
+
+
+@pytest.mark.parametrize("over, ranges", [
+  (dict(heads_q=8, heads_kv=8, seqlen_q=4096, seqlen_kv=4096), 2),                     # 256 row tiles = one round: 212 -> 175 us (+ 21 %)
+  (dict(heads_q=8, heads_kv=2, seqlen_q=4096, seqlen_kv=4096), 2),                     # GQA: + 18 %
+  (dict(heads_q=6, heads_kv=6, seqlen_q=4096, seqlen_kv=4096), 2),                     # 192 workgroups: + 26 %
+  (dict(heads_q=5, heads_kv=5, seqlen_q=4096, seqlen_kv=4096), 2),                     # 160: + 33 %
+  (dict(heads_q=4, heads_kv=4, seqlen_q=8192, seqlen_kv=8192), 2),                     # + 4 %
+  (dict(heads_q=8, heads_kv=8, seqlen_q=4096, seqlen_kv=4096, head_dim=320), 2),       # + 5 %
+  (dict(heads_q=8, heads_kv=8, seqlen_q=4096, seqlen_kv=4096, head_dim=128), 3),       # small tiles, two workgroups per CU: three ranges + 25 % (two: + 15 %)
+  (dict(heads_q=8, heads_kv=8, seqlen_q=3000, seqlen_kv=3000, head_dim=128), 2),       # ... 500 keys per range of the average row tile are too few for three
+  (dict(heads_q=8, heads_kv=8, seqlen_q=3000, seqlen_kv=3000), 2),                     # 750 keys per range: + 22 %
+  (dict(heads_q=2, heads_kv=2, seqlen_q=8192, seqlen_kv=8192, head_dim=1024), 2),      # split-D tiles (64 rows): + 8 % at 2048 keys per range
+  (dict(heads_q=4, heads_kv=4, seqlen_q=4096, seqlen_kv=4096, head_dim=1024), 1),      # ... - 4 % at 1024
+  (dict(heads_q=16, heads_kv=16, seqlen_q=2048, seqlen_kv=2048), 1),                   # 512 keys per range: - 1 %
+  (dict(batch=2, heads_q=8, heads_kv=8, seqlen_q=2048, seqlen_kv=2048), 1),
+  (dict(batch=4, heads_q=8, heads_kv=8, seqlen_q=1024, seqlen_kv=1024), 1),
+  (dict(heads_q=8, heads_kv=8, seqlen_q=4096, seqlen_kv=8192, causal_offset=4096), 1),  # a chunk against a longer context: the longest row tile walks 1.33 x the average one
+  (dict(heads_q=12, heads_kv=12, seqlen_q=4096, seqlen_kv=4096), 1),                   # 1.5 rounds: the short row tiles fill the tail by themselves
+  (dict(heads_q=32, heads_kv=32, seqlen_q=8192, seqlen_kv=8192), 1),                   # the causal headline shape: eight rounds
+  (dict(heads_q=8, heads_kv=8, seqlen_q=4096, seqlen_kv=4096, dropout_p=0.1), 1),      # the dense mode's builds: no dropout, no bias, every row sees a key
+  (dict(heads_q=8, heads_kv=8, seqlen_q=4096, seqlen_kv=2048, causal_offset=-2048), 1),
+])
+def test_causal_tile_range_rule(lib, over, ranges):
+  """Which dense causal launches split every row tile's OWN visible KV tiles (ffpa_capi.hip::pick_tile_ranges; profiles/r06_tile_ranges.txt): one round of
+  workgroups or less (and more than half of one: fewer take the under-filled rule's uniform ranges), the longest row tile >= 1.5 x the average one, a range of the
+  average one >= 640 keys (2048 for the split-D tiles); head dims under 256 take three.  The kernel name says so; no scratch / num_splits = 1 / the deterministic
+  flag / FFPA_FLAG_NO_TILE_RANGES keep one range; FFPA_FLAG_TILE_RANGES | FFPA_FLAG_FORCE_SPLITS with num_splits = n force n.  256-CU fallback: no GPU needed."""
+  base = dict(batch=1, causal=1, causal_offset=0)
+  base.update(over)
+  name = ctypes.create_string_buffer(200)
+  plan = (ctypes.c_int * 4)()
+  p = _params(**base)
+  p.workspace, p.workspace_bytes = 16, 1 << 40
+  assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0 and lib.ffpa_attn_fwd_kernel(ctypes.byref(p), name, len(name)) == 0
+  got = name.value.decode()
+  assert ("KV ranges per row tile" in got) == (ranges > 1), (got, list(plan))
+  if ranges > 1:
+    d = base.get("head_dim", 512)
+    dk = (d + 63) // 64 * 64
+    assert plan[3] == ranges and got.startswith(f"ffpa_fwd_m16_varlen_kernel<bf16, {dk}> (dense launch, head chunks of ") and got.endswith("+ ffpa_fwd_merge_kernel"), (got, list(plan))
+    assert lib.ffpa_attn_fwd_workspace_bytes(ctypes.byref(p)) == ranges * base["batch"] * base["heads_q"] * base["seqlen_q"] * (dk + 1) * 4
+    for change in (dict(flags=hip.FLAG_NO_TILE_RANGES), dict(flags=hip.FLAG_DETERMINISTIC), dict(num_splits=1), dict(workspace=None, workspace_bytes=0)):
+      q = _params(**base)
+      q.workspace, q.workspace_bytes = 16, 1 << 40
+      for key, val in change.items():
+        setattr(q, key, val)
+      assert lib.ffpa_attn_fwd_kernel(ctypes.byref(q), name, len(name)) == 0 and "KV ranges" not in name.value.decode(), (change, name.value)
+    p.workspace_bytes = (ranges - 1) * base["batch"] * base["heads_q"] * base["seqlen_q"] * (dk + 1) * 4 + 64  # a smaller scratch: as many ranges as fit
+    assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0 and plan[3] == ranges - 1
+    p.workspace_bytes = 1 << 40
+  if not base.get("dropout_p") and base["causal_offset"] >= 0:
+    p.flags, p.num_splits = hip.FLAG_TILE_RANGES | hip.FLAG_FORCE_SPLITS, 5
+    assert lib.ffpa_attn_fwd_plan(ctypes.byref(p), plan) == 0 and plan[3] == 5 and lib.ffpa_attn_fwd_kernel(ctypes.byref(p), name, len(name)) == 0
+    assert "KV ranges per row tile" in name.value.decode(), name.value

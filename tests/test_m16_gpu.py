@@ -520,3 +520,57 @@ def test_head_chunk_order_computes_the_same_bits(shape):
   qs, ks, vs = (t.transpose(1, 2).contiguous().transpose(1, 2) for t in (q, k, v))
   o3, lse3 = hip.forward(qs, ks, vs, None, True, D ** -0.5, num_splits=1)
   assert torch.equal(o, o3) and torch.equal(lse, lse3)
+
+
+@pytest.mark.parametrize("shape", [
+  dict(B=1, Hq=8, Hkv=8, Nq=4096, Nkv=4096, D=512, dtype=torch.bfloat16, ranges=0),    # the rule's own: 256 row tiles = one round on 256 CUs
+  dict(B=2, Hq=3, Hkv=1, Nq=1500, Nkv=1900, D=320, dtype=torch.float16, ranges=3),     # forced: batch, GQA, ragged last row tile, tail-aligned against a longer context
+  dict(B=1, Hq=4, Hkv=4, Nq=1000, Nkv=1000, D=1024, dtype=torch.bfloat16, ranges=5),   # split-D tiles, more ranges than the first row tiles have KV tiles
+  dict(B=1, Hq=16, Hkv=2, Nq=640, Nkv=640, D=128, dtype=torch.bfloat16, ranges=2),     # head chunks of 2 AND ranges
+])
+def test_causal_kv_ranges_per_row_tile(shape):
+  """Causal launches of one round of workgroups split every row tile's OWN visible KV tiles (ffpa_capi.hip::pick_tile_ranges; the packed-sequence kernel in its
+  dense mode computes the ranges on the device, the dense merge kernel combines the fp32 partials): the rule's shape and forced counts (FLAG_TILE_RANGES |
+  FLAG_FORCE_SPLITS) against the one-range launch (to merge rounding), the oracle on a row subset and SDPA; strided views; the opt-outs."""
+  from ffpa_attn_amd import hip
+
+  B, Hq, Hkv, Nq, Nkv, D, dtype, ranges = (shape[k] for k in ("B", "Hq", "Hkv", "Nq", "Nkv", "D", "dtype", "ranges"))
+  if ranges == 0 and torch.cuda.get_device_properties(0).multi_processor_count != 256:
+    pytest.skip("the rule's shape is one round of workgroups on 256 CUs")
+  g = torch.Generator(device="cuda").manual_seed(Nq + D)
+  q = torch.randn((B, Hq, Nq, D), dtype=dtype, device="cuda", generator=g)
+  k = torch.randn((B, Hkv, Nkv, D), dtype=dtype, device="cuda", generator=g)
+  v = torch.randn((B, Hkv, Nkv, D), dtype=dtype, device="cuda", generator=g)
+  kw = dict(num_splits=ranges, flags=hip.FLAG_TILE_RANGES | hip.FLAG_FORCE_SPLITS) if ranges else {}
+  plan, plan1 = {}, {}
+  o, lse = hip.forward(q, k, v, None, True, D ** -0.5, plan_out=plan, **kw)
+  o1, lse1 = hip.forward(q, k, v, None, True, D ** -0.5, num_splits=1, plan_out=plan1)
+  assert "KV ranges per row tile" in plan["kernel"] and plan["kernel"].endswith("+ ffpa_fwd_merge_kernel") and plan["splits"] == (ranges or 2), plan
+  assert plan1["splits"] == 1 and "KV ranges" not in plan1["kernel"], plan1
+  # merge rounding (tests/test_varlen_gpu.py::_same_to_merge_rounding): every range rounds its P entries against its own running max — per element one output
+  # spacing + 2^-7 (bf16) / 2^-10 (fp16) of the row's largest |O| (the first rows of a causal launch average a handful of V rows: |O| ~ 1 ... 3)
+  a, b = o.float(), o1.float()
+  eps = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+  allow = torch.maximum(a.abs(), b.abs()).clamp_min(2.0 ** -14) * eps + b.abs().amax(dim=-1, keepdim=True) * eps
+  diff = (a - b).abs()
+  assert torch.all(diff <= allow) and (diff / allow).mean().item() < 0.1, f"O differs from the one-range launch by {(diff / allow).max().item():.2f} x the allowance"
+  assert (lse - lse1).abs().max().item() <= 1e-4
+  rr, cc = torch.arange(Nq, device="cuda")[:, None], torch.arange(Nkv, device="cuda")[None, :]
+  ref = F.scaled_dot_product_attention(q, k, v, attn_mask=cc <= rr + (Nkv - Nq), enable_gqa=Hq != Hkv)
+  _close(o, ref, dtype, f"tile ranges vs SDPA {shape}")
+  # the oracle on whole row tiles of the first and the last quarter of one head (their ranges differ most)
+  for r0 in (0, (Nq - 1) // 128 * 128 - 128):
+    r0 = max(r0, 0)
+    _check_vs_oracle(o[:1, :1], lse[:1, :1], q[:1, :1], k[:1, :1], v[:1, :1], causal=True, rows=(r0, min(Nq, r0 + 256)), block_keys=plan["block_keys"],
+                     name=f"tile ranges vs oracle rows {r0} {shape}", split=True)
+  # strided inputs ([B, N, H, D] storage): the same plan, the same bits
+  qs, ks, vs = (t.transpose(1, 2).contiguous().transpose(1, 2) for t in (q, k, v))
+  o3, lse3 = hip.forward(qs, ks, vs, None, True, D ** -0.5, **kw)
+  assert torch.equal(o, o3) and torch.equal(lse, lse3)
+  # the opt-outs keep one range: the flag, the deterministic flag
+  for flag in (hip.FLAG_NO_TILE_RANGES, hip.FLAG_DETERMINISTIC):
+    p2 = {}
+    o4, lse4 = hip.forward(q, k, v, None, True, D ** -0.5, flags=flag, plan_out=p2)
+    assert "KV ranges" not in p2["kernel"] and (p2["splits"] == 1 or flag == hip.FLAG_NO_TILE_RANGES), p2
+    if p2["splits"] == 1:
+      assert torch.equal(lse4, lse1) and (dtype != torch.bfloat16 or torch.equal(o4, o1))

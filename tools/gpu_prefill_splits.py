@@ -21,10 +21,18 @@ CASES = {
   "h5_n4096": (1, 5, 5, 4096, 8192, 512, False), "h6_n4096": (1, 6, 6, 4096, 8192, 512, False), "h7_n4096": (1, 7, 7, 4096, 8192, 512, False),
   "h5_n4096_short": (1, 5, 5, 4096, 2048, 512, False), "h5_n4096_causal": (1, 5, 5, 4096, 4096, 512, True), "h3_d1024": (1, 3, 3, 4096, 8192, 1024, False),
   "h5_d320": (1, 5, 5, 4096, 8192, 320, False), "h20_n1024": (1, 20, 20, 1024, 8192, 512, False), "h5_n4096_16k": (1, 5, 5, 4096, 16384, 512, False),
+  # CAUSAL launches of one round or less (CUs / 2 < workgroups <= CUs) whose longest row tile walks >= 1.5 x the average one: a whole prompt, few heads per GPU
+  "c_h8_n4096": (1, 8, 8, 4096, 4096, 512, True), "c_h8_n4096_d128": (1, 8, 8, 4096, 4096, 128, True), "c_h8_n4096_d320": (1, 8, 8, 4096, 4096, 320, True),
+  "c_h6_n4096": (1, 6, 6, 4096, 4096, 512, True), "c_b2h8_n2048": (2, 8, 8, 2048, 2048, 512, True), "c_b4h8_n1024": (4, 8, 8, 1024, 1024, 512, True),
+  "c_h16_n2048": (1, 16, 16, 2048, 2048, 512, True), "c_h4_n8192": (1, 4, 4, 8192, 8192, 512, True), "c_h4_n4096_d1024": (1, 4, 4, 4096, 4096, 1024, True),
+  "c_h32g4_n1024": (1, 32, 8, 1024, 1024, 512, True), "c_h8g4_n4096": (1, 8, 2, 4096, 4096, 512, True), "c_h8_n4096_ctx": (1, 8, 8, 4096, 8192, 512, True),
+  "c_h5_n4096": (1, 5, 5, 4096, 4096, 512, True), "c_h7_n4096": (1, 7, 7, 4096, 4096, 512, True), "c_h3_n8192": (1, 3, 3, 8192, 8192, 512, True),
 }
 if os.environ.get("ONLY"):
   CASES = {k_: v_ for k_, v_ in CASES.items() if k_ in os.environ["ONLY"].split(",")}
 hip.load_library()
+# TILE_RANGES=1: forced counts are PER-ROW-TILE ranges of a causal launch (the packed-sequence kernel's dense mode) instead of uniform ranges
+FORCE = hip.FLAG_FORCE_SPLITS | (hip.FLAG_TILE_RANGES if os.environ.get("TILE_RANGES") else 0)
 for name, (B, Hq, Hkv, Nq, Nkv, D, causal) in CASES.items():
   torch.manual_seed(0)
   q = torch.randn(B, Hq, Nq, D, dtype=torch.bfloat16, device="cuda")
@@ -36,14 +44,14 @@ for name, (B, Hq, Hkv, Nq, Nkv, D, causal) in CASES.items():
   plans = {}
   for a in arms:
     p = {}
-    hip.forward(q, k, v, None, causal, D ** -0.5, num_splits=a, return_lse=False, plan_out=p, flags=hip.FLAG_FORCE_SPLITS if a > 1 else 0)
+    hip.forward(q, k, v, None, causal, D ** -0.5, num_splits=a, return_lse=False, plan_out=p, flags=FORCE if a > 1 else 0)
     plans[a] = p.get("splits")
   for _ in range(7):
     for a in arms:
       s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
       s.record()
       for _ in range(5):
-        hip.forward(q, k, v, None, causal, D ** -0.5, num_splits=a, return_lse=False, flags=hip.FLAG_FORCE_SPLITS if a > 1 else 0)
+        hip.forward(q, k, v, None, causal, D ** -0.5, num_splits=a, return_lse=False, flags=FORCE if a > 1 else 0)
       e.record()
       torch.cuda.synchronize()
       times[a].append(s.elapsed_time(e) / 5)

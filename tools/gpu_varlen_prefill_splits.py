@@ -46,6 +46,14 @@ def main():
     (32, 8, 512, True, [(512, 4096)]),
     (32, 8, 512, True, [(256, 32768)]),
   ]
+  if os.environ.get("CASES") == "one_round":
+    # causal launches of one round or less (CUs / 2 < workgroups <= CUs): what the DENSE call would get from this kernel's per-row-tile ranges (tools/gpu_prefill_splits.py c_*: the dense plan's side)
+    cases = [
+      (8, 8, 512, True, [(4096, 4096)]), (8, 8, 128, True, [(4096, 4096)]), (8, 8, 320, True, [(4096, 4096)]), (6, 6, 512, True, [(4096, 4096)]), (8, 8, 512, True, [(2048, 2048)] * 2),
+      (8, 8, 512, True, [(1024, 1024)] * 4), (16, 16, 512, True, [(2048, 2048)]), (4, 4, 512, True, [(8192, 8192)]), (4, 4, 1024, True, [(4096, 4096)]), (32, 8, 512, True, [(1024, 1024)]),
+      (8, 2, 512, True, [(4096, 4096)]), (8, 8, 512, True, [(4096, 8192)]), (5, 5, 512, True, [(4096, 4096)]), (7, 7, 512, True, [(4096, 4096)]), (3, 3, 512, True, [(8192, 8192)]),
+      (8, 8, 256, True, [(4096, 4096)]), (8, 8, 192, True, [(4096, 4096)]), (2, 2, 1024, True, [(8192, 8192)]), (8, 8, 512, True, [(3000, 3000)]),
+    ]
   for hq, hkv, d, causal, seqs in cases:
     lens_q, lens_k = [a for a, _ in seqs], [b for _, b in seqs]
     tq, tk = sum(lens_q), sum(lens_k)
@@ -66,7 +74,7 @@ def main():
     run(0, plan=plan)
     row = []
     best = (None, 1e9)
-    for s in (1, 2, 3, 4, 6, 8, 12, 16, 32):
+    for s in ((1, 2, 3, 4, 6) if os.environ.get("CASES") == "one_round" else (1, 2, 3, 4, 6, 8, 12, 16, 32)):
       pl = {}
       o, l = run(s, hip.FLAG_FORCE_SPLITS if s > 1 else 0, pl)
       if pl["splits"] != s:
