@@ -83,6 +83,9 @@ WORKLOADS = {
   "cross": _w(1, 32, 32, 1024, 8192, 512, note="reference bench case 'cross-attn' (Nq = 1024)"),
   "gqa": _w(1, 32, 8, 8192, 8192, 512, note="reference bench case 'gqa' (Hkv = H/4)"),
   "gqa_causal": _w(1, 32, 8, 8192, 8192, 512, causal=True, note="the reference bench's 'gqa' and 'causal' cases together (LLM-style prefill): the launch the head-chunk workgroup order is for"),
+  "prompt_tp8": _w(1, 8, 8, 4096, 4096, 512, causal=True, one_range_leg=True,
+                   note="a whole 4096-token prompt on a tensor-parallel shard of 8 heads (causal): 256 row tiles = ONE round of workgroups — the launch whose row tiles split their own visible "
+                        "KV tiles (ffpa_capi.hip pick_tile_ranges); `other_launches`: the same call with one KV range per row tile (paired row tiles: what ran before)"),
   "attn_mask": _w(1, 32, 32, 8192, 8192, 512, mask="key_bias", note="reference bench case 'attn-mask': additive [1,1,1,Nkv] randn*0.25 (cli/_runner_fwd.py:75-81)"),
   "dropout": _w(1, 32, 32, 8192, 8192, 512, dropout=0.1, note="reference bench case 'dropout' (p = 0.1, in-kernel Philox)"),
   "non_aligned": _w(1, 8, 8, 8191, 8191, 512, note="reference bench case 'non-aligned' (N-1, H/4 heads)"),
@@ -1151,6 +1154,32 @@ def main() -> None:
               "what": "the same step back to back after >= 150 ms of continuous load, one HIP event pair around the launches; outside the timed region"}
     if w["bound"] == "hbm":
       steady["gbps"] = round(algorithmic_bytes(w, global_B) / (ss_ms * 1e-3) / 1e9, 1)
+  other_launches = None
+  if world == 1 and not sharded and w.get("one_range_leg") and not args.stub_backend:
+    # Context, never `value`: the same call with ONE KV range per row tile (num_splits = 1: the launch before the per-row-tile ranges), interleaved with the plan's launch
+    def one_range():
+      return hip.forward(q, k, v, None, w["causal"], scale, num_splits=1, return_lse=False)[0]
+
+    def plan_launch():
+      return hip.forward(q, k, v, None, w["causal"], scale, return_lse=False)[0]
+
+    legs = {"one_kv_range": [], "plan": []}
+    for _ in range(7):
+      for label, fn in (("one_kv_range", one_range), ("plan", plan_launch)):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(10):
+          fn()
+        ev1.record()
+        torch.cuda.synchronize()
+        legs[label].append(ev0.elapsed_time(ev1) / 10)
+    p1 = {}
+    hip.forward(q, k, v, None, w["causal"], scale, num_splits=1, return_lse=False, plan_out=p1)
+    med = {k_: sorted(v_)[3] for k_, v_ in legs.items()}
+    other_launches = {"what": "interleaved: 7 x 10 launches per arm through hip.forward, median; outside the timed region",
+                      "one_kv_range": {"ms": round(med["one_kv_range"], 4), "tflops": round(flops_local / med["one_kv_range"] / 1e9, 1), "kernel": p1.get("kernel")},
+                      "plan": {"ms": round(med["plan"], 4), "tflops": round(flops_local / med["plan"] / 1e9, 1)},
+                      "plan_over_one_range": round(med["one_kv_range"] / med["plan"], 3)}
   decode_step = None
   if world == 1 and not sharded and "step_graph" in locals():
     try:
@@ -1274,6 +1303,7 @@ def main() -> None:
       "device": device,
       "steady_state": steady,
       **({"decode_step": decode_step} if decode_step is not None else {}),
+      **({"other_launches": other_launches} if other_launches is not None else {}),
       **({"graph_replay": graph_replay} if graph_replay is not None else {}),
       "build": build,
       "plan": {k_: plan.get(k_) for k_ in ("variant", "block_rows", "block_keys", "splits")},

@@ -1025,6 +1025,9 @@ def _random_case(rng):
 # whatever their size; the plan's own rule only takes it for thousands of workgroups)
 _FUZZ = os.environ.get("FFPA_FUZZ_SEEDS", "0:48").split(":")
 _FUZZ_FLAGS = int(os.environ.get("FFPA_FUZZ_FLAGS", "0"), 0)
+# FFPA_FUZZ_SPLITS=<n> with FFPA_FUZZ_FLAGS=0x100040 (FFPA_FLAG_TILE_RANGES | FFPA_FLAG_FORCE_SPLITS): every causal case the dense mode of the packed-sequence
+# kernel has a build for (no bias / dropout, offset >= 0, two row tiles or more) splits every row tile's own visible KV tiles into n ranges; the others run one range
+_FUZZ_SPLITS = int(os.environ.get("FFPA_FUZZ_SPLITS", "0"), 0)
 
 
 @pytest.mark.parametrize("seed", range(int(_FUZZ[0]), int(_FUZZ[1])))
@@ -1058,7 +1061,7 @@ def test_randomized_against_oracle(hip, seed):
     okw.update(dropout_p=0.3, philox_seed=kw["philox_seed"], philox_offset=kw["philox_offset"])
   scale = float(rng.choice([D ** -0.5, 0.03, 0.11]))
   plan = {}
-  o, lse = hip.forward(q, k, v, bias, causal, scale, plan_out=plan, flags=_FUZZ_FLAGS, **kw)
+  o, lse = hip.forward(q, k, v, bias, causal, scale, plan_out=plan, flags=_FUZZ_FLAGS, num_splits=_FUZZ_SPLITS, **kw)
   assert o.shape == (B, Hq, Nq, D) and lse.shape == (B, Hq, Nq)
   qb, dname = fo.torch_to_bits(q)
   kb, _ = fo.torch_to_bits(k)

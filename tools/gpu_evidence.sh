@@ -12,7 +12,7 @@ case $st in
 pytest)
   timeout 1200 python -m pytest tests -m gpu -q > gpurun_out/final/pytest.log 2>&1; echo "pytest exit $?"; tail -2 gpurun_out/final/pytest.log ;;
 bench)
-  for w in cfg2 cfg3 cfg4_mask cfg4_offset0 cfg4_nomask cfg2_causal cross gqa gqa_causal attn_mask dropout non_aligned decode varlen varlen_decode; do
+  for w in cfg2 cfg3 cfg4_mask cfg4_offset0 cfg4_nomask cfg2_causal cross gqa gqa_causal prompt_tp8 attn_mask dropout non_aligned decode varlen varlen_decode; do
     extra="--no-cpu-baseline"; [ $w = cfg2 ] && extra=""
     timeout 300 python bench.py --workload $w --steps 20 --warmup 5 $extra > gpurun_out/final/bench_$w.json 2> gpurun_out/final/bench_$w.err
     python - <<PY

@@ -27,6 +27,10 @@ CASES = {
   "c_h16_n2048": (1, 16, 16, 2048, 2048, 512, True), "c_h4_n8192": (1, 4, 4, 8192, 8192, 512, True), "c_h4_n4096_d1024": (1, 4, 4, 4096, 4096, 1024, True),
   "c_h32g4_n1024": (1, 32, 8, 1024, 1024, 512, True), "c_h8g4_n4096": (1, 8, 2, 4096, 4096, 512, True), "c_h8_n4096_ctx": (1, 8, 8, 4096, 8192, 512, True),
   "c_h5_n4096": (1, 5, 5, 4096, 4096, 512, True), "c_h7_n4096": (1, 7, 7, 4096, 4096, 512, True), "c_h3_n8192": (1, 3, 3, 8192, 8192, 512, True),
+  # UNDER-FILLED causal launches (workgroups <= CUs / 2): the plan's uniform ranges (req 0) next to per-row-tile ranges (TILE_RANGES=1, forced counts)
+  "u_h4_n4096": (1, 4, 4, 4096, 4096, 512, True), "u_h2_n4096": (1, 2, 2, 4096, 4096, 512, True), "u_h2_n8192": (1, 2, 2, 8192, 8192, 512, True), "u_h1_n8192": (1, 1, 1, 8192, 8192, 512, True),
+  "u_h8_n2048": (1, 8, 8, 2048, 2048, 512, True), "u_h4_n4096_d128": (1, 4, 4, 4096, 4096, 128, True), "u_h2_n4096_d1024": (1, 2, 2, 4096, 4096, 1024, True), "u_h8g4_n2048": (1, 8, 2, 2048, 2048, 512, True),
+  "u_h3_n4096": (1, 3, 3, 4096, 4096, 512, True), "u_h4_n2048_ctx": (1, 4, 4, 2048, 8192, 512, True),
 }
 if os.environ.get("ONLY"):
   CASES = {k_: v_ for k_, v_ in CASES.items() if k_ in os.environ["ONLY"].split(",")}
