@@ -31,6 +31,10 @@ CASES = {
   "u_h4_n4096": (1, 4, 4, 4096, 4096, 512, True), "u_h2_n4096": (1, 2, 2, 4096, 4096, 512, True), "u_h2_n8192": (1, 2, 2, 8192, 8192, 512, True), "u_h1_n8192": (1, 1, 1, 8192, 8192, 512, True),
   "u_h8_n2048": (1, 8, 8, 2048, 2048, 512, True), "u_h4_n4096_d128": (1, 4, 4, 4096, 4096, 128, True), "u_h2_n4096_d1024": (1, 2, 2, 4096, 4096, 1024, True), "u_h8g4_n2048": (1, 8, 2, 2048, 2048, 512, True),
   "u_h3_n4096": (1, 3, 3, 4096, 4096, 512, True), "u_h4_n2048_ctx": (1, 4, 4, 2048, 8192, 512, True),
+  # causal launches of ONE TO TWO rounds (CUs < workgroups < 2 CUs): the longest row tile still outlasts the average CU's share
+  "r_h9_n4096": (1, 9, 9, 4096, 4096, 512, True), "r_h10_n4096": (1, 10, 10, 4096, 4096, 512, True), "r_h12_n4096": (1, 12, 12, 4096, 4096, 512, True), "r_h14_n4096": (1, 14, 14, 4096, 4096, 512, True),
+  "r_h16_n4096": (1, 16, 16, 4096, 4096, 512, True), "r_h6_n8192": (1, 6, 6, 8192, 8192, 512, True), "r_h8_n8192": (1, 8, 8, 8192, 8192, 512, True), "r_h12_n4096_d320": (1, 12, 12, 4096, 4096, 320, True),
+  "r_h3_n8192_d1024": (1, 3, 3, 8192, 8192, 1024, True), "r_h24g4_n2048": (1, 24, 6, 2048, 2048, 512, True), "r_h12_n4096_d128": (1, 12, 12, 4096, 4096, 128, True), "r_b3h4_n4096": (3, 4, 4, 4096, 4096, 512, True),
 }
 if os.environ.get("ONLY"):
   CASES = {k_: v_ for k_, v_ in CASES.items() if k_ in os.environ["ONLY"].split(",")}
