@@ -378,16 +378,21 @@ def test_randomized_packed_batches(hip):
     q, k, v = _make(lens_q, lens_k, hq, hkv, d, dtype, seed=seed)
     mq, mk = max(lens_q), max(max(lens_k), 1)
     mq_said = mq + int(rng.integers(0, 200))
-    out, lse = hip.varlen_forward(q, k, v, _cu(lens_q), _cu(lens_k), mq_said, mk, causal, 1.0 / math.sqrt(d))
+    # FFPA_VARLEN_FUZZ_SPLITS=n: every launch splits its KV ranges in n (FLAG_FORCE_SPLITS: prefill launches too — every row tile its own visible tiles; as many as the longest sequence has tiles)
+    forced = int(os.environ.get("FFPA_VARLEN_FUZZ_SPLITS", "0"))
+    plan = {}
+    out, lse = hip.varlen_forward(q, k, v, _cu(lens_q), _cu(lens_k), mq_said, mk, causal, 1.0 / math.sqrt(d), plan_out=plan,
+                                  **(dict(num_splits=forced, flags=hip.FLAG_FORCE_SPLITS) if forced > 1 else {}))
     name = f"fuzz seed {seed}: lens_q={lens_q} lens_k={lens_k} Hq={hq} Hkv={hkv} D={d} {dtype} causal={causal}"
-    _check_packed(hip, q, k, v, lens_q, lens_k, causal, out, lse, oracle=False, sdpa=d <= 512, name=name, max_q=mq_said, max_k=mk)
+    was_split = plan["splits"] > 1
+    _check_packed(hip, q, k, v, lens_q, lens_k, causal, out, lse, oracle=False, sdpa=d <= 512, name=name, max_q=mq_said, max_k=mk, split=was_split)
     live = [i for i, (a, b) in enumerate(zip(lens_q, lens_k)) if a > 0 and b > 0 and not (causal and a > b)]
     if live:
       i = live[seed % len(live)]
       qs, ks = int(sum(lens_q[:i])), int(sum(lens_k[:i]))
       bc = hip.varlen_launch_plan(nseq, hq, hkv, mq, mk, d)["block_keys"]
       _check_vs_oracle(_seq(out, qs, qs + lens_q[i]), lse[:, qs:qs + lens_q[i]].unsqueeze(0), _seq(q, qs, qs + lens_q[i]), _seq(k, ks, ks + lens_k[i]),
-                       _seq(v, ks, ks + lens_k[i]), causal=causal, causal_offset=lens_k[i] - lens_q[i], block_keys=bc, name=name + f" seq {i} vs oracle")
+                       _seq(v, ks, ks + lens_k[i]), causal=causal, causal_offset=lens_k[i] - lens_q[i], block_keys=bc, name=name + f" seq {i} vs oracle", split=was_split)
 
 
 @pytest.mark.parametrize("hq, hkv, d, dtype", [(32, 8, 512, torch.bfloat16), (16, 2, 320, torch.float16), (8, 1, 1024, torch.bfloat16), (24, 8, 128, torch.bfloat16)])
