@@ -40,7 +40,7 @@ if os.environ.get("ONLY"):
   CASES = {k_: v_ for k_, v_ in CASES.items() if k_ in os.environ["ONLY"].split(",")}
 hip.load_library()
 # TILE_RANGES=1: forced counts are PER-ROW-TILE ranges of a causal launch (the packed-sequence kernel's dense mode) instead of uniform ranges
-FORCE = hip.FLAG_FORCE_SPLITS | (hip.FLAG_TILE_RANGES if os.environ.get("TILE_RANGES") else 0)
+FORCE = hip.FLAG_FORCE_SPLITS | (hip.FLAG_TILE_RANGES if os.environ.get("TILE_RANGES") else 0) | int(os.environ.get("EXTRA_FLAGS", "0"), 0)  # (EXTRA_FLAGS: e.g. 0x2 = no XCD remap, 0x400 = a head's row tiles over all eight XCDs)
 for name, (B, Hq, Hkv, Nq, Nkv, D, causal) in CASES.items():
   torch.manual_seed(0)
   q = torch.randn(B, Hq, Nq, D, dtype=torch.bfloat16, device="cuda")
@@ -50,16 +50,20 @@ for name, (B, Hq, Hkv, Nq, Nkv, D, causal) in CASES.items():
   arms = [int(x) for x in os.environ.get('ARMS', '0,1,2,3,4').split(',')]
   times = {a: [] for a in arms}
   plans = {}
+  # arms 3000 + f (TILE_RANGES=1): ranges of f % of the longest row tile's KV tiles — only longer row tiles split, in two, jobs in descending length (num_splits = 2000 + tiles)
+  bc_ = hip.tile_config(hip.padded_head_dim(D))["block_keys"]
+  ntv = -(-Nkv // bc_)
+  nsp = {a: (2000 + -(-ntv * (a - 3000) // 100) if a >= 3000 else a) for a in arms}
   for a in arms:
     p = {}
-    hip.forward(q, k, v, None, causal, D ** -0.5, num_splits=a, return_lse=False, plan_out=p, flags=FORCE if a > 1 else 0)
+    hip.forward(q, k, v, None, causal, D ** -0.5, num_splits=nsp[a], return_lse=False, plan_out=p, flags=FORCE if a > 1 else 0)
     plans[a] = p.get("splits")
   for _ in range(7):
     for a in arms:
       s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
       s.record()
       for _ in range(5):
-        hip.forward(q, k, v, None, causal, D ** -0.5, num_splits=a, return_lse=False, flags=FORCE if a > 1 else 0)
+        hip.forward(q, k, v, None, causal, D ** -0.5, num_splits=nsp[a], return_lse=False, flags=FORCE if a > 1 else 0)
       e.record()
       torch.cuda.synchronize()
       times[a].append(s.elapsed_time(e) / 5)
