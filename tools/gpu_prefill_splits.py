@@ -53,17 +53,18 @@ for name, (B, Hq, Hkv, Nq, Nkv, D, causal) in CASES.items():
   # arms 3000 + f (TILE_RANGES=1): ranges of f % of the longest row tile's KV tiles — only longer row tiles split, in two, jobs in descending length (num_splits = 2000 + tiles)
   bc_ = hip.tile_config(hip.padded_head_dim(D))["block_keys"]
   ntv = -(-Nkv // bc_)
-  nsp = {a: (2000 + -(-ntv * (a - 3000) // 100) if a >= 3000 else a) for a in arms}
+  nsp = {a: (a - 5000 if a >= 5000 else (2000 + -(-ntv * (a - 3000) // 100) if a >= 3000 else a)) for a in arms}  # (5000 + n: n ranges merged by the merge KERNEL: no pair fold)
+  mil = {a: (False if a >= 5000 else None) for a in arms}
   for a in arms:
     p = {}
-    hip.forward(q, k, v, None, causal, D ** -0.5, num_splits=nsp[a], return_lse=False, plan_out=p, flags=FORCE if a > 1 else 0)
+    hip.forward(q, k, v, None, causal, D ** -0.5, num_splits=nsp[a], return_lse=False, plan_out=p, flags=FORCE if a > 1 else 0, merge_in_launch=mil[a])
     plans[a] = p.get("splits")
   for _ in range(7):
     for a in arms:
       s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
       s.record()
       for _ in range(5):
-        hip.forward(q, k, v, None, causal, D ** -0.5, num_splits=nsp[a], return_lse=False, flags=FORCE if a > 1 else 0)
+        hip.forward(q, k, v, None, causal, D ** -0.5, num_splits=nsp[a], return_lse=False, flags=FORCE if a > 1 else 0, merge_in_launch=mil[a])
       e.record()
       torch.cuda.synchronize()
       times[a].append(s.elapsed_time(e) / 5)
