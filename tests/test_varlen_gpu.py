@@ -550,6 +550,8 @@ def test_kv_splits_inside_the_packed_launch(hip, hq, hkv, d, dtype, nq, splits):
   out, lse = hip.varlen_forward(q, k, v, cu_q, cu_k, nq, max(lens_k), True, d ** -0.5, num_splits=splits, flags=hip.FLAG_FORCE_SPLITS if splits else 0, plan_out=ps)
   assert p1["splits"] == 1 and "merge" not in p1["kernel"]
   tiles = -(-max(lens_k) // ps["block_keys"])
+  if not splits and ps["splits"] == 1:
+    pytest.skip("left to the library, this batch does not split on this device's CU count (the rule's tables: tests/test_varlen.py)")
   assert ps["splits"] == (min(splits, tiles) if splits else ps["splits"]) and ps["splits"] > 1 and ps["workgroups"] == p1["workgroups"] * ps["splits"], (p1, ps)
   assert ps["kernel"].endswith("+ ffpa_varlen_merge_kernel"), ps
   _same_to_merge_rounding(out, lse, ref, ref_lse, f"splits {ps['splits']} Hq{hq}/Hkv{hkv} D{d} Nq{nq}")
@@ -582,6 +584,8 @@ def test_kv_splits_of_under_filled_prefill_launches(hip, hq, hkv, d, dtype, spli
   out, lse = hip.varlen_forward(q, k, v, cu_q, cu_k, max(lens_q), max(lens_k), causal, d ** -0.5, num_splits=splits, flags=hip.FLAG_FORCE_SPLITS if splits else 0, plan_out=ps)
   assert p1["splits"] == 1 and "merge" not in p1["kernel"] and p1["row_tiles"] > 1
   tiles = -(-max(lens_k) // ps["block_keys"])
+  if not splits and ps["splits"] == 1:
+    pytest.skip("left to the library, this batch does not split on this device's CU count (the rule's tables: tests/test_varlen.py)")
   assert ps["splits"] == (min(splits, tiles) if splits else ps["splits"]) and ps["splits"] > 1 and ps["workgroups"] == p1["workgroups"] * ps["splits"], (p1, ps)
   assert ps["kernel"].endswith("+ ffpa_varlen_merge_kernel"), ps
   name = f"prefill KV splits {ps['splits']} Hq{hq}/Hkv{hkv} D{d} {'causal' if causal else 'full'}"
