@@ -920,6 +920,7 @@ struct VarlenPlan {
   int splits;        // KV ranges per sequence (1 = the KV axis is not split)
   size_t ws_bytes;   // scratch the split launch uses
   int64_t grid;      // workgroups of the launch (all ranges)
+  int compact;       // > 0: row-tile slots per head of the compact grid (VarlenArgs::compact_tiles)
 };
 
 // Validation shared by the launch and the queries; fills the plan.  Head dims below the first 16x16x32 instantiation run on it (columns past the
@@ -953,6 +954,20 @@ int varlen_plan(const ffpa_varlen_fwd_params* p, VarlenPlan* out) {
   out->pack = (group > 1 && (int64_t)group * p->max_seqlen_q <= out->br && !(p->flags & FFPA_FLAG_NO_PACK_GQA)) ? group : 0;
   out->nqt = out->pack ? 1 : (p->max_seqlen_q + out->br - 1) / out->br;
   out->grid = (int64_t)p->batch * (out->pack ? p->heads_kv : p->heads_q) * out->nqt;
+  // The COMPACT grid: a caller that says how many rows q has (total_q, ABI 6; >= cu_seqlens_q[batch]) lets a ragged prefill batch size its grid by the rows there are —
+  // sum_i ceil(len_i / block rows) <= ceil(total_q / block rows) + batch slots per head — instead of batch x the longest sequence's row tiles, most of which would find
+  // no row and leave (each of them still holds a CU for a launch and a few loads).  The kernel finds a slot's (sequence, row tile) on the device — a scan every
+  // workgroup pays —, so it is taken when at least three quarters of the full grid would be idle: one 16k-token prompt among 63 short ones 7454 -> 7039 us (+ 6 %),
+  // 8192 + 31 short + 4 %, D = 128 one 8k among 127 short ones + 46 %; the bench batch (8 sequences of 256 ... 4864: 55 % idle) - 1 % and not taken
+  // (tools/gpu_varlen_compact.py, profiles/r06_varlen_compact_grid.txt).  FFPA_FLAG_NO_COMPACT_GRID keeps the full grid (same order, same bits).
+  out->compact = 0;
+  if (!out->pack && out->nqt > 1 && p->total_q > 0 && !(p->flags & FFPA_FLAG_NO_COMPACT_GRID)) {
+    const int64_t slots = ((int64_t)p->total_q + out->br - 1) / out->br + p->batch;
+    if (slots * 4 <= (int64_t)p->batch * out->nqt && slots <= 0x7fffffffLL) {
+      out->compact = (int)slots;
+      out->grid = slots * p->heads_q;
+    }
+  }
   // The non-temporal K / V fetch (the dense short-query launches' rule, ffpa_attn_fwd): every K / V byte is read by ONE workgroup — one row tile per (sequence,
   // head), and MHA or packed GQA rows — and the batch's K + V do not fit the 256 MiB Infinity Cache.  The launch side sees only max_seqlen_kv, not the lengths: it
   // prices a ragged batch at half of batch x max (>= 272 MiB of that).  LDS-DMA from HBM: 5.9 TB/s without the hint, 7.3 with it (profiles/r04_kv_stream.txt);
@@ -1145,6 +1160,7 @@ int ffpa_attn_varlen_fwd(const ffpa_varlen_fwd_params* p, void* stream) {
     va.head_chunk = 1;  // (the rows of a tile ARE the group: KV heads share nothing)
   }
 
+  va.compact_tiles = pl.compact;
   va.ws_head_rows = va.ws_split_rows = 0;
   if (pl.splits > 1) {
     // partials [split, query head, token, Dk] fp32 + their LSE [split, query head, token]; the kernel finds a range's tiles from its sequence's own length

@@ -415,6 +415,11 @@ struct VarlenArgs {
   // split * ws_split_rows + head * ws_head_rows + token (ffpa_varlen_merge_kernel, ffpa_varlen_merge.h, combines them: the reference's decode stage 2)
   int64_t ws_head_rows;   // total_q
   int64_t ws_split_rows;  // query heads x total_q
+  // COMPACT grid (packed launches of several row tiles per head whose caller says total_q): > 0 = the grid holds this many row-tile slots per head — an upper
+  // bound of sum_i ceil(len_i / block rows), ceil(total_q / block rows) + batch — instead of batch x ceil(max_seqlen_q / block rows): a ragged batch sizes its grid
+  // by the rows there are, not by its longest sequence (8 sequences of 256 ... 4864 tokens: 304 slots per head of which 128 hold rows -> 136).  Slot -> (sequence,
+  // row tile) on the device: the waves scan the sequences' tile counts 64 at a time (one load per lane, a wave prefix sum, a ballot); same order as the full grid.
+  int compact_tiles;
 };
 
 // NT: the decode-batch build — every K / V piece carries the non-temporal hint (each byte has ONE reader and the batch's K + V do not fit the caches: the launch
@@ -442,12 +447,56 @@ __global__ __launch_bounds__(256) void ffpa_fwd_m16_varlen_kernel(const FwdArgs 
   // ... side by side at the level of ROW TILES: (chunk, sequence, row tile, head in chunk) — a head's tiles alone fill an XCD's 32 CUs for a whole round, so heads
   // that merely follow each other stream the sequence's K / V once each (measured: no fewer HBM bytes than head-major order); interleaved per tile, the same row
   // tile of the chunk's heads runs at the same time on the same keys
-  const int per_seq = a_in.nqt * va.head_chunk, per_chunk = a_in.B * per_seq;
-  const int chunk = vid / per_chunk, in_chunk = vid - chunk * per_chunk;
-  const int seq = in_chunk / per_seq, in_seq = in_chunk - seq * per_seq;
-  int qt = in_seq / va.head_chunk;
-  if (a_in.causal) qt = a_in.nqt - 1 - qt;  // longest rows first
-  const int bh = seq * a_in.Hq + chunk * va.head_chunk + (in_seq - (in_seq / va.head_chunk) * va.head_chunk);
+  int chunk, seq, qt, head_in_chunk;
+  int seq_tiles = a_in.nqt;  // row tiles of this sequence in the grid (compact grid: the sequence's own count)
+  if (va.compact_tiles > 0) {
+    const int per_chunk = va.compact_tiles * va.head_chunk;
+    chunk = vid / per_chunk;
+    const int in_chunk = vid - chunk * per_chunk;
+    const int slot = in_chunk / va.head_chunk;
+    head_in_chunk = in_chunk - slot * va.head_chunk;
+    // slot -> (sequence, row tile): the sequences' tile counts, 64 sequences per step
+    seq = -1, qt = 0;
+    int before = 0;
+    for (int s0 = 0; s0 < a_in.B; s0 += 64) {
+      const int i = s0 + lane;
+      int n = 0;
+      if (i < a_in.B) {
+        const int len = va.cu_q[i + 1] - va.cu_q[i];
+        n = len > 0 ? (len + BR - 1) / BR : 0;
+      }
+      int incl = n;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+      }
+      const int total = __shfl(incl, 63);
+      if (slot < before + total) {
+        const unsigned long long m = __ballot(slot < before + incl);
+        const int l = __ffsll((long long)m) - 1;
+        seq = s0 + l;
+        seq_tiles = __shfl(n, l);
+        qt = slot - (before + __shfl(incl, l) - seq_tiles);
+        break;
+      }
+      before += total;
+    }
+    if (seq < 0) return;  // (a slot past the batch's last row tile: the bound is not tight)
+    seq = __builtin_amdgcn_readfirstlane(seq);
+    seq_tiles = __builtin_amdgcn_readfirstlane(seq_tiles);
+    qt = __builtin_amdgcn_readfirstlane(qt);
+  } else {
+    const int per_seq = a_in.nqt * va.head_chunk, per_chunk = a_in.B * per_seq;
+    chunk = vid / per_chunk;
+    const int in_chunk = vid - chunk * per_chunk;
+    seq = in_chunk / per_seq;
+    const int in_seq = in_chunk - seq * per_seq;
+    qt = in_seq / va.head_chunk;
+    head_in_chunk = in_seq - qt * va.head_chunk;
+  }
+  if (a_in.causal) qt = seq_tiles - 1 - qt;  // longest rows first
+  const int bh = seq * a_in.Hq + chunk * va.head_chunk + head_in_chunk;
   FwdArgs a = a_in;
   int q_lo;  // packed: the sequence's first row of q / o (LSE [Hq, T_q]: its column); dense: the batch element's first LSE row
   int ntok = 1;  // tokens of this sequence (>= 1): packed rows are (row / ntok, row % ntok) = (head of the group, token)

@@ -62,6 +62,7 @@ FLAG_NO_PAIR_TILES = 0x20000  # bench / test: never
 FLAG_NO_HEAD_CHUNKS = 0x80000  # bench / test: causal GQA prefill launches keep the (batch, head, row tile) workgroup order (default: the library decides; same bits either way)
 FLAG_TILE_RANGES = 0x100000  # bench / test: with FLAG_FORCE_SPLITS and num_splits = n, a causal prefill launch splits every row tile's OWN visible KV tiles into n ranges
 FLAG_NO_TILE_RANGES = 0x200000  # bench / test: never (default: causal launches of one round of workgroups take two)
+FLAG_NO_COMPACT_GRID = 0x400000  # bench / test, packed-sequence call: keep the grid of batch x ceil(max_seqlen_q / block rows) row tiles per head (default: sized by total_q for ragged prefill batches)
 FLAG_NO_PACK_GQA = 0x40000  # bench / test, packed-sequence call: decode batches under GQA keep one workgroup per QUERY head (default: a KV group's heads are the rows of one tile)
 FLAG_DETERMINISTIC = 0x4000  # batch-invariant bits: no prefill KV splits, no wide-row tile, short-query splits by the KV length alone (FFPA_HIP_DETERMINISTIC=1 sets it on every call)
 

@@ -80,6 +80,7 @@ enum ffpa_bias_dtype {
 #define FFPA_FLAG_NO_HEAD_CHUNKS   0x80000u /* bench / test, ffpa_attn_fwd: causal GQA prefill launches keep the (batch, head, row tile) workgroup order (default: the launch side takes the head-chunk order — the same row tile of a KV group's heads at the same time — where its rule applies; same bits either way) */
 #define FFPA_FLAG_TILE_RANGES      0x100000u /* bench / test, ffpa_attn_fwd: with FFPA_FLAG_FORCE_SPLITS and num_splits = n, a causal prefill launch splits every row tile's OWN visible KV tiles into n ranges (the packed-sequence kernel's dense mode) instead of n uniform ranges (default: the launch side takes two such ranges for causal launches of one round of workgroups) */
 #define FFPA_FLAG_NO_TILE_RANGES   0x200000u /* bench / test, ffpa_attn_fwd: never */
+#define FFPA_FLAG_NO_COMPACT_GRID   0x400000u /* bench / test, ffpa_attn_varlen_fwd: a ragged prefill batch keeps the grid of batch x ceil(max_seqlen_q / block rows) row tiles per head (default: callers that say total_q get ceil(total_q / block rows) + batch slots per head when three quarters of the full grid would be idle; same order, same bits) */
 #define FFPA_FLAG_NO_PACK_GQA      0x40000u /* bench / test, ffpa_attn_varlen_fwd: short query sequences under GQA (group x max_seqlen_q rows fit one tile: decode, speculative decoding) keep one workgroup per QUERY head (default: the heads of a KV group x the tokens are packed into the rows of one tile) */
 #define FFPA_FLAG_XCD_GROUP(log2p1) ((unsigned)(log2p1) << 8) /* bench-only: bits 8..10 = 1 + log2 of the XCDs that share a head's row tiles (1 -> 1, 2 -> 2, 3 -> 4, 4 -> 8); 0 = the launch side decides */
 

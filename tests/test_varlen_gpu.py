@@ -566,6 +566,31 @@ def test_kv_splits_inside_the_packed_launch(hip, hq, hkv, d, dtype, nq, splits):
 
 
 @pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("lens, hq, hkv, d, dtype", [
+  ([4864, 256, 0, 130, 130, 1, 64, 7], 8, 2, 512, torch.bfloat16),                # one long sequence sizes the full grid: 8 x 38 row-tile slots per head, 43 + 8 in the compact one
+  ([(0 if i % 9 == 0 else 1 + (37 * i) % 300) for i in range(150)] + [2000], 2, 2, 320, torch.float16),  # 151 sequences: three steps of the 64-sequence scan
+  ([2000, 64, 64, 64, 64, 64, 64, 64, 1], 4, 1, 1024, torch.bfloat16),             # 64-row tiles
+])
+def test_compact_grid_of_ragged_prefill_batches(hip, lens, hq, hkv, d, dtype, causal):
+  """A caller that says how many rows q has lets a ragged prefill batch size its grid by the rows there are (ceil(total_q / block rows) + batch row-tile slots per
+  head; the kernel finds a slot's (sequence, row tile) on the device) instead of batch x the longest sequence's row tiles: fewer workgroups, the same order, the
+  same bits as the full grid (FLAG_NO_COMPACT_GRID) — with one KV range and with forced ranges; checked against the dense kernel's bits / SDPA per sequence."""
+  q, k, v = _make(lens, lens, hq, hkv, d, dtype, seed=len(lens) + d)
+  cu = _cu(lens)
+  for kw in (dict(num_splits=1), dict(num_splits=3, flags=hip.FLAG_FORCE_SPLITS)):
+    pc, pf = {}, {}
+    out, lse = hip.varlen_forward(q, k, v, cu, cu, max(lens), max(lens), causal, d ** -0.5, plan_out=pc, **kw)
+    kw_full = dict(kw, flags=kw.get("flags", 0) | hip.FLAG_NO_COMPACT_GRID)
+    full, full_lse = hip.varlen_forward(q, k, v, cu, cu, max(lens), max(lens), causal, d ** -0.5, plan_out=pf, **kw_full)
+    br = pc["block_rows"]
+    slots = -(-sum(lens) // br) + len(lens)
+    assert pc["workgroups"] == slots * hq * pc["splits"] and pf["workgroups"] == len(lens) * pf["row_tiles"] * hq * pf["splits"] and pc["workgroups"] < pf["workgroups"], (pc, pf)
+    assert torch.equal(out, full) and torch.equal(lse, full_lse)
+  out, lse = hip.varlen_forward(q, k, v, cu, cu, max(lens), max(lens), causal, d ** -0.5, num_splits=1)
+  _check_packed(hip, q, k, v, lens, lens, causal, out, lse, oracle=False, sdpa=d <= 512, split=False, name=f"compact grid {len(lens)} sequences D{d}")
+
+
+@pytest.mark.parametrize("causal", [True, False])
 @pytest.mark.parametrize("hq, hkv, d, dtype, splits", [
   (4, 4, 512, torch.bfloat16, 0), (4, 4, 512, torch.bfloat16, 3), (8, 2, 320, torch.float16, 5), (2, 1, 1024, torch.bfloat16, 4), (4, 2, 128, torch.bfloat16, 7), (2, 2, 200, torch.float16, 2),
   (2, 2, 512, torch.bfloat16, 64),
